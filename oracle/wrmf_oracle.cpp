@@ -1,0 +1,437 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+//
+// CPU restatement of rsparse's WRMF/ALS hot path, used as (i) the parity checker for the HIP
+// kernels and (ii) the timed "rsparse-shaped OpenMP" CPU baseline in bench.py (cpu_baseline.kind
+// = "port").  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+//
+// PARITY UNPINNED: the reference itself cannot be built or run here (needs R, Rcpp,
+// RcppArmadillo + BLAS/LAPACK, none present; its tests hold no numeric golden vectors for this
+// path -- tests/testthat/test-wrmf.R asserts shapes only).  This restatement is therefore pinned
+// by closed-form identities instead (tests/test_oracle.py): dense numpy.linalg.solve of the stated
+// normal equations, CG(cg_steps>=k) -> Cholesky answer, fit_transform == transform.
+//
+// Every function cites the reference lines it follows (paths relative to /root/reference).
+// Plain C++17 + OpenMP, no third-party dependency: Armadillo expressions are written out as loops.
+//
+// Layouts (src/utils.cpp:69-78, inst/include/mapped_csc.hpp:8-29):
+//   Conf : CSC, col_ptrs int32[n_cols+1], row_indices int32[nnz] (0-based), values f64[nnz]
+//   X    : rank x n_rows(Conf)   column-major (each entity's rank-vector contiguous), read only
+//   Y    : rank x n_cols(Conf)   column-major, in: CG warm start, out: solution
+//   XtX  : rank x rank, already contains + lambda*I (R/model_WRMF.R:474-486)
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// inst/include/wrmf.hpp:16-22
+constexpr unsigned CHOLESKY = 0;
+constexpr unsigned CONJUGATE_GRADIENT = 1;
+constexpr double CG_TOL = 1e-10;
+
+template <class T>
+inline T dot(const T* a, const T* b, int n) {
+  // arma::dot on short vectors: two running sums in T (op_dot::direct_dot_arma)
+  T s1 = 0, s2 = 0;
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    s1 += a[i] * b[i];
+    s2 += a[i + 1] * b[i + 1];
+  }
+  if (i < n) s1 += a[i] * b[i];
+  return s1 + s2;
+}
+
+// y = A * x, A is k x k column-major (XtX * v, wrmf_implicit.hpp:16,22)
+template <class T>
+inline void gemv_sq(const T* A, const T* x, T* y, int k) {
+  for (int r = 0; r < k; r++) y[r] = 0;
+  for (int c = 0; c < k; c++) {
+    const T xc = x[c];
+    const T* col = A + (size_t)c * k;
+    for (int r = 0; r < k; r++) y[r] += col[r] * xc;
+  }
+}
+
+// t = Xnnz^T * v  (n-vector); Xnnz is k x n column-major
+template <class T>
+inline void gemv_t(const T* Xn, const T* v, T* t, int k, int n) {
+  for (int j = 0; j < n; j++) t[j] = dot(Xn + (size_t)j * k, v, k);
+}
+
+// u (+)= Xnnz * w  (k-vector)
+template <class T>
+inline void gemv_n(const T* Xn, const T* w, T* u, int k, int n, bool accumulate) {
+  if (!accumulate)
+    for (int r = 0; r < k; r++) u[r] = 0;
+  for (int j = 0; j < n; j++) {
+    const T wj = w[j];
+    const T* col = Xn + (size_t)j * k;
+    for (int r = 0; r < k; r++) u[r] += col[r] * wj;
+  }
+}
+
+template <class T>
+struct Scratch {
+  std::vector<T> Xn, conf, t, w, x, r, p, Ap, tmp, lhs, rhs;
+  void ensure(int k, int n) {
+    if ((size_t)k * n > Xn.size()) Xn.resize((size_t)k * n);
+    if ((size_t)n > conf.size()) { conf.resize(n); t.resize(n); w.resize(n); }
+    if ((size_t)k > x.size()) {
+      x.resize(k); r.resize(k); p.resize(k); Ap.resize(k); tmp.resize(k); rhs.resize(k);
+      lhs.resize((size_t)k * k);
+    }
+  }
+};
+
+// inst/include/wrmf_implicit.hpp:8-32  cg_solver_implicit<T>
+//   r = X_nnz*(c - c1 % (X_nnz^T x)) - XtX*x ; p = r ; rsold = r.r           (:16-19)
+//   loop: Ap = XtX*p + X_nnz*(c1 % (X_nnz^T p)); alpha = rsold/(p.Ap);       (:22-23)
+//         x += alpha p; r -= alpha Ap; rsnew = r.r; if rsnew < CG_TOL break; (:24-27)
+//         p = r + p*(rsnew/rsold); rsold = rsnew                             (:28-29)
+// rsold/rsnew/alpha are double even for T=float (:18); a double scalar times an
+// arma::Col<float> is rounded to float first (elem_type conversion).
+template <class T>
+void cg_solver_implicit(Scratch<T>& s, int k, int n, const T* XtX, unsigned n_iter) {
+  T* x = s.x.data(); T* r = s.r.data(); T* p = s.p.data(); T* Ap = s.Ap.data();
+  T* t = s.t.data(); T* w = s.w.data(); T* tmp = s.tmp.data();
+  const T* Xn = s.Xn.data(); const T* c = s.conf.data();
+  gemv_t(Xn, x, t, k, n);
+  for (int j = 0; j < n; j++) w[j] = c[j] - (c[j] - (T)1.0) * t[j];
+  gemv_n(Xn, w, r, k, n, false);
+  gemv_sq(XtX, x, tmp, k);
+  for (int i = 0; i < k; i++) { r[i] -= tmp[i]; p[i] = r[i]; }
+  double rsold = dot(r, r, k), rsnew, alpha;
+  for (unsigned it = 0; it < n_iter; it++) {
+    gemv_sq(XtX, p, Ap, k);
+    gemv_t(Xn, p, t, k, n);
+    for (int j = 0; j < n; j++) w[j] = (c[j] - (T)1.0) * t[j];
+    gemv_n(Xn, w, Ap, k, n, true);
+    alpha = rsold / dot(p, Ap, k);
+    const T a = (T)alpha;
+    for (int i = 0; i < k; i++) { x[i] += a * p[i]; r[i] -= a * Ap[i]; }
+    rsnew = dot(r, r, k);
+    if (rsnew < CG_TOL) break;
+    const T b = (T)(rsnew / rsold);
+    for (int i = 0; i < k; i++) p[i] = r[i] + p[i] * b;
+    rsold = rsnew;
+  }
+}
+
+// inst/include/wrmf_explicit.hpp:8-31  cg_solver_explicit<T>
+//   r = X_nnz*(c - X_nnz^T x) - lambda x ; Ap = X_nnz*(X_nnz^T p) + lambda p  (:15,21)
+template <class T>
+void cg_solver_explicit(Scratch<T>& s, int k, int n, T lambda, unsigned n_iter) {
+  T* x = s.x.data(); T* r = s.r.data(); T* p = s.p.data(); T* Ap = s.Ap.data();
+  T* t = s.t.data(); T* w = s.w.data();
+  const T* Xn = s.Xn.data(); const T* c = s.conf.data();
+  gemv_t(Xn, x, t, k, n);
+  for (int j = 0; j < n; j++) w[j] = c[j] - t[j];
+  gemv_n(Xn, w, r, k, n, false);
+  for (int i = 0; i < k; i++) { r[i] -= lambda * x[i]; p[i] = r[i]; }
+  double rsold = dot(r, r, k), rsnew, alpha;
+  for (unsigned it = 0; it < n_iter; it++) {
+    gemv_t(Xn, p, t, k, n);
+    gemv_n(Xn, t, Ap, k, n, false);
+    for (int i = 0; i < k; i++) Ap[i] += lambda * p[i];
+    alpha = rsold / dot(p, Ap, k);
+    const T a = (T)alpha;
+    for (int i = 0; i < k; i++) { x[i] += a * p[i]; r[i] -= a * Ap[i]; }
+    rsnew = dot(r, r, k);
+    if (rsnew < CG_TOL) break;
+    const T b = (T)(rsnew / rsold);
+    for (int i = 0; i < k; i++) p[i] = r[i] + p[i] * b;
+    rsold = rsnew;
+  }
+}
+
+// arma::solve(lhs, rhs, fast [+ likely_sympd]) (wrmf_implicit.hpp:236, wrmf_explicit.hpp:108):
+// LAPACK posv (Cholesky LL^T, no refinement); if the factorisation fails Armadillo falls back to
+// a general solver -- restated here as LU with partial pivoting (gesv).  A is k x k column-major,
+// overwritten; b overwritten with the solution.  Returns false if singular.
+template <class T>
+bool solve_sympd(T* A, T* b, int k, std::vector<T>& keep) {
+  keep.assign(A, A + (size_t)k * k);
+  bool ok = true;
+  for (int j = 0; j < k && ok; j++) {
+    T d = A[(size_t)j * k + j];
+    for (int m = 0; m < j; m++) d -= A[(size_t)m * k + j] * A[(size_t)m * k + j];
+    if (!(d > 0)) { ok = false; break; }
+    d = std::sqrt(d);
+    A[(size_t)j * k + j] = d;
+    for (int i = j + 1; i < k; i++) {
+      T v = A[(size_t)j * k + i];
+      for (int m = 0; m < j; m++) v -= A[(size_t)m * k + i] * A[(size_t)m * k + j];
+      A[(size_t)j * k + i] = v / d;
+    }
+  }
+  if (ok) {
+    for (int i = 0; i < k; i++) {  // L z = b
+      T v = b[i];
+      for (int m = 0; m < i; m++) v -= A[(size_t)m * k + i] * b[m];
+      b[i] = v / A[(size_t)i * k + i];
+    }
+    for (int i = k - 1; i >= 0; i--) {  // L^T y = z
+      T v = b[i];
+      for (int m = i + 1; m < k; m++) v -= A[(size_t)i * k + m] * b[m];
+      b[i] = v / A[(size_t)i * k + i];
+    }
+    return true;
+  }
+  // gesv fallback
+  std::copy(keep.begin(), keep.end(), A);
+  for (int c = 0; c < k; c++) {
+    int piv = c;
+    T best = std::fabs(A[(size_t)c * k + c]);
+    for (int i = c + 1; i < k; i++)
+      if (std::fabs(A[(size_t)c * k + i]) > best) { best = std::fabs(A[(size_t)c * k + i]); piv = i; }
+    if (best == 0) return false;
+    if (piv != c) {
+      for (int m = 0; m < k; m++) std::swap(A[(size_t)m * k + c], A[(size_t)m * k + piv]);
+      std::swap(b[c], b[piv]);
+    }
+    for (int i = c + 1; i < k; i++) {
+      const T f = A[(size_t)c * k + i] / A[(size_t)c * k + c];
+      if (f == 0) continue;
+      for (int m = c; m < k; m++) A[(size_t)m * k + i] -= f * A[(size_t)m * k + c];
+      b[i] -= f * b[c];
+    }
+  }
+  for (int i = k - 1; i >= 0; i--) {
+    T v = b[i];
+    for (int m = i + 1; m < k; m++) v -= A[(size_t)m * k + i] * b[m];
+    b[i] = v / A[(size_t)i * k + i];
+  }
+  return true;
+}
+
+// arma::accu(X % X) for a dense matrix: two running sums in T over consecutive pairs.
+template <class T>
+T accu_sq(const T* X, size_t n) {
+  T a = 0, b = 0;
+  size_t i = 0;
+  for (; i + 1 < n; i += 2) { a += X[i] * X[i]; b += X[i + 1] * X[i + 1]; }
+  if (i < n) a += X[i] * X[i];
+  return a + b;
+}
+
+// inst/include/wrmf_implicit.hpp:90-305, no-bias / no-global-bias branch only
+// (:160-185 column loop, :195-197 CG, :206-208,231,236 Cholesky, :254 write-back,
+//  :259-261 loss, :272-283 empty column -> zeros, :286-304 + lambda*accu(X%X), / nnz).
+template <class T>
+double als_implicit(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                    const double* values, const T* X, T* Y, const T* XtX, int k, double lambda,
+                    int n_threads, unsigned solver, unsigned cg_steps, int* status) {
+  double loss = 0;
+  int bad = 0;
+  const size_t nnz = (size_t)col_ptrs[n_cols];
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+  {
+    Scratch<T> s;
+    std::vector<T> keep;
+#pragma omp for schedule(dynamic) reduction(+ : loss) reduction(+ : bad)
+    for (int i = 0; i < n_cols; i++) {
+      const int p1 = col_ptrs[i], p2 = col_ptrs[i + 1];
+      T* y = Y + (size_t)i * k;
+      if (p1 < p2) {
+        const int n = p2 - p1;
+        s.ensure(k, n);
+        for (int j = 0; j < n; j++) {
+          s.conf[j] = (T)values[p1 + j];                                  // :182-183 conv_to<T>
+          std::memcpy(&s.Xn[(size_t)j * k], X + (size_t)row_indices[p1 + j] * k, sizeof(T) * k);  // :184
+        }
+        if (solver == CONJUGATE_GRADIENT) {
+          std::memcpy(s.x.data(), y, sizeof(T) * k);                      // :185 warm start
+          cg_solver_implicit<T>(s, k, n, XtX, cg_steps);
+        } else {
+          // lhs = XtX + (X_nnz.each_row() % (c-1)^T) * X_nnz^T ; rhs = X_nnz * c   (:207-208,231)
+          T* lhs = s.lhs.data();
+          std::memcpy(lhs, XtX, sizeof(T) * k * k);
+          for (int j = 0; j < n; j++) {
+            const T c1 = s.conf[j] - (T)1.0;
+            const T* col = &s.Xn[(size_t)j * k];
+            for (int b = 0; b < k; b++) {
+              const T f = col[b] * c1;
+              for (int a = 0; a < k; a++) lhs[(size_t)b * k + a] += col[a] * f;
+            }
+          }
+          gemv_n(s.Xn.data(), s.conf.data(), s.x.data(), k, n, false);
+          if (!solve_sympd(lhs, s.x.data(), k, keep)) bad += 1;
+        }
+        std::memcpy(y, s.x.data(), sizeof(T) * k);                        // :254
+        // loss += dot(square(1 - y^T X_nnz), c) + lambda * dot(y, y)      (:259-261)
+        gemv_t(s.Xn.data(), s.x.data(), s.t.data(), k, n);
+        T l = 0;
+        for (int j = 0; j < n; j++) {
+          const T d = (T)1.0 - s.t[j];
+          l += d * d * s.conf[j];
+        }
+        loss += l + lambda * dot(s.x.data(), s.x.data(), k);
+      } else {
+        for (int r = 0; r < k; r++) y[r] = 0;                             // :281
+      }
+    }
+  }
+  if (lambda > 0) loss += lambda * accu_sq(X, (size_t)k * n_rows);        // :286-301
+  if (status) *status = bad;
+  return loss / (double)nnz;                                              // :304
+}
+
+// inst/include/wrmf_explicit.hpp:33-174, no-bias branch (:68-109 column loop, :78 lambda_use,
+// :103-108 Cholesky, :131-132 loss, :133-144 empty column, :146-173 regulariser on X, / nnz).
+template <class T>
+double als_explicit(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                    const double* values, const T* X, T* Y, const T* cnt_X, int k, double lambda,
+                    int n_threads, unsigned solver, unsigned cg_steps, int dynamic_lambda,
+                    int* status) {
+  double loss = 0;
+  int bad = 0;
+  const size_t nnz = (size_t)col_ptrs[n_cols];
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+  {
+    Scratch<T> s;
+    std::vector<T> keep;
+#pragma omp for schedule(dynamic, 100) reduction(+ : loss) reduction(+ : bad)
+    for (int i = 0; i < n_cols; i++) {
+      const int p1 = col_ptrs[i], p2 = col_ptrs[i + 1];
+      T* y = Y + (size_t)i * k;
+      if (p1 < p2) {
+        const int n = p2 - p1;
+        s.ensure(k, n);
+        const T lambda_use = (T)(lambda * (dynamic_lambda ? (double)(T)n : 1.0));   // :78
+        for (int j = 0; j < n; j++) {
+          s.conf[j] = (T)values[p1 + j];
+          std::memcpy(&s.Xn[(size_t)j * k], X + (size_t)row_indices[p1 + j] * k, sizeof(T) * k);
+        }
+        if (solver == CONJUGATE_GRADIENT) {
+          std::memcpy(s.x.data(), y, sizeof(T) * k);
+          cg_solver_explicit<T>(s, k, n, lambda_use, cg_steps);
+        } else {
+          T* lhs = s.lhs.data();                                          // :103-105
+          std::fill(lhs, lhs + (size_t)k * k, (T)0);
+          for (int j = 0; j < n; j++) {
+            const T* col = &s.Xn[(size_t)j * k];
+            for (int b = 0; b < k; b++) {
+              const T f = col[b];
+              for (int a = 0; a < k; a++) lhs[(size_t)b * k + a] += col[a] * f;
+            }
+          }
+          for (int a = 0; a < k; a++) lhs[(size_t)a * k + a] += lambda_use;
+          gemv_n(s.Xn.data(), s.conf.data(), s.x.data(), k, n, false);
+          if (!solve_sympd(lhs, s.x.data(), k, keep)) bad += 1;
+        }
+        std::memcpy(y, s.x.data(), sizeof(T) * k);
+        gemv_t(s.Xn.data(), s.x.data(), s.t.data(), k, n);                // :131-132
+        T l = 0;
+        for (int j = 0; j < n; j++) {
+          const T d = s.conf[j] - s.t[j];
+          l += d * d;
+        }
+        loss += l + lambda_use * dot(s.x.data(), s.x.data(), k);
+      } else {
+        for (int r = 0; r < k; r++) y[r] = 0;
+      }
+    }
+  }
+  if (lambda > 0) {                                                       // :160-170
+    if (!dynamic_lambda) {
+      loss += lambda * accu_sq(X, (size_t)k * n_rows);
+    } else {
+      // accu((X % X) * cnt_X): row sums weighted by cnt_X, then summed
+      T tot = 0;
+      std::vector<T> rowacc(k, (T)0);
+      for (int j = 0; j < n_rows; j++) {
+        const T* col = X + (size_t)j * k;
+        const T cj = cnt_X ? cnt_X[j] : (T)0;
+        for (int r = 0; r < k; r++) rowacc[r] += col[r] * col[r] * cj;
+      }
+      for (int r = 0; r < k; r++) tot += rowacc[r];
+      loss += lambda * tot;
+    }
+  }
+  if (status) *status = bad;
+  return loss / (double)nnz;
+}
+
+// R/model_WRMF.R:474-486 (and :347-353): XtX = tcrossprod(X) + fl(diag(lambda)).
+// The ridge passes through float::fl(), i.e. lambda is rounded to fp32 even in the double build.
+template <class T>
+void gramian(const T* X, int k, int64_t n, double lambda, T* out) {
+  std::vector<double> acc((size_t)k * k, 0.0);
+#pragma omp parallel
+  {
+    std::vector<T> loc((size_t)k * k, (T)0);
+#pragma omp for schedule(static)
+    for (int64_t j = 0; j < n; j++) {
+      const T* col = X + (size_t)j * k;
+      for (int b = 0; b < k; b++) {
+        const T f = col[b];
+        for (int a = 0; a < k; a++) loc[(size_t)b * k + a] += col[a] * f;
+      }
+    }
+#pragma omp critical
+    for (size_t e = 0; e < (size_t)k * k; e++) acc[e] += (double)loc[e];
+  }
+  const T ridge = (T)(float)lambda;
+  for (int b = 0; b < k; b++)
+    for (int a = 0; a < k; a++) out[(size_t)b * k + a] = (T)acc[(size_t)b * k + a] + (a == b ? ridge : (T)0);
+}
+
+}  // namespace
+
+extern "C" {
+
+double wrmf_oracle_als_implicit_f32(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                    const int32_t* row_indices, const double* values,
+                                    const float* X, float* Y, const float* XtX, int k,
+                                    double lambda, int n_threads, unsigned solver,
+                                    unsigned cg_steps, int* status) {
+  return als_implicit<float>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda,
+                             n_threads, solver, cg_steps, status);
+}
+double wrmf_oracle_als_implicit_f64(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                    const int32_t* row_indices, const double* values,
+                                    const double* X, double* Y, const double* XtX, int k,
+                                    double lambda, int n_threads, unsigned solver,
+                                    unsigned cg_steps, int* status) {
+  return als_implicit<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda,
+                              n_threads, solver, cg_steps, status);
+}
+double wrmf_oracle_als_explicit_f32(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                    const int32_t* row_indices, const double* values,
+                                    const float* X, float* Y, const float* cnt_X, int k,
+                                    double lambda, int n_threads, unsigned solver,
+                                    unsigned cg_steps, int dynamic_lambda, int* status) {
+  return als_explicit<float>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, cnt_X, k,
+                             lambda, n_threads, solver, cg_steps, dynamic_lambda, status);
+}
+double wrmf_oracle_als_explicit_f64(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                    const int32_t* row_indices, const double* values,
+                                    const double* X, double* Y, const double* cnt_X, int k,
+                                    double lambda, int n_threads, unsigned solver,
+                                    unsigned cg_steps, int dynamic_lambda, int* status) {
+  return als_explicit<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, cnt_X, k,
+                              lambda, n_threads, solver, cg_steps, dynamic_lambda, status);
+}
+void wrmf_oracle_gramian_f32(const float* X, int k, int64_t n, double lambda, float* out) {
+  gramian<float>(X, k, n, lambda, out);
+}
+void wrmf_oracle_gramian_f64(const double* X, int k, int64_t n, double lambda, double* out) {
+  gramian<double>(X, k, n, lambda, out);
+}
+int wrmf_oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+}  // extern "C"

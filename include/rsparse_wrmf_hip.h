@@ -1,0 +1,170 @@
+/*
+ * rsparse_wrmf_hip.h -- C ABI of librsparse_wrmf_hip.so: the MI355X (gfx950) implementation of
+ * rsparse's WRMF / ALS hot path.
+ *
+ * Plain C: pointers and sizes only, no R (SEXP), Rcpp, Armadillo or torch types.  Every entry
+ * point returns an int status (0 = ok); nothing throws or exits across the boundary.  After a
+ * non-zero status rsparse_hip_last_error() returns a description (thread-local).
+ *
+ * Two layers:
+ *
+ *  (1) stateless drop-ins -- the argument lists of the four generated `.Call` targets
+ *      _rsparse_als_implicit_{double,float} / _rsparse_als_explicit_{double,float}
+ *      (reference: src/RcppExports.cpp:329-415, src/wrmf_implicit.cpp:4-31,
+ *      src/wrmf_explicit.cpp:4-27) with the S4 / arma objects flattened to the raw buffers those
+ *      functions extract (src/utils.cpp:69-78 dgCMatrix slots, :115-128 float32 payload).
+ *      Host pointers in, `Y` mutated in place, loss returned -- exactly the reference contract
+ *      (R/model_WRMF.R:492,513 "Y is modified in-place").  They upload, run, download.
+ *
+ *  (2) a device-resident layer for callers that keep the matrices in HBM across half-iterations
+ *      (the reference re-passes host memory every call; at 10M x 1M that would re-upload >4 GB of
+ *      CSC per half-iteration).  Device pointers + a HIP stream; no implicit synchronisation
+ *      unless a host result is requested.
+ *
+ * Layouts (identical to the reference):
+ *   Conf    CSC: col_ptrs int32[n_cols+1], row_indices int32[nnz] 0-based, values (f64 on the
+ *           host boundary, f32 once resident); one CSC column = one row solved.
+ *   X       rank x n_rows  column-major (entity vectors contiguous), read only
+ *   Y       rank x n_cols  column-major, in: CG warm start, out: solution
+ *   XtX     rank x rank, must already contain + lambda*I (R/model_WRMF.R:474-486)
+ *
+ * Arithmetic on the device is fp32 (the reference's precision="float" build); the *_double
+ * entry points convert at the boundary.  Stated tolerance vs the reference CPU path: 1e-4
+ * relative Frobenius on the factor matrices.
+ */
+#ifndef RSPARSE_WRMF_HIP_H
+#define RSPARSE_WRMF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define RSPARSE_HIP_OK 0
+#define RSPARSE_HIP_ERR_INVALID 1     /* bad argument (NULL pointer, negative size, rank <= 0 ...) */
+#define RSPARSE_HIP_ERR_UNSUPPORTED 2 /* variant not on the device path: caller keeps its CPU path   */
+#define RSPARSE_HIP_ERR_RUNTIME 3     /* HIP runtime / out of memory / no device                    */
+#define RSPARSE_HIP_ERR_NUMERIC 4     /* a per-row system was not positive definite (the reference's */
+                                      /* arma::solve would throw -> R error, RcppExports.cpp:374,392) */
+
+/* solver codes: inst/include/wrmf.hpp:16-18 */
+#define RSPARSE_SOLVER_CHOLESKY 0
+#define RSPARSE_SOLVER_CONJUGATE_GRADIENT 1
+#define RSPARSE_SOLVER_NNLS 2 /* -> RSPARSE_HIP_ERR_UNSUPPORTED */
+
+#define RSPARSE_HIP_MAX_RANK 128
+
+const char* rsparse_hip_last_error(void);
+int rsparse_hip_abi_version(void);
+/* number of visible HIP devices (0 if none / runtime unavailable) */
+int rsparse_hip_device_count(void);
+int rsparse_hip_set_device(int device);
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) stateless drop-ins, host pointers
+ * ---------------------------------------------------------------------------------------------- */
+
+/* replaces als_implicit_float  (src/wrmf_implicit.cpp:17-31 -> als_implicit<float>,
+ * inst/include/wrmf_implicit.hpp:90-305).  n_rows/n_cols/col_ptrs/row_indices/values are the
+ * dgCMatrix slots Dim[0], Dim[1], p, i, x.  rank = nrow(X).  n_threads is accepted and ignored.
+ * with_biases != 0, global_bias >= sqrt(FLT_EPSILON) or solver == NNLS -> ERR_UNSUPPORTED.
+ * global_bias_base / initialize_bias_base only matter for those variants and may be NULL / 0.
+ * *loss_out = the value the reference returns (loss / nnz). */
+int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                   const int32_t* row_indices, const double* values,
+                                   const float* X, float* Y, const float* XtX, int rank,
+                                   double lambda, int n_threads, unsigned solver,
+                                   unsigned cg_steps, int with_biases, int is_x_bias_last_row,
+                                   double global_bias, float* global_bias_base,
+                                   int initialize_bias_base, double* loss_out);
+
+/* replaces als_implicit_double (src/wrmf_implicit.cpp:5-14).  Buffers are f64 like the reference's;
+ * converted to fp32 for the device and back. */
+int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                    const int32_t* row_indices, const double* values,
+                                    const double* X, double* Y, const double* XtX, int rank,
+                                    double lambda, int n_threads, unsigned solver,
+                                    unsigned cg_steps, int with_biases, int is_x_bias_last_row,
+                                    double global_bias, double* global_bias_base,
+                                    int initialize_bias_base, double* loss_out);
+
+/* replaces als_explicit_float (src/wrmf_explicit.cpp:17-27 -> als_explicit<float>,
+ * inst/include/wrmf_explicit.hpp:33-174).  cnt_X has n_rows entries (used only for the
+ * dynamic_lambda regulariser term of the loss, :160-170); may be NULL when !dynamic_lambda. */
+int rsparse_hip_als_explicit_float(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                   const int32_t* row_indices, const double* values,
+                                   const float* X, float* Y, const float* cnt_X, int rank,
+                                   double lambda, unsigned n_threads, unsigned solver,
+                                   unsigned cg_steps, int dynamic_lambda, int with_biases,
+                                   int is_x_bias_last_row, double* loss_out);
+
+/* replaces als_explicit_double (src/wrmf_explicit.cpp:5-14) */
+int rsparse_hip_als_explicit_double(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                    const int32_t* row_indices, const double* values,
+                                    const double* X, double* Y, const double* cnt_X, int rank,
+                                    double lambda, unsigned n_threads, unsigned solver,
+                                    unsigned cg_steps, int dynamic_lambda, int with_biases,
+                                    int is_x_bias_last_row, double* loss_out);
+
+/* replaces the R-side Gramian  XtX = tcrossprod(X) + fl(diag(lambda))  (R/model_WRMF.R:474-486,
+ * :347-353).  Host pointers; X is rank x n column-major; XtX_out rank x rank. */
+int rsparse_hip_gramian_float(const float* X, int rank, int64_t n, double lambda, float* XtX_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2) device-resident layer
+ * ---------------------------------------------------------------------------------------------- */
+
+/* A CSC matrix resident in HBM plus its launch schedule (row-length buckets).  Replaces the
+ * non-owning MappedCSC view (inst/include/mapped_csc.hpp:8-29, src/utils.cpp:69-78). */
+typedef struct rsparse_hip_csc rsparse_hip_csc;
+
+/* upload from host dgCMatrix slots (values f64 -> f32 on the way) */
+int rsparse_hip_csc_create_host(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                const int32_t* row_indices, const double* values,
+                                rsparse_hip_csc** out);
+/* adopt arrays that already live on the current device (not copied, not freed by destroy;
+ * they must outlive the handle).  d_values are f32. */
+int rsparse_hip_csc_create_device(int n_rows, int n_cols, const int32_t* d_col_ptrs,
+                                  const int32_t* d_row_indices, const float* d_values,
+                                  rsparse_hip_csc** out);
+int rsparse_hip_csc_destroy(rsparse_hip_csc* m);
+/* n_rows, n_cols, nnz, number of rows on the workgroup-per-row path, longest row */
+int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[5]);
+
+/* XtX = X X^T + fl(lambda) I on the device (MFMA).  d_sumsq_out (nullable, device double[1])
+ * receives sum(X^2) = trace before the ridge -- the `accu(X % X)` term of the loss
+ * (inst/include/wrmf_implicit.hpp:299-301) for free.  stream: hipStream_t (NULL = default). */
+int rsparse_hip_gramian_device(const float* d_X, int rank, int64_t n, double lambda,
+                               float* d_XtX_out, double* d_sumsq_out, void* stream);
+
+/* One implicit half-iteration over the columns of `conf` (als_implicit<float>, no-bias branch).
+ * d_Y points at column 0 of this matrix's block (rank x n_cols).  Writes to d_loss_rows_out
+ * (nullable, device double[1]) the un-normalised row part of the loss:
+ *     sum_i [ sum_j c_ij (1 - y_i.x_j)^2 + lambda |y_i|^2 ]          (wrmf_implicit.hpp:259-261)
+ * the caller adds lambda*sum(X^2) and divides by nnz (:286-304) -- kept separate so that shards
+ * on several GPUs can be summed.  Asynchronous on `stream`. */
+int rsparse_hip_als_implicit_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
+                                    const float* d_XtX, int rank, double lambda, unsigned solver,
+                                    unsigned cg_steps, double* d_loss_rows_out, void* stream);
+
+/* One explicit half-iteration (als_explicit<float>, no-bias branch).  Loss row part:
+ *     sum_i [ sum_j (r_ij - y_i.x_j)^2 + lambda_use_i |y_i|^2 ]      (wrmf_explicit.hpp:131-132) */
+int rsparse_hip_als_explicit_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
+                                    int rank, double lambda, unsigned solver, unsigned cg_steps,
+                                    int dynamic_lambda, double* d_loss_rows_out, void* stream);
+
+/* sum_j w_j |X[:,j]|^2 on the device (w = NULL -> 1): the regulariser terms
+ * lambda*accu(X%X) and lambda*accu((X%X)*cnt_X) (wrmf_explicit.hpp:160-170). */
+int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, const float* d_w,
+                                      double* d_out, void* stream);
+
+/* number of per-row systems that failed (not positive definite) since the last call; resets. */
+int rsparse_hip_take_numeric_failures(int64_t* count_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSPARSE_WRMF_HIP_H */

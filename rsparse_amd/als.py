@@ -1,0 +1,102 @@
+"""Host-buffer wrappers with the reference's wrapper signatures.
+
+`als_implicit()` / `als_explicit()` mirror the R functions of the same name
+(R/model_WRMF.R:456-496, :498-515): same argument meaning, `Y` modified in place, loss returned,
+the k x k Gramian `tcrossprod(X) + fl(lambda) I` computed here when `XtX` is not supplied
+(:474-486) -- but every numeric step runs in librsparse_wrmf_hip.so through the stateless C-ABI
+entry points that replace `.Call(_rsparse_als_*)` (R/RcppExports.R:88-102).
+
+Matrices are numpy arrays in the reference's layout: X (rank x n) and Y (rank x m) column-major
+(Fortran order), CSC slots p / i / x exactly as a dgCMatrix holds them.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _f_contig(a, dtype, name):
+    if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags["F_CONTIGUOUS"]:
+        raise ValueError("%s must be a column-major numpy array of dtype %s" % (name, np.dtype(dtype)))
+    return a
+
+
+def _csc_slots(x):
+    """Accepts a scipy.sparse CSC matrix or a (n_rows, n_cols, p, i, x) tuple."""
+    if isinstance(x, tuple):
+        n_rows, n_cols, p, i, v = x
+    else:
+        x = x.tocsc()
+        n_rows, n_cols = x.shape
+        p, i, v = x.indptr, x.indices, x.data
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    i = np.ascontiguousarray(i, dtype=np.int32)
+    v = np.ascontiguousarray(v, dtype=np.float64)   # dgCMatrix@x is always double (src/utils.cpp:71)
+    return int(n_rows), int(n_cols), p, i, v
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def gramian(X, lambda_, precision):
+    """XtX = tcrossprod(X) + fl(diag(lambda))  (R/model_WRMF.R:474-486) on the device."""
+    lib = _lib.load()
+    dt = np.float32 if precision == "float" else np.float64
+    _f_contig(X, dt, "X")
+    k, n = X.shape
+    X32 = X if dt == np.float32 else np.asfortranarray(X, dtype=np.float32)
+    out = np.zeros((k, k), dtype=np.float32, order="F")
+    _lib.check(lib.rsparse_hip_gramian_float(_vp(X32), k, n, float(lambda_), _vp(out)))
+    return out if dt == np.float32 else np.asfortranarray(out, dtype=np.float64)
+
+
+def als_implicit(x, X, Y, lambda_, n_threads, solver_code, cg_steps, precision, with_user_item_bias,
+                 is_bias_last_row, initialize_bias_base=True, global_bias=0.0, XtX=None,
+                 global_bias_base=None):
+    """R/model_WRMF.R:456-496.  Returns loss / nnz; Y is modified in place."""
+    lib = _lib.load()
+    dt = np.float32 if precision == "float" else np.float64
+    n_rows, n_cols, p, i, v = _csc_slots(x)
+    _f_contig(X, dt, "X")
+    _f_contig(Y, dt, "Y")
+    rank = X.shape[0]
+    if X.shape[1] != n_rows or Y.shape != (rank, n_cols):
+        raise ValueError("X must be rank x nrow(x) and Y rank x ncol(x)")
+    if with_user_item_bias or global_bias:
+        # the C ABI reports these as UNSUPPORTED; raise before touching the device
+        _lib.check(lib.rsparse_hip_als_implicit_float(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), None,
+                                                      rank, float(lambda_), int(n_threads), int(solver_code),
+                                                      int(cg_steps), int(bool(with_user_item_bias)),
+                                                      int(bool(is_bias_last_row)), float(global_bias), None,
+                                                      int(bool(initialize_bias_base)), None))
+    if XtX is None:
+        XtX = gramian(X, lambda_, precision)
+    _f_contig(XtX, dt, "XtX")
+    loss = ctypes.c_double(0.0)
+    fn = lib.rsparse_hip_als_implicit_float if precision == "float" else lib.rsparse_hip_als_implicit_double
+    _lib.check(fn(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), _vp(XtX), rank, float(lambda_),
+                  int(n_threads), int(solver_code), int(cg_steps), 0, int(bool(is_bias_last_row)), 0.0,
+                  None, int(bool(initialize_bias_base)), ctypes.addressof(loss)))
+    return loss.value
+
+
+def als_explicit(x, X, Y, cnt_X, lambda_, n_threads, solver_code, cg_steps, dynamic_lambda, precision,
+                 with_user_item_bias, is_bias_last_row):
+    """R/model_WRMF.R:498-515.  Returns loss / nnz; Y is modified in place."""
+    lib = _lib.load()
+    dt = np.float32 if precision == "float" else np.float64
+    n_rows, n_cols, p, i, v = _csc_slots(x)
+    _f_contig(X, dt, "X")
+    _f_contig(Y, dt, "Y")
+    rank = X.shape[0]
+    if X.shape[1] != n_rows or Y.shape != (rank, n_cols):
+        raise ValueError("X must be rank x nrow(x) and Y rank x ncol(x)")
+    cnt = None if cnt_X is None else np.ascontiguousarray(cnt_X, dtype=dt)
+    loss = ctypes.c_double(0.0)
+    fn = lib.rsparse_hip_als_explicit_float if precision == "float" else lib.rsparse_hip_als_explicit_double
+    _lib.check(fn(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), _vp(cnt), rank, float(lambda_),
+                  int(n_threads), int(solver_code), int(cg_steps), int(bool(dynamic_lambda)),
+                  int(bool(with_user_item_bias)), int(bool(is_bias_last_row)), ctypes.addressof(loss)))
+    return loss.value

@@ -1,0 +1,493 @@
+// C ABI of librsparse_wrmf_hip.so (declared in include/rsparse_wrmf_hip.h).
+//
+// Host-side responsibilities only: argument validation with the reference's error behaviour turned
+// into status codes (the reference raises R errors through END_RCPP, src/RcppExports.cpp:374,392),
+// device buffers, the row-length schedule, and the bookkeeping around the kernels in
+// wrmf_kernels.hip.  No torch, no R, no Armadillo types anywhere.
+#include "../../include/rsparse_wrmf_hip.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "wrmf_internal.h"
+
+using namespace rsparse_hip;
+
+struct rsparse_hip_csc {
+  DevCSC d;
+  int device = 0;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  return fail(RSPARSE_HIP_ERR_RUNTIME, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                       \
+  do {                                                      \
+    hipError_t _e = (expr);                                 \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);       \
+  } while (0)
+
+// Grow-only per-process scratch (single host thread drives the library, like the reference's
+// single R thread; not re-entrant across streams).
+struct Workspace {
+  float* gram = nullptr;
+  size_t gram_floats = 0;
+  double* partials = nullptr;
+  size_t partial_slots = 0;
+  double* scalars = nullptr;  // [0] loss rows, [1] sumsq, [2..] spare
+  int* fails = nullptr;
+  int device = -1;
+
+  int ensure_device() {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != device) {  // buffers belong to the device they were allocated on
+      release();
+      device = dev;
+    }
+    if (!scalars) {
+      HIP_TRY(hipMalloc(&scalars, 16 * sizeof(double)));
+      HIP_TRY(hipMemset(scalars, 0, 16 * sizeof(double)));
+    }
+    if (!fails) {
+      HIP_TRY(hipMalloc(&fails, sizeof(int)));
+      HIP_TRY(hipMemset(fails, 0, sizeof(int)));
+    }
+    return RSPARSE_HIP_OK;
+  }
+  int ensure_gram(size_t floats) {
+    if (floats > gram_floats) {
+      if (gram) (void)hipFree(gram);
+      gram = nullptr;
+      gram_floats = 0;
+      HIP_TRY(hipMalloc(&gram, floats * sizeof(float)));
+      gram_floats = floats;
+    }
+    return RSPARSE_HIP_OK;
+  }
+  int ensure_partials(size_t slots) {
+    if (slots < 1024) slots = 1024;
+    if (slots > partial_slots) {
+      if (partials) (void)hipFree(partials);
+      partials = nullptr;
+      partial_slots = 0;
+      HIP_TRY(hipMalloc(&partials, slots * sizeof(double)));
+      partial_slots = slots;
+    }
+    return RSPARSE_HIP_OK;
+  }
+  void release() {
+    if (gram) (void)hipFree(gram);
+    if (partials) (void)hipFree(partials);
+    if (scalars) (void)hipFree(scalars);
+    if (fails) (void)hipFree(fails);
+    gram = nullptr; partials = nullptr; scalars = nullptr; fails = nullptr;
+    gram_floats = 0; partial_slots = 0;
+  }
+};
+Workspace g_ws;
+
+struct DevBuf {  // RAII for the stateless entry points
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+// rows with more than kTileNnz non-zeros, longest first (counting sort on the host; one-off per matrix)
+int build_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
+  const int n = d.n_cols;
+  int max_len = 0;
+  size_t n_long = 0;
+  for (int i = 0; i < n; i++) {
+    const int len = host_col_ptrs[i + 1] - host_col_ptrs[i];
+    if (len < 0) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs is not non-decreasing");
+    max_len = std::max(max_len, len);
+    if (len > kTileNnz) n_long++;
+  }
+  d.max_len = max_len;
+  d.short_max = kTileNnz;
+  d.n_long = (int)n_long;
+  d.long_rows = nullptr;
+  if (!n_long) return RSPARSE_HIP_OK;
+  // counting sort by length, descending; ties keep ascending row order (deterministic)
+  std::vector<int64_t> start((size_t)max_len + 2, 0);
+  for (int i = 0; i < n; i++) {
+    const int len = host_col_ptrs[i + 1] - host_col_ptrs[i];
+    if (len > kTileNnz) start[(size_t)(max_len - len) + 1]++;
+  }
+  for (size_t b = 1; b < start.size(); b++) start[b] += start[b - 1];
+  std::vector<int32_t> order(n_long);
+  for (int i = 0; i < n; i++) {
+    const int len = host_col_ptrs[i + 1] - host_col_ptrs[i];
+    if (len > kTileNnz) order[(size_t)start[(size_t)(max_len - len)]++] = i;
+  }
+  HIP_TRY(hipMalloc(&d.long_rows, n_long * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(d.long_rows, order.data(), n_long * sizeof(int32_t), hipMemcpyHostToDevice));
+  return RSPARSE_HIP_OK;
+}
+
+int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_indices, const void* values,
+                 const void* X, const void* Y, int rank) {
+  if (n_rows < 0 || n_cols < 0) return fail(RSPARSE_HIP_ERR_INVALID, "negative matrix dimension");
+  if (!col_ptrs) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs is NULL");
+  if (!X || !Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
+  if (rank <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive");
+  if (rank > RSPARSE_HIP_MAX_RANK)
+    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  (void)row_indices; (void)values;
+  return RSPARSE_HIP_OK;
+}
+
+int check_variant(unsigned solver, int with_biases, double global_bias) {
+  if (solver == RSPARSE_SOLVER_NNLS)
+    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "solver 'nnls' is not on the device path (inst/include/nnls.hpp stays on the CPU)");
+  if (solver > RSPARSE_SOLVER_NNLS) return fail(RSPARSE_HIP_ERR_INVALID, "unknown solver code");
+  if (with_biases)
+    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "with_user_item_bias is not on the device path");
+  // wrmf_implicit.hpp:108-109: global_bias below sqrt(eps) is treated as zero
+  if (global_bias >= std::sqrt((double)FLT_EPSILON))
+    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "global_bias is not on the device path");
+  return RSPARSE_HIP_OK;
+}
+
+int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* d_X, float* d_Y,
+                       const float* d_XtX, int rank, double lambda, unsigned solver, unsigned cg_steps,
+                       int dynamic_lambda, double* d_loss_rows_out, hipStream_t s) {
+  if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
+  if (!d_X || !d_Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
+  if (implicit && !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "XtX is NULL");
+  if (rank <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  int rc = check_variant(solver, 0, 0.0);
+  if (rc) return rc;
+  if ((rc = g_ws.ensure_device())) return rc;
+  const DevCSC& d = conf->d;
+  const bool cg = solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT;
+  const size_t slots = cg ? cg_loss_slots(d.n_cols, d.n_long) : chol_loss_slots(d.n_cols);
+  if ((rc = g_ws.ensure_partials(slots))) return rc;
+  double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
+  if (d.n_cols == 0) {
+    HIP_TRY(hipMemsetAsync(out, 0, sizeof(double), s));
+    return RSPARSE_HIP_OK;
+  }
+  AlsArgs a;
+  a.col_ptrs = d.col_ptrs; a.row_idx = d.row_idx; a.vals = d.vals;
+  a.X = d_X; a.Y = d_Y; a.XtX = implicit ? d_XtX : nullptr;
+  a.long_rows = d.long_rows; a.n_long = d.n_long; a.n_cols = d.n_cols;
+  a.k = rank; a.cg_steps = (int)cg_steps;
+  a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
+  a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails;
+  hipError_t e = cg ? launch_als_cg(a, implicit, s) : launch_als_chol(a, implicit, s);
+  if (e != hipSuccess) return hip_fail(e, cg ? "launch_als_cg" : "launch_als_chol");
+  e = launch_sum_partials(g_ws.partials, slots, out, s);
+  if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
+  return RSPARSE_HIP_OK;
+}
+
+template <class T>
+std::vector<float> to_f32(const T* src, size_t n) {
+  std::vector<float> v(n);
+  for (size_t i = 0; i < n; i++) v[i] = (float)src[i];
+  return v;
+}
+
+// Shared body of the four stateless drop-ins.  TX = float or double (host element type).
+template <class TX>
+int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+              const double* values, const TX* X, TX* Y, const TX* XtX, const TX* cnt_X, int rank, double lambda,
+              unsigned solver, unsigned cg_steps, int dynamic_lambda, double* loss_out) {
+  rsparse_hip_csc* conf = nullptr;
+  int rc = rsparse_hip_csc_create_host(n_rows, n_cols, col_ptrs, row_indices, values, &conf);
+  if (rc) return rc;
+  struct Guard { rsparse_hip_csc* c; ~Guard() { rsparse_hip_csc_destroy(c); } } guard{conf};
+  const size_t nx = (size_t)rank * n_rows, ny = (size_t)rank * n_cols, ng = (size_t)rank * rank;
+  DevBuf dX, dY, dG, dW;
+  HIP_TRY(dX.alloc(nx * 4));
+  HIP_TRY(dY.alloc(ny * 4));
+  std::vector<float> tmp;
+  auto upload = [&](DevBuf& b, const TX* src, size_t n) -> hipError_t {
+    if (!n) return hipSuccess;
+    if (sizeof(TX) == sizeof(float)) return hipMemcpy(b.p, src, n * 4, hipMemcpyHostToDevice);
+    tmp = to_f32(src, n);
+    return hipMemcpy(b.p, tmp.data(), n * 4, hipMemcpyHostToDevice);
+  };
+  HIP_TRY(upload(dX, X, nx));
+  HIP_TRY(upload(dY, Y, ny));
+  if (implicit) {
+    if (!XtX) return fail(RSPARSE_HIP_ERR_INVALID, "XtX is NULL");
+    HIP_TRY(dG.alloc(ng * 4));
+    HIP_TRY(upload(dG, XtX, ng));
+  }
+  const bool weighted = !implicit && dynamic_lambda;
+  if (weighted && lambda > 0) {
+    if (!cnt_X) return fail(RSPARSE_HIP_ERR_INVALID, "cnt_X is NULL with dynamic_lambda");
+    HIP_TRY(dW.alloc((size_t)n_rows * 4));
+    HIP_TRY(upload(dW, cnt_X, (size_t)n_rows));
+  }
+  if ((rc = g_ws.ensure_device())) return rc;
+  rc = run_half_iteration(conf, implicit, dX.as<float>(), dY.as<float>(), dG.as<float>(), rank, lambda, solver,
+                          cg_steps, dynamic_lambda, g_ws.scalars, nullptr);
+  if (rc) return rc;
+  double reg = 0.0;
+  if (lambda > 0 && nx > 0) {  // + lambda * accu(X % X)  [* cnt_X]
+    hipError_t e = launch_weighted_sumsq(dX.as<float>(), rank, n_rows, weighted ? dW.as<float>() : nullptr,
+                                         g_ws.scalars + 1, g_ws.partials, nullptr);
+    if (e != hipSuccess) return hip_fail(e, "launch_weighted_sumsq");
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  int64_t nfail = 0;
+  rsparse_hip_take_numeric_failures(&nfail);
+  double host_scalars[2] = {0, 0};
+  HIP_TRY(hipMemcpy(host_scalars, g_ws.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost));
+  if (lambda > 0 && nx > 0) reg = lambda * host_scalars[1];
+  if (ny) {
+    if (sizeof(TX) == sizeof(float)) {
+      HIP_TRY(hipMemcpy(Y, dY.p, ny * 4, hipMemcpyDeviceToHost));
+    } else {
+      tmp.resize(ny);
+      HIP_TRY(hipMemcpy(tmp.data(), dY.p, ny * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ny; i++) Y[i] = (TX)tmp[i];
+    }
+  }
+  const double nnz = (double)conf->d.nnz;
+  if (loss_out) *loss_out = (host_scalars[0] + reg) / nnz;  // wrmf_implicit.hpp:304
+  if (nfail)
+    return fail(RSPARSE_HIP_ERR_NUMERIC, std::to_string(nfail) + " per-row systems were not positive definite");
+  return RSPARSE_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rsparse_hip_last_error(void) { return g_err.c_str(); }
+int rsparse_hip_abi_version(void) { return 1; }
+
+int rsparse_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int rsparse_hip_set_device(int device) {
+  HIP_TRY(hipSetDevice(device));
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_csc_create_host(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                                const double* values, rsparse_hip_csc** out) {
+  if (!out) return fail(RSPARSE_HIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n_rows < 0 || n_cols < 0) return fail(RSPARSE_HIP_ERR_INVALID, "negative matrix dimension");
+  if (!col_ptrs) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs is NULL");
+  const int64_t nnz = (int64_t)col_ptrs[n_cols] - col_ptrs[0];
+  if (col_ptrs[0] != 0 || nnz < 0) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs must start at 0 and be non-decreasing");
+  if (nnz > 0 && (!row_indices || !values)) return fail(RSPARSE_HIP_ERR_INVALID, "row_indices or values is NULL");
+  for (int64_t e = 0; e < nnz; e++)
+    if (row_indices[e] < 0 || row_indices[e] >= n_rows)
+      return fail(RSPARSE_HIP_ERR_INVALID, "row index out of range");
+  rsparse_hip_csc* m = new rsparse_hip_csc();
+  struct Guard { rsparse_hip_csc* c; ~Guard() { if (c) rsparse_hip_csc_destroy(c); } } guard{m};
+  if (hipGetDevice(&m->device) != hipSuccess) return fail(RSPARSE_HIP_ERR_RUNTIME, "no HIP device");
+  DevCSC& d = m->d;
+  d.n_rows = n_rows; d.n_cols = n_cols; d.nnz = nnz; d.owns_matrix = true;
+  int32_t *dp = nullptr, *di = nullptr;
+  float* dv = nullptr;
+  HIP_TRY(hipMalloc(&dp, ((size_t)n_cols + 1) * 4));
+  d.col_ptrs = dp;
+  HIP_TRY(hipMalloc(&di, (size_t)std::max<int64_t>(nnz, 4) * 4));
+  d.row_idx = di;
+  HIP_TRY(hipMalloc(&dv, (size_t)std::max<int64_t>(nnz, 4) * 4));
+  d.vals = dv;
+  HIP_TRY(hipMemcpy(dp, col_ptrs, ((size_t)n_cols + 1) * 4, hipMemcpyHostToDevice));
+  if (nnz) {
+    HIP_TRY(hipMemcpy(di, row_indices, (size_t)nnz * 4, hipMemcpyHostToDevice));
+    // values: f64 on the wire (dgCMatrix@x), f32 once resident -- the conversion the reference does per
+    // column with arma::conv_to (wrmf_implicit.hpp:182-183)
+    std::vector<float> v32 = to_f32(values, (size_t)nnz);
+    HIP_TRY(hipMemcpy(dv, v32.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+  }
+  int rc = build_schedule(d, col_ptrs);
+  if (rc) return rc;
+  guard.c = nullptr;
+  *out = m;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_csc_create_device(int n_rows, int n_cols, const int32_t* d_col_ptrs, const int32_t* d_row_indices,
+                                  const float* d_values, rsparse_hip_csc** out) {
+  if (!out) return fail(RSPARSE_HIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n_rows < 0 || n_cols < 0) return fail(RSPARSE_HIP_ERR_INVALID, "negative matrix dimension");
+  if (!d_col_ptrs) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs is NULL");
+  std::vector<int32_t> hp((size_t)n_cols + 1);
+  HIP_TRY(hipMemcpy(hp.data(), d_col_ptrs, hp.size() * 4, hipMemcpyDeviceToHost));
+  if (hp[0] != 0) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs must start at 0");
+  const int64_t nnz = hp[n_cols];
+  if (nnz > 0 && (!d_row_indices || !d_values)) return fail(RSPARSE_HIP_ERR_INVALID, "row_indices or values is NULL");
+  rsparse_hip_csc* m = new rsparse_hip_csc();
+  struct Guard { rsparse_hip_csc* c; ~Guard() { if (c) rsparse_hip_csc_destroy(c); } } guard{m};
+  if (hipGetDevice(&m->device) != hipSuccess) return fail(RSPARSE_HIP_ERR_RUNTIME, "no HIP device");
+  DevCSC& d = m->d;
+  d.n_rows = n_rows; d.n_cols = n_cols; d.nnz = nnz; d.owns_matrix = false;
+  d.col_ptrs = d_col_ptrs; d.row_idx = d_row_indices; d.vals = d_values;
+  int rc = build_schedule(d, hp.data());
+  if (rc) return rc;
+  guard.c = nullptr;
+  *out = m;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
+  if (!m) return RSPARSE_HIP_OK;
+  DevCSC& d = m->d;
+  if (d.long_rows) (void)hipFree(d.long_rows);
+  if (d.owns_matrix) {
+    if (d.col_ptrs) (void)hipFree(const_cast<int32_t*>(d.col_ptrs));
+    if (d.row_idx) (void)hipFree(const_cast<int32_t*>(d.row_idx));
+    if (d.vals) (void)hipFree(const_cast<float*>(d.vals));
+  }
+  delete m;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[5]) {
+  if (!m || !info_out) return fail(RSPARSE_HIP_ERR_INVALID, "NULL argument");
+  info_out[0] = m->d.n_rows; info_out[1] = m->d.n_cols; info_out[2] = m->d.nnz;
+  info_out[3] = m->d.n_long; info_out[4] = m->d.max_len;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_gramian_device(const float* d_X, int rank, int64_t n, double lambda, float* d_XtX_out,
+                               double* d_sumsq_out, void* stream) {
+  if (!d_X || !d_XtX_out) return fail(RSPARSE_HIP_ERR_INVALID, "X or XtX_out is NULL");
+  if (rank <= 0 || n < 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive and n non-negative");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  int rc = g_ws.ensure_device();
+  if (rc) return rc;
+  if ((rc = g_ws.ensure_gram(gramian_scratch_floats(rank, n)))) return rc;
+  const float ridge = (float)lambda;  // float::fl(diag(lambda)), R/model_WRMF.R:476
+  hipError_t e = launch_gramian(d_X, rank, n, ridge, d_XtX_out, d_sumsq_out, g_ws.gram, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "launch_gramian");
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_gramian_float(const float* X, int rank, int64_t n, double lambda, float* XtX_out) {
+  if (!X || !XtX_out) return fail(RSPARSE_HIP_ERR_INVALID, "X or XtX_out is NULL");
+  if (rank <= 0 || n < 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive and n non-negative");
+  DevBuf dX, dG;
+  HIP_TRY(dX.alloc((size_t)rank * n * 4));
+  HIP_TRY(dG.alloc((size_t)rank * rank * 4));
+  if (n) HIP_TRY(hipMemcpy(dX.p, X, (size_t)rank * n * 4, hipMemcpyHostToDevice));
+  int rc = rsparse_hip_gramian_device(dX.as<float>(), rank, n, lambda, dG.as<float>(), nullptr, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(XtX_out, dG.p, (size_t)rank * rank * 4, hipMemcpyDeviceToHost));
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_als_implicit_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, const float* d_XtX,
+                                    int rank, double lambda, unsigned solver, unsigned cg_steps,
+                                    double* d_loss_rows_out, void* stream) {
+  return run_half_iteration(conf, true, d_X, d_Y, d_XtX, rank, lambda, solver, cg_steps, 0, d_loss_rows_out,
+                            (hipStream_t)stream);
+}
+
+int rsparse_hip_als_explicit_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, int rank,
+                                    double lambda, unsigned solver, unsigned cg_steps, int dynamic_lambda,
+                                    double* d_loss_rows_out, void* stream) {
+  return run_half_iteration(conf, false, d_X, d_Y, nullptr, rank, lambda, solver, cg_steps, dynamic_lambda,
+                            d_loss_rows_out, (hipStream_t)stream);
+}
+
+int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, const float* d_w, double* d_out,
+                                      void* stream) {
+  if (!d_X || !d_out) return fail(RSPARSE_HIP_ERR_INVALID, "X or out is NULL");
+  if (rank <= 0 || n < 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive and n non-negative");
+  int rc = g_ws.ensure_device();
+  if (rc) return rc;
+  if ((rc = g_ws.ensure_partials(1024))) return rc;
+  hipError_t e = launch_weighted_sumsq(d_X, rank, n, d_w, d_out, g_ws.partials, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "launch_weighted_sumsq");
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_take_numeric_failures(int64_t* count_out) {
+  if (!count_out) return fail(RSPARSE_HIP_ERR_INVALID, "count_out is NULL");
+  *count_out = 0;
+  if (!g_ws.fails) return RSPARSE_HIP_OK;
+  int v = 0;
+  HIP_TRY(hipMemcpy(&v, g_ws.fails, sizeof(int), hipMemcpyDeviceToHost));
+  if (v) HIP_TRY(hipMemset(g_ws.fails, 0, sizeof(int)));
+  *count_out = v;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                                   const double* values, const float* X, float* Y, const float* XtX, int rank,
+                                   double lambda, int n_threads, unsigned solver, unsigned cg_steps,
+                                   int with_biases, int is_x_bias_last_row, double global_bias,
+                                   float* global_bias_base, int initialize_bias_base, double* loss_out) {
+  (void)n_threads; (void)is_x_bias_last_row; (void)global_bias_base; (void)initialize_bias_base;
+  int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
+  if (rc) return rc;
+  if ((rc = check_variant(solver, with_biases, global_bias))) return rc;
+  return stateless<float>(true, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, nullptr, rank, lambda,
+                          solver, cg_steps, 0, loss_out);
+}
+
+int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                                    const double* values, const double* X, double* Y, const double* XtX, int rank,
+                                    double lambda, int n_threads, unsigned solver, unsigned cg_steps,
+                                    int with_biases, int is_x_bias_last_row, double global_bias,
+                                    double* global_bias_base, int initialize_bias_base, double* loss_out) {
+  (void)n_threads; (void)is_x_bias_last_row; (void)global_bias_base; (void)initialize_bias_base;
+  int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
+  if (rc) return rc;
+  if ((rc = check_variant(solver, with_biases, global_bias))) return rc;
+  return stateless<double>(true, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, nullptr, rank, lambda,
+                           solver, cg_steps, 0, loss_out);
+}
+
+int rsparse_hip_als_explicit_float(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                                   const double* values, const float* X, float* Y, const float* cnt_X, int rank,
+                                   double lambda, unsigned n_threads, unsigned solver, unsigned cg_steps,
+                                   int dynamic_lambda, int with_biases, int is_x_bias_last_row, double* loss_out) {
+  (void)n_threads; (void)is_x_bias_last_row;
+  int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
+  if (rc) return rc;
+  if ((rc = check_variant(solver, with_biases, 0.0))) return rc;
+  return stateless<float>(false, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, nullptr, cnt_X, rank, lambda,
+                          solver, cg_steps, dynamic_lambda, loss_out);
+}
+
+int rsparse_hip_als_explicit_double(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                                    const double* values, const double* X, double* Y, const double* cnt_X, int rank,
+                                    double lambda, unsigned n_threads, unsigned solver, unsigned cg_steps,
+                                    int dynamic_lambda, int with_biases, int is_x_bias_last_row, double* loss_out) {
+  (void)n_threads; (void)is_x_bias_last_row;
+  int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
+  if (rc) return rc;
+  if ((rc = check_variant(solver, with_biases, 0.0))) return rc;
+  return stateless<double>(false, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, nullptr, cnt_X, rank, lambda,
+                           solver, cg_steps, dynamic_lambda, loss_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Internal interface between the C-ABI layer (wrmf_capi.cpp) and the kernel launchers
+// (wrmf_kernels.hip).  Not installed; the public boundary is include/rsparse_wrmf_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace rsparse_hip {
+
+// Device-resident CSC + launch schedule.
+struct DevCSC {
+  int n_rows = 0;  // = number of entities on the fixed side (columns of X)
+  int n_cols = 0;  // = rows solved
+  int64_t nnz = 0;
+  const int32_t* col_ptrs = nullptr;
+  const int32_t* row_idx = nullptr;
+  const float* vals = nullptr;
+  // rows with more than `short_max` non-zeros, longest first: solved one workgroup per row
+  int32_t* long_rows = nullptr;
+  int n_long = 0;
+  int short_max = 0;  // tile capacity T the schedule was built for
+  int max_len = 0;
+  bool owns_matrix = false;
+};
+
+struct AlsArgs {
+  const int32_t* col_ptrs;
+  const int32_t* row_idx;
+  const float* vals;
+  const float* X;    // k x n_rows, ld = k
+  float* Y;          // k x n_cols, ld = k
+  const float* XtX;  // k x k (implicit) or nullptr
+  const int32_t* long_rows;
+  int n_long;
+  int n_cols;
+  int k;
+  int cg_steps;
+  float lambda;        // lambda as the kernels use it in fp32 (regulariser inside the explicit system)
+  double lambda_loss;  // lambda of the loss term (double, wrmf_implicit.hpp:259-261)
+  int dynamic_lambda;
+  double* loss_partials;  // one double per wave (short kernel) / per workgroup (long kernel)
+  int* fail_counter;      // Cholesky: rows whose system was not positive definite
+};
+
+// tile capacity (non-zeros per wave tile) the CG kernels are instantiated for
+constexpr int kTileNnz = 32;
+constexpr int kWavesPerWG = 4;
+constexpr int kRowsPerWGShort = 64;  // rows handed to one short-row workgroup
+constexpr int kRowsPerWGLong = 8;    // rows handed to one long-row workgroup
+
+constexpr int kCholMaxGrid = 256 * 8;  // Cholesky workgroups (grid-stride over rows)
+
+// number of loss partial slots each launcher writes
+size_t cg_loss_slots(int n_cols, int n_long);
+size_t chol_loss_slots(int n_cols);
+
+hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s);
+hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s);
+hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s);
+
+// Gramian: scratch must hold gramian_scratch_floats(k, n) floats.
+size_t gramian_scratch_floats(int k, int64_t n);
+hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* XtX, double* sumsq,
+                          float* scratch, hipStream_t s);
+hipError_t launch_weighted_sumsq(const float* X, int k, int64_t n, const float* w, double* out,
+                                 double* scratch /* >= 1024 doubles */, hipStream_t s);
+hipError_t launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s);
+hipError_t launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t s);
+
+int padded_rank(int k);  // 32 / 64 / 128, or 0 if unsupported
+
+}  // namespace rsparse_hip

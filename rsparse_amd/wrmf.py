@@ -1,0 +1,151 @@
+"""`WRMF` -- host-side mirror of the reference's R6 class (R/model_WRMF.R:35-454).
+
+Same constructor arguments, `fit_transform()` / `transform()` semantics and returned objects as
+`rsparse::WRMF`; the numeric work is done by librsparse_wrmf_hip.so on one MI355X (data stays
+resident in HBM across iterations).  R is not available in the build image, so the mirror is
+Python over the C ABI; INTEGRATION.md shows the Rcpp shim that binds the same ABI from R.
+
+Differences forced by the host language, nothing else:
+  * `lambda` is a Python keyword -> `lambda_`;
+  * `x` is a scipy.sparse matrix (users x items) instead of a Matrix::sparseMatrix;
+  * R's global RNG (large_rand_matrix / flrnorm, src/utils.cpp:131-143) -> `rng` (seed or Generator);
+  * user/item bias, global bias and solver="nnls" are not on the device path: the C ABI answers
+    RSPARSE_HIP_ERR_UNSUPPORTED and this class raises NotImplementedError (an R shim would keep
+    the package's CPU code for them).
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+from .engine import SOLVER_CODES, HipBackend, ShardedALS
+
+
+def _identity(x):
+    return x
+
+
+class WRMF:
+    def __init__(self, rank=10, lambda_=0.0, dynamic_lambda=True, init=None, preprocess=_identity,
+                 feedback="implicit", solver="conjugate_gradient", with_user_item_bias=False,
+                 with_global_bias=False, cg_steps=3, precision="double", rng=None, device=None):
+        if init is not None and not isinstance(init, np.ndarray):
+            raise TypeError("init must be NULL or a matrix")                      # :84
+        if solver not in SOLVER_CODES:
+            raise ValueError("solver must be one of %s" % list(SOLVER_CODES))     # match.arg :85
+        if feedback not in ("implicit", "explicit"):
+            raise ValueError("feedback must be 'implicit' or 'explicit'")
+        if precision not in ("double", "float"):
+            raise ValueError("precision must be 'double' or 'float'")
+        if not isinstance(cg_steps, (int, np.integer)):
+            raise TypeError("cg_steps must be an integer")                        # :107
+        if not callable(preprocess):
+            raise TypeError("preprocess must be a function")                      # :165
+        self._non_negative = solver == "nnls"
+        if solver == "nnls":
+            raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "solver 'nnls' is not on the device path")
+        if with_user_item_bias or with_global_bias:
+            raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED,
+                                           "user/item and global biases are not on the device path")
+        self._solver_code = SOLVER_CODES[solver]                                   # :99-100
+        self._precision, self._feedback = precision, feedback
+        self._lambda, self._dynamic_lambda = float(lambda_), bool(dynamic_lambda)
+        self._cg_steps, self._rank = int(cg_steps), int(rank)
+        self._preprocess = preprocess
+        self.components = init
+        self.global_bias = 0.0
+        self._rng = rng if isinstance(rng, np.random.Generator) else np.random.default_rng(rng)
+        self._device = device
+        self._be = None
+        self._V = None       # item factors on the device, (n_item, rank)
+        self._XtX = None
+        self._cnt_item = None
+        self.losses = []     # (items-half loss, users-half loss) per iteration, as the reference logs them
+
+    # ------------------------------------------------------------------------------------------
+    def _backend(self):
+        if self._be is None:
+            self._be = HipBackend(self._device)
+        return self._be
+
+    def _np_dtype(self):
+        return np.float64 if self._precision == "double" else np.float32
+
+    def _upload_csc(self, m):
+        be = self._backend()
+        return (be.to_device(m.indptr, torch.int32), be.to_device(m.indices, torch.int32),
+                be.to_device(m.data, torch.float32))
+
+    def fit_transform(self, x, n_iter=10, convergence_tol=None):
+        """R/model_WRMF.R:173-360.  Returns the user embeddings (n_user x rank)."""
+        if convergence_tol is None:
+            convergence_tol = 0.005 if self._feedback == "implicit" else 0.001
+        be = self._backend()
+        c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))               # :184-188
+        c_ui.sort_indices()
+        c_iu = sp.csc_matrix((c_ui.T).tocsc())                                     # :190 t_shallow(as.csr)
+        c_iu.sort_indices()
+        if self._feedback != "explicit" and c_ui.nnz and c_ui.data.min() < 0:
+            raise ValueError("all(c_ui@x >= 0) is not TRUE")                       # :195-197
+        n_user, n_item = c_ui.shape
+        k = self._rank
+        # large_rand_matrix(rank, n_user): N(0,1)/100, column-major rank x n_user  (:204-205)
+        U0 = (self._rng.standard_normal((n_user, k)) * 0.01).astype(np.float32)
+        if self.components is None:
+            if self._solver_code == 1:                                             # CG -> zeros (:219-231)
+                V0 = np.zeros((n_item, k), dtype=np.float32)
+            else:
+                V0 = (self._rng.standard_normal((n_item, k)) * 0.01).astype(np.float32)
+        else:
+            if self.components.shape != (k, n_item):                               # :246-248
+                raise ValueError("init must be rank x n_item")
+            V0 = np.ascontiguousarray(self.components.T, dtype=np.float32)
+        als = ShardedALS(be, n_user, n_item, k, self._upload_csc(c_ui), self._upload_csc(c_iu), c_ui.nnz,
+                         feedback=self._feedback, lambda_=self._lambda, dynamic_lambda=self._dynamic_lambda,
+                         cg_steps=self._cg_steps)
+        als.cnt_user = be.to_device(np.diff(c_iu.indptr), torch.float32)           # cnt_i in the reference (:312)
+        als.cnt_item = be.to_device(np.diff(c_ui.indptr), torch.float32)           # cnt_u (:311)
+        U = be.to_device(U0, torch.float32)
+        V = be.to_device(V0, torch.float32)
+        loss_prev = float("inf")
+        self.losses = []
+        for it in range(int(n_iter)):
+            li = als.half_iteration("items", U, V, self._solver_code)              # :321
+            lu = als.half_iteration("users", U, V, self._solver_code)              # :327
+            self.losses.append((li, lu))
+            if loss_prev / lu - 1 < convergence_tol:                               # :332-335
+                break
+            loss_prev = lu
+        be.check_numeric()
+        self._V, self._cnt_item = V, als.cnt_item
+        if self._feedback == "implicit":
+            self._XtX = als.gramian(V, n_item, als.Bi, als.ib).clone()             # :347-353
+        self.components = np.asfortranarray(V.cpu().numpy().T.astype(self._np_dtype()))   # rank x n_item
+        # the returned embeddings come from one more exact solve, not from U (:355-359)
+        return self._transform(als.csc_users, n_user)
+
+    def _transform(self, csc_users, n_new):
+        """R/model_WRMF.R:412-452: one user half-iteration from zeros against the final item factors,
+        Cholesky whenever the model's solver is CG (avoid_cg, :112)."""
+        be = self._backend()
+        res = torch.zeros((n_new, self._rank), dtype=torch.float32, device=self._V.device)   # :423-427
+        solver = 0 if self._solver_code == 1 else self._solver_code                          # :112
+        loss = torch.zeros(1, dtype=torch.float64, device=self._V.device)
+        be.half_iteration(csc_users, self._feedback == "implicit", self._V, res, self._XtX, self._lambda,
+                          solver, self._cg_steps, self._dynamic_lambda, loss)
+        be.check_numeric()
+        return res.cpu().numpy().astype(self._np_dtype())                                    # t(res), :444
+
+    def transform(self, x):
+        """R/model_WRMF.R:365-385: embeddings for new rows of a users x items matrix."""
+        if self._V is None:
+            raise RuntimeError("model is not fitted")
+        x = sp.csr_matrix(x, dtype=np.float64)
+        if x.shape[1] != self._V.shape[0]:
+            raise ValueError("ncol(x) == ncol(self$components) is not TRUE")       # :367
+        xt = sp.csc_matrix(x.T)            # CSC of x^T (items x users) == CSR of x reinterpreted
+        xt = self._preprocess(xt)
+        xt.sort_indices()
+        be = self._backend()
+        csc = be.make_csc(xt.shape[0], xt.shape[1], *self._upload_csc(xt))
+        return self._transform(csc, x.shape[0])

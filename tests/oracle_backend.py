@@ -1,0 +1,82 @@
+"""Test-only stand-in for rsparse_amd.engine.HipBackend that runs the CPU oracle on CPU tensors,
+so the multi-rank control flow of ShardedALS (sharding, Gramian all-reduce, factor all-gather,
+loss all-reduce) can run under gloo without a GPU.  Never imported by the product."""
+import numpy as np
+import torch
+
+from oracle import wrmf_oracle as O
+
+
+class _Csc:
+    def __init__(self, n_rows, n_cols, p, i, x):
+        self.n_rows, self.n_cols = n_rows, n_cols
+        self.p = p.numpy().astype(np.int32)
+        self.i = i.numpy().astype(np.int32)
+        self.x = x.numpy().astype(np.float64)
+
+    def info(self):
+        return dict(n_rows=self.n_rows, n_cols=self.n_cols, nnz=int(self.p[-1]), n_long=0, max_len=0)
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def to_device(self, a, dtype):
+        return torch.as_tensor(a, dtype=dtype).contiguous()
+
+    def make_csc(self, n_rows, n_cols, p, i, x):
+        return _Csc(n_rows, n_cols, p, i, x)
+
+    @staticmethod
+    def _f(t):  # (n, k) row-major tensor -> (k, n) column-major numpy view
+        return t.numpy().T
+
+    def gramian(self, F, lambda_, out, sumsq_out):
+        Ff = np.asfortranarray(self._f(F))
+        G = O.gramian(Ff, lambda_) if Ff.shape[1] else np.float32(lambda_) * np.eye(Ff.shape[0], dtype=np.float32)
+        out.copy_(torch.from_numpy(np.ascontiguousarray(G)))
+        if sumsq_out is not None:
+            sumsq_out[0] = float((Ff.astype(np.float64) ** 2).sum())
+
+    def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out):
+        X = np.asfortranarray(self._f(F))
+        Y = np.asfortranarray(self._f(S_block)).copy(order="F")
+        if csc.n_cols == 0:
+            loss_out[0] = 0.0
+            return
+        if implicit:
+            Gn = np.asfortranarray(G.numpy().T)
+            O.als_implicit(csc.p, csc.i, csc.x, X, Y, Gn, lambda_, solver, cg_steps)
+        else:
+            cnt = np.zeros(X.shape[1], dtype=X.dtype)   # regulariser on X is added by the engine
+            O.als_explicit(csc.p, csc.i, csc.x, X, Y, cnt, lambda_, solver, cg_steps, dynamic_lambda)
+        rows = _row_loss(csc, X, Y, implicit, lambda_, dynamic_lambda)
+        S_block.copy_(torch.from_numpy(np.ascontiguousarray(Y.T)))
+        loss_out[0] = rows
+
+    def weighted_sumsq(self, F, w, out):
+        Ff = self._f(F).astype(np.float64)
+        s = (Ff ** 2).sum(axis=0)
+        out[0] = float((s * w.numpy().astype(np.float64)).sum() if w is not None else s.sum())
+
+    def check_numeric(self):
+        pass
+
+
+def _row_loss(csc, X, Y, implicit, lambda_, dynamic_lambda):
+    """un-normalised row part of the loss (wrmf_implicit.hpp:259-261 / wrmf_explicit.hpp:131-132), float64"""
+    X = X.astype(np.float64)
+    Y = Y.astype(np.float64)
+    tot = 0.0
+    for c in range(csc.n_cols):
+        p1, p2 = csc.p[c], csc.p[c + 1]
+        if p1 == p2:
+            continue
+        t = Y[:, c] @ X[:, csc.i[p1:p2]]
+        v = csc.x[p1:p2]
+        yy = float(Y[:, c] @ Y[:, c])
+        if implicit:
+            tot += float(((1.0 - t) ** 2) @ v) + lambda_ * yy
+        else:
+            tot += float(((v - t) ** 2).sum()) + lambda_ * ((p2 - p1) if dynamic_lambda else 1.0) * yy
+    return tot

@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- ALS iterations/s of the WRMF implicit CG hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched through
+torch.distributed.run, one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+
+Workload = BASELINE.json's metric configuration (configs[2]): synthetic 10M users x 1M items,
+~500M nnz, rank 128, implicit feedback, CG solver with 3 steps, lambda 0.1 -- it fits one GPU
+(~20 GB resident), so N=1 runs the full problem and N>1 shards the same problem (strong scaling).
+A "step" is one ALS iteration = item half-iteration + user half-iteration, each including its
+Gramian (+ all-reduce), the solve kernels, the factor all-gather (N>1) and the loss reduction --
+exactly what `private$solver` does twice per iteration in R/model_WRMF.R:318-335.  Inputs are
+resident in HBM when the timed region starts.
+
+Extra objects on the line:
+  roofline      dominant kernel (the long-row CG kernel), algorithmic bytes / measured duration
+                (HIP events on the launch stream, recorded inside the library) vs the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (rsparse-shaped C++/OpenMP port, oracle/) timed on this node's host
+                cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from rsparse_amd import synth  # noqa: E402
+from rsparse_amd.engine import HipBackend, ShardedALS, block_bounds  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def shard_csc(p, i, x, c0, c1):
+    p64 = p.to(torch.int64)
+    lo, hi = int(p64[c0]), int(p64[c1])
+    return (p64[c0:c1 + 1] - lo).to(torch.int32).contiguous(), i[lo:hi].contiguous(), x[lo:hi].contiguous()
+
+
+def algorithmic_bytes(n_rows, nnz, k, n_empty=0):
+    """B_half of SURVEY.md 8(d) / BASELINE.md 3 for a set of rows: every non-zero gathers one k-vector
+    (4k B) + its index (4 B) + its value (4 B, fp32 once resident); every row reads its warm start and
+    writes its solution (2*4k B) and its row pointer (4 B); one Gramian read (4k^2 B)."""
+    return nnz * (4 * k + 8) + (n_rows - n_empty) * 8 * k + n_empty * 4 * k + (n_rows + 1) * 4 + 4 * k * k
+
+
+def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0):
+    """Time the oracle on host cores over the leading users / items of the same matrices."""
+    from oracle import wrmf_oracle as O
+    threads = len(os.sched_getaffinity(0))
+    try:
+        O.lib(native=True)
+        native = True
+    except Exception:
+        native = False
+    Vh = np.asfortranarray(V.cpu().numpy().T)       # k x n_item
+    Uh = np.asfortranarray(U.cpu().numpy().T)       # k x n_user
+    out = {}
+
+    def run(csc, X, Yfull, n_take):
+        p, i, x = csc
+        p = p[:n_take + 1].cpu().numpy().astype(np.int32)
+        nnz = int(p[-1])
+        i = i[:nnz].cpu().numpy().astype(np.int32)
+        x = x[:nnz].cpu().numpy().astype(np.float64)
+        Y = np.asfortranarray(Yfull[:, :n_take]).copy(order="F")
+        G = O.gramian(X, lam, native=native)
+        t0 = time.perf_counter()
+        O.als_implicit(p, i, x, X, Y, G, lam, 1, cg_steps, n_threads=threads, native=native)
+        return time.perf_counter() - t0, nnz
+
+    n_user, n_item, nnz_tot = data["n_users"], data["n_items"], data["nnz"]
+    # probe, then size the samples so that each half costs about target_s/2
+    probe_u = min(n_user, 20000)
+    t, z = run(data["c_iu"], Vh, Uh, probe_u)
+    take_u = int(min(n_user, max(probe_u, probe_u * (target_s / 2) / max(t, 1e-3))))
+    tu, zu = run(data["c_iu"], Vh, Uh, take_u)
+    probe_i = min(n_item, 2000)
+    t, z = run(data["c_ui"], Uh, Vh, probe_i)
+    take_i = int(min(n_item, max(probe_i, probe_i * (target_s / 2) / max(t, 1e-3))))
+    ti, zi = run(data["c_ui"], Uh, Vh, take_i)
+    est_iter_s = tu * (nnz_tot / max(zu, 1)) + ti * (nnz_tot / max(zi, 1))
+    out = {
+        "value": 1.0 / est_iter_s, "unit": "iterations/s", "cores": threads, "kind": "port",
+        "sample": "oracle/wrmf_oracle.cpp (C++/OpenMP restatement, fp32, %s) on the first %d of %d users "
+                  "(%.2fs, %d nnz) and the first %d of %d items (%.2fs, %d nnz); iteration time extrapolated "
+                  "linearly in nnz, Gramians excluded" % ("-march=native" if native else "-march=x86-64-v3", take_u,
+                                                           n_user, tu, zu, take_i, n_item, ti, zi),
+        "user_rows_per_s": take_u / tu, "item_rows_per_s": take_i / ti,
+    }
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--users", type=int, default=10_000_000)
+    ap.add_argument("--items", type=int, default=1_000_000)
+    ap.add_argument("--rank", type=int, default=128)
+    ap.add_argument("--mean-deg", type=float, default=50.0)
+    ap.add_argument("--cg-steps", type=int, default=3)
+    ap.add_argument("--lambda", dest="lam", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20250222)
+    args = ap.parse_args()
+
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws != args.gpus:
+        if ws == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (ws, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if ws > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device("cuda", local_rank))
+    be = HipBackend(local_rank)
+    dev = be.device
+    k, lam = args.rank, args.lam
+
+    # ---- synthetic data, generated on the device (identical on every rank: counter-based) ----
+    t0 = time.perf_counter()
+    data = synth.make_dataset(args.users, args.items, seed=args.seed, mean_deg=args.mean_deg, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    n_user, n_item, nnz = data["n_users"], data["n_items"], data["nnz"]
+    Bu, ub = block_bounds(n_user, ws)
+    Bi, ib = block_bounds(n_item, ws)
+    c_ui_blk = shard_csc(*data["c_ui"], *ib[rank]) if ws > 1 else data["c_ui"]
+    c_iu_blk = shard_csc(*data["c_iu"], *ub[rank]) if ws > 1 else data["c_iu"]
+    als = ShardedALS(be, n_user, n_item, k, c_ui_blk, c_iu_blk, nnz, feedback="implicit", lambda_=lam,
+                     cg_steps=args.cg_steps, world_size=ws, my_rank=rank)
+    if ws > 1:
+        data = {"n_users": n_user, "n_items": n_item, "nnz": nnz}   # drop the full copies
+        torch.cuda.empty_cache()
+    # initial factors: U ~ N(0, 0.01^2), item factors zero for CG (R/model_WRMF.R:204-231)
+    g = torch.Generator(device=dev).manual_seed(args.seed)
+    U = als.alloc_factors(n_user, Bu, dev)
+    V = als.alloc_factors(n_item, Bi, dev)
+    U[:n_user] = torch.randn(n_user, k, generator=g, device=dev) * 0.01
+
+    def step(want_loss=True):
+        li = als.half_iteration("items", U, V, 1, want_loss=want_loss)
+        lu = als.half_iteration("users", U, V, 1, want_loss=want_loss)
+        return li, lu
+
+    def barrier():
+        if ws > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(step())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if ws > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+
+    # ---- per-kernel durations (HIP events inside the library, same stream), separate pass ----
+    be.profile(True)
+    kern = {"items": {"short": [], "long": [], "gram": []}, "users": {"short": [], "long": [], "gram": []}}
+    half_ms = {"items": [], "users": []}
+    for _ in range(max(1, min(args.steps, 3))):
+        for side in ("items", "users"):
+            F, nF, BF, bF = (U, n_user, Bu, ub) if side == "items" else (V, n_item, Bi, ib)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            G = als.gramian(F, nF, BF, bF)
+            gm = be.profile_last()
+            als.half_iteration(side, U, V, 1, G=G, want_loss=True)
+            pm = be.profile_last()
+            torch.cuda.synchronize()
+            half_ms[side].append(1e3 * (time.perf_counter() - th))
+            kern[side]["gram"].append(gm[0] + gm[1])
+            kern[side]["short"].append(pm[0])
+            kern[side]["long"].append(pm[1])
+    be.profile(False)
+    mean = lambda v: float(np.mean(v)) if len(v) else 0.0
+    info_u, info_i = als.csc_users.info(), als.csc_items.info()
+    # dominant kernel = als_cg_long_kernel<128,32,4,true,true>: launched once per half-iteration
+    long_ms = 0.5 * (mean(kern["items"]["long"]) + mean(kern["users"]["long"]))
+    b_long = 0.5 * (algorithmic_bytes(info_u["n_long"], info_u["nnz_long"], k) +
+                    algorithmic_bytes(info_i["n_long"], info_i["nnz_long"], k))
+    achieved = b_long / (long_ms * 1e-3) / 1e9 if long_ms > 0 else 0.0
+    b_iter = (algorithmic_bytes(info_u["n_cols"], info_u["nnz"], k, info_u["n_empty"]) +
+              algorithmic_bytes(info_i["n_cols"], info_i["nnz"], k, info_i["n_empty"]))
+    traffic = None
+    tf = ROOT / "profiles" / "pmc_traffic.json"
+    if tf.exists():
+        try:
+            traffic = json.loads(tf.read_text()).get("als_cg_long_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": "als_cg_long_kernel<128,32,4,implicit,vec>", "achieved": achieved,
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "bytes_per_launch": b_long, "avg_launch_ms": long_ms,
+        "whole_iteration_algorithmic_GBps_per_gpu": b_iter / (ms_per_step * 1e-3) / 1e9,
+        "kernel_ms": {s: {kk: mean(v) for kk, v in kern[s].items()} for s in kern},
+        "half_iteration_ms": {s: mean(v) for s, v in half_ms.items()},
+    }
+
+    cpu = None
+    if rank == 0 and ws == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(data, U[:n_user], V[:n_item], k, lam, args.cg_steps)
+        except Exception as e:   # the baseline is a report, never a reason to lose the measurement
+            cpu = {"value": None, "unit": "iterations/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+                   "sample": "failed: %r" % (e,)}
+
+    if rank == 0:
+        user_half_ms = mean(half_ms["users"])
+        line = {
+            "metric": "als_iterations_per_sec", "value": args.steps / elapsed, "unit": "iterations/s",
+            "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "WRMF implicit ALS, CG(%d), synthetic %dx%d, %d nnz, rank %d, lambda %g"
+                                   % (args.cg_steps, n_user, n_item, nnz, k, lam),
+                       "n_users": n_user, "n_items": n_item, "nnz": nnz, "rank": k, "solver": "conjugate_gradient",
+                       "cg_steps": args.cg_steps, "parallelism": "rows sharded x%d, factors replicated" % ws},
+            "user_rows_per_sec": n_user / (user_half_ms * 1e-3) if user_half_ms > 0 else None,
+            "loss_users_last": losses[-1][1] if losses else None,
+            "datagen_s": t_gen,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if ws > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -131,8 +131,9 @@ int rsparse_hip_csc_create_device(int n_rows, int n_cols, const int32_t* d_col_p
                                   const int32_t* d_row_indices, const float* d_values,
                                   rsparse_hip_csc** out);
 int rsparse_hip_csc_destroy(rsparse_hip_csc* m);
-/* n_rows, n_cols, nnz, number of rows on the workgroup-per-row path, longest row */
-int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[5]);
+/* info_out: [0] n_rows, [1] n_cols, [2] nnz, [3] rows on the workgroup-per-row path ("long" rows),
+ * [4] longest row, [5] non-zeros in long rows, [6] empty rows, [7] tile capacity (short-row limit) */
+int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[8]);
 
 /* XtX = X X^T + fl(lambda) I on the device (MFMA).  d_sumsq_out (nullable, device double[1])
  * receives sum(X^2) = trace before the ridge -- the `accu(X % X)` term of the loss
@@ -160,6 +161,13 @@ int rsparse_hip_als_explicit_device(const rsparse_hip_csc* conf, const float* d_
  * lambda*accu(X%X) and lambda*accu((X%X)*cnt_X) (wrmf_explicit.hpp:160-170). */
 int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, const float* d_w,
                                       double* d_out, void* stream);
+
+/* Kernel timing for measurement harnesses (bench.py): when enabled, every device-layer call brackets
+ * its kernels with HIP events on the caller's stream.  rsparse_hip_profile_last() waits for the last
+ * call and returns milliseconds: half-iterations -> [0] short-row CG kernel (or the Cholesky kernel),
+ * [1] long-row CG kernel, [2] loss reduction; Gramian -> [0] MFMA partial kernel, [1] reduction. */
+int rsparse_hip_profile_enable(int on);
+int rsparse_hip_profile_last(double ms_out[4]);
 
 /* number of per-row systems that failed (not positive definite) since the last call; resets. */
 int rsparse_hip_take_numeric_failures(int64_t* count_out);

@@ -100,6 +100,20 @@ struct Workspace {
 };
 Workspace g_ws;
 
+struct Profiler {
+  bool on = false;
+  bool have = false;
+  int nseg = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t* begin() {
+    have = false;
+    if (!on) return nullptr;
+    for (auto& e : ev)
+      if (!e && hipEventCreate(&e) != hipSuccess) return nullptr;
+    return ev;
+  }
+} g_prof;
+
 struct DevBuf {  // RAII for the stateless entry points
   void* p = nullptr;
   ~DevBuf() { if (p) (void)hipFree(p); }
@@ -112,13 +126,18 @@ int build_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   const int n = d.n_cols;
   int max_len = 0;
   size_t n_long = 0;
+  int64_t nnz_long = 0;
+  int n_empty = 0;
   for (int i = 0; i < n; i++) {
     const int len = host_col_ptrs[i + 1] - host_col_ptrs[i];
     if (len < 0) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs is not non-decreasing");
     max_len = std::max(max_len, len);
-    if (len > kTileNnz) n_long++;
+    if (len > kTileNnz) { n_long++; nnz_long += len; }
+    if (len == 0) n_empty++;
   }
   d.max_len = max_len;
+  d.nnz_long = nnz_long;
+  d.n_empty = n_empty;
   d.short_max = kTileNnz;
   d.n_long = (int)n_long;
   d.long_rows = nullptr;
@@ -191,10 +210,16 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails;
-  hipError_t e = cg ? launch_als_cg(a, implicit, s) : launch_als_chol(a, implicit, s);
+  hipEvent_t* ev = g_prof.begin();
+  hipError_t e = cg ? launch_als_cg(a, implicit, s, ev) : launch_als_chol(a, implicit, s, ev);
   if (e != hipSuccess) return hip_fail(e, cg ? "launch_als_cg" : "launch_als_chol");
   e = launch_sum_partials(g_ws.partials, slots, out, s);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
+  if (ev) {
+    HIP_TRY(hipEventRecord(ev[3], s));
+    g_prof.have = true;
+    g_prof.nseg = 3;
+  }
   return RSPARSE_HIP_OK;
 }
 
@@ -368,10 +393,30 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   return RSPARSE_HIP_OK;
 }
 
-int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[5]) {
+int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[8]) {
   if (!m || !info_out) return fail(RSPARSE_HIP_ERR_INVALID, "NULL argument");
   info_out[0] = m->d.n_rows; info_out[1] = m->d.n_cols; info_out[2] = m->d.nnz;
-  info_out[3] = m->d.n_long; info_out[4] = m->d.max_len;
+  info_out[3] = m->d.n_long; info_out[4] = m->d.max_len; info_out[5] = m->d.nnz_long;
+  info_out[6] = m->d.n_empty; info_out[7] = m->d.short_max;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_profile_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.have = false;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_profile_last(double ms_out[4]) {
+  if (!ms_out) return fail(RSPARSE_HIP_ERR_INVALID, "ms_out is NULL");
+  for (int i = 0; i < 4; i++) ms_out[i] = 0.0;
+  if (!g_prof.on || !g_prof.have) return fail(RSPARSE_HIP_ERR_INVALID, "no profiled call to report");
+  HIP_TRY(hipEventSynchronize(g_prof.ev[g_prof.nseg]));
+  for (int i = 0; i < g_prof.nseg; i++) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+    ms_out[i] = ms;
+  }
   return RSPARSE_HIP_OK;
 }
 
@@ -384,8 +429,13 @@ int rsparse_hip_gramian_device(const float* d_X, int rank, int64_t n, double lam
   if (rc) return rc;
   if ((rc = g_ws.ensure_gram(gramian_scratch_floats(rank, n)))) return rc;
   const float ridge = (float)lambda;  // float::fl(diag(lambda)), R/model_WRMF.R:476
-  hipError_t e = launch_gramian(d_X, rank, n, ridge, d_XtX_out, d_sumsq_out, g_ws.gram, (hipStream_t)stream);
+  hipEvent_t* ev = g_prof.begin();
+  hipError_t e = launch_gramian(d_X, rank, n, ridge, d_XtX_out, d_sumsq_out, g_ws.gram, (hipStream_t)stream, ev);
   if (e != hipSuccess) return hip_fail(e, "launch_gramian");
+  if (ev) {
+    g_prof.have = true;
+    g_prof.nseg = 2;
+  }
   return RSPARSE_HIP_OK;
 }
 

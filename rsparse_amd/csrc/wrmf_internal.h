@@ -19,6 +19,8 @@ struct DevCSC {
   int n_long = 0;
   int short_max = 0;  // tile capacity T the schedule was built for
   int max_len = 0;
+  int64_t nnz_long = 0;
+  int n_empty = 0;
   bool owns_matrix = false;
 };
 
@@ -53,14 +55,16 @@ constexpr int kCholMaxGrid = 256 * 8;  // Cholesky workgroups (grid-stride over 
 size_t cg_loss_slots(int n_cols, int n_long);
 size_t chol_loss_slots(int n_cols);
 
-hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s);
-hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s);
+// Optional per-kernel timing: when `ev` is non-null the launchers record ev[0] before the first
+// kernel, ev[1] between kernels and ev[2] after the last one (all on stream s).
+hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
+hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s);
 
 // Gramian: scratch must hold gramian_scratch_floats(k, n) floats.
 size_t gramian_scratch_floats(int k, int64_t n);
 hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* XtX, double* sumsq,
-                          float* scratch, hipStream_t s);
+                          float* scratch, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_weighted_sumsq(const float* X, int k, int64_t n, const float* w, double* out,
                                  double* scratch /* >= 1024 doubles */, hipStream_t s);
 hipError_t launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s);

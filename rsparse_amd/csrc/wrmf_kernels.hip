@@ -656,17 +656,19 @@ hipError_t set_lds(K kernel, size_t bytes) {
 }
 
 template <int KP, bool IMPLICIT, bool VEC>
-hipError_t launch_cg_t(const AlsArgs& a, hipStream_t s) {
+hipError_t launch_cg_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   constexpr int T = kTileNnz, W = kWavesPerWG;
   using SM = CgSmem<KP, T, W, IMPLICIT>;
   hipError_t err;
   const int grid_s = (a.n_cols + kRowsPerWGShort - 1) / kRowsPerWGShort;
+  if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
   if (grid_s > 0) {
     auto ks = als_cg_short_kernel<KP, T, W, IMPLICIT, VEC>;
     if ((err = set_lds(ks, SM::short_bytes)) != hipSuccess) return err;
     hipLaunchKernelGGL(ks, dim3(grid_s), dim3(W * 64), SM::short_bytes, s, a);
     if ((err = hipGetLastError()) != hipSuccess) return err;
   }
+  if (ev && (err = hipEventRecord(ev[1], s)) != hipSuccess) return err;
   if (a.n_long > 0) {
     const int grid_l = (a.n_long + kRowsPerWGLong - 1) / kRowsPerWGLong;
     auto kl = als_cg_long_kernel<KP, T, W, IMPLICIT, VEC>;
@@ -674,18 +676,25 @@ hipError_t launch_cg_t(const AlsArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kl, dim3(grid_l), dim3(W * 64), SM::long_bytes, s, a, (size_t)grid_s * W);
     if ((err = hipGetLastError()) != hipSuccess) return err;
   }
+  if (ev && (err = hipEventRecord(ev[2], s)) != hipSuccess) return err;
   return hipSuccess;
 }
 
 template <int KP, bool IMPLICIT>
-hipError_t launch_chol_t(const AlsArgs& a, hipStream_t s) {
+hipError_t launch_chol_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   using SM = CholSmem<KP, IMPLICIT>;
   hipError_t err;
   const int grid = (int)chol_loss_slots(a.n_cols);
   auto kc = als_chol_kernel<KP, IMPLICIT>;
   if ((err = set_lds(kc, SM::bytes)) != hipSuccess) return err;
+  if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
   hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a);
-  return hipGetLastError();
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  if (ev) {
+    if ((err = hipEventRecord(ev[1], s)) != hipSuccess) return err;
+    if ((err = hipEventRecord(ev[2], s)) != hipSuccess) return err;
+  }
+  return hipSuccess;
 }
 
 }  // namespace
@@ -709,13 +718,13 @@ size_t chol_loss_slots(int n_cols) {  // = Cholesky grid: one slot per workgroup
   return (size_t)(n_cols < kCholMaxGrid ? (n_cols > 0 ? n_cols : 1) : kCholMaxGrid);
 }
 
-hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s) {
+hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(a.k);
   const bool vec = (a.k % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
 #define RSP_DISPATCH(KPV)                                                             \
   if (KP == KPV) {                                                                    \
-    if (implicit) return vec ? launch_cg_t<KPV, true, true>(a, s) : launch_cg_t<KPV, true, false>(a, s); \
-    return vec ? launch_cg_t<KPV, false, true>(a, s) : launch_cg_t<KPV, false, false>(a, s);             \
+    if (implicit) return vec ? launch_cg_t<KPV, true, true>(a, s, ev) : launch_cg_t<KPV, true, false>(a, s, ev); \
+    return vec ? launch_cg_t<KPV, false, true>(a, s, ev) : launch_cg_t<KPV, false, false>(a, s, ev);             \
   }
   RSP_DISPATCH(32)
   RSP_DISPATCH(64)
@@ -724,10 +733,10 @@ hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s) {
+hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(a.k);
 #define RSP_DISPATCH(KPV)                                                  \
-  if (KP == KPV) return implicit ? launch_chol_t<KPV, true>(a, s) : launch_chol_t<KPV, false>(a, s);
+  if (KP == KPV) return implicit ? launch_chol_t<KPV, true>(a, s, ev) : launch_chol_t<KPV, false>(a, s, ev);
   RSP_DISPATCH(32)
   RSP_DISPATCH(64)
   RSP_DISPATCH(128)
@@ -753,18 +762,20 @@ size_t gramian_scratch_floats(int k, int64_t n) {
 }
 
 hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* XtX, double* sumsq,
-                          float* scratch, hipStream_t s) {
+                          float* scratch, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(k);
   if (!KP) return hipErrorInvalidValue;
   const int waves = gramian_waves(n);
   float* partials = scratch;
   double* diag = reinterpret_cast<double*>(scratch + (((size_t)waves * KP * KP + 1) & ~(size_t)1));
   const int grid = waves / 4;
+  if (ev) (void)hipEventRecord(ev[0], s);
   if (KP == 32) hipLaunchKernelGGL(gramian_partial_kernel<32>, dim3(grid), dim3(256), 0, s, X, k, n, partials);
   else if (KP == 64) hipLaunchKernelGGL(gramian_partial_kernel<64>, dim3(grid), dim3(256), 0, s, X, k, n, partials);
   else hipLaunchKernelGGL(gramian_partial_kernel<128>, dim3(grid), dim3(256), 0, s, X, k, n, partials);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
+  if (ev) (void)hipEventRecord(ev[1], s);
   hipLaunchKernelGGL(gramian_reduce_kernel, dim3((k * k + 255) / 256), dim3(256), 0, s, partials, waves, KP, k,
                      ridge, XtX, diag);
   if ((err = hipGetLastError()) != hipSuccess) return err;
@@ -772,6 +783,7 @@ hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* 
     hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(64), 0, s, diag, k, sumsq);
     err = hipGetLastError();
   }
+  if (ev) (void)hipEventRecord(ev[2], s);
   return err;
 }
 

@@ -87,6 +87,15 @@ class HipBackend:
                                                               None if w is None else w.data_ptr(),
                                                               out.data_ptr(), self._stream()))
 
+    def profile(self, on):
+        _lib.check(self.lib.rsparse_hip_profile_enable(int(bool(on))))
+
+    def profile_last(self):
+        """milliseconds of the kernels of the last device-layer call (see rsparse_hip_profile_last)"""
+        buf = (ctypes.c_double * 4)()
+        _lib.check(self.lib.rsparse_hip_profile_last(buf))
+        return list(buf)
+
     def check_numeric(self):
         c = ctypes.c_int64(0)
         _lib.check(self.lib.rsparse_hip_take_numeric_failures(ctypes.byref(c)))
@@ -100,9 +109,10 @@ class _CscHandle:
         self.n_rows, self.n_cols = n_rows, n_cols
 
     def info(self):
-        buf = (ctypes.c_int64 * 5)()
+        buf = (ctypes.c_int64 * 8)()
         _lib.check(self.lib.rsparse_hip_csc_info(self.h, buf))
-        return dict(n_rows=buf[0], n_cols=buf[1], nnz=buf[2], n_long=buf[3], max_len=buf[4])
+        return dict(n_rows=buf[0], n_cols=buf[1], nnz=buf[2], n_long=buf[3], max_len=buf[4], nnz_long=buf[5],
+                    n_empty=buf[6], tile_nnz=buf[7])
 
     def __del__(self):
         try:

@@ -60,6 +60,7 @@ class WRMF:
         self._V = None       # item factors on the device, (n_item, rank)
         self._XtX = None
         self._cnt_item = None
+        self._init_user_factors = None   # (n_user, rank) float32; replaces the RNG draw (parity tests)
         self.losses = []     # (items-half loss, users-half loss) per iteration, as the reference logs them
 
     # ------------------------------------------------------------------------------------------
@@ -90,7 +91,12 @@ class WRMF:
         n_user, n_item = c_ui.shape
         k = self._rank
         # large_rand_matrix(rank, n_user): N(0,1)/100, column-major rank x n_user  (:204-205)
-        U0 = (self._rng.standard_normal((n_user, k)) * 0.01).astype(np.float32)
+        if self._init_user_factors is not None:
+            U0 = np.ascontiguousarray(self._init_user_factors, dtype=np.float32)
+            if U0.shape != (n_user, k):
+                raise ValueError("initial user factors must be n_user x rank")
+        else:
+            U0 = (self._rng.standard_normal((n_user, k)) * 0.01).astype(np.float32)
         if self.components is None:
             if self._solver_code == 1:                                             # CG -> zeros (:219-231)
                 V0 = np.zeros((n_item, k), dtype=np.float32)

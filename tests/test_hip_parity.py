@@ -1,0 +1,209 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on identical inputs.
+
+Tolerance (north star): 1e-4 relative Frobenius on factor matrices vs the reference-shaped CPU
+arithmetic; device arithmetic is fp32, so the per-half-iteration checks compare against the fp64
+oracle run on the same fp32 inputs.  Losses: 1e-4 relative.
+Nothing here reads /root/reference; inputs are seeded synthetic data, the movielens fixture and the
+committed goldens.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import GOLDEN, rel_fro
+from oracle import wrmf_oracle as O
+from rsparse_amd import als, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _problem(n_user, n_item, k, seed, mean_deg=12, d_max=400, feedback="implicit", scale=0.1):
+    d = synth.make_dataset(n_user, n_item, seed=seed, mean_deg=mean_deg, d_max=d_max, feedback=feedback, device="cpu")
+    p, i, x = d["c_iu"]          # columns = users
+    p, i, x = p.numpy(), i.numpy(), x.numpy().astype(np.float64)
+    rng = np.random.default_rng(seed)
+    X = np.asfortranarray((rng.standard_normal((k, n_item)) * scale).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, n_user)) * scale).astype(np.float32))
+    return (n_item, n_user, p, i, x), X, Y0
+
+
+def _oracle64(csc, X, Y0, lam, solver, cg_steps, implicit, dynamic_lambda=True, cnt=None):
+    n_rows, n_cols, p, i, x = csc
+    X64 = np.asfortranarray(X, dtype=np.float64)
+    Y64 = np.asfortranarray(Y0, dtype=np.float64).copy(order="F")
+    if implicit:
+        G = O.gramian(X64, lam)
+        loss = O.als_implicit(p, i, x, X64, Y64, G, lam, solver, cg_steps)
+    else:
+        loss = O.als_explicit(p, i, x, X64, Y64, cnt, lam, solver, cg_steps, dynamic_lambda)
+    return Y64, loss
+
+
+@pytest.mark.parametrize("k,n", [(8, 1), (10, 7), (16, 1000), (64, 5000), (128, 20011), (100, 333)])
+def test_gramian(k, n):
+    rng = np.random.default_rng(k * 1000 + n)
+    X = np.asfortranarray(rng.standard_normal((k, n)).astype(np.float32))
+    X[0, :] += 3.0   # asymmetric, non-zero-mean: catches transposed / mirrored tiles
+    for lam in (0.0, 0.1):
+        G = als.gramian(X, lam, "float")
+        ref = X.astype(np.float64) @ X.astype(np.float64).T + float(np.float32(lam)) * np.eye(k)
+        assert rel_fro(G, ref) < 2e-6
+        assert np.array_equal(G, G.T)
+
+
+@pytest.mark.parametrize("k", [8, 10, 16, 32, 64, 100, 128])
+@pytest.mark.parametrize("cg_steps", [0, 1, 3])
+def test_implicit_cg_half_iteration(k, cg_steps):
+    csc, X, Y0 = _problem(1500, 400, k, seed=k + cg_steps)      # rows of 1..400 nnz: short, resident-long, streamed-long
+    lam = 0.1
+    Yref, lref = _oracle64(csc, X, Y0, lam, 1, cg_steps, True)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, lam, 1, 1, cg_steps, "float", False, False)
+    assert rel_fro(Y, Yref) < TOL
+    assert abs(loss - lref) <= TOL * abs(lref)
+    if cg_steps == 0:
+        assert np.array_equal(Y, Y0)        # warm start returned untouched
+
+
+@pytest.mark.parametrize("k", [6, 16, 64, 128])
+@pytest.mark.parametrize("dynamic_lambda", [True, False])
+def test_explicit_cg_half_iteration(k, dynamic_lambda):
+    csc, X, Y0 = _problem(1200, 300, k, seed=50 + k, feedback="explicit", scale=0.3)
+    lam = 0.1
+    cnt = np.diff(sp.csc_matrix((csc[4], csc[3], csc[2]), shape=(csc[0], csc[1])).tocsr().indptr).astype(np.float64)
+    Yref, lref = _oracle64(csc, X, Y0, lam, 1, 3, False, dynamic_lambda, cnt)
+    Y = Y0.copy(order="F")
+    loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), lam, 1, 1, 3, dynamic_lambda, "float", False, False)
+    assert rel_fro(Y, Yref) < TOL
+    assert abs(loss - lref) <= TOL * abs(lref)
+
+
+@pytest.mark.parametrize("k", [5, 16, 40, 64, 128])
+@pytest.mark.parametrize("implicit", [True, False])
+def test_cholesky_half_iteration(k, implicit):
+    csc, X, Y0 = _problem(700, 500, k, seed=90 + k, feedback="implicit" if implicit else "explicit", scale=0.3)
+    lam = 0.1
+    cnt = np.diff(sp.csc_matrix((csc[4], csc[3], csc[2]), shape=(csc[0], csc[1])).tocsr().indptr).astype(np.float64)
+    Yref, lref = _oracle64(csc, X, Y0, lam, 0, 3, implicit, True, cnt)
+    Y = Y0.copy(order="F")
+    if implicit:
+        loss = als.als_implicit(csc, X, Y, lam, 1, 0, 3, "float", False, False)
+    else:
+        loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), lam, 1, 0, 3, True, "float", False, False)
+    assert rel_fro(Y, Yref) < TOL
+    assert abs(loss - lref) <= TOL * abs(lref)
+
+
+def test_double_entry_points_and_empty_columns(ml_train):
+    """movielens train (test-wrmf.R:6) has items nobody rated -> zero columns (wrmf_implicit.hpp:281)."""
+    n_user, n_item, p, i, x = ml_train
+    k, lam = 16, 0.1
+    rng = np.random.default_rng(3)
+    U = np.asfortranarray(rng.standard_normal((k, n_user)) * 0.1)
+    Y0 = np.asfortranarray(rng.standard_normal((k, n_item)) * 0.1)
+    for solver in (1, 0):
+        Yref = Y0.copy(order="F")
+        lref = O.als_implicit(p, i, x, U, Yref, O.gramian(U, lam), lam, solver, 3)
+        Y = Y0.copy(order="F")
+        loss = als.als_implicit((n_user, n_item, p, i, x), U, Y, lam, 1, solver, 3, "double", False, False)
+        assert Y.dtype == np.float64 and rel_fro(Y, Yref) < TOL
+        assert abs(loss - lref) <= TOL * abs(lref)
+        empty = np.diff(p) == 0
+        assert empty.any() and np.all(Y[:, empty] == 0)
+    # degenerate shapes: no columns at all; all-empty columns
+    z = als.als_implicit((n_user, 0, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0)), U,
+                         np.zeros((k, 0), order="F"), lam, 1, 1, 3, "double", False, False, XtX=O.gramian(U, lam))
+    Y = np.asfortranarray(np.ones((k, 3)))
+    als.als_implicit((n_user, 3, np.zeros(4, np.int32), np.zeros(0, np.int32), np.zeros(0)), U, Y, lam, 1, 1, 3,
+                     "double", False, False)
+    assert np.all(Y == 0)
+
+
+def _fixed_init(m, U0):
+    m._init_user_factors = np.ascontiguousarray(U0.T, dtype=np.float32)
+
+
+@pytest.mark.parametrize("feedback", ["implicit", "explicit"])
+@pytest.mark.parametrize("solver", ["conjugate_gradient", "cholesky"])
+def test_fit_transform_matches_goldens(ml_train, feedback, solver):
+    """BASELINE config 1 protocol (test-wrmf.R:6,48-57): 5 iterations on movielens train from the
+    committed initial factors; factors and per-iteration losses vs the fp64 oracle goldens."""
+    from rsparse_amd import WRMF
+    g = np.load(GOLDEN / "wrmf_movielens_goldens.npz")
+    n_user, n_item, p, i, x = ml_train
+    tag = "%s_%s" % (feedback, solver)
+    k, lam = int(g[tag + "_rank"]), float(g[tag + "_lambda"])
+    init = g[tag + "_init_components"] if solver == "cholesky" else None
+    m = WRMF(rank=k, lambda_=lam, feedback=feedback, solver=solver, precision="float", init=init)
+    _fixed_init(m, g["init_U_k%d" % k])
+    train = sp.csc_matrix((x, i, p), shape=(n_user, n_item))
+    emb = m.fit_transform(train, n_iter=5, convergence_tol=-1)
+    assert emb.shape == (n_user, k) and emb.dtype == np.float32
+    assert m.components.shape == (k, n_item)
+    assert np.allclose([l[0] for l in m.losses], g[tag + "_loss_items"], rtol=TOL)
+    assert np.allclose([l[1] for l in m.losses], g[tag + "_loss_users"], rtol=TOL)
+    assert rel_fro(m.components, g[tag + "_components"]) < TOL
+    assert rel_fro(emb, g[tag + "_user_emb"]) < TOL
+    # fit_transform(train) == transform(train)   (test-wrmf.R:57)
+    again = m.transform(train)
+    assert np.array_equal(emb, again)
+
+
+def test_rows_are_independent_of_their_neighbours():
+    """Size-independent property: a row's solution depends only on that row's data, so solving a
+    shuffled subset of the rows reproduces the same vectors bit for bit (short and long rows alike)."""
+    csc, X, Y0 = _problem(3000, 600, 64, seed=7, mean_deg=30, d_max=500)
+    n_rows, n_cols, p, i, x = csc
+    Y = Y0.copy(order="F")
+    als.als_implicit(csc, X, Y, 0.1, 1, 1, 3, "float", False, False)
+    rng = np.random.default_rng(0)
+    pick = rng.permutation(n_cols)[:500]
+    lens = np.diff(p)[pick]
+    p2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = np.concatenate([np.arange(p[c], p[c + 1]) for c in pick])
+    Ysub = np.asfortranarray(Y0[:, pick])
+    als.als_implicit((n_rows, len(pick), p2, i[idx], x[idx]), X, Ysub, 0.1, 1, 1, 3, "float", False, False,
+                     XtX=als.gramian(X, 0.1, "float"))
+    assert np.array_equal(Ysub, Y[:, pick])
+
+
+def test_config2_scale_properties():
+    """BASELINE config 2 shape (1M x 100k, ~50M nnz, k=64) on the device-resident path: Cholesky
+    rows satisfy their normal equations, CG loss decreases, replicas of a half-iteration are
+    deterministic."""
+    from rsparse_amd.engine import HipBackend, ShardedALS
+    be = HipBackend()
+    n_user, n_item, k, lam = 1_000_000, 100_000, 64, 0.1
+    d = synth.make_dataset(n_user, n_item, device=be.device)
+    als_ = ShardedALS(be, n_user, n_item, k, d["c_ui"], d["c_iu"], d["nnz"], lambda_=lam)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    U = (torch.randn(n_user, k, generator=g) * 0.01).to(be.device)
+    V = torch.zeros(n_item, k, device=be.device)
+    losses = []
+    for _ in range(3):
+        als_.half_iteration("items", U, V, 1)
+        losses.append(als_.half_iteration("users", U, V, 1))
+    assert all(np.isfinite(losses)) and losses[2] < losses[1] < losses[0]
+    U2 = U.clone()
+    als_.half_iteration("users", U2, V, 1, want_loss=False)
+    U3 = U.clone()
+    als_.half_iteration("users", U3, V, 1, want_loss=False)
+    assert torch.equal(U2, U3)                                    # run-to-run deterministic
+    # exact solve: residual of the normal equations on sampled users
+    G = als_.gramian(V, n_item, als_.Bi, als_.ib).clone()
+    Uc = torch.zeros_like(U)
+    als_.half_iteration("users", Uc, V, 0, G=G, want_loss=False)
+    be.check_numeric()
+    p, i, x = [t.cpu() for t in d["c_iu"]]
+    Vc, Gc, Ucc = V.cpu().double(), G.cpu().double(), Uc.cpu().double()
+    worst = 0.0
+    for u in torch.randint(0, n_user, (200,), generator=g).tolist():
+        idx = i[p[u]:p[u + 1]].long()
+        c = x[p[u]:p[u + 1]].double()
+        Xn = Vc[idx]                                             # n_i x k
+        A = Gc + (Xn * (c - 1)[:, None]).T @ Xn
+        b = Xn.T @ c
+        worst = max(worst, float(torch.linalg.norm(A @ Ucc[u] - b) / torch.linalg.norm(b)))
+    assert worst < 1e-4

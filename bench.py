@@ -76,15 +76,19 @@ def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0):
         return time.perf_counter() - t0, nnz
 
     n_user, n_item, nnz_tot = data["n_users"], data["n_items"], data["nnz"]
-    # probe, then size the samples so that each half costs about target_s/2
-    probe_u = min(n_user, 20000)
-    t, z = run(data["c_iu"], Vh, Uh, probe_u)
-    take_u = int(min(n_user, max(probe_u, probe_u * (target_s / 2) / max(t, 1e-3))))
-    tu, zu = run(data["c_iu"], Vh, Uh, take_u)
-    probe_i = min(n_item, 2000)
-    t, z = run(data["c_ui"], Uh, Vh, probe_i)
-    take_i = int(min(n_item, max(probe_i, probe_i * (target_s / 2) / max(t, 1e-3))))
-    ti, zi = run(data["c_ui"], Uh, Vh, take_i)
+    # grow each sample until it costs about target_s/2 of wall time (the first calls include thread start-up)
+    def sized(csc, X, Yfull, n_all, start):
+        take = min(n_all, start)
+        t, z = run(csc, X, Yfull, take)
+        for _ in range(4):
+            if t >= 0.6 * target_s / 2 or take >= n_all:
+                break
+            take = int(min(n_all, take * min(8.0, max(1.5, (target_s / 2) / max(t, 1e-3)))))
+            t, z = run(csc, X, Yfull, take)
+        return take, t, z
+
+    take_u, tu, zu = sized(data["c_iu"], Vh, Uh, n_user, 50000)
+    take_i, ti, zi = sized(data["c_ui"], Uh, Vh, n_item, 5000)
     est_iter_s = tu * (nnz_tot / max(zu, 1)) + ti * (nnz_tot / max(zi, 1))
     out = {
         "value": 1.0 / est_iter_s, "unit": "iterations/s", "cores": threads, "kind": "port",

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Dump the per-kernel statistics (rocprofv3 --kernel-trace --stats) from a rocpd .db or *_kernel_stats.csv
+into a small text table that can be committed under profiles/."""
+import csv
+import sqlite3
+import sys
+from pathlib import Path
+
+
+def from_db(path, top=15):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    return [(n, int(c), float(t), float(a), float(p)) for n, c, t, a, p in rows][:top]
+
+
+def from_csv(path, top=15):
+    out = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            out.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3,
+                        float(r["Percentage"])))
+    return out[:top]
+
+
+def main():
+    path = Path(sys.argv[1])
+    rows = from_db(path) if path.suffix == ".db" else from_csv(path)
+    print("%-100s %6s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+    for n, c, t, a, p in rows:
+        print("%-100s %6d %14.1f %12.1f %7.2f" % (n[:100], c, t, a, p))
+
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,7 @@ exactly what `private$solver` does twice per iteration in R/model_WRMF.R:318-335
 resident in HBM when the timed region starts.
 
 Extra objects on the line:
-  roofline      dominant kernel (the long-row CG kernel), algorithmic bytes / measured duration
+  roofline      dominant kernel (the CG launch with the largest share of the iteration), algorithmic bytes / measured duration
                 (HIP events on the launch stream, recorded inside the library) vs the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (rsparse-shaped C++/OpenMP port, oracle/) timed on this node's host
                 cores on a bounded sample of the same workload (rank 0, N=1 only)
@@ -181,7 +181,8 @@ def main():
 
     # ---- per-kernel durations (HIP events inside the library, same stream), separate pass ----
     be.profile(True)
-    kern = {"items": {"short": [], "long": [], "gram": []}, "users": {"short": [], "long": [], "gram": []}}
+    nb = 5
+    kern = {sd: {"bucket": [[] for _ in range(nb)], "gram": []} for sd in ("items", "users")}
     half_ms = {"items": [], "users": []}
     for _ in range(max(1, min(args.steps, 3))):
         for side in ("items", "users"):
@@ -195,32 +196,50 @@ def main():
             torch.cuda.synchronize()
             half_ms[side].append(1e3 * (time.perf_counter() - th))
             kern[side]["gram"].append(gm[0] + gm[1])
-            kern[side]["short"].append(pm[0])
-            kern[side]["long"].append(pm[1])
+            for b in range(nb):
+                kern[side]["bucket"][b].append(pm[b])
     be.profile(False)
     mean = lambda v: float(np.mean(v)) if len(v) else 0.0
-    info_u, info_i = als.csc_users.info(), als.csc_items.info()
-    # dominant kernel = als_cg_long_kernel<128,32,4,true,true>: launched once per half-iteration
-    long_ms = 0.5 * (mean(kern["items"]["long"]) + mean(kern["users"]["long"]))
-    b_long = 0.5 * (algorithmic_bytes(info_u["n_long"], info_u["nnz_long"], k) +
-                    algorithmic_bytes(info_i["n_long"], info_i["nnz_long"], k))
-    achieved = b_long / (long_ms * 1e-3) / 1e9 if long_ms > 0 else 0.0
-    b_iter = (algorithmic_bytes(info_u["n_cols"], info_u["nnz"], k, info_u["n_empty"]) +
-              algorithmic_bytes(info_i["n_cols"], info_i["nnz"], k, info_i["n_empty"]))
+    info = {"users": als.csc_users.info(), "items": als.csc_items.info()}
+    cfg = int(info["users"]["cgq_cfg"])
+    waves, capq = (16, 8) if cfg == 0 else (8, 16)
+    # per bucket: launches (one per half-iteration that has rows in it), mean duration, algorithmic bytes
+    buckets = []
+    for b in range(nb):
+        wpr = waves >> b
+        if wpr <= 0:
+            continue
+        ms = [mean(kern[sd]["bucket"][b]) for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
+        by = [algorithmic_bytes(info[sd]["bucket_rows"][b], info[sd]["bucket_nnz"][b], k,
+                                info[sd]["n_empty"] if wpr == 1 else 0)
+              for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
+        if ms:
+            buckets.append({"kernel": "als_cgq_kernel<%d,%d,%d,%d,implicit>" % (k if k in (32, 64, 128) else k, capq, waves, wpr),
+                            "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),
+                            "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms))})
+    dom = max(buckets, key=lambda d: d["total_ms_per_iteration"]) if buckets else None
+    solve_ms = sum(d["total_ms_per_iteration"] for d in buckets)
+    solve_bytes = sum(d["bytes_per_launch"] * d["launches_per_iteration"] for d in buckets)
+    b_iter = (algorithmic_bytes(info["users"]["n_cols"], info["users"]["nnz"], k, info["users"]["n_empty"]) +
+              algorithmic_bytes(info["items"]["n_cols"], info["items"]["nnz"], k, info["items"]["n_empty"]))
     traffic = None
     tf = ROOT / "profiles" / "pmc_traffic.json"
-    if tf.exists():
+    if tf.exists() and dom:
         try:
-            traffic = json.loads(tf.read_text()).get("als_cg_long_kernel_bytes_per_launch")
+            traffic = json.loads(tf.read_text()).get(dom["kernel"])
         except Exception:
             traffic = None
+    achieved = dom["bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9 if dom and dom["avg_launch_ms"] > 0 else 0.0
     roofline = {
-        "bound": "hbm", "kernel": "als_cg_long_kernel<128,32,4,implicit,vec>", "achieved": achieved,
+        "bound": "hbm", "kernel": dom["kernel"] if dom else None, "achieved": achieved,
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "bytes_per_launch": b_long, "avg_launch_ms": long_ms,
+        "bytes_per_launch": dom["bytes_per_launch"] if dom else None,
+        "avg_launch_ms": dom["avg_launch_ms"] if dom else None,
+        "all_cg_kernels_GBps": solve_bytes / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else None,
         "whole_iteration_algorithmic_GBps_per_gpu": b_iter / (ms_per_step * 1e-3) / 1e9,
-        "kernel_ms": {s: {kk: mean(v) for kk, v in kern[s].items()} for s in kern},
-        "half_iteration_ms": {s: mean(v) for s, v in half_ms.items()},
+        "cg_kernels": buckets,
+        "gramian_ms": {sd: mean(kern[sd]["gram"]) for sd in kern},
+        "half_iteration_ms": {sd: mean(v) for sd, v in half_ms.items()},
     }
 
     cpu = None

@@ -10,6 +10,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -104,7 +105,7 @@ struct Profiler {
   bool on = false;
   bool have = false;
   int nseg = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t* begin() {
     have = false;
     if (!on) return nullptr;
@@ -159,6 +160,43 @@ int build_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   return RSPARSE_HIP_OK;
 }
 
+// every row, longest first, with the bucket boundaries of the quad-layout CG kernels
+int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
+  const int n = d.n_cols;
+  for (int b = 0; b < 6; b++) d.q_off[b] = 0;
+  for (int b = 0; b < 5; b++) d.q_nnz[b] = 0;
+  d.q_order = nullptr;
+  d.q_cfg = cgq_default_cfg();
+  if (n <= 0) return RSPARSE_HIP_OK;
+  const int max_len = d.max_len;
+  std::vector<int64_t> start((size_t)max_len + 2, 0);
+  int cnt_b[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    const int len = host_col_ptrs[i + 1] - host_col_ptrs[i];
+    start[(size_t)(max_len - len) + 1]++;
+    const int b = cgq_bucket_of(len, d.q_cfg);
+    cnt_b[b]++;
+    d.q_nnz[b] += len;
+  }
+  for (size_t b = 1; b < start.size(); b++) start[b] += start[b - 1];
+  std::vector<int32_t> order((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const int len = host_col_ptrs[i + 1] - host_col_ptrs[i];
+    order[(size_t)start[(size_t)(max_len - len)]++] = i;
+  }
+  for (int b = 0; b < 5; b++) d.q_off[b + 1] = d.q_off[b] + cnt_b[b];
+  HIP_TRY(hipMalloc(&d.q_order, (size_t)n * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(d.q_order, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+  return RSPARSE_HIP_OK;
+}
+
+// which CG implementation: "q" (register-resident quad layout, default when rank % 4 == 0) or "lds"
+bool use_cgq(int rank, const void* X, const void* Y) {
+  static const char* env = std::getenv("RSPARSE_HIP_CG");
+  if (env && std::strcmp(env, "lds") == 0) return false;
+  return rank % 4 == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0;
+}
+
 int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_indices, const void* values,
                  const void* X, const void* Y, int rank) {
   if (n_rows < 0 || n_cols < 0) return fail(RSPARSE_HIP_ERR_INVALID, "negative matrix dimension");
@@ -196,7 +234,12 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if ((rc = g_ws.ensure_device())) return rc;
   const DevCSC& d = conf->d;
   const bool cg = solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT;
-  const size_t slots = cg ? cg_loss_slots(d.n_cols, d.n_long) : chol_loss_slots(d.n_cols);
+  const bool cgq = cg && use_cgq(rank, d_X, d_Y);
+  QSchedule qs;
+  qs.order = d.q_order;
+  qs.cfg = d.q_cfg;
+  for (int b = 0; b < 6; b++) qs.off[b] = d.q_off[b];
+  const size_t slots = cgq ? cgq_loss_slots(qs) : (cg ? cg_loss_slots(d.n_cols, d.n_long) : chol_loss_slots(d.n_cols));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
   double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
   if (d.n_cols == 0) {
@@ -211,14 +254,16 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails;
   hipEvent_t* ev = g_prof.begin();
-  hipError_t e = cg ? launch_als_cg(a, implicit, s, ev) : launch_als_chol(a, implicit, s, ev);
-  if (e != hipSuccess) return hip_fail(e, cg ? "launch_als_cg" : "launch_als_chol");
+  hipError_t e = cgq ? launch_als_cgq(a, qs, implicit, s, ev)
+                     : (cg ? launch_als_cg(a, implicit, s, ev) : launch_als_chol(a, implicit, s, ev));
+  if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
   e = launch_sum_partials(g_ws.partials, slots, out, s);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
   if (ev) {
-    HIP_TRY(hipEventRecord(ev[3], s));
+    const int last = cgq ? 6 : 3;
+    HIP_TRY(hipEventRecord(ev[last], s));
     g_prof.have = true;
-    g_prof.nseg = 3;
+    g_prof.nseg = last;
   }
   return RSPARSE_HIP_OK;
 }
@@ -351,6 +396,7 @@ int rsparse_hip_csc_create_host(int n_rows, int n_cols, const int32_t* col_ptrs,
   }
   int rc = build_schedule(d, col_ptrs);
   if (rc) return rc;
+  if ((rc = build_q_schedule(d, col_ptrs))) return rc;
   guard.c = nullptr;
   *out = m;
   return RSPARSE_HIP_OK;
@@ -375,6 +421,7 @@ int rsparse_hip_csc_create_device(int n_rows, int n_cols, const int32_t* d_col_p
   d.col_ptrs = d_col_ptrs; d.row_idx = d_row_indices; d.vals = d_values;
   int rc = build_schedule(d, hp.data());
   if (rc) return rc;
+  if ((rc = build_q_schedule(d, hp.data()))) return rc;
   guard.c = nullptr;
   *out = m;
   return RSPARSE_HIP_OK;
@@ -384,6 +431,7 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   if (!m) return RSPARSE_HIP_OK;
   DevCSC& d = m->d;
   if (d.long_rows) (void)hipFree(d.long_rows);
+  if (d.q_order) (void)hipFree(d.q_order);
   if (d.owns_matrix) {
     if (d.col_ptrs) (void)hipFree(const_cast<int32_t*>(d.col_ptrs));
     if (d.row_idx) (void)hipFree(const_cast<int32_t*>(d.row_idx));
@@ -393,8 +441,14 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   return RSPARSE_HIP_OK;
 }
 
-int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[8]) {
+int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[24]) {
   if (!m || !info_out) return fail(RSPARSE_HIP_ERR_INVALID, "NULL argument");
+  for (int b = 0; b < 24; b++) info_out[b] = 0;
+  for (int b = 0; b < 5; b++) {
+    info_out[8 + b] = m->d.q_off[b + 1] - m->d.q_off[b];
+    info_out[13 + b] = m->d.q_nnz[b];
+  }
+  info_out[18] = m->d.q_cfg;
   info_out[0] = m->d.n_rows; info_out[1] = m->d.n_cols; info_out[2] = m->d.nnz;
   info_out[3] = m->d.n_long; info_out[4] = m->d.max_len; info_out[5] = m->d.nnz_long;
   info_out[6] = m->d.n_empty; info_out[7] = m->d.short_max;
@@ -407,9 +461,9 @@ int rsparse_hip_profile_enable(int on) {
   return RSPARSE_HIP_OK;
 }
 
-int rsparse_hip_profile_last(double ms_out[4]) {
+int rsparse_hip_profile_last(double ms_out[8]) {
   if (!ms_out) return fail(RSPARSE_HIP_ERR_INVALID, "ms_out is NULL");
-  for (int i = 0; i < 4; i++) ms_out[i] = 0.0;
+  for (int i = 0; i < 8; i++) ms_out[i] = 0.0;
   if (!g_prof.on || !g_prof.have) return fail(RSPARSE_HIP_ERR_INVALID, "no profiled call to report");
   HIP_TRY(hipEventSynchronize(g_prof.ev[g_prof.nseg]));
   for (int i = 0; i < g_prof.nseg; i++) {

@@ -1,0 +1,468 @@
+// CG half-iteration, register-resident "quad layout" (gfx950, wave64).
+//
+// Same arithmetic as als_cg_short/long_kernel (cg_solver_implicit<T>, inst/include/wrmf_implicit.hpp:8-32;
+// cg_solver_explicit<T>, inst/include/wrmf_explicit.hpp:8-31; column loop :160-283 / :68-144), re-laid-out
+// so that the gathered factor vectors of a row live in the REGISTER FILE instead of LDS.  The LDS-tile
+// kernels fit only 4 waves per CU (64 KB Gramian + 17 KB tile per wave) and are latency-bound; a CU has
+// 512 KB of VGPRs, so here 16 waves per CU each keep 32 gathered vectors (64 VGPRs) resident and LDS holds
+// only the shared Gramian and a few hundred bytes per wave.
+//
+// Layout: a wave is 4 DPP rows ("groups") of 16 lanes.  A rank-KP vector is spread over the 16 lanes of a
+// group, RPN = KP/16 floats per lane (k=128: floats [4i,4i+4) and [64+4i,64+4i+4) for lane i -> every load
+// instruction reads whole 256-B half vectors).  The 4 groups hold 4 DIFFERENT non-zeros of the row at a
+// time (a "quad"); CG state (x, r, p, Ap) is replicated in the 4 groups.  Then, per quad:
+//     t_j  = x_j . v      RPN FMAs + a 4-step DPP reduction inside the 16-lane row (no cross-row traffic)
+//     acc += w_j * x_j    RPN FMAs, w_j is already uniform inside the group (no readlane, no LDS)
+// and once per sweep the 4 group partials are all-reduced (2 xor-shuffles per register).  The dense
+// G*v product is split over the groups by k-range and folded into the same all-reduce.
+//
+// Rows longer than one wave's capacity (CAP = 32 non-zeros) are solved by teams of WPR = 2/4/8/16 waves
+// of one 1024-thread workgroup: every wave keeps its own 32-nnz chunk resident, partial vectors are
+// combined through LDS with one barrier per CG sweep.  Rows beyond 16*CAP are streamed: each wave
+// re-gathers its chunks (L2 / Infinity Cache hits) in every sweep.
+#include <cstdlib>
+
+#include "wrmf_internal.h"
+#include "wrmf_device.h"
+
+namespace rsparse_hip {
+namespace {
+
+using namespace dev;
+
+constexpr float kCgTolQ = 1e-10f;  // CG_TOL, inst/include/wrmf.hpp:22
+
+template <int KP>
+struct QG {
+  static constexpr int RPN = KP / 16;            // floats of one vector per lane
+  static constexpr int VW = RPN >= 4 ? 4 : RPN;  // floats per load piece
+  static constexpr int NV = RPN / VW;            // pieces per vector per lane
+  // position inside the vector of register r of lane i
+  __device__ static __forceinline__ int elem(int i, int r) { return (r / VW) * (16 * VW) + i * VW + (r % VW); }
+};
+
+template <int VW>
+struct Piece;
+template <>
+struct Piece<4> { using type = float4; };
+template <>
+struct Piece<2> { using type = float2; };
+
+// sum over the 16 lanes of a DPP row; every lane of the row gets the result (needs full EXEC)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp<0xB1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v += dpp<0x141>(v);  // row_half_mirror
+  v += dpp<0x140>(v);  // row_mirror
+  return v;
+}
+// sum over the 4 groups (lanes l, l^16, l^32, l^48); commutative pairing -> bitwise identical in all 4
+__device__ __forceinline__ float groups_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int KP, int WAVES, int WPR, bool IMPLICIT>
+struct QSmem {
+  static constexpr size_t gram_floats = IMPLICIT ? (size_t)KP * KP : 0;
+  static constexpr size_t vec_floats = IMPLICIT ? (size_t)WAVES * KP : 0;
+  static constexpr size_t red_floats = WPR > 1 ? (size_t)2 * WAVES * KP + 2 * WAVES : 0;
+  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats) * 4 + 16;
+};
+
+template <int KP, int CAPQ, int WAVES, int WPR, bool IMPLICIT>
+__global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
+                                                             int rows_per_team, size_t loss_slot0) {
+  using G_ = QG<KP>;
+  constexpr int RPN = G_::RPN, VW = G_::VW, NV = G_::NV, CAP = CAPQ * 4, TEAMS = WAVES / WPR;
+  using piece_t = typename Piece<VW>::type;
+  static_assert(WAVES % WPR == 0, "teams must tile the workgroup");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sG = reinterpret_cast<float*>(smem);
+  float* sVec = sG + QSmem<KP, WAVES, WPR, IMPLICIT>::gram_floats;
+  float* sRed = sVec + QSmem<KP, WAVES, WPR, IMPLICIT>::vec_floats;  // [2][WAVES][KP]
+  float* sRedL = sRed + (WPR > 1 ? 2 * WAVES * KP : 0);              // [2][WAVES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  const int team = wv / WPR, tw = wv % WPR;
+  const int k = a.k;
+  if constexpr (IMPLICIT) {
+    for (int e = tid; e < KP * KP; e += WAVES * 64) {
+      const int r = e / KP, c = e % KP;
+      sG[e] = (r < k && c < k) ? a.XtX[(size_t)r * k + c] : 0.f;
+    }
+  }
+  for (int e = tid; e < (int)(QSmem<KP, WAVES, WPR, IMPLICIT>::vec_floats + QSmem<KP, WAVES, WPR, IMPLICIT>::red_floats);
+       e += WAVES * 64)
+    sVec[e] = 0.f;
+  __syncthreads();
+
+  float* vec = sVec + wv * KP;
+  int buf = 0;
+  double wloss = 0.0;
+  const int team_global = blockIdx.x * TEAMS + team;
+  const int total_teams = gridDim.x * TEAMS;
+
+  for (int it = 0; it < rows_per_team; ++it) {
+    const int ri = team_global + it * total_teams;
+    const bool have = ri < n_rows;
+    if (WPR == 1 && !have) break;  // no barriers on this path: a wave may simply stop
+    const int row = have ? rfl(rows[ri]) : 0;
+    const int p1 = have ? rfl(a.col_ptrs[row]) : 0;
+    const int p2 = have ? rfl(a.col_ptrs[row + 1]) : 0;
+    const int cnt = p2 - p1;
+    float* yrow = a.Y + (size_t)row * k;
+    if (WPR == 1 && cnt <= 0) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
+      for (int e = lane; e < k; e += 64) yrow[e] = 0.f;
+      continue;
+    }
+    const int nchunks = (cnt + CAP - 1) / CAP;
+    // only the full-workgroup teams ever see rows beyond their resident capacity (bucket thresholds)
+    const bool resident = (WPR == WAVES) ? (nchunks <= WPR) : true;
+    const float lam_use =
+        IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)cnt : 1.0));
+
+    float xt[CAPQ][RPN];  // gathered vectors: quad q, group g holds non-zero 4q+g of the chunk
+    float cv[CAPQ];       // its confidence / rating (uniform inside the group)
+    int ccnt = 0;
+
+    auto gather = [&](const int base, const int n) {
+#pragma unroll
+      for (int q = 0; q < CAPQ; q++) {
+        cv[q] = 0.f;
+#pragma unroll
+        for (int r = 0; r < RPN; r++) xt[q][r] = 0.f;
+        if (4 * q < n) {  // wave-uniform
+          const int j = 4 * q + g;
+          if (j < n) {
+            const int id = a.row_idx[base + j];
+            cv[q] = a.vals[base + j];
+            const float* src = a.X + (size_t)id * k;
+#pragma unroll
+            for (int b = 0; b < NV; b++) {
+              const int off = b * 16 * VW + i * VW;
+              if (off < k) {
+                const piece_t pc = *reinterpret_cast<const piece_t*>(src + off);
+                const float* pf = reinterpret_cast<const float*>(&pc);
+#pragma unroll
+                for (int c = 0; c < VW; c++) xt[q][b * VW + c] = pf[c];
+              }
+            }
+          }
+        }
+      }
+    };
+
+    if (resident && tw < nchunks) {
+      ccnt = min(CAP, cnt - tw * CAP);
+      gather(p1 + tw * CAP, ccnt);
+    }
+
+    float x[RPN], r[RPN], p[RPN], ap[RPN];
+#pragma unroll
+    for (int b = 0; b < NV; b++) {
+      const int off = b * 16 * VW + i * VW;
+      piece_t pc;
+      float* pf = reinterpret_cast<float*>(&pc);
+#pragma unroll
+      for (int c = 0; c < VW; c++) pf[c] = 0.f;
+      if (have && off < k) pc = *reinterpret_cast<const piece_t*>(yrow + off);  // warm start
+#pragma unroll
+      for (int c = 0; c < VW; c++) x[b * VW + c] = pf[c];
+    }
+
+    // one pass over the resident quads: t = X_nnz^T v, then acc += X_nnz w  (or the loss terms)
+    auto quad_pass = [&](const float(&v)[RPN], const int mode, float(&acc)[RPN], float& lacc) {
+#pragma unroll
+      for (int q = 0; q < CAPQ; q++) {
+        if (4 * q < ccnt) {  // wave-uniform
+          float s = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < RPN; rr++) s = fmaf(xt[q][rr], v[rr], s);
+          const float t = row16_sum(s);
+          const bool valid = 4 * q + g < ccnt;
+          const float c = cv[q];
+          if (mode == 2) {
+            const float d = IMPLICIT ? 1.f - t : c - t;
+            lacc += valid ? (IMPLICIT ? c * d * d : d * d) : 0.f;
+          } else {
+            float w;
+            if (mode == 0) w = IMPLICIT ? c - (c - 1.f) * t : c - t;
+            else w = IMPLICIT ? (c - 1.f) * t : t;
+            w = valid ? w : 0.f;
+#pragma unroll
+            for (int rr = 0; rr < RPN; rr++) acc[rr] = fmaf(w, xt[q][rr], acc[rr]);
+          }
+        }
+      }
+    };
+
+    // mode 0: out = X_nnz (c - c1 % X_nnz^T v) - G v ; mode 1: out = X_nnz (c1 % X_nnz^T v) + G v ; mode 2: loss
+    auto sweep = [&](const float(&v)[RPN], const int mode, float(&out)[RPN], float& loss_out, const bool live) {
+      float acc[RPN];
+#pragma unroll
+      for (int rr = 0; rr < RPN; rr++) acc[rr] = 0.f;
+      float lacc = 0.f;
+      if (live) {
+        if constexpr (IMPLICIT) {
+          if (mode != 2) {  // publish v for the broadcast reads of the G*v product
+            wave_sync();
+            if (g == 0) {
+#pragma unroll
+              for (int b = 0; b < NV; b++) {
+                piece_t pc;
+                float* pf = reinterpret_cast<float*>(&pc);
+#pragma unroll
+                for (int c = 0; c < VW; c++) pf[c] = v[b * VW + c];
+                *reinterpret_cast<piece_t*>(vec + b * 16 * VW + i * VW) = pc;
+              }
+            }
+            wave_sync();
+          }
+        }
+        if (resident) {
+          quad_pass(v, mode, acc, lacc);
+        } else {
+          for (int ch = tw; ch < nchunks; ch += WPR) {
+            ccnt = min(CAP, cnt - ch * CAP);
+            gather(p1 + ch * CAP, ccnt);
+            quad_pass(v, mode, acc, lacc);
+          }
+        }
+        if (mode != 2) {
+          if constexpr (IMPLICIT) {
+            const float sign = mode == 0 ? -1.f : 1.f;
+            for (int s4 = tw * 4 + g; s4 < KP / 4; s4 += WPR * 4) {
+              const int kk = 4 * s4;
+              const float4 vb = *reinterpret_cast<const float4*>(vec + kk);
+              const float vv[4] = {sign * vb.x, sign * vb.y, sign * vb.z, sign * vb.w};
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const float* grow = sG + (kk + u) * KP;
+#pragma unroll
+                for (int b = 0; b < NV; b++) {
+                  const piece_t pc = *reinterpret_cast<const piece_t*>(grow + b * 16 * VW + i * VW);
+                  const float* pf = reinterpret_cast<const float*>(&pc);
+#pragma unroll
+                  for (int c = 0; c < VW; c++) acc[b * VW + c] = fmaf(vv[u], pf[c], acc[b * VW + c]);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < RPN; rr++) acc[rr] = groups_sum(acc[rr]);
+        } else {
+          lacc = groups_sum(lacc);
+        }
+      }
+      if constexpr (WPR > 1) {
+        float* red = sRed + buf * WAVES * KP;
+        if (mode != 2) {
+          if (g == 0) {
+#pragma unroll
+            for (int b = 0; b < NV; b++) {
+              piece_t pc;
+              float* pf = reinterpret_cast<float*>(&pc);
+#pragma unroll
+              for (int c = 0; c < VW; c++) pf[c] = acc[b * VW + c];
+              *reinterpret_cast<piece_t*>(red + wv * KP + b * 16 * VW + i * VW) = pc;
+            }
+          }
+        } else if (lane == 0) {
+          sRedL[buf * WAVES + wv] = lacc;
+        }
+        __syncthreads();
+        if (mode != 2) {
+#pragma unroll
+          for (int rr = 0; rr < RPN; rr++) acc[rr] = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < WPR; w2++) {
+#pragma unroll
+            for (int b = 0; b < NV; b++) {
+              const piece_t pc = *reinterpret_cast<const piece_t*>(red + (team * WPR + w2) * KP + b * 16 * VW + i * VW);
+              const float* pf = reinterpret_cast<const float*>(&pc);
+#pragma unroll
+              for (int c = 0; c < VW; c++) acc[b * VW + c] += pf[c];
+            }
+          }
+        } else {
+          lacc = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < WPR; w2++) lacc += sRedL[buf * WAVES + team * WPR + w2];
+        }
+        buf ^= 1;
+      }
+      if (mode != 2) {
+#pragma unroll
+        for (int rr = 0; rr < RPN; rr++) out[rr] = acc[rr];
+        if constexpr (!IMPLICIT) {
+#pragma unroll
+          for (int rr = 0; rr < RPN; rr++) out[rr] = fmaf(mode == 0 ? -lam_use : lam_use, v[rr], out[rr]);
+        }
+      } else {
+        loss_out = lacc;
+      }
+    };
+
+    auto dot16 = [&](const float(&u)[RPN], const float(&w)[RPN]) {
+      float s = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < RPN; rr++) s = fmaf(u[rr], w[rr], s);
+      return row16_sum(s);  // the 16 lanes of a group cover the whole vector; groups are replicas
+    };
+
+    const bool live = have && cnt > 0;
+    float dummy = 0.f;
+    sweep(x, 0, r, dummy, live);
+#pragma unroll
+    for (int rr = 0; rr < RPN; rr++) p[rr] = r[rr];
+    float rsold = dot16(r, r);
+    bool conv = false;
+    for (int itc = 0; itc < a.cg_steps; ++itc) {
+      if (WPR == 1 && conv) break;
+      sweep(p, 1, ap, dummy, live && !conv);
+      if (!conv) {
+        const float pap = dot16(p, ap);
+        const float alpha = rsold / pap;
+#pragma unroll
+        for (int rr = 0; rr < RPN; rr++) {
+          x[rr] = fmaf(alpha, p[rr], x[rr]);
+          r[rr] = fmaf(-alpha, ap[rr], r[rr]);
+        }
+        const float rsnew = dot16(r, r);
+        if (rsnew < kCgTolQ) {
+          conv = true;
+        } else {
+          const float beta = rsnew / rsold;
+#pragma unroll
+          for (int rr = 0; rr < RPN; rr++) p[rr] = fmaf(p[rr], beta, r[rr]);
+          rsold = rsnew;
+        }
+      }
+    }
+    float rl = 0.f;
+    sweep(x, 2, ap, rl, live);
+    if (live && tw == 0) {
+      const float xx = dot16(x, x);
+      wloss += IMPLICIT ? (double)rl + a.lambda_loss * (double)xx : (double)(rl + lam_use * xx);
+      if (g == 0) {
+#pragma unroll
+        for (int b = 0; b < NV; b++) {
+          const int off = b * 16 * VW + i * VW;
+          if (off < k) {
+            piece_t pc;
+            float* pf = reinterpret_cast<float*>(&pc);
+#pragma unroll
+            for (int c = 0; c < VW; c++) pf[c] = x[b * VW + c];
+            *reinterpret_cast<piece_t*>(yrow + off) = pc;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) a.loss_partials[loss_slot0 + (size_t)blockIdx.x * WAVES + wv] = wloss;
+}
+
+// Two build-time geometries, chosen at run time (RSPARSE_HIP_CGQ_CFG):
+//   cfg 0: 16 waves per workgroup (4 per SIMD, 128-VGPR budget), 8 quads = 32 non-zeros resident per wave
+//   cfg 1:  8 waves per workgroup (2 per SIMD, 256-VGPR budget), 16 quads = 64 non-zeros resident per wave
+template <int CFG> struct QCfg;
+template <> struct QCfg<0> { static constexpr int WAVES = 16, CAPQ = 8; };
+template <> struct QCfg<1> { static constexpr int WAVES = 8, CAPQ = 16; };
+
+inline int cfg_waves(int cfg) { return cfg == 0 ? QCfg<0>::WAVES : QCfg<1>::WAVES; }
+inline int cfg_cap(int cfg) { return 4 * (cfg == 0 ? QCfg<0>::CAPQ : QCfg<1>::CAPQ); }
+inline int bucket_wpr(int cfg, int b) { return cfg_waves(cfg) >> b; }  // 0 -> bucket unused
+
+template <int KP, int CFG, int WPR, bool IMPLICIT>
+hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, size_t slot0, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  constexpr int WAVES = QCfg<CFG>::WAVES, CAPQ = QCfg<CFG>::CAPQ, TEAMS = WAVES / WPR;
+  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, IMPLICIT>;
+  const size_t lds = QSmem<KP, WAVES, WPR, IMPLICIT>::bytes;
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  const int grid = cgq_bucket_grid(n_rows, WPR, CFG);
+  const int total_teams = grid * TEAMS;
+  const int rpt = (n_rows + total_teams - 1) / total_teams;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a, rows, n_rows, rpt, slot0);
+  return hipGetLastError();
+}
+
+template <int KP, int CFG, bool IMPLICIT>
+hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEvent_t* ev) {
+  constexpr int WAVES = QCfg<CFG>::WAVES;
+  hipError_t err;
+  size_t slot = 0;
+  // longest rows first: bucket b = teams of WAVES >> b waves per row (bucket 0 also streams over-long rows)
+#define RSP_BUCKET(B)                                                                                      \
+  {                                                                                                        \
+    constexpr int WPRV = (WAVES >> B) > 0 ? (WAVES >> B) : 1;                                              \
+    const int n = q.off[B + 1] - q.off[B];                                                                 \
+    if (ev && (err = hipEventRecord(ev[B], s)) != hipSuccess) return err;                                  \
+    if ((WAVES >> B) > 0) {                                                                                \
+      if ((err = launch_bucket<KP, CFG, WPRV, IMPLICIT>(a, q.order + q.off[B], n, slot, s)) != hipSuccess) return err; \
+      slot += (size_t)cgq_bucket_grid(n, WPRV, CFG) * WAVES;                                               \
+    }                                                                                                      \
+  }
+  RSP_BUCKET(0)
+  RSP_BUCKET(1)
+  RSP_BUCKET(2)
+  RSP_BUCKET(3)
+  RSP_BUCKET(4)
+#undef RSP_BUCKET
+  if (ev && (err = hipEventRecord(ev[5], s)) != hipSuccess) return err;
+  return hipSuccess;
+}
+
+}  // namespace
+
+int cgq_bucket_grid(int n_rows, int wpr, int cfg) {
+  if (n_rows <= 0) return 0;
+  const int teams = cfg_waves(cfg) / wpr;
+  const int rows_per_team = wpr == 1 ? 16 : (wpr <= 4 ? 8 : 4);  // amortise the 64 KB Gramian load
+  const long per_wg = (long)teams * rows_per_team;
+  long grid = (n_rows + per_wg - 1) / per_wg;
+  if (grid < 1) grid = 1;
+  return (int)grid;
+}
+
+int cgq_bucket_of(int len, int cfg) {  // smallest team whose resident capacity holds the row
+  const int cap = cfg_cap(cfg);
+  int b = 0;
+  while (b < 4 && bucket_wpr(cfg, b + 1) > 0 && len <= cap * bucket_wpr(cfg, b + 1)) b++;
+  return b;
+}
+
+size_t cgq_loss_slots(const QSchedule& q) {
+  size_t n = 0;
+  for (int b = 0; b < 5; b++) {
+    const int wpr = bucket_wpr(q.cfg, b);
+    if (wpr > 0) n += (size_t)cgq_bucket_grid(q.off[b + 1] - q.off[b], wpr, q.cfg) * cfg_waves(q.cfg);
+  }
+  return n;
+}
+
+int cgq_default_cfg() {
+  static const char* env = std::getenv("RSPARSE_HIP_CGQ_CFG");
+  return (env && env[0] == '1') ? 1 : 0;
+}
+
+hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev) {
+  const int KP = padded_rank(a.k);
+#define RSP_DISPATCH(KPV)                                                                                   \
+  if (KP == KPV) {                                                                                          \
+    if (q.cfg == 0) return implicit ? launch_all<KPV, 0, true>(a, q, s, ev) : launch_all<KPV, 0, false>(a, q, s, ev); \
+    return implicit ? launch_all<KPV, 1, true>(a, q, s, ev) : launch_all<KPV, 1, false>(a, q, s, ev);       \
+  }
+  RSP_DISPATCH(32)
+  RSP_DISPATCH(64)
+  RSP_DISPATCH(128)
+#undef RSP_DISPATCH
+  return hipErrorInvalidValue;
+}
+
+}  // namespace rsparse_hip

@@ -92,7 +92,7 @@ class HipBackend:
 
     def profile_last(self):
         """milliseconds of the kernels of the last device-layer call (see rsparse_hip_profile_last)"""
-        buf = (ctypes.c_double * 4)()
+        buf = (ctypes.c_double * 8)()
         _lib.check(self.lib.rsparse_hip_profile_last(buf))
         return list(buf)
 
@@ -109,10 +109,11 @@ class _CscHandle:
         self.n_rows, self.n_cols = n_rows, n_cols
 
     def info(self):
-        buf = (ctypes.c_int64 * 8)()
+        buf = (ctypes.c_int64 * 24)()
         _lib.check(self.lib.rsparse_hip_csc_info(self.h, buf))
         return dict(n_rows=buf[0], n_cols=buf[1], nnz=buf[2], n_long=buf[3], max_len=buf[4], nnz_long=buf[5],
-                    n_empty=buf[6], tile_nnz=buf[7])
+                    n_empty=buf[6], tile_nnz=buf[7], bucket_rows=list(buf[8:13]), bucket_nnz=list(buf[13:18]),
+                    cgq_cfg=buf[18])
 
     def __del__(self):
         try:

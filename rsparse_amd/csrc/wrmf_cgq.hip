@@ -105,13 +105,36 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
   const int team_global = blockIdx.x * TEAMS + team;
   const int total_teams = gridDim.x * TEAMS;
 
+  // Row metadata runs two iterations ahead of the solve (row id) / one ahead (row pointers), so the
+  // rows[] -> col_ptrs[] dependent loads are off the critical path.
+  auto row_index = [&](int itn) { return team_global + itn * total_teams; };
+  int row_c = 0, p1_c = 0, p2_c = 0, row_n = 0;
+  if (rows_per_team > 0 && row_index(0) < n_rows) {
+    row_c = rows[row_index(0)];
+    p1_c = a.col_ptrs[row_c];
+    p2_c = a.col_ptrs[row_c + 1];
+  }
+  if (rows_per_team > 1 && row_index(1) < n_rows) row_n = rows[row_index(1)];
+
   for (int it = 0; it < rows_per_team; ++it) {
-    const int ri = team_global + it * total_teams;
+    const int ri = row_index(it);
     const bool have = ri < n_rows;
     if (WPR == 1 && !have) break;  // no barriers on this path: a wave may simply stop
-    const int row = have ? rfl(rows[ri]) : 0;
-    const int p1 = have ? rfl(a.col_ptrs[row]) : 0;
-    const int p2 = have ? rfl(a.col_ptrs[row + 1]) : 0;
+    const int row = have ? rfl(row_c) : 0;
+    const int p1 = have ? rfl(p1_c) : 0;
+    const int p2 = have ? rfl(p2_c) : 0;
+    {  // issue the loads for the next iterations now; they are consumed at the top of the next iteration
+      int p1_n = 0, p2_n = 0, row_nn = 0;
+      if (it + 1 < rows_per_team && row_index(it + 1) < n_rows) {
+        p1_n = a.col_ptrs[row_n];
+        p2_n = a.col_ptrs[row_n + 1];
+      }
+      if (it + 2 < rows_per_team && row_index(it + 2) < n_rows) row_nn = rows[row_index(it + 2)];
+      row_c = row_n;
+      p1_c = p1_n;
+      p2_c = p2_n;
+      row_n = row_nn;
+    }
     const int cnt = p2 - p1;
     float* yrow = a.Y + (size_t)row * k;
     if (WPR == 1 && cnt <= 0) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
@@ -128,27 +151,38 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
     float cv[CAPQ];       // its confidence / rating (uniform inside the group)
     int ccnt = 0;
 
+    // Gather n (1..CAP) non-zeros starting at `base` into the registers.  Two branch-light phases so that
+    // all index loads, then all vector loads, are in flight together (two dependent HBM round trips per
+    // chunk instead of two per quad).  Slots beyond n are clamped duplicates of the last non-zero (finite
+    // data, masked out by `valid` in quad_pass); blocks of QB quads beyond n are skipped (wave-uniform).
     auto gather = [&](const int base, const int n) {
+      constexpr int QB = 4;
+      static_assert(CAPQ % QB == 0, "CAPQ must be a multiple of the quad block");
+      int id[CAPQ];
 #pragma unroll
-      for (int q = 0; q < CAPQ; q++) {
-        cv[q] = 0.f;
+      for (int q0 = 0; q0 < CAPQ; q0 += QB) {
+        if (4 * q0 < n) {
 #pragma unroll
-        for (int r = 0; r < RPN; r++) xt[q][r] = 0.f;
-        if (4 * q < n) {  // wave-uniform
-          const int j = 4 * q + g;
-          if (j < n) {
-            const int id = a.row_idx[base + j];
+          for (int q = q0; q < q0 + QB; q++) {
+            const int j = min(4 * q + g, n - 1);
+            id[q] = a.row_idx[base + j];
             cv[q] = a.vals[base + j];
-            const float* src = a.X + (size_t)id * k;
+          }
+        }
+      }
+#pragma unroll
+      for (int q0 = 0; q0 < CAPQ; q0 += QB) {
+        if (4 * q0 < n) {
+#pragma unroll
+          for (int q = q0; q < q0 + QB; q++) {
+            const float* src = a.X + (size_t)id[q] * k;
 #pragma unroll
             for (int b = 0; b < NV; b++) {
               const int off = b * 16 * VW + i * VW;
-              if (off < k) {
-                const piece_t pc = *reinterpret_cast<const piece_t*>(src + off);
-                const float* pf = reinterpret_cast<const float*>(&pc);
+              const piece_t pc = *reinterpret_cast<const piece_t*>(src + min(off, k - VW));
+              const float* pf = reinterpret_cast<const float*>(&pc);
 #pragma unroll
-                for (int c = 0; c < VW; c++) xt[q][b * VW + c] = pf[c];
-              }
+              for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
             }
           }
         }
@@ -175,25 +209,36 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
 
     // one pass over the resident quads: t = X_nnz^T v, then acc += X_nnz w  (or the loss terms)
     auto quad_pass = [&](const float(&v)[RPN], const int mode, float(&acc)[RPN], float& lacc) {
+      constexpr int QB = 4;  // quads per block: 4 independent dot/DPP chains interleave inside one basic block
 #pragma unroll
-      for (int q = 0; q < CAPQ; q++) {
-        if (4 * q < ccnt) {  // wave-uniform
-          float s = 0.f;
+      for (int q0 = 0; q0 < CAPQ; q0 += QB) {
+        if (4 * q0 < ccnt) {  // wave-uniform
+          float t[QB];
 #pragma unroll
-          for (int rr = 0; rr < RPN; rr++) s = fmaf(xt[q][rr], v[rr], s);
-          const float t = row16_sum(s);
-          const bool valid = 4 * q + g < ccnt;
-          const float c = cv[q];
-          if (mode == 2) {
-            const float d = IMPLICIT ? 1.f - t : c - t;
-            lacc += valid ? (IMPLICIT ? c * d * d : d * d) : 0.f;
-          } else {
-            float w;
-            if (mode == 0) w = IMPLICIT ? c - (c - 1.f) * t : c - t;
-            else w = IMPLICIT ? (c - 1.f) * t : t;
-            w = valid ? w : 0.f;
+          for (int u = 0; u < QB; u++) {
+            float s = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < RPN; rr++) acc[rr] = fmaf(w, xt[q][rr], acc[rr]);
+            for (int rr = 0; rr < RPN; rr++) s = fmaf(xt[q0 + u][rr], v[rr], s);
+            t[u] = s;
+          }
+#pragma unroll
+          for (int u = 0; u < QB; u++) t[u] = row16_sum(t[u]);
+#pragma unroll
+          for (int u = 0; u < QB; u++) {
+            const int q = q0 + u;
+            const bool valid = 4 * q + g < ccnt;
+            const float c = cv[q];
+            if (mode == 2) {
+              const float d = IMPLICIT ? 1.f - t[u] : c - t[u];
+              lacc += valid ? (IMPLICIT ? c * d * d : d * d) : 0.f;
+            } else {
+              float w;
+              if (mode == 0) w = IMPLICIT ? c - (c - 1.f) * t[u] : c - t[u];
+              else w = IMPLICIT ? (c - 1.f) * t[u] : t[u];
+              w = valid ? w : 0.f;
+#pragma unroll
+              for (int rr = 0; rr < RPN; rr++) acc[rr] = fmaf(w, xt[q][rr], acc[rr]);
+            }
           }
         }
       }

@@ -181,7 +181,7 @@ def main():
 
     # ---- per-kernel durations (HIP events inside the library, same stream), separate pass ----
     be.profile(True)
-    nb = 5
+    nb = 6
     kern = {sd: {"bucket": [[] for _ in range(nb)], "gram": []} for sd in ("items", "users")}
     half_ms = {"items": [], "users": []}
     for _ in range(max(1, min(args.steps, 3))):
@@ -201,20 +201,19 @@ def main():
     be.profile(False)
     mean = lambda v: float(np.mean(v)) if len(v) else 0.0
     info = {"users": als.csc_users.info(), "items": als.csc_items.info()}
-    cfg = int(info["users"]["cgq_cfg"])
-    waves, capq = (16, 8) if cfg == 0 else (8, 16)
+    waves = int(info["users"]["cgq_waves"])
     # per bucket: launches (one per half-iteration that has rows in it), mean duration, algorithmic bytes
     buckets = []
     for b in range(nb):
-        wpr = waves >> b
+        wpr = int(info["users"]["bucket_wpr"][b])
         if wpr <= 0:
             continue
         ms = [mean(kern[sd]["bucket"][b]) for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
         by = [algorithmic_bytes(info[sd]["bucket_rows"][b], info[sd]["bucket_nnz"][b], k,
-                                info[sd]["n_empty"] if wpr == 1 else 0)
+                                info[sd]["n_empty"] if b == nb - 1 or info["users"]["bucket_wpr"][min(b + 1, nb - 1)] <= 0 else 0)
               for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
         if ms:
-            buckets.append({"kernel": "als_cgq_kernel<%d,%d,%d,%d,implicit>" % (k if k in (32, 64, 128) else k, capq, waves, wpr),
+            buckets.append({"kernel": "als_cgq_kernel bucket %d (W=%d, %d waves/row%s)" % (b, waves, wpr, ", streamed" if b == 0 else ""),
                             "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),
                             "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms))})
     dom = max(buckets, key=lambda d: d["total_ms_per_iteration"]) if buckets else None

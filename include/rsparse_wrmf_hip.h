@@ -133,9 +133,9 @@ int rsparse_hip_csc_create_device(int n_rows, int n_cols, const int32_t* d_col_p
 int rsparse_hip_csc_destroy(rsparse_hip_csc* m);
 /* info_out: [0] n_rows, [1] n_cols, [2] nnz, [3] rows with more than [7] non-zeros ("long" rows),
  * [4] longest row, [5] non-zeros in long rows, [6] empty rows, [7] per-wave tile capacity (32),
- * [8..12] rows and [13..17] non-zeros per CG launch bucket (bucket b = teams of W>>b waves per row),
- * [18] CG geometry (0: W = 16 waves x 32 resident non-zeros, 1: W = 8 waves x 64), rest reserved (0). */
-int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[24]);
+ * [8..13] rows and [14..19] non-zeros per CG launch bucket, [20] CG geometry id, [21] waves per
+ * workgroup, [22..27] waves per row (team size) of each bucket (0 = bucket unused), rest reserved (0). */
+int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[32]);
 
 /* XtX = X X^T + fl(lambda) I on the device (MFMA).  d_sumsq_out (nullable, device double[1])
  * receives sum(X^2) = trace before the ridge -- the `accu(X % X)` term of the loss
@@ -166,8 +166,8 @@ int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, con
 
 /* Kernel timing for measurement harnesses (bench.py): when enabled, every device-layer call brackets
  * its kernels with HIP events on the caller's stream.  rsparse_hip_profile_last() waits for the last
- * call and returns milliseconds per kernel in launch order: CG half-iterations -> [0..4] the five
- * als_cgq_kernel launches (teams of 16/8/4/2/1 waves per row), [5] loss reduction (with the LDS-tile
+ * call and returns milliseconds per kernel in launch order: CG half-iterations -> [0..5] the
+ * als_cgq_kernel launches (one per bucket of rsparse_hip_csc_info), [6] loss reduction (with the LDS-tile
  * fallback kernels: [0] short-row, [1] long-row, [2] loss); Cholesky -> [0]; Gramian -> [0] MFMA partial
  * kernel, [1] reduction. */
 int rsparse_hip_profile_enable(int on);

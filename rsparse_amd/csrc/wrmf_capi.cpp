@@ -105,7 +105,7 @@ struct Profiler {
   bool on = false;
   bool have = false;
   int nseg = 0;
-  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t* begin() {
     have = false;
     if (!on) return nullptr;
@@ -163,14 +163,14 @@ int build_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
 // every row, longest first, with the bucket boundaries of the quad-layout CG kernels
 int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   const int n = d.n_cols;
-  for (int b = 0; b < 6; b++) d.q_off[b] = 0;
-  for (int b = 0; b < 5; b++) d.q_nnz[b] = 0;
+  for (int b = 0; b < 7; b++) d.q_off[b] = 0;
+  for (int b = 0; b < 6; b++) d.q_nnz[b] = 0;
   d.q_order = nullptr;
   d.q_cfg = cgq_default_cfg();
   if (n <= 0) return RSPARSE_HIP_OK;
   const int max_len = d.max_len;
   std::vector<int64_t> start((size_t)max_len + 2, 0);
-  int cnt_b[5] = {0, 0, 0, 0, 0};
+  int cnt_b[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < n; i++) {
     const int len = host_col_ptrs[i + 1] - host_col_ptrs[i];
     start[(size_t)(max_len - len) + 1]++;
@@ -184,7 +184,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     const int len = host_col_ptrs[i + 1] - host_col_ptrs[i];
     order[(size_t)start[(size_t)(max_len - len)]++] = i;
   }
-  for (int b = 0; b < 5; b++) d.q_off[b + 1] = d.q_off[b] + cnt_b[b];
+  for (int b = 0; b < 6; b++) d.q_off[b + 1] = d.q_off[b] + cnt_b[b];
   HIP_TRY(hipMalloc(&d.q_order, (size_t)n * sizeof(int32_t)));
   HIP_TRY(hipMemcpy(d.q_order, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
   return RSPARSE_HIP_OK;
@@ -238,7 +238,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   QSchedule qs;
   qs.order = d.q_order;
   qs.cfg = d.q_cfg;
-  for (int b = 0; b < 6; b++) qs.off[b] = d.q_off[b];
+  for (int b = 0; b < 7; b++) qs.off[b] = d.q_off[b];
   const size_t slots = cgq ? cgq_loss_slots(qs) : (cg ? cg_loss_slots(d.n_cols, d.n_long) : chol_loss_slots(d.n_cols));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
   double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
@@ -260,7 +260,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   e = launch_sum_partials(g_ws.partials, slots, out, s);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
   if (ev) {
-    const int last = cgq ? 6 : 3;
+    const int last = cgq ? 7 : 3;
     HIP_TRY(hipEventRecord(ev[last], s));
     g_prof.have = true;
     g_prof.nseg = last;
@@ -441,14 +441,16 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   return RSPARSE_HIP_OK;
 }
 
-int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[24]) {
+int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[32]) {
   if (!m || !info_out) return fail(RSPARSE_HIP_ERR_INVALID, "NULL argument");
-  for (int b = 0; b < 24; b++) info_out[b] = 0;
-  for (int b = 0; b < 5; b++) {
+  for (int b = 0; b < 32; b++) info_out[b] = 0;
+  for (int b = 0; b < 6; b++) {
     info_out[8 + b] = m->d.q_off[b + 1] - m->d.q_off[b];
-    info_out[13 + b] = m->d.q_nnz[b];
+    info_out[14 + b] = m->d.q_nnz[b];
   }
-  info_out[18] = m->d.q_cfg;
+  info_out[20] = m->d.q_cfg;
+  info_out[21] = cgq_cfg_waves(m->d.q_cfg);
+  for (int b = 0; b < 6; b++) info_out[22 + b] = cgq_bucket_wpr(m->d.q_cfg, b);
   info_out[0] = m->d.n_rows; info_out[1] = m->d.n_cols; info_out[2] = m->d.nnz;
   info_out[3] = m->d.n_long; info_out[4] = m->d.max_len; info_out[5] = m->d.nnz_long;
   info_out[6] = m->d.n_empty; info_out[7] = m->d.short_max;

@@ -16,10 +16,10 @@
 // and once per sweep the 4 group partials are all-reduced (2 xor-shuffles per register).  The dense
 // G*v product is split over the groups by k-range and folded into the same all-reduce.
 //
-// Rows longer than one wave's capacity (CAP = 32 non-zeros) are solved by teams of WPR = 2/4/8/16 waves
-// of one 1024-thread workgroup: every wave keeps its own 32-nnz chunk resident, partial vectors are
-// combined through LDS with one barrier per CG sweep.  Rows beyond 16*CAP are streamed: each wave
-// re-gathers its chunks (L2 / Infinity Cache hits) in every sweep.
+// Rows longer than one wave's capacity (64 non-zeros = 128 VGPRs) are solved by teams of WPR = 2/4/8
+// waves of one workgroup: every wave keeps its own chunk resident, partial vectors are combined through
+// LDS with one barrier per CG sweep.  Rows beyond the workgroup's capacity are streamed: each wave
+// re-gathers its chunks (L2 / Infinity Cache hits) in every sweep (STREAM = 1 instantiation).
 #include <cstdlib>
 
 #include "wrmf_internal.h"
@@ -71,7 +71,7 @@ struct QSmem {
   static constexpr size_t bytes = (gram_floats + vec_floats + red_floats) * 4 + 16;
 };
 
-template <int KP, int CAPQ, int WAVES, int WPR, bool IMPLICIT>
+template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT>
 __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
                                                              int rows_per_team, size_t loss_slot0) {
   using G_ = QG<KP>;
@@ -142,8 +142,9 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
       continue;
     }
     const int nchunks = (cnt + CAP - 1) / CAP;
-    // only the full-workgroup teams ever see rows beyond their resident capacity (bucket thresholds)
-    const bool resident = (WPR == WAVES) ? (nchunks <= WPR) : true;
+    // STREAM == 0: every row of this launch fits the team's resident capacity (bucket thresholds);
+    // STREAM == 1: rows beyond it -- each wave re-gathers its chunks in every sweep.
+    constexpr bool resident = STREAM == 0;
     const float lam_use =
         IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)cnt : 1.0));
 
@@ -151,40 +152,28 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
     float cv[CAPQ];       // its confidence / rating (uniform inside the group)
     int ccnt = 0;
 
-    // Gather n (1..CAP) non-zeros starting at `base` into the registers.  Two branch-light phases so that
-    // all index loads, then all vector loads, are in flight together (two dependent HBM round trips per
-    // chunk instead of two per quad).  Slots beyond n are clamped duplicates of the last non-zero (finite
-    // data, masked out by `valid` in quad_pass); blocks of QB quads beyond n are skipped (wave-uniform).
+    // Gather n (1..CAP) non-zeros starting at `base` into the registers: all index loads, then all vector
+    // loads, with no control flow in between (two dependent HBM round trips per chunk; per-block branches
+    // here cost ~40 VGPRs of PHI copies and spill).  Slots beyond n are clamped duplicates of the last
+    // non-zero (same cache lines, finite data) and are masked out by `valid` in quad_pass.
     auto gather = [&](const int base, const int n) {
-      constexpr int QB = 4;
-      static_assert(CAPQ % QB == 0, "CAPQ must be a multiple of the quad block");
       int id[CAPQ];
 #pragma unroll
-      for (int q0 = 0; q0 < CAPQ; q0 += QB) {
-        if (4 * q0 < n) {
-#pragma unroll
-          for (int q = q0; q < q0 + QB; q++) {
-            const int j = min(4 * q + g, n - 1);
-            id[q] = a.row_idx[base + j];
-            cv[q] = a.vals[base + j];
-          }
-        }
+      for (int q = 0; q < CAPQ; q++) {
+        const int j = min(4 * q + g, n - 1);
+        id[q] = a.row_idx[base + j];
+        cv[q] = a.vals[base + j];
       }
 #pragma unroll
-      for (int q0 = 0; q0 < CAPQ; q0 += QB) {
-        if (4 * q0 < n) {
+      for (int q = 0; q < CAPQ; q++) {
+        const float* src = a.X + (size_t)id[q] * k;
 #pragma unroll
-          for (int q = q0; q < q0 + QB; q++) {
-            const float* src = a.X + (size_t)id[q] * k;
+        for (int b = 0; b < NV; b++) {
+          const int off = b * 16 * VW + i * VW;
+          const piece_t pc = *reinterpret_cast<const piece_t*>(src + min(off, k - VW));
+          const float* pf = reinterpret_cast<const float*>(&pc);
 #pragma unroll
-            for (int b = 0; b < NV; b++) {
-              const int off = b * 16 * VW + i * VW;
-              const piece_t pc = *reinterpret_cast<const piece_t*>(src + min(off, k - VW));
-              const float* pf = reinterpret_cast<const float*>(&pc);
-#pragma unroll
-              for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
-            }
-          }
+          for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
         }
       }
     };
@@ -338,6 +327,10 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
           for (int w2 = 0; w2 < WPR; w2++) lacc += sRedL[buf * WAVES + team * WPR + w2];
         }
         buf ^= 1;
+      } else {
+        // no barrier on this path: pin the schedule at sweep boundaries like the barrier does for teams,
+        // otherwise the scheduler hoists the next sweep's LDS/global loads and the allocator spills
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (mode != 2) {
 #pragma unroll
@@ -410,27 +403,31 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
   if (lane == 0) a.loss_partials[loss_slot0 + (size_t)blockIdx.x * WAVES + wv] = wloss;
 }
 
-// Two build-time geometries, chosen at run time (RSPARSE_HIP_CGQ_CFG):
-//   cfg 0: 16 waves per workgroup (4 per SIMD, 128-VGPR budget), 8 quads = 32 non-zeros resident per wave
-//   cfg 1:  8 waves per workgroup (2 per SIMD, 256-VGPR budget), 16 quads = 64 non-zeros resident per wave
-template <int CFG> struct QCfg;
-template <> struct QCfg<0> { static constexpr int WAVES = 16, CAPQ = 8; };
-template <> struct QCfg<1> { static constexpr int WAVES = 8, CAPQ = 16; };
+// Launch table.  A geometry is (waves per workgroup W, quads resident per wave); rows are bucketed by
+// length and each bucket gets the smallest team whose resident capacity holds the row:
+//   bucket 0  streamed rows (longer than W*64), teams of W waves
+//   bucket 1..  resident rows, teams of W, W/2, ... 1 waves (64 non-zeros per wave)
+//   last      rows of <= 32 non-zeros, one wave per row, 32-slot tile (half the redundant gather slots)
+// cfg 0: W = 8 (one 512-thread workgroup per CU); cfg 1: W = 4 (two 256-thread workgroups per CU, which
+// run out of phase and overlap one workgroup's gather with the other's sweeps).  Both use <= 256 VGPRs.
+struct BucketDef { int wpr, capq, stream, max_len; };
+constexpr int kNB = 6;
+constexpr BucketDef kBuckets[2][kNB] = {
+    {{8, 16, 1, 0x7fffffff}, {8, 16, 0, 512}, {4, 16, 0, 256}, {2, 16, 0, 128}, {1, 16, 0, 64}, {1, 8, 0, 32}},
+    {{4, 16, 1, 0x7fffffff}, {4, 16, 0, 256}, {2, 16, 0, 128}, {1, 16, 0, 64}, {1, 8, 0, 32}, {0, 0, 0, -1}},
+};
+constexpr int kCfgWaves[2] = {8, 4};
 
-inline int cfg_waves(int cfg) { return cfg == 0 ? QCfg<0>::WAVES : QCfg<1>::WAVES; }
-inline int cfg_cap(int cfg) { return 4 * (cfg == 0 ? QCfg<0>::CAPQ : QCfg<1>::CAPQ); }
-inline int bucket_wpr(int cfg, int b) { return cfg_waves(cfg) >> b; }  // 0 -> bucket unused
-
-template <int KP, int CFG, int WPR, bool IMPLICIT>
-hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, size_t slot0, hipStream_t s) {
+template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT>
+hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int cfg, size_t slot0, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
-  constexpr int WAVES = QCfg<CFG>::WAVES, CAPQ = QCfg<CFG>::CAPQ, TEAMS = WAVES / WPR;
-  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, IMPLICIT>;
+  constexpr int TEAMS = WAVES / WPR;
+  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>;
   const size_t lds = QSmem<KP, WAVES, WPR, IMPLICIT>::bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  const int grid = cgq_bucket_grid(n_rows, WPR, CFG);
+  const int grid = cgq_bucket_grid(n_rows, WPR, cfg);
   const int total_teams = grid * TEAMS;
   const int rpt = (n_rows + total_teams - 1) / total_teams;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a, rows, n_rows, rpt, slot0);
@@ -439,55 +436,60 @@ hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, size
 
 template <int KP, int CFG, bool IMPLICIT>
 hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEvent_t* ev) {
-  constexpr int WAVES = QCfg<CFG>::WAVES;
+  constexpr int W = kCfgWaves[CFG];
   hipError_t err;
   size_t slot = 0;
-  // longest rows first: bucket b = teams of WAVES >> b waves per row (bucket 0 also streams over-long rows)
-#define RSP_BUCKET(B)                                                                                      \
-  {                                                                                                        \
-    constexpr int WPRV = (WAVES >> B) > 0 ? (WAVES >> B) : 1;                                              \
-    const int n = q.off[B + 1] - q.off[B];                                                                 \
-    if (ev && (err = hipEventRecord(ev[B], s)) != hipSuccess) return err;                                  \
-    if ((WAVES >> B) > 0) {                                                                                \
-      if ((err = launch_bucket<KP, CFG, WPRV, IMPLICIT>(a, q.order + q.off[B], n, slot, s)) != hipSuccess) return err; \
-      slot += (size_t)cgq_bucket_grid(n, WPRV, CFG) * WAVES;                                               \
-    }                                                                                                      \
+#define RSP_BUCKET(B)                                                                                       \
+  {                                                                                                         \
+    constexpr BucketDef D = kBuckets[CFG][B];                                                               \
+    if (ev && (err = hipEventRecord(ev[B], s)) != hipSuccess) return err;                                   \
+    if constexpr (D.wpr > 0) {                                                                              \
+      const int n = q.off[B + 1] - q.off[B];                                                                \
+      if ((err = launch_bucket<KP, W, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, CFG, slot, s)) != \
+          hipSuccess)                                                                                       \
+        return err;                                                                                         \
+      slot += (size_t)cgq_bucket_grid(n, D.wpr, CFG) * W;                                                   \
+    }                                                                                                       \
   }
   RSP_BUCKET(0)
   RSP_BUCKET(1)
   RSP_BUCKET(2)
   RSP_BUCKET(3)
   RSP_BUCKET(4)
+  RSP_BUCKET(5)
 #undef RSP_BUCKET
-  if (ev && (err = hipEventRecord(ev[5], s)) != hipSuccess) return err;
+  if (ev && (err = hipEventRecord(ev[kNB], s)) != hipSuccess) return err;
   return hipSuccess;
 }
 
 }  // namespace
 
+int cgq_num_buckets() { return kNB; }
+int cgq_bucket_wpr(int cfg, int b) { return kBuckets[cfg][b].wpr; }
+int cgq_bucket_capq(int cfg, int b) { return kBuckets[cfg][b].capq; }
+int cgq_cfg_waves(int cfg) { return kCfgWaves[cfg]; }
+
 int cgq_bucket_grid(int n_rows, int wpr, int cfg) {
-  if (n_rows <= 0) return 0;
-  const int teams = cfg_waves(cfg) / wpr;
-  const int rows_per_team = wpr == 1 ? 16 : (wpr <= 4 ? 8 : 4);  // amortise the 64 KB Gramian load
+  if (n_rows <= 0 || wpr <= 0) return 0;
+  const int teams = kCfgWaves[cfg] / wpr;
+  const int rows_per_team = wpr == 1 ? 16 : (wpr == 2 ? 8 : 4);  // amortise the 64 KB Gramian load
   const long per_wg = (long)teams * rows_per_team;
   long grid = (n_rows + per_wg - 1) / per_wg;
   if (grid < 1) grid = 1;
   return (int)grid;
 }
 
-int cgq_bucket_of(int len, int cfg) {  // smallest team whose resident capacity holds the row
-  const int cap = cfg_cap(cfg);
-  int b = 0;
-  while (b < 4 && bucket_wpr(cfg, b + 1) > 0 && len <= cap * bucket_wpr(cfg, b + 1)) b++;
-  return b;
+int cgq_bucket_of(int len, int cfg) {  // last (smallest-team) bucket whose capacity holds the row
+  int best = 0;
+  for (int b = 0; b < kNB; b++)
+    if (kBuckets[cfg][b].wpr > 0 && len <= kBuckets[cfg][b].max_len) best = b;
+  return best;
 }
 
 size_t cgq_loss_slots(const QSchedule& q) {
   size_t n = 0;
-  for (int b = 0; b < 5; b++) {
-    const int wpr = bucket_wpr(q.cfg, b);
-    if (wpr > 0) n += (size_t)cgq_bucket_grid(q.off[b + 1] - q.off[b], wpr, q.cfg) * cfg_waves(q.cfg);
-  }
+  for (int b = 0; b < kNB; b++)
+    n += (size_t)cgq_bucket_grid(q.off[b + 1] - q.off[b], kBuckets[q.cfg][b].wpr, q.cfg) * kCfgWaves[q.cfg];
   return n;
 }
 

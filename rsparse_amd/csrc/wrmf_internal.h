@@ -20,11 +20,11 @@ struct DevCSC {
   int short_max = 0;  // tile capacity T the schedule was built for
   int max_len = 0;
   // quad-layout CG schedule: every row, longest first; bucket b occupies order[q_off[b], q_off[b+1])
-  // (b = 0..4 -> teams of 16/8/4/2/1 waves per row)
+  // (bucket table: wrmf_cgq.hip kBuckets)
   int32_t* q_order = nullptr;
-  int q_off[6] = {0, 0, 0, 0, 0, 0};
+  int q_off[7] = {0, 0, 0, 0, 0, 0, 0};
   int q_cfg = 0;
-  int64_t q_nnz[5] = {0, 0, 0, 0, 0};
+  int64_t q_nnz[6] = {0, 0, 0, 0, 0, 0};
   int64_t nnz_long = 0;
   int n_empty = 0;
   bool owns_matrix = false;
@@ -51,14 +51,18 @@ struct AlsArgs {
 
 struct QSchedule {
   const int32_t* order;
-  int off[6];
-  int cfg;  // geometry the schedule was built for (see wrmf_cgq.hip QCfg)
+  int off[7];
+  int cfg;  // geometry the schedule was built for (see wrmf_cgq.hip kBuckets)
 };
 int cgq_default_cfg();
+int cgq_num_buckets();               // 6
+int cgq_bucket_wpr(int cfg, int b);  // waves per row of bucket b (0 = unused)
+int cgq_bucket_capq(int cfg, int b);
+int cgq_cfg_waves(int cfg);
 int cgq_bucket_grid(int n_rows, int wpr, int cfg);
 int cgq_bucket_of(int len, int cfg);
 size_t cgq_loss_slots(const QSchedule& q);
-// ev (optional): 6 events, ev[b] before bucket b's kernel, ev[5] after the last one
+// ev (optional): 7 events, ev[b] before bucket b's kernel, ev[6] after the last one
 hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 
 // tile capacity (non-zeros per wave tile) the CG kernels are instantiated for

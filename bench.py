@@ -213,7 +213,9 @@ def main():
                                 info[sd]["n_empty"] if b == nb - 1 or info["users"]["bucket_wpr"][min(b + 1, nb - 1)] <= 0 else 0)
               for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
         if ms:
-            buckets.append({"kernel": "als_cgq_kernel bucket %d (W=%d, %d waves/row%s)" % (b, waves, wpr, ", streamed" if b == 0 else ""),
+            kp = 32 if k <= 32 else (64 if k <= 64 else 128)
+            buckets.append({"kernel": "als_cgq_kernel<%d, %d, %d, %d, %d, true>" % (kp, info["users"]["bucket_capq"][b], waves, wpr, 1 if b == 0 else 0),
+                            "what": "rows on teams of %d wave(s)%s" % (wpr, ", streamed (longer than the workgroup's resident capacity)" if b == 0 else ", register-resident"),
                             "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),
                             "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms))})
     dom = max(buckets, key=lambda d: d["total_ms_per_iteration"]) if buckets else None

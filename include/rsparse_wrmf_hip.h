@@ -134,8 +134,10 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m);
 /* info_out: [0] n_rows, [1] n_cols, [2] nnz, [3] rows with more than [7] non-zeros ("long" rows),
  * [4] longest row, [5] non-zeros in long rows, [6] empty rows, [7] per-wave tile capacity (32),
  * [8..13] rows and [14..19] non-zeros per CG launch bucket, [20] CG geometry id, [21] waves per
- * workgroup, [22..27] waves per row (team size) of each bucket (0 = bucket unused), rest reserved (0). */
-int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[32]);
+ * workgroup, [22..27] waves per row (team size) of each bucket (0 = bucket unused; bucket 0 streams rows
+ * longer than the workgroup's resident capacity), [28..33] resident quads (4 non-zeros) per wave of each
+ * bucket, rest reserved (0). */
+int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[40]);
 
 /* XtX = X X^T + fl(lambda) I on the device (MFMA).  d_sumsq_out (nullable, device double[1])
  * receives sum(X^2) = trace before the ridge -- the `accu(X % X)` term of the loss

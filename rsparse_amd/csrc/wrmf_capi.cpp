@@ -441,16 +441,19 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   return RSPARSE_HIP_OK;
 }
 
-int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[32]) {
+int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[40]) {
   if (!m || !info_out) return fail(RSPARSE_HIP_ERR_INVALID, "NULL argument");
-  for (int b = 0; b < 32; b++) info_out[b] = 0;
+  for (int b = 0; b < 40; b++) info_out[b] = 0;
   for (int b = 0; b < 6; b++) {
     info_out[8 + b] = m->d.q_off[b + 1] - m->d.q_off[b];
     info_out[14 + b] = m->d.q_nnz[b];
   }
   info_out[20] = m->d.q_cfg;
   info_out[21] = cgq_cfg_waves(m->d.q_cfg);
-  for (int b = 0; b < 6; b++) info_out[22 + b] = cgq_bucket_wpr(m->d.q_cfg, b);
+  for (int b = 0; b < 6; b++) {
+    info_out[22 + b] = cgq_bucket_wpr(m->d.q_cfg, b);
+    info_out[28 + b] = cgq_bucket_capq(m->d.q_cfg, b);
+  }
   info_out[0] = m->d.n_rows; info_out[1] = m->d.n_cols; info_out[2] = m->d.nnz;
   info_out[3] = m->d.n_long; info_out[4] = m->d.max_len; info_out[5] = m->d.nnz_long;
   info_out[6] = m->d.n_empty; info_out[7] = m->d.short_max;

@@ -13,10 +13,18 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
             name = r.get("Kernel_Name", "")
             if "rsparse" not in name:
                 continue
-            short = name.split("(")[0].replace("void rsparse_hip::(anonymous namespace)::", "")
+            import re
+            m = re.search(r"(als_\w+|gramian_\w+|sum_partials_kernel|trace_kernel|weighted_\w+)(<[^>]*>)?", name)
+            short = (m.group(1) + (m.group(2) or "")) if m else name[:60]
             agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
-    print(k)
-    for c in sorted(agg[k]):
-        v = agg[k][c]
-        print("   %-28s n=%3d mean=%.4g" % (c, len(v), sum(v) / len(v)))
+    d = {c: sum(v) / len(v) for c, v in agg[k].items()}
+    print(k, "dispatches", len(next(iter(agg[k].values()))))
+    for c in sorted(d):
+        print("   %-28s %.4g" % (c, d[c]))
+    if "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"] > 0 and "SQ_WAVES" in d:
+        wc, w = d["SQ_WAVE_CYCLES"], d["SQ_WAVES"]
+        print("   -> of wave-cycles: wait_any %.2f wait_inst %.2f active %.2f | per wave: valu %.0f lds %.0f vmem_rd %.0f vmem_wr %.0f salu %.0f"
+              % (d.get("SQ_WAIT_ANY", 0) / wc, d.get("SQ_WAIT_INST_ANY", 0) / wc, d.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                 d.get("SQ_INSTS_VALU", 0) / w, d.get("SQ_INSTS_LDS", 0) / w, d.get("SQ_INSTS_VMEM_RD", 0) / w,
+                 d.get("SQ_INSTS_VMEM_WR", 0) / w, d.get("SQ_INSTS_SALU", 0) / w))

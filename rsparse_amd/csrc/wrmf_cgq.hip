@@ -56,10 +56,22 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp<0x140>(v);  // row_mirror
   return v;
 }
-// sum over the 4 groups (lanes l, l^16, l^32, l^48); commutative pairing -> bitwise identical in all 4
+// sum over the 4 groups (lanes l, l^16, l^32, l^48), result in all 4, bitwise identical everywhere.
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half of the first with the lower half of the second; fed two copies of v
+// they leave {v_even, v_even | ...} and {v_odd, v_odd | ...}, whose sum is the pairwise all-reduce --
+// pure VALU, no LDS round trip (ds_bpermute costs ~100+ cycles of latency per stage).
 __device__ __forceinline__ float groups_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
   return v;
 }
 

@@ -489,10 +489,10 @@ int cgq_bucket_wpr(int cfg, int b) { return kBuckets[cfg][b].wpr; }
 int cgq_bucket_capq(int cfg, int b) { return kBuckets[cfg][b].capq; }
 int cgq_cfg_waves(int cfg) { return kCfgWaves[cfg]; }
 
-int cgq_bucket_grid(int n_rows, int wpr, int cfg) {
-  if (n_rows <= 0 || wpr <= 0) return 0;
+int cgq_bucket_grid(int n_rows, int wpr, int cfg) {  // wpr < 0 encodes the streamed bucket
   const bool streamed = wpr < 0;
   if (streamed) wpr = -wpr;
+  if (n_rows <= 0 || wpr == 0) return 0;
   const int teams = kCfgWaves[cfg] / wpr;
   // amortise the per-workgroup start-up (64 KB Gramian load, LDS clear) over enough rows; the streamed
   // bucket holds few, very long rows and keeps small workgroup quotas for balance

@@ -253,10 +253,6 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails;
-  {
-    static const char* ab = std::getenv("RSPARSE_HIP_ABLATE");
-    a.ablate = ab ? std::atoi(ab) : 0;
-  }
   hipEvent_t* ev = g_prof.begin();
   hipError_t e = cgq ? launch_als_cgq(a, qs, implicit, s, ev)
                      : (cg ? launch_als_cg(a, implicit, s, ev) : launch_als_chol(a, implicit, s, ev));

@@ -83,7 +83,7 @@ struct QSmem {
   static constexpr size_t bytes = (gram_floats + vec_floats + red_floats) * 4 + 16;
 };
 
-template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, bool PADK>
+template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT>
 __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
                                                              int rows_per_team, size_t loss_slot0) {
   using G_ = QG<KP>;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
 #pragma unroll
       for (int q = 0; q < CAPQ; q++) {
         const int j = min(4 * q + g, n - 1);
-        id[q] = (a.ablate & 4) ? 0 : a.row_idx[base + j];
+        id[q] = a.row_idx[base + j];
         cv[q] = a.vals[base + j];
       }
 #pragma unroll
@@ -182,17 +182,10 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
 #pragma unroll
         for (int b = 0; b < NV; b++) {
           const int off = b * 16 * VW + i * VW;
-          if constexpr (PADK) {  // rank < KP: clamp the address, zero the pad lanes
-            const piece_t pc = *reinterpret_cast<const piece_t*>(src + min(off, k - VW));
-            const float* pf = reinterpret_cast<const float*>(&pc);
+          const piece_t pc = *reinterpret_cast<const piece_t*>(src + min(off, k - VW));
+          const float* pf = reinterpret_cast<const float*>(&pc);
 #pragma unroll
-            for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
-          } else {               // rank == KP: straight vector loads
-            const piece_t pc = *reinterpret_cast<const piece_t*>(src + off);
-            const float* pf = reinterpret_cast<const float*>(&pc);
-#pragma unroll
-            for (int c = 0; c < VW; c++) xt[q][b * VW + c] = pf[c];
-          }
+          for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
         }
       }
     };
@@ -275,8 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
             wave_sync();
           }
         }
-        if (a.ablate & 2) {
-        } else if (resident) {
+        if (resident) {
           quad_pass(v, mode, acc, lacc);
         } else {
           for (int ch = tw; ch < nchunks; ch += WPR) {
@@ -286,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
           }
         }
         if (mode != 2) {
-          if (IMPLICIT && !(a.ablate & 1)) {
+          if constexpr (IMPLICIT) {
             const float sign = mode == 0 ? -1.f : 1.f;
             for (int s4 = tw * 4 + g; s4 < KP / 4; s4 += WPR * 4) {
               const int kk = 4 * s4;
@@ -401,7 +393,7 @@ __global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const in
       }
     }
     float rl = 0.f;
-    sweep(x, 2, ap, rl, live && !(a.ablate & 16));
+    sweep(x, 2, ap, rl, live);
     if (live && tw == 0) {
       const float xx = dot16(x, x);
       wloss += IMPLICIT ? (double)rl + a.lambda_loss * (double)xx : (double)(rl + lam_use * xx);
@@ -438,23 +430,23 @@ constexpr BucketDef kBuckets[2][kNB] = {
 };
 constexpr int kCfgWaves[2] = {8, 4};
 
-template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT, bool PADK>
+template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT>
 hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int cfg, size_t slot0, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   constexpr int TEAMS = WAVES / WPR;
-  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, PADK>;
+  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>;
   const size_t lds = QSmem<KP, WAVES, WPR, IMPLICIT>::bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  const int grid = cgq_bucket_grid(n_rows, STREAM ? -WPR : WPR, cfg);
+  const int grid = cgq_bucket_grid(n_rows, WPR, cfg);
   const int total_teams = grid * TEAMS;
   const int rpt = (n_rows + total_teams - 1) / total_teams;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a, rows, n_rows, rpt, slot0);
   return hipGetLastError();
 }
 
-template <int KP, int CFG, bool IMPLICIT, bool PADK>
+template <int KP, int CFG, bool IMPLICIT>
 hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEvent_t* ev) {
   constexpr int W = kCfgWaves[CFG];
   hipError_t err;
@@ -465,10 +457,10 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
     if (ev && (err = hipEventRecord(ev[B], s)) != hipSuccess) return err;                                   \
     if constexpr (D.wpr > 0) {                                                                              \
       const int n = q.off[B + 1] - q.off[B];                                                                \
-      if ((err = launch_bucket<KP, W, D.capq, D.wpr, D.stream, IMPLICIT, PADK>(a, q.order + q.off[B], n, CFG, slot, s)) != \
+      if ((err = launch_bucket<KP, W, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, CFG, slot, s)) != \
           hipSuccess)                                                                                       \
         return err;                                                                                         \
-      slot += (size_t)cgq_bucket_grid(n, D.stream ? -D.wpr : D.wpr, CFG) * W;                                                  \
+      slot += (size_t)cgq_bucket_grid(n, D.wpr, CFG) * W;                                                   \
     }                                                                                                       \
   }
   RSP_BUCKET(0)
@@ -489,14 +481,13 @@ int cgq_bucket_wpr(int cfg, int b) { return kBuckets[cfg][b].wpr; }
 int cgq_bucket_capq(int cfg, int b) { return kBuckets[cfg][b].capq; }
 int cgq_cfg_waves(int cfg) { return kCfgWaves[cfg]; }
 
-int cgq_bucket_grid(int n_rows, int wpr, int cfg) {  // wpr < 0 encodes the streamed bucket
-  const bool streamed = wpr < 0;
-  if (streamed) wpr = -wpr;
-  if (n_rows <= 0 || wpr == 0) return 0;
+int cgq_bucket_grid(int n_rows, int wpr, int cfg) {
+  if (n_rows <= 0 || wpr <= 0) return 0;
   const int teams = kCfgWaves[cfg] / wpr;
-  // amortise the per-workgroup start-up (64 KB Gramian load, LDS clear) over enough rows; the streamed
-  // bucket holds few, very long rows and keeps small workgroup quotas for balance
-  const int rows_per_team = streamed ? 4 : (wpr == 1 ? 32 : 16);
+  // rows per team: amortises the per-workgroup start-up (64 KB Gramian load, LDS clear)
+  static const char* env = std::getenv("RSPARSE_HIP_RPT");
+  const int scale = env ? std::atoi(env) : 1;
+  const int rows_per_team = (wpr == 1 ? 16 : (wpr == 2 ? 8 : 4)) * (scale > 0 ? scale : 1);
   const long per_wg = (long)teams * rows_per_team;
   long grid = (n_rows + per_wg - 1) / per_wg;
   if (grid < 1) grid = 1;
@@ -513,8 +504,7 @@ int cgq_bucket_of(int len, int cfg) {  // last (smallest-team) bucket whose capa
 size_t cgq_loss_slots(const QSchedule& q) {
   size_t n = 0;
   for (int b = 0; b < kNB; b++)
-    n += (size_t)cgq_bucket_grid(q.off[b + 1] - q.off[b], kBuckets[q.cfg][b].stream ? -kBuckets[q.cfg][b].wpr : kBuckets[q.cfg][b].wpr, q.cfg) *
-         kCfgWaves[q.cfg];
+    n += (size_t)cgq_bucket_grid(q.off[b + 1] - q.off[b], kBuckets[q.cfg][b].wpr, q.cfg) * kCfgWaves[q.cfg];
   return n;
 }
 
@@ -523,17 +513,13 @@ int cgq_default_cfg() {
   return (env && env[0] == '1') ? 1 : 0;
 }
 
-template <int KP, int CFG>
-hipError_t launch_cfg(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev) {
-  const bool pad = a.k != KP;
-  if (implicit) return pad ? launch_all<KP, CFG, true, true>(a, q, s, ev) : launch_all<KP, CFG, true, false>(a, q, s, ev);
-  return pad ? launch_all<KP, CFG, false, true>(a, q, s, ev) : launch_all<KP, CFG, false, false>(a, q, s, ev);
-}
-
 hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(a.k);
-#define RSP_DISPATCH(KPV) \
-  if (KP == KPV) return q.cfg == 0 ? launch_cfg<KPV, 0>(a, q, implicit, s, ev) : launch_cfg<KPV, 1>(a, q, implicit, s, ev);
+#define RSP_DISPATCH(KPV)                                                                                   \
+  if (KP == KPV) {                                                                                          \
+    if (q.cfg == 0) return implicit ? launch_all<KPV, 0, true>(a, q, s, ev) : launch_all<KPV, 0, false>(a, q, s, ev); \
+    return implicit ? launch_all<KPV, 1, true>(a, q, s, ev) : launch_all<KPV, 1, false>(a, q, s, ev);       \
+  }
   RSP_DISPATCH(32)
   RSP_DISPATCH(64)
   RSP_DISPATCH(128)

@@ -47,7 +47,6 @@ struct AlsArgs {
   int dynamic_lambda;
   double* loss_partials;  // one double per wave (short kernel) / per workgroup (long kernel)
   int* fail_counter;      // Cholesky: rows whose system was not positive definite
-  int ablate;             // timing experiments only (RSPARSE_HIP_ABLATE bit mask, 0 in production)
 };
 
 struct QSchedule {

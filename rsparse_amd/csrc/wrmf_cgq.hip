@@ -84,7 +84,7 @@ struct QSmem {
 };
 
 template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT>
-__global__ __launch_bounds__(WAVES * 64) void als_cgq_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
+__global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
                                                              int rows_per_team, size_t loss_slot0) {
   using G_ = QG<KP>;
   constexpr int RPN = G_::RPN, VW = G_::VW, NV = G_::NV, CAP = CAPQ * 4, TEAMS = WAVES / WPR;
@@ -487,7 +487,7 @@ int cgq_bucket_grid(int n_rows, int wpr, int cfg) {
   // rows per team: amortises the per-workgroup start-up (64 KB Gramian load, LDS clear)
   static const char* env = std::getenv("RSPARSE_HIP_RPT");
   const int scale = env ? std::atoi(env) : 1;
-  const int rows_per_team = (wpr == 1 ? 16 : (wpr == 2 ? 8 : 4)) * (scale > 0 ? scale : 1);
+  const int rows_per_team = (wpr == 1 ? 64 : (wpr == 2 ? 32 : 16)) * (scale > 0 ? scale : 1);
   const long per_wg = (long)teams * rows_per_team;
   long grid = (n_rows + per_wg - 1) / per_wg;
   if (grid < 1) grid = 1;

@@ -201,7 +201,6 @@ def main():
     be.profile(False)
     mean = lambda v: float(np.mean(v)) if len(v) else 0.0
     info = {"users": als.csc_users.info(), "items": als.csc_items.info()}
-    waves = int(info["users"]["cgq_waves"])
     # per bucket: launches (one per half-iteration that has rows in it), mean duration, algorithmic bytes
     buckets = []
     for b in range(nb):
@@ -214,8 +213,9 @@ def main():
               for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
         if ms:
             kp = 32 if k <= 32 else (64 if k <= 64 else 128)
-            buckets.append({"kernel": "als_cgq_kernel<%d, %d, %d, %d, %d, true>" % (kp, info["users"]["bucket_capq"][b], waves, wpr, 1 if b == 0 else 0),
-                            "what": "rows on teams of %d wave(s)%s" % (wpr, ", streamed (longer than the workgroup's resident capacity)" if b == 0 else ", register-resident"),
+            iu = info["users"]
+            buckets.append({"kernel": "als_cgq_kernel<%d, %d, %d, %d, %d, true>" % (kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, iu["bucket_stream"][b]),
+                            "what": "rows on teams of %d wave(s)%s" % (wpr, ", streamed (longer than the workgroup's resident capacity)" if iu["bucket_stream"][b] else ", register-resident"),
                             "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),
                             "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms))})
     dom = max(buckets, key=lambda d: d["total_ms_per_iteration"]) if buckets else None

@@ -133,10 +133,9 @@ int rsparse_hip_csc_create_device(int n_rows, int n_cols, const int32_t* d_col_p
 int rsparse_hip_csc_destroy(rsparse_hip_csc* m);
 /* info_out: [0] n_rows, [1] n_cols, [2] nnz, [3] rows with more than [7] non-zeros ("long" rows),
  * [4] longest row, [5] non-zeros in long rows, [6] empty rows, [7] per-wave tile capacity (32),
- * [8..13] rows and [14..19] non-zeros per CG launch bucket, [20] CG geometry id, [21] waves per
- * workgroup, [22..27] waves per row (team size) of each bucket (0 = bucket unused; bucket 0 streams rows
- * longer than the workgroup's resident capacity), [28..33] resident quads (4 non-zeros) per wave of each
- * bucket, rest reserved (0). */
+ * [8..13] rows and [14..19] non-zeros per CG launch bucket, [20] launch-table id, [22..27] waves per row
+ * (team size) of each bucket (0 = bucket unused), [28..33] resident quads (4 non-zeros) per wave,
+ * [34..39] waves per workgroup (negative = the bucket streams rows longer than the resident capacity). */
 int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[40]);
 
 /* XtX = X X^T + fl(lambda) I on the device (MFMA).  d_sumsq_out (nullable, device double[1])

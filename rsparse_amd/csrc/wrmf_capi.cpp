@@ -449,10 +449,10 @@ int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[40]) {
     info_out[14 + b] = m->d.q_nnz[b];
   }
   info_out[20] = m->d.q_cfg;
-  info_out[21] = cgq_cfg_waves(m->d.q_cfg);
   for (int b = 0; b < 6; b++) {
     info_out[22 + b] = cgq_bucket_wpr(m->d.q_cfg, b);
     info_out[28 + b] = cgq_bucket_capq(m->d.q_cfg, b);
+    info_out[34 + b] = cgq_bucket_waves(m->d.q_cfg, b) * (cgq_bucket_stream(m->d.q_cfg, b) ? -1 : 1);
   }
   info_out[0] = m->d.n_rows; info_out[1] = m->d.n_cols; info_out[2] = m->d.nnz;
   info_out[3] = m->d.n_long; info_out[4] = m->d.max_len; info_out[5] = m->d.nnz_long;

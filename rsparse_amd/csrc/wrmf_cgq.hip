@@ -415,23 +415,26 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   if (lane == 0) a.loss_partials[loss_slot0 + (size_t)blockIdx.x * WAVES + wv] = wloss;
 }
 
-// Launch table.  A geometry is (waves per workgroup W, quads resident per wave); rows are bucketed by
-// length and each bucket gets the smallest team whose resident capacity holds the row:
-//   bucket 0  streamed rows (longer than W*64), teams of W waves
-//   bucket 1..  resident rows, teams of W, W/2, ... 1 waves (64 non-zeros per wave)
-//   last      rows of <= 32 non-zeros, one wave per row, 32-slot tile (half the redundant gather slots)
-// cfg 0: W = 8 (one 512-thread workgroup per CU); cfg 1: W = 4 (two 256-thread workgroups per CU, which
-// run out of phase and overlap one workgroup's gather with the other's sweeps).  Both use <= 256 VGPRs.
-struct BucketDef { int wpr, capq, stream, max_len; };
+// Launch table.  Rows are bucketed by length; each bucket is one launch of the kernel instantiated for
+// (waves per workgroup W, waves per row WPR, resident quads per wave, streamed?):
+//   bucket 0  streamed rows (longer than 512 non-zeros): teams of 8 waves, 512-thread workgroups
+//   bucket 1  257..512 non-zeros: resident on 8-wave teams
+//   bucket 2.. 129..256 / 65..128 / 33..64 non-zeros: resident on teams of 4 / 2 / 1 waves of 256-thread
+//             workgroups (two per CU: they run out of phase, one gathers while the other sweeps)
+//   bucket 5  <= 32 non-zeros: one wave per row with a 32-slot tile (half the redundant gather slots)
+// Every instantiation is capped at 256 VGPRs (2 waves per SIMD, 8 waves per CU).
+// cfg 1 / cfg 2 are the uniform W = 8 / W = 4 tables kept for A/B runs (RSPARSE_HIP_CGQ_CFG).
+struct BucketDef { int waves, wpr, capq, stream, max_len; };
 constexpr int kNB = 6;
-constexpr BucketDef kBuckets[2][kNB] = {
-    {{8, 16, 1, 0x7fffffff}, {8, 16, 0, 512}, {4, 16, 0, 256}, {2, 16, 0, 128}, {1, 16, 0, 64}, {1, 8, 0, 32}},
-    {{4, 16, 1, 0x7fffffff}, {4, 16, 0, 256}, {2, 16, 0, 128}, {1, 16, 0, 64}, {1, 8, 0, 32}, {0, 0, 0, -1}},
+constexpr int kNCfg = 3;
+constexpr BucketDef kBuckets[kNCfg][kNB] = {
+    {{8, 8, 16, 1, 0x7fffffff}, {8, 8, 16, 0, 512}, {4, 4, 16, 0, 256}, {4, 2, 16, 0, 128}, {4, 1, 16, 0, 64}, {4, 1, 8, 0, 32}},
+    {{8, 8, 16, 1, 0x7fffffff}, {8, 8, 16, 0, 512}, {8, 4, 16, 0, 256}, {8, 2, 16, 0, 128}, {8, 1, 16, 0, 64}, {8, 1, 8, 0, 32}},
+    {{4, 4, 16, 1, 0x7fffffff}, {4, 4, 16, 0, 256}, {4, 2, 16, 0, 128}, {4, 1, 16, 0, 64}, {4, 1, 8, 0, 32}, {0, 0, 0, 0, -1}},
 };
-constexpr int kCfgWaves[2] = {8, 4};
 
 template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT>
-hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int cfg, size_t slot0, hipStream_t s) {
+hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int grid, size_t slot0, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   constexpr int TEAMS = WAVES / WPR;
   auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>;
@@ -439,7 +442,6 @@ hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int 
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  const int grid = cgq_bucket_grid(n_rows, WPR, cfg);
   const int total_teams = grid * TEAMS;
   const int rpt = (n_rows + total_teams - 1) / total_teams;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a, rows, n_rows, rpt, slot0);
@@ -448,7 +450,6 @@ hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int 
 
 template <int KP, int CFG, bool IMPLICIT>
 hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEvent_t* ev) {
-  constexpr int W = kCfgWaves[CFG];
   hipError_t err;
   size_t slot = 0;
 #define RSP_BUCKET(B)                                                                                       \
@@ -457,10 +458,11 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
     if (ev && (err = hipEventRecord(ev[B], s)) != hipSuccess) return err;                                   \
     if constexpr (D.wpr > 0) {                                                                              \
       const int n = q.off[B + 1] - q.off[B];                                                                \
-      if ((err = launch_bucket<KP, W, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, CFG, slot, s)) != \
-          hipSuccess)                                                                                       \
+      const int grid = cgq_bucket_grid(n, B, CFG);                                                          \
+      if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, grid, slot, \
+                                                                              s)) != hipSuccess)            \
         return err;                                                                                         \
-      slot += (size_t)cgq_bucket_grid(n, D.wpr, CFG) * W;                                                   \
+      slot += (size_t)grid * D.waves;                                                                       \
     }                                                                                                       \
   }
   RSP_BUCKET(0)
@@ -479,15 +481,19 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
 int cgq_num_buckets() { return kNB; }
 int cgq_bucket_wpr(int cfg, int b) { return kBuckets[cfg][b].wpr; }
 int cgq_bucket_capq(int cfg, int b) { return kBuckets[cfg][b].capq; }
-int cgq_cfg_waves(int cfg) { return kCfgWaves[cfg]; }
+int cgq_bucket_waves(int cfg, int b) { return kBuckets[cfg][b].waves; }
+int cgq_bucket_stream(int cfg, int b) { return kBuckets[cfg][b].stream; }
 
-int cgq_bucket_grid(int n_rows, int wpr, int cfg) {
-  if (n_rows <= 0 || wpr <= 0) return 0;
-  const int teams = kCfgWaves[cfg] / wpr;
-  // rows per team: amortises the per-workgroup start-up (64 KB Gramian load, LDS clear)
+int cgq_bucket_grid(int n_rows, int b, int cfg) {
+  const BucketDef d = kBuckets[cfg][b];
+  if (n_rows <= 0 || d.wpr <= 0) return 0;
+  const int teams = d.waves / d.wpr;
+  // rows per team: amortises the per-workgroup start-up (64 KB Gramian load, LDS clear); the streamed
+  // bucket holds few, very long rows and keeps a small quota for balance
   static const char* env = std::getenv("RSPARSE_HIP_RPT");
   const int scale = env ? std::atoi(env) : 1;
-  const int rows_per_team = (wpr == 1 ? 64 : (wpr == 2 ? 32 : 16)) * (scale > 0 ? scale : 1);
+  const int base = d.stream ? 4 : (d.wpr == 1 ? 64 : (d.wpr == 2 ? 32 : 16));
+  const int rows_per_team = base * (scale > 0 ? scale : 1);
   const long per_wg = (long)teams * rows_per_team;
   long grid = (n_rows + per_wg - 1) / per_wg;
   if (grid < 1) grid = 1;
@@ -503,14 +509,14 @@ int cgq_bucket_of(int len, int cfg) {  // last (smallest-team) bucket whose capa
 
 size_t cgq_loss_slots(const QSchedule& q) {
   size_t n = 0;
-  for (int b = 0; b < kNB; b++)
-    n += (size_t)cgq_bucket_grid(q.off[b + 1] - q.off[b], kBuckets[q.cfg][b].wpr, q.cfg) * kCfgWaves[q.cfg];
+  for (int b = 0; b < kNB; b++) n += (size_t)cgq_bucket_grid(q.off[b + 1] - q.off[b], b, q.cfg) * kBuckets[q.cfg][b].waves;
   return n;
 }
 
 int cgq_default_cfg() {
   static const char* env = std::getenv("RSPARSE_HIP_CGQ_CFG");
-  return (env && env[0] == '1') ? 1 : 0;
+  const int c = env ? std::atoi(env) : 0;
+  return (c >= 0 && c < kNCfg) ? c : 0;
 }
 
 hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev) {
@@ -518,7 +524,8 @@ hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, h
 #define RSP_DISPATCH(KPV)                                                                                   \
   if (KP == KPV) {                                                                                          \
     if (q.cfg == 0) return implicit ? launch_all<KPV, 0, true>(a, q, s, ev) : launch_all<KPV, 0, false>(a, q, s, ev); \
-    return implicit ? launch_all<KPV, 1, true>(a, q, s, ev) : launch_all<KPV, 1, false>(a, q, s, ev);       \
+    if (q.cfg == 1) return implicit ? launch_all<KPV, 1, true>(a, q, s, ev) : launch_all<KPV, 1, false>(a, q, s, ev); \
+    return implicit ? launch_all<KPV, 2, true>(a, q, s, ev) : launch_all<KPV, 2, false>(a, q, s, ev);       \
   }
   RSP_DISPATCH(32)
   RSP_DISPATCH(64)

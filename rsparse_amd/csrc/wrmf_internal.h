@@ -58,8 +58,9 @@ int cgq_default_cfg();
 int cgq_num_buckets();               // 6
 int cgq_bucket_wpr(int cfg, int b);  // waves per row of bucket b (0 = unused)
 int cgq_bucket_capq(int cfg, int b);
-int cgq_cfg_waves(int cfg);
-int cgq_bucket_grid(int n_rows, int wpr, int cfg);
+int cgq_bucket_waves(int cfg, int b);  // waves per workgroup of bucket b's kernel
+int cgq_bucket_stream(int cfg, int b);
+int cgq_bucket_grid(int n_rows, int bucket, int cfg);
 int cgq_bucket_of(int len, int cfg);
 size_t cgq_loss_slots(const QSchedule& q);
 // ev (optional): 7 events, ev[b] before bucket b's kernel, ev[6] after the last one

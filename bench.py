@@ -123,12 +123,20 @@ def main():
         if ws == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (ws, args.gpus))
+    # RSPARSE_BENCH_BACKEND=gloo is a dry-run aid: all ranks share cuda:0 and collectives go through gloo, so the
+    # N>1 control flow (sharding, padding, in-place all-gather) can be exercised on a single-GPU box.
+    dry = os.environ.get("RSPARSE_BENCH_BACKEND", "nccl") == "gloo"
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if ws > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=ws)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device("cuda", local_rank))
     be = HipBackend(local_rank)
     dev = be.device
     k, lam = args.rank, args.lam

@@ -164,6 +164,12 @@ class ShardedALS:
 
     def _all_gather_blocks(self, S, B):
         if self.ws > 1:
+            if S.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+                # dry-run configuration only (several ranks sharing one GPU): gloo has no device all-gather
+                host = S.cpu()
+                torch.distributed.all_gather_into_tensor(host, host[self.me * B:(self.me + 1) * B].clone(), group=self.group)
+                S.copy_(host)
+                return
             mine = S[self.me * B:(self.me + 1) * B]
             torch.distributed.all_gather_into_tensor(S, mine, group=self.group)
 

@@ -96,6 +96,36 @@ def test_cholesky_half_iteration(k, implicit):
     assert abs(loss - lref) <= TOL * abs(lref)
 
 
+@pytest.mark.parametrize("k", [128, 96, 64, 20])
+@pytest.mark.parametrize("implicit", [True, False])
+def test_cg_long_rows_all_buckets(k, implicit):
+    """Rows from 1 to ~2500 non-zeros: exercises every launch bucket of the quad-layout CG kernels
+    (one wave per row, teams of 2/4/8 waves, and the streamed path beyond 512 non-zeros), with
+    rank == KP (128, 64) and rank < KP (96, 20) padding."""
+    fb = "implicit" if implicit else "explicit"
+    d = synth.make_dataset(260, 3000, seed=11 + k, mean_deg=400, d_max=2500, feedback=fb, device="cpu")
+    p, i, x = (t.numpy() for t in d["c_iu"])
+    x = x.astype(np.float64)
+    lens = np.diff(p)
+    assert lens.max() > 1024 and (lens <= 32).any() and ((lens > 128) & (lens <= 256)).any()
+    rng = np.random.default_rng(k)
+    X = np.asfortranarray((rng.standard_normal((k, 3000)) * 0.05).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, 260)) * 0.05).astype(np.float32))
+    csc = (3000, 260, p, i, x)
+    cnt = np.bincount(i, minlength=3000).astype(np.float64)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 1, 3, implicit, True, cnt)
+    Y = Y0.copy(order="F")
+    if implicit:
+        loss = als.als_implicit(csc, X, Y, 0.1, 1, 1, 3, "float", False, False)
+    else:
+        loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), 0.1, 1, 1, 3, True, "float", False, False)
+    assert rel_fro(Y, Yref) < TOL
+    assert abs(loss - lref) <= TOL * abs(lref)
+    # per-row check so that one bad bucket cannot hide in the Frobenius norm
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < 5e-4, (int(err.argmax()), int(lens[err.argmax()]), float(err.max()))
+
+
 def test_double_entry_points_and_empty_columns(ml_train):
     """movielens train (test-wrmf.R:6) has items nobody rated -> zero columns (wrmf_implicit.hpp:281)."""
     n_user, n_item, p, i, x = ml_train

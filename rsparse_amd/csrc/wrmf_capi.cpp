@@ -254,8 +254,11 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails;
   hipEvent_t* ev = g_prof.begin();
+  static const char* chol_env = std::getenv("RSPARSE_HIP_CHOL");
+  const bool chol_lds = chol_env && std::strcmp(chol_env, "lds") == 0;
   hipError_t e = cgq ? launch_als_cgq(a, qs, implicit, s, ev)
-                     : (cg ? launch_als_cg(a, implicit, s, ev) : launch_als_chol(a, implicit, s, ev));
+                     : (cg ? launch_als_cg(a, implicit, s, ev)
+                           : (chol_lds ? launch_als_chol(a, implicit, s, ev) : launch_als_chol2(a, implicit, s, ev)));
   if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
   e = launch_sum_partials(g_ws.partials, slots, out, s);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");

@@ -1,0 +1,343 @@
+// Exact (Cholesky) half-iteration, register-blocked (gfx950, wave64).
+//
+// Replaces the solver == CHOLESKY branch of als_implicit<T> / als_explicit<T>
+// (inst/include/wrmf_implicit.hpp:206-208,231,236; inst/include/wrmf_explicit.hpp:103-108):
+//     lhs = XtX + X_nnz diag(c-1) X_nnz^T   (explicit: X_nnz X_nnz^T + lambda_use I),  rhs = X_nnz c,
+//     y = solve(lhs, rhs)   -- Armadillo: LAPACK posv.
+//
+// One 256-thread workgroup per row.  The k x k system never touches LDS as a matrix: thread (I, K) of a
+// 16 x 16 grid owns the BS x BS block (BS = KP/16) of the lower triangle in REGISTERS from the rank-one
+// assembly through the factorisation:
+//   assembly   chunks of 32 gathered vectors staged in LDS, acc[a][b] += x[I*BS+a] * c1 * x[K*BS+b]
+//   factorise  right-looking blocked Cholesky over the 16 block columns: the diagonal thread factors its
+//              block in registers, the panel threads do a BS x BS triangular solve, the trailing threads a
+//              BS^3 update from two BS x BS blocks read from LDS (4 KB panel) -- 2 barriers per block column
+//   solve      forward substitution with 16-lane DPP reductions along block rows, backward substitution
+//              accumulating L^T y into an LDS vector (distinct addresses per thread, no atomics)
+// The Gramian is read from L2 (64 KB per row, cached) instead of LDS, so a workgroup needs only ~25 KB of
+// LDS and several rows are in flight per CU, overlapping one row's serial phases with another's.
+#include "wrmf_internal.h"
+#include "wrmf_device.h"
+
+namespace rsparse_hip {
+namespace {
+
+using namespace dev;
+
+__device__ __forceinline__ float row16_sum_c(float v) {
+  v += dpp<0xB1>(v);
+  v += dpp<0x4E>(v);
+  v += dpp<0x141>(v);
+  v += dpp<0x140>(v);
+  return v;
+}
+
+template <int KP>
+struct Chol2Smem {
+  static constexpr int BS = KP / 16;
+  static constexpr int TC = 32;
+  static constexpr int LDT = KP + 4;
+  static constexpr size_t tile_floats = (size_t)TC * LDT;          // gathered chunk
+  static constexpr size_t panel_floats = (size_t)16 * BS * BS;     // L_IJ blocks of the current block column
+  static constexpr size_t diag_floats = (size_t)BS * BS + BS;      // L_JJ + reciprocals of its diagonal
+  static constexpr size_t vec_floats = (size_t)3 * KP + 2 * TC;    // rhs/z/y, S accumulator, spare, c, c1
+  static constexpr size_t bytes = (tile_floats + panel_floats + diag_floats + vec_floats + 16) * 4 + 64;
+};
+
+template <int KP, bool IMPLICIT>
+__global__ __launch_bounds__(256) void als_chol2_kernel(AlsArgs a) {
+  using SM = Chol2Smem<KP>;
+  constexpr int BS = SM::BS, TC = SM::TC, LDT = SM::LDT, NB = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sT = reinterpret_cast<float*>(smem);
+  float* sL = sT + SM::tile_floats;        // [NB][BS][BS]
+  float* sD = sL + SM::panel_floats;       // [BS][BS] L_JJ, then [BS] 1/diag
+  float* sV = sD + SM::diag_floats;        // [KP] rhs -> z -> y
+  float* sS = sV + KP;                     // [KP] backward accumulator
+  float* sC = sS + 2 * KP;                 // [TC] confidence / rating
+  float* sC1 = sC + TC;                    // [TC] rank-one weight
+  int* sFlag = reinterpret_cast<int*>(sC1 + TC);
+  double* sLoss = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(sFlag + 2) + 7) & ~(uintptr_t)7);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
+  const int I = tid >> 4, K = tid & 15;  // block row / block column owned by this thread
+  const bool lower = I >= K;
+  const int k = a.k;
+  for (int e = tid; e < (int)SM::tile_floats; e += 256) sT[e] = 0.f;
+  if (tid == 0) *sFlag = 0;
+  __syncthreads();
+  double wloss = 0.0;
+
+  for (int row = blockIdx.x; row < a.n_cols; row += gridDim.x) {
+    const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
+    const int cnt = p2 - p1;
+    float* yrow = a.Y + (size_t)row * k;
+    if (cnt <= 0) {
+      for (int e = tid; e < k; e += 256) yrow[e] = 0.f;
+      continue;
+    }
+    const float lam_use =
+        IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)cnt : 1.0));
+
+    // ---------------- assembly ----------------
+    float acc[BS][BS];
+#pragma unroll
+    for (int x = 0; x < BS; x++)
+#pragma unroll
+      for (int y = 0; y < BS; y++) acc[x][y] = 0.f;
+    float rhs = 0.f;  // thread tid < KP owns rhs[tid]
+    for (int base = p1; base < p2; base += TC) {
+      const int ccnt = min(TC, p2 - base);
+      __syncthreads();  // previous chunk (and the previous row's vectors) fully consumed
+      if (tid < ccnt) {
+        const float cvv = a.vals[base + tid];
+        sC[tid] = cvv;
+        sC1[tid] = IMPLICIT ? cvv - 1.f : 1.f;
+      }
+      for (int j = wv; j < ccnt; j += 4) {  // wave w gathers vectors w, w+4, ...
+        const int id = rfl(a.row_idx[base + j]);
+        const float* src = a.X + (size_t)id * k;
+        for (int e = lane; e < k; e += 64) sT[j * LDT + e] = src[e];
+      }
+      __syncthreads();
+      if (lower) {
+        for (int j = 0; j < ccnt; j++) {
+          const float c1 = sC1[j];
+          float av[BS], bv[BS];
+#pragma unroll
+          for (int x = 0; x < BS; x++) {
+            av[x] = sT[j * LDT + I * BS + x];
+            bv[x] = sT[j * LDT + K * BS + x] * c1;
+          }
+#pragma unroll
+          for (int x = 0; x < BS; x++)
+#pragma unroll
+            for (int y = 0; y < BS; y++) acc[x][y] = fmaf(av[x], bv[y], acc[x][y]);
+        }
+      }
+      if (tid < KP) {
+        float s = 0.f;
+        for (int j = 0; j < ccnt; j++) s = fmaf(sC[j], sT[j * LDT + tid], s);
+        rhs += s;
+      }
+    }
+    // + Gramian (implicit, from L2) or lambda_use I (explicit); identity on the padded diagonal
+    if (lower) {
+#pragma unroll
+      for (int x = 0; x < BS; x++)
+#pragma unroll
+        for (int y = 0; y < BS; y++) {
+          const int rr = I * BS + x, cc = K * BS + y;
+          float gv;
+          if (rr >= k || cc >= k) gv = (rr == cc) ? 1.f : 0.f;
+          else if (IMPLICIT) gv = a.XtX[(size_t)rr * k + cc];
+          else gv = (rr == cc) ? lam_use : 0.f;
+          acc[x][y] += gv;
+        }
+    }
+    __syncthreads();
+    if (tid < KP) sV[tid] = rhs;
+    if (tid < KP) sS[tid] = 0.f;
+
+    // ---------------- blocked Cholesky, lower triangle ----------------
+    for (int J = 0; J < NB; J++) {
+      if (I == J && K == J) {  // factor the diagonal block in registers
+        float inv[BS];
+#pragma unroll
+        for (int c = 0; c < BS; c++) {
+          float d = acc[c][c];
+#pragma unroll
+          for (int m = 0; m < BS; m++)
+            if (m < c) d = fmaf(-acc[c][m], acc[c][m], d);
+          if (!(d > 0.f)) { *sFlag = 1; d = 1.f; }
+          const float l = sqrtf(d);
+          acc[c][c] = l;
+          inv[c] = 1.f / l;
+#pragma unroll
+          for (int r2 = 0; r2 < BS; r2++) {
+            if (r2 > c) {
+              float v = acc[r2][c];
+#pragma unroll
+              for (int m = 0; m < BS; m++)
+                if (m < c) v = fmaf(-acc[r2][m], acc[c][m], v);
+              acc[r2][c] = v * inv[c];
+            }
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < BS; x++) {
+#pragma unroll
+          for (int y = 0; y < BS; y++) sD[x * BS + y] = y <= x ? acc[x][y] : 0.f;
+          sD[BS * BS + x] = inv[x];
+        }
+      }
+      __syncthreads();
+      if (K == J && I > J) {  // panel: L_IJ = A_IJ L_JJ^{-T}
+#pragma unroll
+        for (int x = 0; x < BS; x++) {
+#pragma unroll
+          for (int c = 0; c < BS; c++) {
+            float v = acc[x][c];
+#pragma unroll
+            for (int m = 0; m < BS; m++)
+              if (m < c) v = fmaf(-acc[x][m], sD[c * BS + m], v);
+            acc[x][c] = v * sD[BS * BS + c];
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < BS; x++)
+#pragma unroll
+          for (int y = 0; y < BS; y++) sL[(I * BS + x) * BS + y] = acc[x][y];
+      }
+      __syncthreads();
+      if (K > J && I >= K) {  // trailing update: A_IK -= L_IJ L_KJ^T
+        float li[BS][BS], lk[BS][BS];
+#pragma unroll
+        for (int x = 0; x < BS; x++)
+#pragma unroll
+          for (int y = 0; y < BS; y++) {
+            li[x][y] = sL[(I * BS + x) * BS + y];
+            lk[x][y] = sL[(K * BS + x) * BS + y];
+          }
+#pragma unroll
+        for (int x = 0; x < BS; x++)
+#pragma unroll
+          for (int y = 0; y < BS; y++) {
+            float v = acc[x][y];
+#pragma unroll
+            for (int m = 0; m < BS; m++) v = fmaf(-li[x][m], lk[y][m], v);
+            acc[x][y] = v;
+          }
+      }
+      // no barrier: the next diagonal thread only needs its own registers; sD / sL are rewritten only
+      // after barriers that every thread reaches after finishing this update
+    }
+
+    // ---------------- forward substitution  L z = b  (z overwrites sV) ----------------
+    for (int J = 0; J < NB; J++) {
+      __syncthreads();  // z blocks < J published
+      if (I == J) {
+        float part[BS];
+#pragma unroll
+        for (int x = 0; x < BS; x++) part[x] = 0.f;
+        if (K < J) {
+#pragma unroll
+          for (int y = 0; y < BS; y++) {
+            const float zk = sV[K * BS + y];
+#pragma unroll
+            for (int x = 0; x < BS; x++) part[x] = fmaf(acc[x][y], zk, part[x]);
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < BS; x++) part[x] = row16_sum_c(part[x]);  // the 16 threads of block row J are one DPP row
+        if (K == J) {
+          float z[BS];
+#pragma unroll
+          for (int c = 0; c < BS; c++) {
+            float v = sV[J * BS + c] - part[c];
+#pragma unroll
+            for (int m = 0; m < BS; m++)
+              if (m < c) v = fmaf(-acc[c][m], z[m], v);
+            z[c] = v / acc[c][c];
+          }
+#pragma unroll
+          for (int c = 0; c < BS; c++) sV[J * BS + c] = z[c];
+        }
+      }
+    }
+    // ---------------- backward substitution  L^T y = z  (y overwrites sV) ----------------
+    for (int J = NB - 1; J >= 0; J--) {
+      __syncthreads();  // sS complete for block J, y blocks > J published
+      if (I == J && K == J) {
+        float y[BS];
+#pragma unroll
+        for (int c = BS - 1; c >= 0; c--) {
+          float v = sV[J * BS + c] - sS[J * BS + c];
+#pragma unroll
+          for (int m = 0; m < BS; m++)
+            if (m > c) v = fmaf(-acc[m][c], y[m], v);
+          y[c] = v / acc[c][c];
+        }
+#pragma unroll
+        for (int c = 0; c < BS; c++) sV[J * BS + c] = y[c];
+      }
+      __syncthreads();
+      if (I == J && K < J) {  // S_K += L_JK^T y_J   (one thread per K: no conflicts)
+#pragma unroll
+        for (int y2 = 0; y2 < BS; y2++) {
+          float s = sS[K * BS + y2];
+#pragma unroll
+          for (int x = 0; x < BS; x++) s = fmaf(acc[x][y2], sV[J * BS + x], s);
+          sS[K * BS + y2] = s;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < k) yrow[tid] = sV[tid];
+
+    // ---------------- loss row term (wrmf_implicit.hpp:259-261 / wrmf_explicit.hpp:131-132) ----------------
+    {
+      float lpart = 0.f;
+      for (int j = wv; j < cnt; j += 4) {
+        const int id = rfl(a.row_idx[p1 + j]);
+        const float cvv = a.vals[p1 + j];
+        const float* src = a.X + (size_t)id * k;
+        float part = 0.f;
+        for (int e = lane; e < k; e += 64) part = fmaf(src[e], sV[e], part);
+        const float t = wave_sum(part);
+        const float d = IMPLICIT ? 1.f - t : cvv - t;
+        lpart += IMPLICIT ? cvv * d * d : d * d;
+      }
+      float xxp = 0.f;
+      if (wv == 0) {
+        for (int e = lane; e < k; e += 64) xxp = fmaf(sV[e], sV[e], xxp);
+        xxp = wave_sum(xxp);
+      }
+      if (lane == 0) {
+        wloss += (double)lpart;
+        if (wv == 0) wloss += IMPLICIT ? a.lambda_loss * (double)xxp : (double)(lam_use * xxp);
+      }
+    }
+  }
+  __syncthreads();
+  if (lane == 0) sLoss[wv] = wloss;
+  __syncthreads();
+  if (tid == 0) {
+    a.loss_partials[blockIdx.x] = (sLoss[0] + sLoss[1]) + (sLoss[2] + sLoss[3]);
+    if (*sFlag) atomicAdd(a.fail_counter, 1);
+  }
+}
+
+template <int KP, bool IMPLICIT>
+hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
+  using SM = Chol2Smem<KP>;
+  hipError_t err;
+  const int grid = (int)chol_loss_slots(a.n_cols);
+  auto kc = als_chol2_kernel<KP, IMPLICIT>;
+  if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)SM::bytes)) != hipSuccess)
+    return err;
+  if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
+  hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a);
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  if (ev) {
+    if ((err = hipEventRecord(ev[1], s)) != hipSuccess) return err;
+    if ((err = hipEventRecord(ev[2], s)) != hipSuccess) return err;
+  }
+  return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev) {
+  const int KP = padded_rank(a.k);
+#define RSP_DISPATCH(KPV) \
+  if (KP == KPV) return implicit ? launch_chol2_t<KPV, true>(a, s, ev) : launch_chol2_t<KPV, false>(a, s, ev);
+  RSP_DISPATCH(32)
+  RSP_DISPATCH(64)
+  RSP_DISPATCH(128)
+#undef RSP_DISPATCH
+  return hipErrorInvalidValue;
+}
+
+}  // namespace rsparse_hip

@@ -82,6 +82,8 @@ size_t chol_loss_slots(int n_cols);
 // kernel, ev[1] between kernels and ev[2] after the last one (all on stream s).
 hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
+// register-blocked Cholesky (wrmf_chol.hip); launch_als_chol is the older LDS-matrix version kept for A/B
+hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s);
 
 // Gramian: scratch must hold gramian_scratch_floats(k, n) floats.

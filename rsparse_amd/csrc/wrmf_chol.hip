@@ -44,7 +44,36 @@ struct Chol2Smem {
   static constexpr size_t bytes = (tile_floats + panel_floats + diag_floats + vec_floats + 16) * 4 + 64;
 };
 
-template <int KP, bool IMPLICIT>
+// The 4 waves gather one 32-vector chunk: wave w fetches tile rows [8w, 8w+8).  VEC: all index loads, then
+// all 16-byte vector loads of the wave are in flight together (2 dependent round trips per chunk).
+template <int KP, bool VEC>
+__device__ __forceinline__ void chol_gather_chunk(const AlsArgs& a, int base, int ccnt, float* sT, int wv, int lane) {
+  constexpr int LDT = KP + 4;
+  const int k = a.k;
+  if constexpr (VEC) {
+    constexpr int LPV = KP / 4, VPI = 64 / LPV, NQ = 8 / VPI;
+    const int c4 = lane % LPV, jo = lane / LPV;
+    int ids[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) ids[q] = a.row_idx[base + min(8 * wv + q * VPI + jo, ccnt - 1)];
+    float4 v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) v[q] = *reinterpret_cast<const float4*>(a.X + (size_t)ids[q] * k + min(c4 * 4, k - 4));
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int j = 8 * wv + q * VPI + jo;
+      if (j < ccnt && c4 * 4 < k) *reinterpret_cast<float4*>(sT + j * LDT + c4 * 4) = v[q];
+    }
+  } else {
+    for (int j = 8 * wv; j < min(8 * wv + 8, ccnt); j++) {
+      const int id = rfl(a.row_idx[base + j]);
+      const float* src = a.X + (size_t)id * k;
+      for (int e = lane; e < k; e += 64) sT[j * LDT + e] = src[e];
+    }
+  }
+}
+
+template <int KP, bool IMPLICIT, bool VEC>
 __global__ __launch_bounds__(256) void als_chol2_kernel(AlsArgs a) {
   using SM = Chol2Smem<KP>;
   constexpr int BS = SM::BS, TC = SM::TC, LDT = SM::LDT, NB = 16;
@@ -94,11 +123,7 @@ __global__ __launch_bounds__(256) void als_chol2_kernel(AlsArgs a) {
         sC[tid] = cvv;
         sC1[tid] = IMPLICIT ? cvv - 1.f : 1.f;
       }
-      for (int j = wv; j < ccnt; j += 4) {  // wave w gathers vectors w, w+4, ...
-        const int id = rfl(a.row_idx[base + j]);
-        const float* src = a.X + (size_t)id * k;
-        for (int e = lane; e < k; e += 64) sT[j * LDT + e] = src[e];
-      }
+      chol_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
       __syncthreads();
       if (lower) {
         for (int j = 0; j < ccnt; j++) {
@@ -276,26 +301,30 @@ __global__ __launch_bounds__(256) void als_chol2_kernel(AlsArgs a) {
     if (tid < k) yrow[tid] = sV[tid];
 
     // ---------------- loss row term (wrmf_implicit.hpp:259-261 / wrmf_explicit.hpp:131-132) ----------------
+    // second pass over the row's chunks: t_j = y . x_j with the lane-per-non-zero dot of the CG kernels
     {
-      float lpart = 0.f;
-      for (int j = wv; j < cnt; j += 4) {
-        const int id = rfl(a.row_idx[p1 + j]);
-        const float cvv = a.vals[p1 + j];
-        const float* src = a.X + (size_t)id * k;
-        float part = 0.f;
-        for (int e = lane; e < k; e += 64) part = fmaf(src[e], sV[e], part);
-        const float t = wave_sum(part);
-        const float d = IMPLICIT ? 1.f - t : cvv - t;
-        lpart += IMPLICIT ? cvv * d * d : d * d;
+      float lacc = 0.f;
+      for (int base = p1; base < p2; base += TC) {
+        const int ccnt = min(TC, p2 - base);
+        __syncthreads();  // tile free (and y published in sV on the first pass)
+        if (tid < ccnt) sC[tid] = a.vals[base + tid];
+        chol_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
+        __syncthreads();
+        if (wv == 0) {
+          const float t = tile_dot<KP, TC>(sT, sV, lane);
+          const int jl = lane % TC;
+          const float cvv = sC[jl < ccnt ? jl : 0];
+          const float d = IMPLICIT ? 1.f - t : cvv - t;
+          lacc += (jl < ccnt && lane < TC) ? (IMPLICIT ? cvv * d * d : d * d) : 0.f;
+        }
       }
-      float xxp = 0.f;
       if (wv == 0) {
+        const float lpart = wave_sum(lacc);
+        float xxp = 0.f;
         for (int e = lane; e < k; e += 64) xxp = fmaf(sV[e], sV[e], xxp);
         xxp = wave_sum(xxp);
-      }
-      if (lane == 0) {
-        wloss += (double)lpart;
-        if (wv == 0) wloss += IMPLICIT ? a.lambda_loss * (double)xxp : (double)(lam_use * xxp);
+        if (lane == 0)
+          wloss += IMPLICIT ? (double)lpart + a.lambda_loss * (double)xxp : (double)(lpart + lam_use * xxp);
       }
     }
   }
@@ -308,12 +337,12 @@ __global__ __launch_bounds__(256) void als_chol2_kernel(AlsArgs a) {
   }
 }
 
-template <int KP, bool IMPLICIT>
+template <int KP, bool IMPLICIT, bool VEC>
 hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   using SM = Chol2Smem<KP>;
   hipError_t err;
   const int grid = (int)chol_loss_slots(a.n_cols);
-  auto kc = als_chol2_kernel<KP, IMPLICIT>;
+  auto kc = als_chol2_kernel<KP, IMPLICIT, VEC>;
   if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)SM::bytes)) != hipSuccess)
     return err;
@@ -331,8 +360,12 @@ hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
 
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(a.k);
-#define RSP_DISPATCH(KPV) \
-  if (KP == KPV) return implicit ? launch_chol2_t<KPV, true>(a, s, ev) : launch_chol2_t<KPV, false>(a, s, ev);
+  const bool vec = (a.k % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+#define RSP_DISPATCH(KPV)                                                                                  \
+  if (KP == KPV) {                                                                                         \
+    if (implicit) return vec ? launch_chol2_t<KPV, true, true>(a, s, ev) : launch_chol2_t<KPV, true, false>(a, s, ev); \
+    return vec ? launch_chol2_t<KPV, false, true>(a, s, ev) : launch_chol2_t<KPV, false, false>(a, s, ev); \
+  }
   RSP_DISPATCH(32)
   RSP_DISPATCH(64)
   RSP_DISPATCH(128)

@@ -6,7 +6,9 @@ loudly (build it with `python -m rsparse_amd.build` or `__graft_entry__.build()`
 import ctypes
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "lib" / "librsparse_wrmf_hip.so"
+import os
+
+LIB_PATH = Path(os.environ.get("RSPARSE_HIP_LIB", Path(__file__).resolve().parent / "lib" / "librsparse_wrmf_hip.so"))
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_NUMERIC = 0, 1, 2, 3, 4
 SOLVER_CHOLESKY, SOLVER_CG, SOLVER_NNLS = 0, 1, 2

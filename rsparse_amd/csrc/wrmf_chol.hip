@@ -12,8 +12,8 @@
 //   factorise  right-looking blocked Cholesky over the 16 block columns: the diagonal thread factors its
 //              block in registers, the panel threads do a BS x BS triangular solve, the trailing threads a
 //              BS^3 update from two BS x BS blocks read from LDS (4 KB panel) -- 2 barriers per block column
-//   solve      the forward substitution rides along the factorisation (rhs carried like an extra column);
-//              the backward substitution accumulates L^T y into an LDS vector (one thread per block, no atomics)
+//   solve      forward substitution with 16-lane DPP reductions along block rows, backward substitution
+//              accumulating L^T y into an LDS vector (distinct addresses per thread, no atomics)
 // The Gramian is read from L2 (64 KB per row, cached) instead of LDS, so a workgroup needs only ~25 KB of
 // LDS and several rows are in flight per CU, overlapping one row's serial phases with another's.
 #include "wrmf_internal.h"
@@ -23,6 +23,14 @@ namespace rsparse_hip {
 namespace {
 
 using namespace dev;
+
+__device__ __forceinline__ float row16_sum_c(float v) {
+  v += dpp<0xB1>(v);
+  v += dpp<0x4E>(v);
+  v += dpp<0x141>(v);
+  v += dpp<0x140>(v);
+  return v;
+}
 
 template <int KP>
 struct Chol2Smem {
@@ -140,37 +148,26 @@ __global__ __launch_bounds__(256, 2) void als_chol2_kernel(AlsArgs a) {
     }
     // + Gramian (implicit, from L2) or lambda_use I (explicit); identity on the padded diagonal
     if (lower) {
-      // one block row at a time (a fully unrolled version keeps 64 loads + addresses live and spills)
-#pragma unroll 1
-      for (int x = 0; x < BS; x++) {
-        const int rr = I * BS + x;
-        float gv[BS];
+#pragma unroll
+      for (int x = 0; x < BS; x++)
 #pragma unroll
         for (int y = 0; y < BS; y++) {
-          const int cc = K * BS + y;
-          if (rr >= k || cc >= k) gv[y] = (rr == cc) ? 1.f : 0.f;
-          else if (IMPLICIT) gv[y] = a.XtX[(size_t)rr * k + cc];
-          else gv[y] = (rr == cc) ? lam_use : 0.f;
+          const int rr = I * BS + x, cc = K * BS + y;
+          float gv;
+          if (rr >= k || cc >= k) gv = (rr == cc) ? 1.f : 0.f;
+          else if (IMPLICIT) gv = a.XtX[(size_t)rr * k + cc];
+          else gv = (rr == cc) ? lam_use : 0.f;
+          acc[x][y] += gv;
         }
-        // acc is indexed by the loop variable: keep the update fully unrolled over x with a uniform select
-#pragma unroll
-        for (int x2 = 0; x2 < BS; x2++)
-#pragma unroll
-          for (int y = 0; y < BS; y++) acc[x2][y] += (x2 == x) ? gv[y] : 0.f;
-      }
     }
     __syncthreads();
     if (tid < KP) sV[tid] = rhs;
     if (tid < KP) sS[tid] = 0.f;
 
-    // ---------------- blocked Cholesky, lower triangle, with the forward substitution L z = b folded in ------
-    // (b is carried in sV like an extra column of the matrix: after block column J, sV[J] = z_J and every
-    //  b_I, I > J, has had L_IJ z_J subtracted -- no extra barriers)
-    float dinv[BS];  // diagonal threads: reciprocals of their L_JJ diagonal (kept for the backward pass)
-#pragma unroll
-    for (int c = 0; c < BS; c++) dinv[c] = 1.f;
+    // ---------------- blocked Cholesky, lower triangle ----------------
     for (int J = 0; J < NB; J++) {
       if (I == J && K == J) {  // factor the diagonal block in registers
+        float inv[BS];
 #pragma unroll
         for (int c = 0; c < BS; c++) {
           float d = acc[c][c];
@@ -178,10 +175,9 @@ __global__ __launch_bounds__(256, 2) void als_chol2_kernel(AlsArgs a) {
           for (int m = 0; m < BS; m++)
             if (m < c) d = fmaf(-acc[c][m], acc[c][m], d);
           if (!(d > 0.f)) { *sFlag = 1; d = 1.f; }
-          float rs = __builtin_amdgcn_rsqf(d);           // v_rsq_f32 (~1 ulp) + one Newton step
-          rs = rs * fmaf(-0.5f * d * rs, rs, 1.5f);
-          dinv[c] = rs;
-          acc[c][c] = d * rs;
+          const float l = sqrtf(d);
+          acc[c][c] = l;
+          inv[c] = 1.f / l;
 #pragma unroll
           for (int r2 = 0; r2 < BS; r2++) {
             if (r2 > c) {
@@ -189,29 +185,19 @@ __global__ __launch_bounds__(256, 2) void als_chol2_kernel(AlsArgs a) {
 #pragma unroll
               for (int m = 0; m < BS; m++)
                 if (m < c) v = fmaf(-acc[r2][m], acc[c][m], v);
-              acc[r2][c] = v * rs;
+              acc[r2][c] = v * inv[c];
             }
           }
-        }
-        float z[BS];
-#pragma unroll
-        for (int c = 0; c < BS; c++) {  // z_J = L_JJ^{-1} b_J
-          float v = sV[J * BS + c];
-#pragma unroll
-          for (int m = 0; m < BS; m++)
-            if (m < c) v = fmaf(-acc[c][m], z[m], v);
-          z[c] = v * dinv[c];
         }
 #pragma unroll
         for (int x = 0; x < BS; x++) {
 #pragma unroll
           for (int y = 0; y < BS; y++) sD[x * BS + y] = y <= x ? acc[x][y] : 0.f;
-          sD[BS * BS + x] = dinv[x];
-          sV[J * BS + x] = z[x];
+          sD[BS * BS + x] = inv[x];
         }
       }
       __syncthreads();
-      if (K == J && I > J) {  // panel: L_IJ = A_IJ L_JJ^{-T};  b_I -= L_IJ z_J
+      if (K == J && I > J) {  // panel: L_IJ = A_IJ L_JJ^{-T}
 #pragma unroll
         for (int x = 0; x < BS; x++) {
 #pragma unroll
@@ -224,15 +210,9 @@ __global__ __launch_bounds__(256, 2) void als_chol2_kernel(AlsArgs a) {
           }
         }
 #pragma unroll
-        for (int x = 0; x < BS; x++) {
-          float bx = sV[I * BS + x];
+        for (int x = 0; x < BS; x++)
 #pragma unroll
-          for (int y = 0; y < BS; y++) {
-            sL[(I * BS + y) * BS + x] = acc[x][y];
-            bx = fmaf(-acc[x][y], sV[J * BS + y], bx);
-          }
-          sV[I * BS + x] = bx;
-        }
+          for (int y = 0; y < BS; y++) sL[(I * BS + y) * BS + x] = acc[x][y];
       }
       __syncthreads();
       if (K > J && I >= K) {  // trailing update: A_IK -= L_IJ L_KJ^T, one rank-one step per panel column m
@@ -252,9 +232,41 @@ __global__ __launch_bounds__(256, 2) void als_chol2_kernel(AlsArgs a) {
             for (int y = 0; y < BS; y++) acc[x][y] = fmaf(-li[x], lk[y], acc[x][y]);
         }
       }
-      // no barrier: the next diagonal thread only needs its own registers and its own block of sV (last
-      // written by thread (J+1, J) before the barrier above); sD / sL are rewritten only after barriers
-      // that every thread reaches after finishing this update
+      // no barrier: the next diagonal thread only needs its own registers; sD / sL are rewritten only
+      // after barriers that every thread reaches after finishing this update
+    }
+
+    // ---------------- forward substitution  L z = b  (z overwrites sV) ----------------
+    for (int J = 0; J < NB; J++) {
+      __syncthreads();  // z blocks < J published
+      if (I == J) {
+        float part[BS];
+#pragma unroll
+        for (int x = 0; x < BS; x++) part[x] = 0.f;
+        if (K < J) {
+#pragma unroll
+          for (int y = 0; y < BS; y++) {
+            const float zk = sV[K * BS + y];
+#pragma unroll
+            for (int x = 0; x < BS; x++) part[x] = fmaf(acc[x][y], zk, part[x]);
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < BS; x++) part[x] = row16_sum_c(part[x]);  // the 16 threads of block row J are one DPP row
+        if (K == J) {
+          float z[BS];
+#pragma unroll
+          for (int c = 0; c < BS; c++) {
+            float v = sV[J * BS + c] - part[c];
+#pragma unroll
+            for (int m = 0; m < BS; m++)
+              if (m < c) v = fmaf(-acc[c][m], z[m], v);
+            z[c] = v / acc[c][c];
+          }
+#pragma unroll
+          for (int c = 0; c < BS; c++) sV[J * BS + c] = z[c];
+        }
+      }
     }
     // ---------------- backward substitution  L^T y = z  (y overwrites sV) ----------------
     for (int J = NB - 1; J >= 0; J--) {
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void als_chol2_kernel(AlsArgs a) {
 #pragma unroll
           for (int m = 0; m < BS; m++)
             if (m > c) v = fmaf(-acc[m][c], y[m], v);
-          y[c] = v * dinv[c];
+          y[c] = v / acc[c][c];
         }
 #pragma unroll
         for (int c = 0; c < BS; c++) sV[J * BS + c] = y[c];

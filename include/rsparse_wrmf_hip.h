@@ -165,6 +165,32 @@ int rsparse_hip_als_explicit_device(const rsparse_hip_csc* conf, const float* d_
 int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, const float* d_w,
                                       double* d_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * `$predict`: top-k of the dense product (next step after the solve on the same operator boundary)
+ * ---------------------------------------------------------------------------------------------- */
+
+#define RSPARSE_HIP_NA_INTEGER INT32_MIN /* R's NA_integer_: fewer than k admissible items */
+#define RSPARSE_HIP_MAX_TOPK 128
+
+/* replaces top_product (src/matrix_top_product.cpp:20-102; .Call `_rsparse_top_product`,
+ * R/RcppExports.R).  x: nr x rank and y: rank x nc, both column-major doubles as arma::mat holds them;
+ * not_recommend as dgRMatrix slots p (nr+1) / j (sorted per row), NULL = nothing to filter; exclude: 1-based
+ * item indices excluded for every row.  res: nr x k column-major 1-based indices (NA_integer_ where fewer
+ * than k items are admissible), scores: nr x k column-major (+ glob_mean), best first; equal scores keep the
+ * reference's order (larger index first).  Scores are computed in fp32 on the device (the reference
+ * multiplies in double).  k > 128 -> ERR_UNSUPPORTED.  n_threads is accepted and ignored. */
+int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, int rank, unsigned k,
+                            unsigned n_threads, const int32_t* not_recommend_p,
+                            const int32_t* not_recommend_j, const int32_t* exclude, int n_exclude,
+                            double glob_mean, int32_t* res, double* scores);
+
+/* device-resident form: d_U n_users x rank and d_V n_items x rank row-major fp32 (= rank x n column-major),
+ * d_exclude0: sorted 0-based item indices, d_res / d_scores: n_users x k row-major. */
+int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_users, int n_items, int rank,
+                                   int k, const int32_t* d_not_recommend_p, const int32_t* d_not_recommend_j,
+                                   const int32_t* d_exclude0, int n_exclude, double glob_mean,
+                                   int32_t* d_res, float* d_scores, void* stream);
+
 /* Kernel timing for measurement harnesses (bench.py): when enabled, every device-layer call brackets
  * its kernels with HIP events on the caller's stream.  rsparse_hip_profile_last() waits for the last
  * call and returns milliseconds per kernel in launch order: CG half-iterations -> [0..5] the

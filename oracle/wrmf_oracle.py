@@ -255,3 +255,54 @@ class OracleWRMF:
     def transform(self, p_iu, i_iu, x_iu):
         """x given as CSC of x^T (items x users), i.e. CSR of the users x items matrix (:365-385)."""
         return self._transform(p_iu, i_iu, x_iu)
+
+
+# ----------------------------------------------------------------------------------------------
+# $predict: top-k of the dense product
+# ----------------------------------------------------------------------------------------------
+
+NA_INTEGER = -2147483648
+
+
+def top_product(x, y, k, nr_p=None, nr_j=None, exclude=(), glob_mean=0.0):
+    """Restatement of top_product() (src/matrix_top_product.cpp:20-102) with its exact heap semantics:
+    x: nr x rank, y: rank x nc (float64, like find_top_product's dbl() casts, R/utils.R:35-36);
+    not_recommend as sorted CSR (nr_p, nr_j) consumed with a moving pointer (:52,70-75); `exclude` holds
+    1-based item indices (:78); min-heap of (score, index) pairs, replacement only if top.first < val
+    (:80-85); output filled from the end (:88-95) -> best first, equal scores with the larger index first.
+    Returns (res 1-based with NA_INTEGER, scores with NaN)."""
+    import heapq
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    nr, nc = x.shape[0], y.shape[1]
+    res = np.full((nr, k), NA_INTEGER, dtype=np.int32)
+    scores = np.full((nr, k), np.nan)
+    excl = set(int(e) for e in exclude)
+    filt = nr_p is not None and len(nr_p) > 0 and int(nr_p[-1]) > 0
+    for j in range(nr):
+        yvec = x[j] @ y
+        cols = nr_j[nr_p[j]:nr_p[j + 1]] if filt else ()
+        u = 0
+        q = []
+        for i in range(nc):
+            val = float(yvec[i])
+            skip = False
+            if filt and len(cols) > 0 and u < len(cols):
+                if i == cols[u]:
+                    skip = True
+                    u += 1
+            if (i + 1) in excl:
+                skip = True
+            if len(q) < k:
+                if not skip:
+                    heapq.heappush(q, (val, i))
+            elif q[0][0] < val and not skip:
+                heapq.heapreplace(q, (val, i))
+        qs = len(q)
+        for t in range(qs):
+            v, i = heapq.heappop(q)
+            res[j, qs - t - 1] = i + 1
+            scores[j, qs - t - 1] = v
+    if glob_mean != 0.0:
+        scores += glob_mean
+    return res, scores

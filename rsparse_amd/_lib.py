@@ -39,6 +39,8 @@ SIGNATURES = {
     "rsparse_hip_als_implicit_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_uint, _vp, _vp]),
     "rsparse_hip_als_explicit_device": (_c_int, [_vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_uint, _c_int, _vp, _vp]),
     "rsparse_hip_weighted_sumsq_device": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp]),
+    "rsparse_hip_top_product": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_uint, _c_uint, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp]),
+    "rsparse_hip_top_product_device": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _vp]),
     "rsparse_hip_profile_enable": (_c_int, [_c_int]),
     "rsparse_hip_profile_last": (_c_int, [ctypes.POINTER(_c_dbl)]),
     "rsparse_hip_take_numeric_failures": (_c_int, [ctypes.POINTER(_c_i64)]),

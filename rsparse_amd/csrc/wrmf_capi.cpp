@@ -541,6 +541,78 @@ int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, con
   return RSPARSE_HIP_OK;
 }
 
+int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_users, int n_items, int rank, int k,
+                                   const int32_t* d_nr_p, const int32_t* d_nr_j, const int32_t* d_excl0,
+                                   int n_exclude, double glob_mean, int32_t* d_res, float* d_scores, void* stream) {
+  if (!d_U || !d_V || !d_res || !d_scores) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or output");
+  if (n_users < 0 || n_items < 0 || rank <= 0 || k < 1) return fail(RSPARSE_HIP_ERR_INVALID, "bad dimensions");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 128 is not on the device path");
+  if (n_exclude > 0 && !d_excl0) return fail(RSPARSE_HIP_ERR_INVALID, "exclude is NULL");
+  hipError_t e = launch_top_product(d_U, d_V, n_users, n_items, rank, k, d_nr_p, d_nr_p ? d_nr_j : nullptr, d_excl0,
+                                    n_exclude, (float)glob_mean, d_res, d_scores, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "launch_top_product");
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, int rank, unsigned k, unsigned n_threads,
+                            const int32_t* nr_p, const int32_t* nr_j, const int32_t* exclude, int n_exclude,
+                            double glob_mean, int32_t* res, double* scores) {
+  (void)n_threads;
+  if (!x || !y || !res || !scores) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or output");
+  if (nr < 0 || nc < 0 || rank <= 0 || k < 1) return fail(RSPARSE_HIP_ERR_INVALID, "bad dimensions");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 128 is not on the device path");
+  if (n_exclude < 0 || (n_exclude > 0 && !exclude)) return fail(RSPARSE_HIP_ERR_INVALID, "bad exclude");
+  // x is nr x rank column-major -> row-major fp32; y (rank x nc column-major) already has item vectors contiguous
+  std::vector<float> U((size_t)nr * rank), V((size_t)nc * rank);
+  for (int j = 0; j < nr; j++)
+    for (int r = 0; r < rank; r++) U[(size_t)j * rank + r] = (float)x[(size_t)r * nr + j];
+  for (size_t e = 0; e < V.size(); e++) V[e] = (float)y[e];
+  std::vector<int32_t> ex;
+  for (int e = 0; e < n_exclude; e++)
+    if (exclude[e] >= 1 && exclude[e] <= nc) ex.push_back(exclude[e] - 1);   // R indices are 1-based
+  std::sort(ex.begin(), ex.end());
+  ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
+  const int64_t nr_nnz = (nr_p && nr > 0) ? (int64_t)nr_p[nr] : 0;
+  DevBuf dU, dV, dP, dJ, dE, dR, dS;
+  HIP_TRY(dU.alloc(U.size() * 4));
+  HIP_TRY(dV.alloc(V.size() * 4));
+  HIP_TRY(dR.alloc((size_t)nr * k * 4));
+  HIP_TRY(dS.alloc((size_t)nr * k * 4));
+  if (!U.empty()) HIP_TRY(hipMemcpy(dU.p, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+  if (!V.empty()) HIP_TRY(hipMemcpy(dV.p, V.data(), V.size() * 4, hipMemcpyHostToDevice));
+  const bool filter = nr_nnz > 0 && nr_j;   // `not_empty_filter_matrix`, matrix_top_product.cpp:33
+  if (filter) {
+    HIP_TRY(dP.alloc(((size_t)nr + 1) * 4));
+    HIP_TRY(dJ.alloc((size_t)nr_nnz * 4));
+    HIP_TRY(hipMemcpy(dP.p, nr_p, ((size_t)nr + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dJ.p, nr_j, (size_t)nr_nnz * 4, hipMemcpyHostToDevice));
+  }
+  if (!ex.empty()) {
+    HIP_TRY(dE.alloc(ex.size() * 4));
+    HIP_TRY(hipMemcpy(dE.p, ex.data(), ex.size() * 4, hipMemcpyHostToDevice));
+  }
+  int rc = rsparse_hip_top_product_device(dU.as<float>(), dV.as<float>(), nr, nc, rank, (int)k,
+                                          filter ? dP.as<int32_t>() : nullptr, filter ? dJ.as<int32_t>() : nullptr,
+                                          ex.empty() ? nullptr : dE.as<int32_t>(), (int)ex.size(), glob_mean,
+                                          dR.as<int32_t>(), dS.as<float>(), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<int32_t> hr((size_t)nr * k);
+  std::vector<float> hs((size_t)nr * k);
+  if (!hr.empty()) {
+    HIP_TRY(hipMemcpy(hr.data(), dR.p, hr.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hs.data(), dS.p, hs.size() * 4, hipMemcpyDeviceToHost));
+  }
+  for (int j = 0; j < nr; j++)
+    for (unsigned c = 0; c < k; c++) {
+      res[(size_t)c * nr + j] = hr[(size_t)j * k + c];
+      scores[(size_t)c * nr + j] = (double)hs[(size_t)j * k + c];
+    }
+  return RSPARSE_HIP_OK;
+}
+
 int rsparse_hip_take_numeric_failures(int64_t* count_out) {
   if (!count_out) return fail(RSPARSE_HIP_ERR_INVALID, "count_out is NULL");
   *count_out = 0;

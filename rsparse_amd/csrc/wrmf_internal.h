@@ -95,6 +95,12 @@ hipError_t launch_weighted_sumsq(const float* X, int k, int64_t n, const float* 
 hipError_t launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t s);
 
+// scores = U V^T per user fused with top-k and exclusions (wrmf_topk.hip); U: n_users x k, V: n_items x k,
+// both row-major; res / scores: n_users x topk row-major, indices 1-based, INT32_MIN / NaN when fewer than topk
+hipError_t launch_top_product(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
+                              const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
+                              float glob_mean, int32_t* res, float* scores, hipStream_t s);
+
 int padded_rank(int k);  // 32 / 64 / 128, or 0 if unsupported
 
 }  // namespace rsparse_hip

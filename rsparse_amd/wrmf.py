@@ -25,6 +25,12 @@ def _identity(x):
     return x
 
 
+class TopItems(np.ndarray):
+    """Result of `WRMF.predict`: (n_users x k) item indices with the scores attached, like the `scores`
+    attribute of the reference's integer matrix (R/MatrixFactorizationRecommender.R:68-76)."""
+    scores = None
+
+
 class WRMF:
     def __init__(self, rank=10, lambda_=0.0, dynamic_lambda=True, init=None, preprocess=_identity,
                  feedback="implicit", solver="conjugate_gradient", with_user_item_bias=False,
@@ -131,8 +137,19 @@ class WRMF:
         return self._transform(als.csc_users, n_user)
 
     def _transform(self, csc_users, n_new):
+        return self._transform_dev(csc_users, n_new).cpu().numpy().astype(self._np_dtype())     # t(res), :444
+
+    def _transform_device(self, x_csr):
+        xt = sp.csc_matrix(x_csr.T)
+        xt = self._preprocess(xt)
+        xt.sort_indices()
+        be = self._backend()
+        csc = be.make_csc(xt.shape[0], xt.shape[1], *self._upload_csc(xt))
+        return self._transform_dev(csc, x_csr.shape[0])
+
+    def _transform_dev(self, csc_users, n_new):
         """R/model_WRMF.R:412-452: one user half-iteration from zeros against the final item factors,
-        Cholesky whenever the model's solver is CG (avoid_cg, :112)."""
+        Cholesky whenever the model's solver is CG (avoid_cg, :112).  Returns the device tensor."""
         be = self._backend()
         res = torch.zeros((n_new, self._rank), dtype=torch.float32, device=self._V.device)   # :423-427
         solver = 0 if self._solver_code == 1 else self._solver_code                          # :112
@@ -140,7 +157,54 @@ class WRMF:
         be.half_iteration(csc_users, self._feedback == "implicit", self._V, res, self._XtX, self._lambda,
                           solver, self._cg_steps, self._dynamic_lambda, loss)
         be.check_numeric()
-        return res.cpu().numpy().astype(self._np_dtype())                                    # t(res), :444
+        return res
+
+    def predict(self, x, k, not_recommend="x", items_exclude=()):
+        """R/MatrixFactorizationRecommender.R:24-34 -> find_top_product (R/utils.R:31-59): embeddings of the
+        rows of `x` by `transform`, then the k best items per row on the device, skipping each row's
+        `not_recommend` entries (default: `x` itself, as in the reference; None = nothing) and the globally
+        excluded `items_exclude` (0-based here, 1-based in R).  Returns a `TopItems` array (n x k item
+        indices, 0-based, -1 where fewer than k items are admissible) with `.scores` (n x k)."""
+        import ctypes
+        if self._V is None:
+            raise RuntimeError("model is not fitted")
+        x = sp.csr_matrix(x, dtype=np.float64)
+        n_new, n_item = x.shape[0], self._V.shape[0]
+        if x.shape[1] != n_item:
+            raise ValueError("ncol(x) == ncol(self$components) is not TRUE")
+        k = int(k)
+        excl = np.unique(np.asarray(list(items_exclude), dtype=np.int64))
+        if excl.size and (excl.min() < 0 or excl.max() >= n_item):
+            raise ValueError("some of items_exclude indices are bigger than number of items")      # :59-60
+        if isinstance(not_recommend, str) and not_recommend == "x":
+            not_recommend = x
+        if not_recommend is not None and not sp.issparse(not_recommend):
+            raise TypeError("'not_recommend' should be NULL or 'sparseMatrix'")                     # R/utils.R:47
+        be = self._backend()
+        emb = self._transform_device(x)
+        nr_p = nr_j = None
+        if not_recommend is not None:
+            nr = sp.csr_matrix(not_recommend)
+            if nr.shape != (n_new, n_item):
+                raise ValueError("not_recommend must have the shape of x")                          # R/utils.R:55-56
+            nr.sort_indices()
+            if nr.nnz:
+                nr_p = be.to_device(nr.indptr, torch.int32)
+                nr_j = be.to_device(nr.indices, torch.int32)
+        d_ex = be.to_device(excl, torch.int32) if excl.size else None
+        res = torch.empty((n_new, k), dtype=torch.int32, device=emb.device)
+        sc = torch.empty((n_new, k), dtype=torch.float32, device=emb.device)
+        lib = be.lib
+        _lib.check(lib.rsparse_hip_top_product_device(
+            emb.data_ptr(), self._V.data_ptr(), n_new, n_item, self._rank, k,
+            None if nr_p is None else nr_p.data_ptr(), None if nr_j is None else nr_j.data_ptr(),
+            None if d_ex is None else d_ex.data_ptr(), int(excl.size), float(self.global_bias),
+            res.data_ptr(), sc.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)))
+        idx = res.cpu().numpy().astype(np.int64)
+        idx = np.where(idx == -2147483648, -1, idx - 1)       # R is 1-based with NA_integer_
+        out = idx.view(TopItems)
+        out.scores = sc.cpu().numpy().astype(self._np_dtype())
+        return out
 
     def transform(self, x):
         """R/model_WRMF.R:365-385: embeddings for new rows of a users x items matrix."""

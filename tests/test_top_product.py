@@ -1,0 +1,122 @@
+"""$predict / top_product: the reference's own value-level test (tests/testthat/test-top-product.R:3-14:
+top-k of one row equals order(decreasing)[1:k]) for the oracle on CPU, and GPU parity of the HIP kernel
+against the oracle including exclusions, ties and NA fill."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import wrmf_oracle as O
+from rsparse_amd import _lib
+
+
+def test_oracle_matches_order_decreasing():
+    rng = np.random.default_rng(1)
+    nr, k, nc = 100, 10, 50                       # test-top-product.R:4-6
+    m1 = rng.random((nr, k))
+    m2 = rng.random((k, nc))
+    m3 = m1 @ m2
+    res, scores = O.top_product(m1, m2, k)
+    for row in (0, 17, 99):
+        expect = np.argsort(-m3[row], kind="stable")[:k] + 1
+        assert np.array_equal(res[row], expect)
+        assert np.allclose(scores[row], m3[row][expect - 1])
+
+
+def test_oracle_exclusions_ties_and_na():
+    x = np.zeros((2, 3))
+    x[1] = [1.0, 0.0, 0.0]
+    y = np.arange(18, dtype=np.float64).reshape(3, 6)
+    # row 0: all scores 0 -> the heap keeps the first k admissible items, output has the larger index first
+    res, sc = O.top_product(x, y, 3)
+    assert list(res[0]) == [3, 2, 1] and np.all(sc[0] == 0)
+    assert list(res[1]) == [6, 5, 4]
+    nr = sp.csr_matrix(np.array([[0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1]]))
+    res, sc = O.top_product(x, y, 3, nr.indptr, nr.indices, exclude=[5])
+    assert list(res[0]) == [4, 3, 1] and list(res[1]) == [4, 3, 2]
+    res, sc = O.top_product(x, y, 5, exclude=[1, 2, 3])
+    assert list(res[0][:3]) == [6, 5, 4] and np.all(res[0][3:] == O.NA_INTEGER) and np.isnan(sc[0][3:]).all()
+
+
+def _hip_top_product(x, y, k, nr=None, exclude=(), glob_mean=0.0):
+    lib = _lib.load()
+    nrow, rank = x.shape
+    nc = y.shape[1]
+    xf = np.asfortranarray(x, dtype=np.float64)
+    yf = np.asfortranarray(y, dtype=np.float64)
+    res = np.zeros((nrow, k), dtype=np.int32, order="F")
+    sc = np.zeros((nrow, k), dtype=np.float64, order="F")
+    vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    p = j = None
+    if nr is not None:
+        nr = sp.csr_matrix(nr)
+        nr.sort_indices()
+        p, j = nr.indptr.astype(np.int32), nr.indices.astype(np.int32)
+    ex = np.asarray(list(exclude), dtype=np.int32)
+    _lib.check(lib.rsparse_hip_top_product(vp(xf), vp(yf), nrow, nc, rank, k, 1, vp(p), vp(j), vp(ex) if ex.size else None,
+                                           int(ex.size), float(glob_mean), vp(res), vp(sc)))
+    return res, sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rank,nr,nc,k", [(10, 100, 50, 10), (16, 70, 3001, 25), (64, 33, 777, 7), (128, 129, 5000, 100),
+                                          (20, 5, 40, 12)])
+def test_hip_matches_oracle(rank, nr, nc, k):
+    rng = np.random.default_rng(rank + nr)
+    x = rng.standard_normal((nr, rank)).astype(np.float32).astype(np.float64)
+    y = rng.standard_normal((rank, nc)).astype(np.float32).astype(np.float64)
+    notrec = sp.random(nr, nc, density=0.05, random_state=3, format="csr")
+    excl = [1, 7, nc]                                     # 1-based like R
+    for args in (dict(), dict(nr=notrec), dict(nr=notrec, exclude=excl, glob_mean=0.5)):
+        ref_i, ref_s = O.top_product(x, y, k, *(None, None) if "nr" not in args else (notrec.indptr, notrec.indices),
+                                     exclude=args.get("exclude", ()), glob_mean=args.get("glob_mean", 0.0))
+        got_i, got_s = _hip_top_product(x, y, k, **args)
+        assert np.allclose(got_s, ref_s, rtol=1e-4, atol=1e-5, equal_nan=True)
+        # indices agree wherever the neighbouring scores are separated by more than fp32 noise
+        gap_ok = np.ones_like(ref_i, dtype=bool)
+        d = np.abs(np.diff(ref_s, axis=1))
+        tol = 1e-4 * np.maximum(1.0, np.abs(ref_s[:, :-1]))
+        gap_ok[:, :-1] &= d > tol
+        gap_ok[:, 1:] &= d > tol
+        assert np.array_equal(got_i[gap_ok], ref_i[gap_ok])
+
+
+@pytest.mark.gpu
+def test_hip_ties_and_na_fill():
+    x = np.zeros((3, 4))
+    x[1] = [1.0, 0, 0, 0]
+    y = np.arange(40, dtype=np.float64).reshape(4, 10)
+    ref_i, ref_s = O.top_product(x, y, 4)
+    got_i, got_s = _hip_top_product(x, y, 4)
+    assert np.array_equal(got_i, ref_i) and np.array_equal(got_s, ref_s)       # all-zero rows: ties everywhere
+    ref_i, ref_s = O.top_product(x, y, 6, exclude=[1, 2, 3, 4, 5, 6, 7])
+    got_i, got_s = _hip_top_product(x, y, 6, exclude=[1, 2, 3, 4, 5, 6, 7])
+    assert np.array_equal(got_i, ref_i) and np.array_equal(np.isnan(got_s), np.isnan(ref_s))
+    assert (got_i[:, 3:] == O.NA_INTEGER).all()
+
+
+@pytest.mark.gpu
+def test_wrmf_predict(movielens, ml_train):
+    """test-wrmf.R:59-61: predict(cv, k = K) has nrow(cv) rows and K columns; never recommends seen items."""
+    from conftest import csc_drop_rows
+    from rsparse_amd import WRMF
+    n_user_all, n_item, p, i, x = movielens
+    n_user, _, tp, ti, tx = ml_train
+    train = sp.csc_matrix((tx, ti, tp), shape=(n_user, n_item))
+    cp, ci, cx = csc_drop_rows(900, p, i, x)
+    cv = sp.csc_matrix((cx, ci, cp), shape=(n_user_all - 900, n_item)).tocsr()
+    m = WRMF(rank=8, lambda_=0.1, feedback="implicit", solver="conjugate_gradient", precision="float", rng=1)
+    m.fit_transform(train, n_iter=3, convergence_tol=-1)
+    K = 7
+    preds = m.predict(cv, K)
+    assert preds.shape == (cv.shape[0], K) and preds.scores.shape == (cv.shape[0], K)
+    emb = m.transform(cv)
+    dense = emb.astype(np.float64) @ m.components.astype(np.float64)
+    for r in range(cv.shape[0]):
+        seen = set(cv.indices[cv.indptr[r]:cv.indptr[r + 1]])
+        assert not (set(preds[r]) & seen)
+        assert np.all(np.diff(preds.scores[r]) <= 1e-6)
+        assert np.allclose(preds.scores[r], dense[r, preds[r]], rtol=1e-4, atol=1e-5)
+    none = m.predict(cv, K, not_recommend=None, items_exclude=[0, 1, 2])
+    assert not (set(none.ravel()) & {0, 1, 2})

@@ -67,6 +67,11 @@ def load():
             raise RuntimeError(
                 "%s not found -- the HIP extension is required (no CPU fallback). "
                 "Build it with `python -m rsparse_amd.build`." % LIB_PATH)
+        try:  # let torch take its first look at the GPU before this library initialises the HIP runtime:
+            import torch  # torch.cuda.is_available() answers False if it is first asked afterwards
+            torch.cuda.is_available()
+        except ImportError:
+            pass
         lib = ctypes.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             f = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

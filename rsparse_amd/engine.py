@@ -44,7 +44,7 @@ class HipBackend:
 
     def __init__(self, device=None):
         self.lib = _lib.load()
-        if not torch.cuda.is_available() or self.lib.rsparse_hip_device_count() < 1:
+        if torch.cuda.device_count() < 1 or self.lib.rsparse_hip_device_count() < 1:
             raise RuntimeError("rsparse_amd: no HIP device visible (the device path has no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         torch.cuda.set_device(self.device)

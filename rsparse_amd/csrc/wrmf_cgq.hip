@@ -448,10 +448,44 @@ hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int 
   return hipGetLastError();
 }
 
+// Side streams for overlapping the bucket launches (they touch disjoint rows): forked from / joined to the
+// caller's stream with events, so the call stays asynchronous and ordered on that stream.
+struct BucketStreams {
+  hipStream_t st[kNB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t fork = nullptr;
+  hipEvent_t done[kNB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int device = -1;
+  hipError_t ensure() {
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    if (dev == device) return hipSuccess;
+    device = dev;  // streams belong to a device; a process drives one GPU, so this happens once
+    if ((err = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return err;
+    for (int b = 0; b < kNB; b++) {
+      if ((err = hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking)) != hipSuccess) return err;
+      if ((err = hipEventCreateWithFlags(&done[b], hipEventDisableTiming)) != hipSuccess) return err;
+    }
+    return hipSuccess;
+  }
+};
+BucketStreams g_bs;
+
+bool concurrent_buckets() {
+  static const char* env = std::getenv("RSPARSE_HIP_CONCURRENT");
+  return !(env && env[0] == '0');
+}
+
 template <int KP, int CFG, bool IMPLICIT>
 hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEvent_t* ev) {
   hipError_t err;
   size_t slot = 0;
+  // per-kernel timing (ev != nullptr) needs the launches back to back on one stream
+  const bool overlap = !ev && concurrent_buckets();
+  if (overlap) {
+    if ((err = g_bs.ensure()) != hipSuccess) return err;
+    if ((err = hipEventRecord(g_bs.fork, s)) != hipSuccess) return err;
+  }
 #define RSP_BUCKET(B)                                                                                       \
   {                                                                                                         \
     constexpr BucketDef D = kBuckets[CFG][B];                                                               \
@@ -459,9 +493,20 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
     if constexpr (D.wpr > 0) {                                                                              \
       const int n = q.off[B + 1] - q.off[B];                                                                \
       const int grid = cgq_bucket_grid(n, B, CFG);                                                          \
-      if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, grid, slot, \
-                                                                              s)) != hipSuccess)            \
-        return err;                                                                                         \
+      if (n > 0) {                                                                                          \
+        hipStream_t bs = s;                                                                                 \
+        if (overlap) {                                                                                      \
+          bs = g_bs.st[B];                                                                                  \
+          if ((err = hipStreamWaitEvent(bs, g_bs.fork, 0)) != hipSuccess) return err;                       \
+        }                                                                                                   \
+        if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, grid, slot, \
+                                                                                bs)) != hipSuccess)         \
+          return err;                                                                                       \
+        if (overlap) {                                                                                      \
+          if ((err = hipEventRecord(g_bs.done[B], bs)) != hipSuccess) return err;                           \
+          if ((err = hipStreamWaitEvent(s, g_bs.done[B], 0)) != hipSuccess) return err;                     \
+        }                                                                                                   \
+      }                                                                                                     \
       slot += (size_t)grid * D.waves;                                                                       \
     }                                                                                                       \
   }

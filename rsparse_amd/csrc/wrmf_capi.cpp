@@ -50,6 +50,8 @@ struct Workspace {
   size_t partial_slots = 0;
   double* scalars = nullptr;  // [0] loss rows, [1] sumsq, [2..] spare
   int* fails = nullptr;
+  float* tscr = nullptr;   // streamed CG rows: per-non-zero dot products of every sweep
+  size_t tscr_floats = 0;
   int device = -1;
 
   int ensure_device() {
@@ -90,7 +92,20 @@ struct Workspace {
     }
     return RSPARSE_HIP_OK;
   }
+  int ensure_tscr(size_t floats) {
+    if (floats > tscr_floats) {
+      if (tscr) (void)hipFree(tscr);
+      tscr = nullptr;
+      tscr_floats = 0;
+      HIP_TRY(hipMalloc(&tscr, floats * sizeof(float)));
+      tscr_floats = floats;
+    }
+    return RSPARSE_HIP_OK;
+  }
   void release() {
+    if (tscr) (void)hipFree(tscr);
+    tscr = nullptr;
+    tscr_floats = 0;
     if (gram) (void)hipFree(gram);
     if (partials) (void)hipFree(partials);
     if (scalars) (void)hipFree(scalars);
@@ -166,6 +181,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   for (int b = 0; b < 7; b++) d.q_off[b] = 0;
   for (int b = 0; b < 6; b++) d.q_nnz[b] = 0;
   d.q_order = nullptr;
+  d.q_stream_off = nullptr;
   d.q_cfg = cgq_default_cfg();
   if (n <= 0) return RSPARSE_HIP_OK;
   const int max_len = d.max_len;
@@ -187,6 +203,17 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   for (int b = 0; b < 6; b++) d.q_off[b + 1] = d.q_off[b] + cnt_b[b];
   HIP_TRY(hipMalloc(&d.q_order, (size_t)n * sizeof(int32_t)));
   HIP_TRY(hipMemcpy(d.q_order, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+  // streamed bucket (bucket 0): slot of each row's first non-zero in the per-sweep scratch
+  const int n_stream = d.q_off[1];
+  if (n_stream > 0) {
+    std::vector<int64_t> soff((size_t)n_stream + 1, 0);
+    for (int r = 0; r < n_stream; r++) {
+      const int row = order[(size_t)r];
+      soff[(size_t)r + 1] = soff[(size_t)r] + (host_col_ptrs[row + 1] - host_col_ptrs[row]);
+    }
+    HIP_TRY(hipMalloc(&d.q_stream_off, soff.size() * sizeof(int64_t)));
+    HIP_TRY(hipMemcpy(d.q_stream_off, soff.data(), soff.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  }
   return RSPARSE_HIP_OK;
 }
 
@@ -253,6 +280,15 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails;
+  a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
+  {
+    static const char* ts_env = std::getenv("RSPARSE_HIP_TSCRATCH");
+    const bool ts_on = !(ts_env && ts_env[0] == '0');
+    if (cgq && ts_on && d.q_stream_off && d.q_nnz[0] > 0 && cg_steps >= 1 && cg_steps <= 4) {
+      if ((rc = g_ws.ensure_tscr((size_t)(cg_steps + 1) * (size_t)d.q_nnz[0]))) return rc;
+      a.tscr = g_ws.tscr;
+    }
+  }
   hipEvent_t* ev = g_prof.begin();
   static const char* chol_env = std::getenv("RSPARSE_HIP_CHOL");
   const bool chol_lds = chol_env && std::strcmp(chol_env, "lds") == 0;
@@ -435,6 +471,7 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   DevCSC& d = m->d;
   if (d.long_rows) (void)hipFree(d.long_rows);
   if (d.q_order) (void)hipFree(d.q_order);
+  if (d.q_stream_off) (void)hipFree(d.q_stream_off);
   if (d.owns_matrix) {
     if (d.col_ptrs) (void)hipFree(const_cast<int32_t*>(d.col_ptrs));
     if (d.row_idx) (void)hipFree(const_cast<int32_t*>(d.row_idx));

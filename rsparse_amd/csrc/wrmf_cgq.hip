@@ -31,6 +31,7 @@ namespace {
 using namespace dev;
 
 constexpr float kCgTolQ = 1e-10f;  // CG_TOL, inst/include/wrmf.hpp:22
+constexpr int kMaxSavedSweeps = 4;  // streamed rows keep the dot products of up to this many CG steps
 
 template <int KP>
 struct QG {
@@ -160,6 +161,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     const float lam_use =
         IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)cnt : 1.0));
 
+    // streamed rows only: scratch for the per-non-zero dot products of every sweep (see the loss pass)
+    float* tscr = nullptr;
+    float alph[kMaxSavedSweeps];
+#pragma unroll
+    for (int s2 = 0; s2 < kMaxSavedSweeps; s2++) alph[s2] = 0.f;
+    if constexpr (STREAM == 1) {
+      if (a.tscr && have && a.cg_steps <= kMaxSavedSweeps) tscr = a.tscr + a.stream_off[ri];
+    }
+
     float xt[CAPQ][RPN];  // gathered vectors: quad q, group g holds non-zero 4q+g of the chunk
     float cv[CAPQ];       // its confidence / rating (uniform inside the group)
     int ccnt = 0;
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     }
 
     // one pass over the resident quads: t = X_nnz^T v, then acc += X_nnz w  (or the loss terms)
-    auto quad_pass = [&](const float(&v)[RPN], const int mode, float(&acc)[RPN], float& lacc) {
+    auto quad_pass = [&](const float(&v)[RPN], const int mode, float(&acc)[RPN], float& lacc, float* tsave) {
       constexpr int QB = 4;  // quads per block: 4 independent dot/DPP chains interleave inside one basic block
 #pragma unroll
       for (int q0 = 0; q0 < CAPQ; q0 += QB) {
@@ -229,6 +239,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
             const int q = q0 + u;
             const bool valid = 4 * q + g < ccnt;
             const float c = cv[q];
+            if constexpr (STREAM == 1) {  // keep t_j = x_j . v of this sweep: the loss is rebuilt from them
+              if (tsave && valid && i == 0) tsave[4 * q + g] = t[u];
+            }
             if (mode == 2) {
               const float d = IMPLICIT ? 1.f - t[u] : c - t[u];
               lacc += valid ? (IMPLICIT ? c * d * d : d * d) : 0.f;
@@ -246,7 +259,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     };
 
     // mode 0: out = X_nnz (c - c1 % X_nnz^T v) - G v ; mode 1: out = X_nnz (c1 % X_nnz^T v) + G v ; mode 2: loss
-    auto sweep = [&](const float(&v)[RPN], const int mode, float(&out)[RPN], float& loss_out, const bool live) {
+    auto sweep = [&](const float(&v)[RPN], const int mode, float(&out)[RPN], float& loss_out, const bool live,
+                     const int sidx = 0) {
       float acc[RPN];
 #pragma unroll
       for (int rr = 0; rr < RPN; rr++) acc[rr] = 0.f;
@@ -269,12 +283,29 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           }
         }
         if (resident) {
-          quad_pass(v, mode, acc, lacc);
+          quad_pass(v, mode, acc, lacc, nullptr);
+        } else if (mode == 2 && tscr) {
+          // streamed rows: t_final = t_0 + sum_s alpha_s t_s from the scratch written by the sweeps -- 20 bytes
+          // per non-zero instead of re-gathering its 512-byte vector
+          for (int ch = tw; ch < nchunks; ch += WPR) {
+            const int n = min(CAP, cnt - ch * CAP);
+            if (lane < n) {
+              const size_t pos = (size_t)ch * CAP + lane;
+              float t = tscr[pos];
+#pragma unroll
+              for (int s2 = 0; s2 < kMaxSavedSweeps; s2++)
+                if (s2 < a.cg_steps) t = fmaf(alph[s2], tscr[(size_t)(s2 + 1) * a.stream_nnz + pos], t);
+              const float c = a.vals[p1 + pos];
+              const float d = IMPLICIT ? 1.f - t : c - t;
+              lacc += IMPLICIT ? c * d * d : d * d;
+            }
+          }
+          lacc = row16_sum(lacc);  // groups_sum below finishes the wave sum
         } else {
           for (int ch = tw; ch < nchunks; ch += WPR) {
             ccnt = min(CAP, cnt - ch * CAP);
             gather(p1 + ch * CAP, ccnt);
-            quad_pass(v, mode, acc, lacc);
+            quad_pass(v, mode, acc, lacc, tscr ? tscr + (size_t)sidx * a.stream_nnz + (size_t)ch * CAP : nullptr);
           }
         }
         if (mode != 2) {
@@ -372,10 +403,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     bool conv = false;
     for (int itc = 0; itc < a.cg_steps; ++itc) {
       if (WPR == 1 && conv) break;
-      sweep(p, 1, ap, dummy, live && !conv);
+      sweep(p, 1, ap, dummy, live && !conv, itc + 1);
       if (!conv) {
         const float pap = dot16(p, ap);
         const float alpha = rsold / pap;
+#pragma unroll
+        for (int s2 = 0; s2 < kMaxSavedSweeps; s2++)
+          if (s2 == itc) alph[s2] = alpha;
 #pragma unroll
         for (int rr = 0; rr < RPN; rr++) {
           x[rr] = fmaf(alpha, p[rr], x[rr]);

@@ -25,6 +25,7 @@ struct DevCSC {
   int q_off[7] = {0, 0, 0, 0, 0, 0, 0};
   int q_cfg = 0;
   int64_t q_nnz[6] = {0, 0, 0, 0, 0, 0};
+  int64_t* q_stream_off = nullptr;  // prefix sums of the streamed bucket's row lengths (device)
   int64_t nnz_long = 0;
   int n_empty = 0;
   bool owns_matrix = false;
@@ -47,6 +48,11 @@ struct AlsArgs {
   int dynamic_lambda;
   double* loss_partials;  // one double per wave (short kernel) / per workgroup (long kernel)
   int* fail_counter;      // Cholesky: rows whose system was not positive definite
+  // streamed CG rows: scratch [cg_steps+1][stream_nnz] for the per-non-zero dot products of every sweep,
+  // stream_off[r] = first slot of the r-th streamed row (rows in schedule order); nullptr = re-gather for the loss
+  float* tscr;
+  const int64_t* stream_off;
+  int64_t stream_nnz;
 };
 
 struct QSchedule {

@@ -113,9 +113,14 @@ def main():
     ap.add_argument("--cg-steps", type=int, default=3)
     ap.add_argument("--lambda", dest="lam", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-launches", action="store_true",
+                    help="issue the CG bucket kernels back to back instead of overlapping them on side streams "
+                         "(use under rocprofv3 so that per-kernel durations are well defined)")
     ap.add_argument("--seed", type=int, default=20250222)
     args = ap.parse_args()
 
+    if args.serial_launches:
+        os.environ["RSPARSE_HIP_CONCURRENT"] = "0"   # read by the library at its first CG launch
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -271,6 +276,8 @@ def main():
                        "cg_steps": args.cg_steps, "parallelism": "rows sharded x%d, factors replicated" % ws},
             "user_rows_per_sec": n_user / (user_half_ms * 1e-3) if user_half_ms > 0 else None,
             "loss_users_last": losses[-1][1] if losses else None,
+            "launch_mode": "serial" if os.environ.get("RSPARSE_HIP_CONCURRENT", "1") == "0" else
+                           "overlapped (the per-kernel times under roofline are measured in a serialised pass)",
             "datagen_s": t_gen,
             "roofline": roofline,
             "cpu_baseline": cpu,

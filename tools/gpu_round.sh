@@ -24,7 +24,7 @@ timeout 1200 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; echo
 cat $OUT/bench_full.json >> $OUT/summary.txt; tail -5 $OUT/bench_full.err >> $OUT/summary.txt
 echo "== rocprofv3 kernel stats of the full bench" | tee -a $OUT/summary.txt
 REPO=$PWD
-(cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof -o bench -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $REPO/$OUT/prof_bench.json 2> $REPO/$OUT/prof_bench.err); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
+(cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof -o bench -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial-launches > $REPO/$OUT/prof_bench.json 2> $REPO/$OUT/prof_bench.err); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 find $OUT/prof -name "*kernel_stats*" | head -3 | while read f; do echo "--- $f"; python tools/rocpd_summary.py "$f" | cut -c1-160 | head -10; done >> $OUT/summary.txt 2>&1
 # keep only the small summaries (the trace itself can be large)
 find $OUT/prof -name "*kernel_trace*" -size +20M -delete 2>/dev/null

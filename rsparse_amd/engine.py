@@ -170,7 +170,9 @@ class ShardedALS:
                 torch.distributed.all_gather_into_tensor(host, host[self.me * B:(self.me + 1) * B].clone(), group=self.group)
                 S.copy_(host)
                 return
-            mine = S[self.me * B:(self.me + 1) * B]
+            # the input is a copy of this rank's block (not a view of the output): no reliance on the
+            # backend's in-place all-gather semantics, for the price of one on-device block copy
+            mine = S[self.me * B:(self.me + 1) * B].clone()
             torch.distributed.all_gather_into_tensor(S, mine, group=self.group)
 
     def gramian(self, F, n, B, bounds):

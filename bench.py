@@ -152,8 +152,7 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     n_user, n_item, nnz = data["n_users"], data["n_items"], data["nnz"]
-    Bu, ub = block_bounds(n_user, ws)
-    Bi, ib = block_bounds(n_item, ws)
+    Bu, ub, Bi, ib, _ = ShardedALS.partition(n_user, n_item, ws)
     c_ui_blk = shard_csc(*data["c_ui"], *ib[rank]) if ws > 1 else data["c_ui"]
     c_iu_blk = shard_csc(*data["c_iu"], *ub[rank]) if ws > 1 else data["c_iu"]
     als = ShardedALS(be, n_user, n_item, k, c_ui_blk, c_iu_blk, nnz, feedback="implicit", lambda_=lam,

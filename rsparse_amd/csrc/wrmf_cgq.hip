@@ -30,6 +30,8 @@ namespace {
 
 using namespace dev;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr float kCgTolQ = 1e-10f;  // CG_TOL, inst/include/wrmf.hpp:22
 constexpr int kMaxSavedSweeps = 4;  // streamed rows keep the dot products of up to this many CG steps
 
@@ -227,10 +229,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           float t[QB];
 #pragma unroll
           for (int u = 0; u < QB; u++) {
-            float s = 0.f;
+            // two interleaved partial sums -> v_pk_fma_f32 (RPN is even for every supported rank)
+            f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-            for (int rr = 0; rr < RPN; rr++) s = fmaf(xt[q0 + u][rr], v[rr], s);
-            t[u] = s;
+            for (int rr = 0; rr < RPN; rr += 2) {
+              const f32x2 xa = {xt[q0 + u][rr], xt[q0 + u][rr + 1]};
+              const f32x2 va = {v[rr], v[rr + 1]};
+              s2 = __builtin_elementwise_fma(xa, va, s2);
+            }
+            t[u] = s2.x + s2.y;
           }
 #pragma unroll
           for (int u = 0; u < QB; u++) t[u] = row16_sum(t[u]);

@@ -31,10 +31,21 @@ from . import _lib
 SOLVER_CODES = {"cholesky": 0, "conjugate_gradient": 1, "nnls": 2}   # R/model_WRMF.R:99-100
 
 
-def block_bounds(n, world_size):
-    """Equal row blocks (the last ones padded): rank r owns rows [r*B, min(n, (r+1)*B))."""
+def block_bounds(n, world_size, multiple=1):
+    """Equal row blocks (the last ones padded): rank r owns rows [r*B, min(n, (r+1)*B)); B is a multiple
+    of `multiple` (sub-blocks for communication/compute overlap)."""
     B = max(1, math.ceil(n / world_size)) if n > 0 else 1
+    B = -(-B // multiple) * multiple
     return B, [(min(n, r * B), min(n, (r + 1) * B)) for r in range(world_size)]
+
+
+def default_user_subblocks(world_size):
+    """Sub-blocks per rank for the user half: with several ranks the all-gather of the solved user block
+    (5 GB at 10M x 128) costs about as much as the solve, so it is pipelined sub-block by sub-block."""
+    import os
+    if world_size <= 1:
+        return 1
+    return max(1, int(os.environ.get("RSPARSE_USER_SUBBLOCKS", "4")))
 
 
 class HipBackend:
@@ -140,8 +151,7 @@ class ShardedALS:
         self.implicit = feedback == "implicit"
         self.lambda_, self.dynamic_lambda, self.cg_steps = float(lambda_), bool(dynamic_lambda), int(cg_steps)
         self.group, self.ws, self.me = group, int(world_size), int(my_rank)
-        self.Bu, self.ub = block_bounds(n_user, self.ws)
-        self.Bi, self.ib = block_bounds(n_item, self.ws)
+        self.Bu, self.ub, self.Bi, self.ib, self.n_sub = self.partition(n_user, n_item, self.ws)
         u0, u1 = self.ub[self.me]
         i0, i1 = self.ib[self.me]
         # item half: fixed side = users (n_user rows of X), solved = my items
@@ -149,10 +159,33 @@ class ShardedALS:
         # user half: fixed side = items, solved = my users
         self.csc_users = backend.make_csc(n_item, u1 - u0, *c_iu_block)
         dev = c_ui_block[0].device
+        # sub-blocks of my user block, each with its own schedule (only used when world_size > 1)
+        self.Bs = self.Bu // self.n_sub
+        self.sub_users = []
+        if self.n_sub > 1:
+            p, i, x = c_iu_block
+            p64 = p.to(torch.int64)
+            n_my = u1 - u0
+            for j in range(self.n_sub):
+                c0, c1 = min(n_my, j * self.Bs), min(n_my, (j + 1) * self.Bs)
+                lo, hi = int(p64[c0]), int(p64[c1])
+                sp_ = (p64[c0:c1 + 1] - lo).to(torch.int32).contiguous()
+                self.sub_users.append((c0, c1, backend.make_csc(n_item, c1 - c0, sp_, i[lo:hi].contiguous(),
+                                                                x[lo:hi].contiguous())))
+        self.scal_sub = torch.zeros(max(1, self.n_sub), dtype=torch.float64, device=dev)
         self.G = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float64, device=dev)   # [0] sumsq, [1] loss rows, [2] reg
         self.cnt_user = None   # nnz per user (weights of the explicit regulariser on U)
         self.cnt_item = None
+
+    @staticmethod
+    def partition(n_user, n_item, world_size):
+        """(Bu, user bounds, Bi, item bounds, user sub-blocks per rank) -- callers shard their CSC blocks with
+        exactly these bounds."""
+        n_sub = default_user_subblocks(world_size)
+        Bu, ub = block_bounds(n_user, world_size, multiple=n_sub)
+        Bi, ib = block_bounds(n_item, world_size)
+        return Bu, ub, Bi, ib, n_sub
 
     # -- factor storage: (n_pad, k) row-major == k x n_pad column-major, padded to world_size * B rows
     def alloc_factors(self, n, B, dev):
@@ -174,6 +207,19 @@ class ShardedALS:
             # backend's in-place all-gather semantics, for the price of one on-device block copy
             mine = S[self.me * B:(self.me + 1) * B].clone()
             torch.distributed.all_gather_into_tensor(S, mine, group=self.group)
+
+    def _all_gather_sub(self, S, B, j):
+        """Start the all-gather of sub-block j of every rank's block of S; returns a work handle (or None)."""
+        Bs = self.Bs
+        mine = S[self.me * B + j * Bs:self.me * B + (j + 1) * Bs]
+        if S.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+            host = [torch.empty(mine.shape, dtype=S.dtype) for _ in range(self.ws)]   # dry-run configuration only
+            torch.distributed.all_gather(host, mine.cpu(), group=self.group)
+            for r in range(self.ws):
+                S[r * B + j * Bs:r * B + (j + 1) * Bs].copy_(host[r])
+            return None
+        outs = [S[r * B + j * Bs:r * B + (j + 1) * Bs] for r in range(self.ws)]
+        return torch.distributed.all_gather(outs, mine.clone(), group=self.group, async_op=True)
 
     def gramian(self, F, n, B, bounds):
         """G = F[:n] F[:n]^T + fl(lambda) I, reduced over the ranks' blocks; scal[0] = sum(F^2)."""
@@ -199,9 +245,23 @@ class ShardedALS:
             G = self.gramian(F, nF, BF, bF)
         s0, s1 = bS[self.me]
         S_block = S[s0:s1]
-        self.be.half_iteration(csc, self.implicit, F[:nF], S_block, G, self.lambda_, solver, self.cg_steps,
-                               self.dynamic_lambda, self.scal[1:2])
-        self._all_gather_blocks(S, BS)
+        if side == "users" and self.ws > 1 and self.n_sub > 1:
+            # pipelined: solve sub-block j, start its all-gather, solve sub-block j+1 meanwhile
+            works = []
+            self.scal_sub.zero_()
+            for j, (c0, c1, sub) in enumerate(self.sub_users):
+                if c1 > c0:
+                    self.be.half_iteration(sub, self.implicit, F[:nF], S_block[c0:c1], G, self.lambda_, solver,
+                                           self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1])
+                works.append(self._all_gather_sub(S, BS, j))
+            for w in works:
+                if w is not None:
+                    w.wait()
+            self.scal[1:2] = self.scal_sub.sum()
+        else:
+            self.be.half_iteration(csc, self.implicit, F[:nF], S_block, G, self.lambda_, solver, self.cg_steps,
+                                   self.dynamic_lambda, self.scal[1:2])
+            self._all_gather_blocks(S, BS)
         if not want_loss:
             return None
         # regulariser on the fixed side (wrmf_implicit.hpp:286-301, wrmf_explicit.hpp:146-173)

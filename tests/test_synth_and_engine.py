@@ -41,6 +41,10 @@ def test_block_bounds():
     assert B == 3 and b == [(0, 3), (3, 6), (6, 9), (9, 10)]
     B, b = block_bounds(2, 4)
     assert B == 1 and b == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    B, b = block_bounds(10, 2, multiple=4)          # blocks padded to a multiple of the sub-block count
+    assert B == 8 and b == [(0, 8), (8, 10)]
+    Bu, ub, Bi, ib, n_sub = ShardedALS.partition(301, 97, 2)
+    assert n_sub == 4 and Bu % 4 == 0 and ub[1][1] == 301 and ShardedALS.partition(301, 97, 1)[4] == 1
 
 
 def _shard_csc(p, i, x, c0, c1):
@@ -53,8 +57,7 @@ def run_sharded(rank, ws, group, feedback, solver, n_iter=2):
     from oracle_backend import OracleBackend
     n_user, n_item, k, lam = 301, 97, 8, 0.1
     d = synth.make_dataset(n_user, n_item, mean_deg=12, d_max=60, feedback=feedback, device="cpu")
-    Bu, ub = block_bounds(n_user, ws)
-    Bi, ib = block_bounds(n_item, ws)
+    Bu, ub, Bi, ib, n_sub = ShardedALS.partition(n_user, n_item, ws)
     als = ShardedALS(OracleBackend(), n_user, n_item, k, _shard_csc(*d["c_ui"], *ib[rank]),
                      _shard_csc(*d["c_iu"], *ub[rank]), d["nnz"], feedback=feedback, lambda_=lam,
                      dynamic_lambda=True, cg_steps=3, group=group, world_size=ws, my_rank=rank)

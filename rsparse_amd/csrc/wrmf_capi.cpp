@@ -50,6 +50,7 @@ struct Workspace {
   size_t partial_slots = 0;
   double* scalars = nullptr;  // [0] loss rows, [1] sumsq, [2..] spare
   int* fails = nullptr;
+  float* zero_row = nullptr;  // 256 zero floats (padding slots of the CG gathers)
   float* tscr = nullptr;   // streamed CG rows: per-non-zero dot products of every sweep
   size_t tscr_floats = 0;
   int device = -1;
@@ -68,6 +69,10 @@ struct Workspace {
     if (!fails) {
       HIP_TRY(hipMalloc(&fails, sizeof(int)));
       HIP_TRY(hipMemset(fails, 0, sizeof(int)));
+    }
+    if (!zero_row) {
+      HIP_TRY(hipMalloc(&zero_row, 256 * sizeof(float)));
+      HIP_TRY(hipMemset(zero_row, 0, 256 * sizeof(float)));
     }
     return RSPARSE_HIP_OK;
   }
@@ -110,7 +115,8 @@ struct Workspace {
     if (partials) (void)hipFree(partials);
     if (scalars) (void)hipFree(scalars);
     if (fails) (void)hipFree(fails);
-    gram = nullptr; partials = nullptr; scalars = nullptr; fails = nullptr;
+    if (zero_row) (void)hipFree(zero_row);
+    gram = nullptr; partials = nullptr; scalars = nullptr; fails = nullptr; zero_row = nullptr;
     gram_floats = 0; partial_slots = 0;
   }
 };
@@ -279,7 +285,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.long_rows = d.long_rows; a.n_long = d.n_long; a.n_cols = d.n_cols;
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
-  a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails;
+  a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails; a.zero_row = g_ws.zero_row;
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
   {
     static const char* ts_env = std::getenv("RSPARSE_HIP_TSCRATCH");

@@ -32,6 +32,17 @@ using namespace dev;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// tuning switches (resident kernels with CAPQ >= the value use the feature)
+#ifndef RSP_ZPAD_MINCAPQ
+#define RSP_ZPAD_MINCAPQ 0
+#endif
+#ifndef RSP_TSAVE_MINCAPQ
+#define RSP_TSAVE_MINCAPQ 0
+#endif
+#ifndef RSP_GVFIRST_MINCAPQ
+#define RSP_GVFIRST_MINCAPQ 16
+#endif
+
 constexpr float kCgTolQ = 1e-10f;  // CG_TOL, inst/include/wrmf.hpp:22
 constexpr int kMaxSavedSweeps = 4;  // streamed rows keep the dot products of up to this many CG steps
 
@@ -78,12 +89,15 @@ __device__ __forceinline__ float groups_sum(float v) {
   return v;
 }
 
-template <int KP, int WAVES, int WPR, bool IMPLICIT>
+template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT>
 struct QSmem {
   static constexpr size_t gram_floats = IMPLICIT ? (size_t)KP * KP : 0;
   static constexpr size_t vec_floats = IMPLICIT ? (size_t)WAVES * KP : 0;
   static constexpr size_t red_floats = WPR > 1 ? (size_t)2 * WAVES * KP + 2 * WAVES : 0;
-  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats) * 4 + 16;
+  // resident rows: per wave, t_acc[CAP] = x_j . y accumulated over the CG steps and t_cur[CAP] = x_j . p of the
+  // current step (the loss is rebuilt from them instead of a fifth pass over the registers)
+  static constexpr size_t tsv_floats = STREAM ? 0 : (size_t)WAVES * 2 * CAPQ * 4;
+  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats) * 4 + 16;
 };
 
 template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT>
@@ -92,12 +106,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   using G_ = QG<KP>;
   constexpr int RPN = G_::RPN, VW = G_::VW, NV = G_::NV, CAP = CAPQ * 4, TEAMS = WAVES / WPR;
   using piece_t = typename Piece<VW>::type;
+  using SM = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>;
   static_assert(WAVES % WPR == 0, "teams must tile the workgroup");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sG = reinterpret_cast<float*>(smem);
-  float* sVec = sG + QSmem<KP, WAVES, WPR, IMPLICIT>::gram_floats;
-  float* sRed = sVec + QSmem<KP, WAVES, WPR, IMPLICIT>::vec_floats;  // [2][WAVES][KP]
+  float* sVec = sG + QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>::gram_floats;
+  float* sRed = sVec + QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>::vec_floats;  // [2][WAVES][KP]
   float* sRedL = sRed + (WPR > 1 ? 2 * WAVES * KP : 0);              // [2][WAVES]
+  float* sTsv = sVec + SM::vec_floats + SM::red_floats;              // [WAVES][2][CAP]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
@@ -109,12 +125,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       sG[e] = (r < k && c < k) ? a.XtX[(size_t)r * k + c] : 0.f;
     }
   }
-  for (int e = tid; e < (int)(QSmem<KP, WAVES, WPR, IMPLICIT>::vec_floats + QSmem<KP, WAVES, WPR, IMPLICIT>::red_floats);
-       e += WAVES * 64)
-    sVec[e] = 0.f;
+  for (int e = tid; e < (int)(SM::vec_floats + SM::red_floats + SM::tsv_floats); e += WAVES * 64) sVec[e] = 0.f;
   __syncthreads();
 
   float* vec = sVec + wv * KP;
+  float* tacc = sTsv + wv * 2 * CAP;  // resident rows only
+  float* tcur = tacc + CAP;
   int buf = 0;
   double wloss = 0.0;
   const int team_global = blockIdx.x * TEAMS + team;
@@ -174,23 +190,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 
     float xt[CAPQ][RPN];  // gathered vectors: quad q, group g holds non-zero 4q+g of the chunk
     float cv[CAPQ];       // its confidence / rating (uniform inside the group)
+    float cl = 0.f;       // resident rows: confidence / rating of non-zero `lane` of the chunk (loss)
     int ccnt = 0;
 
     // Gather n (1..CAP) non-zeros starting at `base` into the registers: all index loads, then all vector
     // loads, with no control flow in between (two dependent HBM round trips per chunk; per-block branches
-    // here cost ~40 VGPRs of PHI copies and spill).  Slots beyond n are clamped duplicates of the last
-    // non-zero (same cache lines, finite data) and are masked out by `valid` in quad_pass.
+    // here cost ~40 VGPRs of PHI copies and spill).  Resident rows (gathered once): slots beyond n read the
+    // all-zero row and carry c = 0, so t = 0 and every weight derived from (c, t) is 0 -- they drop out of all
+    // sums without a select in the sweeps.  Streamed rows (gathered every sweep): clamped duplicates of the
+    // last non-zero, masked by `valid` in quad_pass (cheaper than the pointer selects per gather).
+    constexpr bool ZPAD = STREAM == 0 && CAPQ >= RSP_ZPAD_MINCAPQ;
+    constexpr bool TSAVE = STREAM == 0 && CAPQ >= RSP_TSAVE_MINCAPQ;
+    constexpr bool GVFIRST = STREAM == 0 && CAPQ >= RSP_GVFIRST_MINCAPQ;
     auto gather = [&](const int base, const int n) {
       int id[CAPQ];
 #pragma unroll
       for (int q = 0; q < CAPQ; q++) {
         const int j = min(4 * q + g, n - 1);
         id[q] = a.row_idx[base + j];
-        cv[q] = a.vals[base + j];
+        const float c = a.vals[base + j];
+        cv[q] = (!ZPAD || 4 * q + g < n) ? c : 0.f;
       }
+      if constexpr (TSAVE) cl = lane < n ? a.vals[base + lane] : 0.f;
 #pragma unroll
       for (int q = 0; q < CAPQ; q++) {
-        const float* src = a.X + (size_t)id[q] * k;
+        const float* src = (!ZPAD || 4 * q + g < n) ? a.X + (size_t)id[q] * k : a.zero_row;
 #pragma unroll
         for (int b = 0; b < NV; b++) {
           const int off = b * 16 * VW + i * VW;
@@ -222,6 +246,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 
     // one pass over the resident quads: t = X_nnz^T v, then acc += X_nnz w  (or the loss terms)
     auto quad_pass = [&](const float(&v)[RPN], const int mode, float(&acc)[RPN], float& lacc, float* tsave) {
+      float* trec = (mode == 0 ? tacc : tcur) + g;  // resident rows: slot 4q+g <- t (same value from the 16 lanes)
       constexpr int QB = 4;  // quads per block: 4 independent dot/DPP chains interleave inside one basic block
 #pragma unroll
       for (int q0 = 0; q0 < CAPQ; q0 += QB) {
@@ -244,10 +269,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 #pragma unroll
           for (int u = 0; u < QB; u++) {
             const int q = q0 + u;
-            const bool valid = 4 * q + g < ccnt;
+            const bool valid = ZPAD || 4 * q + g < ccnt;
             const float c = cv[q];
             if constexpr (STREAM == 1) {  // keep t_j = x_j . v of this sweep: the loss is rebuilt from them
               if (tsave && valid && i == 0) tsave[4 * q + g] = t[u];
+            } else if constexpr (TSAVE) {
+              trec[4 * q] = t[u];
             }
             if (mode == 2) {
               const float d = IMPLICIT ? 1.f - t[u] : c - t[u];
@@ -289,8 +316,41 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
             wave_sync();
           }
         }
+        // dense part: acc -/+= G v, the groups split the rows of G.  Resident rows run it before the quad pass (its
+        // LDS reads are in flight meanwhile); streamed rows after, where acc is not live across the gathers.
+        auto dense_part = [&]() {
+          if (IMPLICIT && mode != 2) {
+            const float sign = mode == 0 ? -1.f : 1.f;
+            for (int s4 = tw * 4 + g; s4 < KP / 4; s4 += WPR * 4) {
+              const int kk = 4 * s4;
+              const float4 vb = *reinterpret_cast<const float4*>(vec + kk);
+              const float vv[4] = {sign * vb.x, sign * vb.y, sign * vb.z, sign * vb.w};
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const float* grow = sG + (kk + u) * KP;
+#pragma unroll
+                for (int b = 0; b < NV; b++) {
+                  const piece_t pc = *reinterpret_cast<const piece_t*>(grow + b * 16 * VW + i * VW);
+                  const float* pf = reinterpret_cast<const float*>(&pc);
+#pragma unroll
+                  for (int c = 0; c < VW; c++) acc[b * VW + c] = fmaf(vv[u], pf[c], acc[b * VW + c]);
+                }
+              }
+            }
+          }
+        };
+        if constexpr (GVFIRST) dense_part();
         if (resident) {
-          quad_pass(v, mode, acc, lacc, nullptr);
+          if (mode != 2 || !TSAVE) {
+            quad_pass(v, mode, acc, lacc, nullptr);
+          } else {
+            // loss from t_acc = X_nnz^T y built up by the sweeps (the vectors are not touched again)
+            wave_sync();
+            const float t = tacc[lane & (CAP - 1)];
+            const float d = IMPLICIT ? 1.f - t : cl - t;
+            const float e = IMPLICIT ? cl * d * d : d * d;
+            lacc = row16_sum(lane < ccnt ? e : 0.f);  // groups_sum below finishes the wave sum
+          }
         } else if (mode == 2 && tscr) {
           // streamed rows: t_final = t_0 + sum_s alpha_s t_s from the scratch written by the sweeps -- 20 bytes
           // per non-zero instead of re-gathering its 512-byte vector
@@ -315,26 +375,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
             quad_pass(v, mode, acc, lacc, tscr ? tscr + (size_t)sidx * a.stream_nnz + (size_t)ch * CAP : nullptr);
           }
         }
+        if constexpr (!GVFIRST) dense_part();
         if (mode != 2) {
-          if constexpr (IMPLICIT) {
-            const float sign = mode == 0 ? -1.f : 1.f;
-            for (int s4 = tw * 4 + g; s4 < KP / 4; s4 += WPR * 4) {
-              const int kk = 4 * s4;
-              const float4 vb = *reinterpret_cast<const float4*>(vec + kk);
-              const float vv[4] = {sign * vb.x, sign * vb.y, sign * vb.z, sign * vb.w};
-#pragma unroll
-              for (int u = 0; u < 4; u++) {
-                const float* grow = sG + (kk + u) * KP;
-#pragma unroll
-                for (int b = 0; b < NV; b++) {
-                  const piece_t pc = *reinterpret_cast<const piece_t*>(grow + b * 16 * VW + i * VW);
-                  const float* pf = reinterpret_cast<const float*>(&pc);
-#pragma unroll
-                  for (int c = 0; c < VW; c++) acc[b * VW + c] = fmaf(vv[u], pf[c], acc[b * VW + c]);
-                }
-              }
-            }
-          }
 #pragma unroll
           for (int rr = 0; rr < RPN; rr++) acc[rr] = groups_sum(acc[rr]);
         } else {
@@ -417,6 +459,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 #pragma unroll
         for (int s2 = 0; s2 < kMaxSavedSweeps; s2++)
           if (s2 == itc) alph[s2] = alpha;
+        if constexpr (TSAVE) {  // t_acc += alpha * t_cur  (x += alpha p  =>  X_nnz^T x += alpha X_nnz^T p)
+          wave_sync();
+          const int sl = lane & (CAP - 1);
+          tacc[sl] = fmaf(alpha, tcur[sl], tacc[sl]);
+          wave_sync();
+        }
 #pragma unroll
         for (int rr = 0; rr < RPN; rr++) {
           x[rr] = fmaf(alpha, p[rr], x[rr]);
@@ -479,7 +527,7 @@ hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int 
   if (n_rows <= 0) return hipSuccess;
   constexpr int TEAMS = WAVES / WPR;
   auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>;
-  const size_t lds = QSmem<KP, WAVES, WPR, IMPLICIT>::bytes;
+  const size_t lds = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>::bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;

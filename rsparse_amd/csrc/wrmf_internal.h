@@ -50,6 +50,7 @@ struct AlsArgs {
   int* fail_counter;      // Cholesky: rows whose system was not positive definite
   // streamed CG rows: scratch [cg_steps+1][stream_nnz] for the per-non-zero dot products of every sweep,
   // stream_off[r] = first slot of the r-th streamed row (rows in schedule order); nullptr = re-gather for the loss
+  const float* zero_row;  // >= 128 zero floats: what the padding slots of a gather read
   float* tscr;
   const int64_t* stream_off;
   int64_t stream_nnz;

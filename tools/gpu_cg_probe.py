@@ -1,6 +1,6 @@
 """Per-row cost of the CG kernels for uniform row lengths, with the gathered factor matrix (a) small enough
 to stay in L2 and (b) far larger than every cache: (b) - (a) is what the gather phase costs."""
-import sys, time, json
+import os, sys, time, json
 import torch
 sys.path.insert(0, ".")
 from rsparse_amd.engine import HipBackend
@@ -10,9 +10,9 @@ dev = be.device
 k = 128
 G = torch.eye(k, device=dev) * 0.1
 res = []
-for L in (16, 32, 64, 128, 256, 512, 1024):
+for L in [int(v) for v in os.environ.get('PROBE_L', '16 32 64 128 256 512 1024').split()]:
     n_cols = max(20000, int(6e7 // L))
-    for n_rows in (4096, 4000000):
+    for n_rows in [int(v) for v in os.environ.get('PROBE_ROWS', '4096 4000000').split()]:
         g = torch.Generator(device=dev).manual_seed(L)
         X = torch.randn(n_rows, k, generator=g, device=dev) * 0.05
         G = (X[:4096].T @ X[:4096]) * (n_rows / 4096) + 0.1 * torch.eye(k, device=dev)

@@ -12,6 +12,11 @@ Gramian (+ all-reduce), the solve kernels, the factor all-gather (N>1) and the l
 exactly what `private$solver` does twice per iteration in R/model_WRMF.R:318-335.  Inputs are
 resident in HBM when the timed region starts.
 
+Other SURVEY.md 8(d) configurations (parity-test scale cases, reported in DESIGN.md, not the bench line):
+  --config 2   1M x 100k, rank 64, implicit CG(3)          --config 4   config 3 with the Cholesky solver
+  --config 5   5M x 500k, rank 64, explicit feedback, CG(3), dynamic lambda (add --solver cholesky for 5b)
+or any mix of --users/--items/--rank/--solver/--feedback.
+
 Extra objects on the line:
   roofline      dominant kernel (the CG launch with the largest share of the iteration), algorithmic bytes / measured duration
                 (HIP events on the launch stream, recorded inside the library) vs the 8 TB/s HBM peak
@@ -34,6 +39,13 @@ sys.path.insert(0, str(ROOT))
 from rsparse_amd import synth  # noqa: E402
 from rsparse_amd.engine import HipBackend, ShardedALS, block_bounds  # noqa: E402
 
+FP32_PEAK_TFLOPS = 157.3   # MI355X vector fp32 (= matrix fp32) peak
+CONFIGS = {
+    2: dict(users=1_000_000, items=100_000, rank=64, solver="cg", feedback="implicit"),
+    3: dict(users=10_000_000, items=1_000_000, rank=128, solver="cg", feedback="implicit"),
+    4: dict(users=10_000_000, items=1_000_000, rank=128, solver="cholesky", feedback="implicit"),
+    5: dict(users=5_000_000, items=500_000, rank=64, solver="cg", feedback="explicit"),
+}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -50,7 +62,7 @@ def algorithmic_bytes(n_rows, nnz, k, n_empty=0):
     return nnz * (4 * k + 8) + (n_rows - n_empty) * 8 * k + n_empty * 4 * k + (n_rows + 1) * 4 + 4 * k * k
 
 
-def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0):
+def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0, implicit=True, solver=1):
     """Time the oracle on host cores over the leading users / items of the same matrices."""
     from oracle import wrmf_oracle as O
     threads = len(os.sched_getaffinity(0))
@@ -72,7 +84,11 @@ def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0):
         Y = np.asfortranarray(Yfull[:, :n_take]).copy(order="F")
         G = O.gramian(X, lam, native=native)
         t0 = time.perf_counter()
-        O.als_implicit(p, i, x, X, Y, G, lam, 1, cg_steps, n_threads=threads, native=native)
+        if implicit:
+            O.als_implicit(p, i, x, X, Y, G, lam, solver, cg_steps, n_threads=threads, native=native)
+        else:
+            O.als_explicit(p, i, x, X, Y, None, lam, solver, cg_steps, dynamic_lambda=True, n_threads=threads,
+                           native=native)
         return time.perf_counter() - t0, nnz
 
     n_user, n_item, nnz_tot = data["n_users"], data["n_items"], data["nnz"]
@@ -106,9 +122,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--users", type=int, default=10_000_000)
-    ap.add_argument("--items", type=int, default=1_000_000)
-    ap.add_argument("--rank", type=int, default=128)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="SURVEY.md 8(d) configuration; 3 (default) is the one BASELINE.json's metric is quoted on")
+    ap.add_argument("--users", type=int, default=None)
+    ap.add_argument("--items", type=int, default=None)
+    ap.add_argument("--rank", type=int, default=None)
+    ap.add_argument("--solver", choices=("cg", "cholesky"), default=None)
+    ap.add_argument("--feedback", choices=("implicit", "explicit"), default=None)
     ap.add_argument("--mean-deg", type=float, default=50.0)
     ap.add_argument("--cg-steps", type=int, default=3)
     ap.add_argument("--lambda", dest="lam", type=float, default=0.1)
@@ -118,6 +138,11 @@ def main():
                          "(use under rocprofv3 so that per-kernel durations are well defined)")
     ap.add_argument("--seed", type=int, default=20250222)
     args = ap.parse_args()
+    for key, val in CONFIGS[args.config].items():
+        if getattr(args, key) is None:
+            setattr(args, key, val)
+    implicit = args.feedback == "implicit"
+    solver = 1 if args.solver == "cg" else 0          # inst/include/wrmf.hpp:16-20 codes
 
     if args.serial_launches:
         os.environ["RSPARSE_HIP_CONCURRENT"] = "0"   # read by the library at its first CG launch
@@ -148,27 +173,33 @@ def main():
 
     # ---- synthetic data, generated on the device (identical on every rank: counter-based) ----
     t0 = time.perf_counter()
-    data = synth.make_dataset(args.users, args.items, seed=args.seed, mean_deg=args.mean_deg, device=dev)
+    data = synth.make_dataset(args.users, args.items, seed=args.seed, mean_deg=args.mean_deg, device=dev,
+                              feedback=args.feedback)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     n_user, n_item, nnz = data["n_users"], data["n_items"], data["nnz"]
     Bu, ub, Bi, ib, _ = ShardedALS.partition(n_user, n_item, ws)
     c_ui_blk = shard_csc(*data["c_ui"], *ib[rank]) if ws > 1 else data["c_ui"]
     c_iu_blk = shard_csc(*data["c_iu"], *ub[rank]) if ws > 1 else data["c_iu"]
-    als = ShardedALS(be, n_user, n_item, k, c_ui_blk, c_iu_blk, nnz, feedback="implicit", lambda_=lam,
+    als = ShardedALS(be, n_user, n_item, k, c_ui_blk, c_iu_blk, nnz, feedback=args.feedback, lambda_=lam,
                      cg_steps=args.cg_steps, world_size=ws, my_rank=rank)
+    if not implicit:   # nnz per user / item: weights of the explicit regulariser (wrmf_explicit.hpp:160-170)
+        als.cnt_user = torch.diff(data["c_iu"][0]).to(torch.float32)
+        als.cnt_item = torch.diff(data["c_ui"][0]).to(torch.float32)
     if ws > 1:
         data = {"n_users": n_user, "n_items": n_item, "nnz": nnz}   # drop the full copies
         torch.cuda.empty_cache()
-    # initial factors: U ~ N(0, 0.01^2), item factors zero for CG (R/model_WRMF.R:204-231)
+    # initial factors: U ~ N(0, 0.01^2); item factors zero for CG, N(0, 0.01^2) otherwise (R/model_WRMF.R:204-231)
     g = torch.Generator(device=dev).manual_seed(args.seed)
     U = als.alloc_factors(n_user, Bu, dev)
     V = als.alloc_factors(n_item, Bi, dev)
     U[:n_user] = torch.randn(n_user, k, generator=g, device=dev) * 0.01
+    if solver == 0:
+        V[:n_item] = torch.randn(n_item, k, generator=g, device=dev) * 0.01
 
     def step(want_loss=True):
-        li = als.half_iteration("items", U, V, 1, want_loss=want_loss)
-        lu = als.half_iteration("users", U, V, 1, want_loss=want_loss)
+        li = als.half_iteration("items", U, V, solver, want_loss=want_loss)
+        lu = als.half_iteration("users", U, V, solver, want_loss=want_loss)
         return li, lu
 
     def barrier():
@@ -201,9 +232,11 @@ def main():
             F, nF, BF, bF = (U, n_user, Bu, ub) if side == "items" else (V, n_item, Bi, ib)
             torch.cuda.synchronize()
             th = time.perf_counter()
-            G = als.gramian(F, nF, BF, bF)
-            gm = be.profile_last()
-            als.half_iteration(side, U, V, 1, G=G, want_loss=True)
+            G, gm = None, [0.0, 0.0]
+            if implicit:
+                G = als.gramian(F, nF, BF, bF)
+                gm = be.profile_last()
+            als.half_iteration(side, U, V, solver, G=G, want_loss=True)
             pm = be.profile_last()
             torch.cuda.synchronize()
             half_ms[side].append(1e3 * (time.perf_counter() - th))
@@ -215,7 +248,22 @@ def main():
     info = {"users": als.csc_users.info(), "items": als.csc_items.info()}
     # per bucket: launches (one per half-iteration that has rows in it), mean duration, algorithmic bytes
     buckets = []
-    for b in range(nb):
+    kp = 32 if k <= 32 else (64 if k <= 64 else 128)
+    tf_flag = "true" if implicit else "false"
+    if solver == 0:
+        # one kernel per half-iteration; no warm-start read (Cholesky ignores it): drop one N*k*4 from B_half
+        ms = [mean(kern[sd]["bucket"][0]) for sd in ("items", "users")]
+        by = [algorithmic_bytes(info[sd]["n_cols"], info[sd]["nnz"], k, info[sd]["n_empty"]) -
+              (info[sd]["n_cols"] - info[sd]["n_empty"]) * 4 * k for sd in ("items", "users")]
+        fl = [2.0 * k * k * info[sd]["nnz"] + (info[sd]["n_cols"] - info[sd]["n_empty"]) * (k ** 3 / 3.0 + 2.0 * k * k)
+              for sd in ("items", "users")]
+        buckets.append({"kernel": "als_chol2_kernel<%d, %s, true>" % (kp, tf_flag),
+                        "what": "one 256-thread workgroup per row: normal equations assembled in registers, blocked "
+                                "Cholesky, two triangular solves (compute/LDS bound, see roofline.compute)",
+                        "launches_per_iteration": 2, "avg_launch_ms": float(np.mean(ms)),
+                        "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms)),
+                        "flops_per_launch": float(np.mean(fl))})
+    for b in range(nb if solver == 1 else 0):
         wpr = int(info["users"]["bucket_wpr"][b])
         if wpr <= 0:
             continue
@@ -224,9 +272,8 @@ def main():
                                 info[sd]["n_empty"] if b == nb - 1 or info["users"]["bucket_wpr"][min(b + 1, nb - 1)] <= 0 else 0)
               for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
         if ms:
-            kp = 32 if k <= 32 else (64 if k <= 64 else 128)
             iu = info["users"]
-            buckets.append({"kernel": "als_cgq_kernel<%d, %d, %d, %d, %d, true>" % (kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, iu["bucket_stream"][b]),
+            buckets.append({"kernel": "als_cgq_kernel<%d, %d, %d, %d, %d, %s>" % (kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, iu["bucket_stream"][b], tf_flag),
                             "what": "rows on teams of %d wave(s)%s" % (wpr, ", streamed (longer than the workgroup's resident capacity)" if iu["bucket_stream"][b] else ", register-resident"),
                             "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),
                             "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms))})
@@ -254,11 +301,17 @@ def main():
         "gramian_ms": {sd: mean(kern[sd]["gram"]) for sd in kern},
         "half_iteration_ms": {sd: mean(v) for sd, v in half_ms.items()},
     }
+    if solver == 0 and dom:
+        tfl = dom["flops_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e12
+        roofline["compute"] = {"achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_PEAK_TFLOPS,
+                               "note": "the Cholesky solver is compute/LDS bound (about 2 k^2 n_i + k^3/3 flops per row "
+                                       "against ~n_i (4k+8) bytes); the hbm figures above are reported as the contract asks"}
 
     cpu = None
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(data, U[:n_user], V[:n_item], k, lam, args.cg_steps)
+            cpu = cpu_baseline(data, U[:n_user], V[:n_item], k, lam, args.cg_steps, implicit=implicit, solver=solver,
+                               target_s=12.0 if solver == 1 else 20.0)
         except Exception as e:   # the baseline is a report, never a reason to lose the measurement
             cpu = {"value": None, "unit": "iterations/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
                    "sample": "failed: %r" % (e,)}
@@ -269,9 +322,12 @@ def main():
             "metric": "als_iterations_per_sec", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "WRMF implicit ALS, CG(%d), synthetic %dx%d, %d nnz, rank %d, lambda %g"
-                                   % (args.cg_steps, n_user, n_item, nnz, k, lam),
-                       "n_users": n_user, "n_items": n_item, "nnz": nnz, "rank": k, "solver": "conjugate_gradient",
+            "config": {"workload": "WRMF %s ALS, %s, synthetic %dx%d, %d nnz, rank %d, lambda %g%s"
+                                   % (args.feedback, "CG(%d)" % args.cg_steps if solver == 1 else "Cholesky", n_user, n_item,
+                                      nnz, k, lam, "" if implicit else ", dynamic_lambda"),
+                       "survey_config": args.config, "feedback": args.feedback,
+                       "n_users": n_user, "n_items": n_item, "nnz": nnz, "rank": k,
+                       "solver": "conjugate_gradient" if solver == 1 else "cholesky",
                        "cg_steps": args.cg_steps, "parallelism": "rows sharded x%d, factors replicated" % ws},
             "user_rows_per_sec": n_user / (user_half_ms * 1e-3) if user_half_ms > 0 else None,
             "loss_users_last": losses[-1][1] if losses else None,

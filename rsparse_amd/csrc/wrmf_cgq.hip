@@ -627,7 +627,12 @@ int cgq_bucket_grid(int n_rows, int b, int cfg) {
   static const char* env = std::getenv("RSPARSE_HIP_RPT");
   const int scale = env ? std::atoi(env) : 1;
   const int base = d.stream ? 4 : (d.wpr == 1 ? 64 : (d.wpr == 2 ? 32 : 16));
-  const int rows_per_team = base * (scale > 0 ? scale : 1);
+  int rows_per_team = base * (scale > 0 ? scale : 1);
+  // small buckets (shards of a multi-GPU run, tiny matrices): spread the rows over the CUs first -- the quota
+  // only grows once there are two workgroups per CU
+  const long spread = (long)teams * 512;
+  if ((long)n_rows < spread * rows_per_team) rows_per_team = (int)((n_rows + spread - 1) / spread);
+  if (rows_per_team < 1) rows_per_team = 1;
   const long per_wg = (long)teams * rows_per_team;
   long grid = (n_rows + per_wg - 1) / per_wg;
   if (grid < 1) grid = 1;

@@ -131,6 +131,19 @@ int rsparse_hip_csc_create_device(int n_rows, int n_cols, const int32_t* d_col_p
                                   const int32_t* d_row_indices, const float* d_values,
                                   rsparse_hip_csc** out);
 int rsparse_hip_csc_destroy(rsparse_hip_csc* m);
+
+/* On-device ingest -- replaces the host-side second orientation of a fit,
+ * c_iu = t_shallow(as.csr.matrix(c_ui)) (R/model_WRMF.R:184-191), and the per-column arma::conv_to of the
+ * values (inst/include/wrmf_implicit.hpp:182-183): the caller hands over ONE orientation.
+ *
+ * rsparse_hip_csc_transpose_device: CSC (d_p int32[n_cols+1], d_i int32[nnz], d_x f32[nnz]) of an
+ * n_rows x n_cols matrix -> CSC of its transpose (d_pt int32[n_rows+1], d_it int32[nnz], d_xt f32[nnz]), row
+ * indices ascending inside every output column (stable counting sort by row index).  All pointers are device
+ * pointers; outputs are caller-allocated.  A row index outside [0, n_rows) -> RSPARSE_HIP_ERR_INVALID.
+ * rsparse_hip_values_to_float_device: d_dst[e] = (float)d_src[e] (dgCMatrix@x is f64 on the wire). */
+int rsparse_hip_csc_transpose_device(int n_rows, int n_cols, const int32_t* d_p, const int32_t* d_i,
+                                     const float* d_x, int32_t* d_pt, int32_t* d_it, float* d_xt, void* stream);
+int rsparse_hip_values_to_float_device(int64_t n, const double* d_src, float* d_dst, void* stream);
 /* info_out: [0] n_rows, [1] n_cols, [2] nnz, [3] rows with more than [7] non-zeros ("long" rows),
  * [4] longest row, [5] non-zeros in long rows, [6] empty rows, [7] per-wave tile capacity (32),
  * [8..13] rows and [14..19] non-zeros per CG launch bucket, [20] launch-table id, [22..27] waves per row

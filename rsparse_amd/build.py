@@ -6,7 +6,8 @@ import subprocess
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-SRC = [PKG / "csrc" / "wrmf_kernels.hip", PKG / "csrc" / "wrmf_cgq.hip", PKG / "csrc" / "wrmf_chol.hip", PKG / "csrc" / "wrmf_topk.hip", PKG / "csrc" / "wrmf_capi.cpp"]
+SRC = [PKG / "csrc" / "wrmf_kernels.hip", PKG / "csrc" / "wrmf_cgq.hip", PKG / "csrc" / "wrmf_chol.hip", PKG / "csrc" / "wrmf_topk.hip", PKG / "csrc" / "wrmf_ingest.hip",
+       PKG / "csrc" / "wrmf_capi.cpp"]
 DEPS = SRC + [PKG / "csrc" / "wrmf_internal.h", PKG / "csrc" / "wrmf_device.h",
               PKG.parent / "include" / "rsparse_wrmf_hip.h"]
 OUT = PKG / "lib" / "librsparse_wrmf_hip.so"

@@ -472,6 +472,34 @@ int rsparse_hip_csc_create_device(int n_rows, int n_cols, const int32_t* d_col_p
   return RSPARSE_HIP_OK;
 }
 
+int rsparse_hip_csc_transpose_device(int n_rows, int n_cols, const int32_t* d_p, const int32_t* d_i, const float* d_x,
+                                     int32_t* d_pt, int32_t* d_it, float* d_xt, void* stream) {
+  if (n_rows < 0 || n_cols < 0) return fail(RSPARSE_HIP_ERR_INVALID, "negative matrix dimension");
+  if (!d_p || !d_pt) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs (input or output) is NULL");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int32_t ends[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(&ends[0], d_p, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&ends[1], d_p + n_cols, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const int64_t nnz = (int64_t)ends[1] - ends[0];
+  if (ends[0] != 0 || nnz < 0) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs must start at 0 and be non-decreasing");
+  if (nnz > 0 && (!d_i || !d_x || !d_it || !d_xt)) return fail(RSPARSE_HIP_ERR_INVALID, "index or value array is NULL");
+  int bad = 0;
+  hipError_t e = transpose_csc_device(n_rows, n_cols, nnz, d_p, d_i, d_x, d_pt, d_it, d_xt, s, &bad);
+  if (bad) return fail(RSPARSE_HIP_ERR_INVALID, "row index out of range");
+  if (e != hipSuccess) return hip_fail(e, "transpose_csc_device");
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_values_to_float_device(int64_t n, const double* d_src, float* d_dst, void* stream) {
+  if (n < 0) return fail(RSPARSE_HIP_ERR_INVALID, "negative length");
+  if (n > 0 && (!d_src || !d_dst)) return fail(RSPARSE_HIP_ERR_INVALID, "NULL array");
+  if (n == 0) return RSPARSE_HIP_OK;
+  hipError_t e = launch_f64_to_f32(d_src, d_dst, (size_t)n, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail(e, "launch_f64_to_f32");
+  return RSPARSE_HIP_OK;
+}
+
 int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   if (!m) return RSPARSE_HIP_OK;
   DevCSC& d = m->d;

@@ -74,6 +74,27 @@ class HipBackend:
                                                           x.data_ptr(), ctypes.byref(h)))
         return _CscHandle(self.lib, h, (p, i, x), n_rows, n_cols)
 
+    def transpose_csc(self, n_rows, n_cols, p, i, x):
+        """CSC (p, i, x) of an n_rows x n_cols matrix, on the device -> CSC of its transpose, row indices ascending
+        inside every column (the second orientation of a fit, R/model_WRMF.R:190)."""
+        assert p.dtype == torch.int32 and i.dtype == torch.int32 and x.dtype == torch.float32
+        nnz = int(i.numel())
+        pt = torch.empty(n_rows + 1, dtype=torch.int32, device=self.device)
+        it = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.device)[:nnz]
+        xt = torch.empty(max(nnz, 1), dtype=torch.float32, device=self.device)[:nnz]
+        _lib.check(self.lib.rsparse_hip_csc_transpose_device(int(n_rows), int(n_cols), p.data_ptr(), i.data_ptr(),
+                                                             x.data_ptr(), pt.data_ptr(), it.data_ptr(), xt.data_ptr(),
+                                                             self._stream()))
+        return pt, it, xt
+
+    def values_to_float(self, x64):
+        """f64 values as they arrive from a dgCMatrix -> f32 resident values (wrmf_implicit.hpp:182-183)."""
+        assert x64.dtype == torch.float64 and x64.is_cuda
+        out = torch.empty(x64.shape, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.rsparse_hip_values_to_float_device(int(x64.numel()), x64.data_ptr(), out.data_ptr(),
+                                                               self._stream()))
+        return out
+
     def gramian(self, F, lambda_, out, sumsq_out):
         n, k = F.shape
         _lib.check(self.lib.rsparse_hip_gramian_device(F.data_ptr(), k, n, float(lambda_), out.data_ptr(),

@@ -90,8 +90,6 @@ class WRMF:
         be = self._backend()
         c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))               # :184-188
         c_ui.sort_indices()
-        c_iu = sp.csc_matrix((c_ui.T).tocsc())                                     # :190 t_shallow(as.csr)
-        c_iu.sort_indices()
         if self._feedback != "explicit" and c_ui.nnz and c_ui.data.min() < 0:
             raise ValueError("all(c_ui@x >= 0) is not TRUE")                       # :195-197
         n_user, n_item = c_ui.shape
@@ -112,11 +110,16 @@ class WRMF:
             if self.components.shape != (k, n_item):                               # :246-248
                 raise ValueError("init must be rank x n_item")
             V0 = np.ascontiguousarray(self.components.T, dtype=np.float32)
-        als = ShardedALS(be, n_user, n_item, k, self._upload_csc(c_ui), self._upload_csc(c_iu), c_ui.nnz,
+        # one orientation crosses the boundary (f64 values as in dgCMatrix@x); the item-user orientation
+        # c_iu = t_shallow(as.csr.matrix(c_ui)) (:190) and the f32 values are produced on the device
+        d_ui = (be.to_device(c_ui.indptr, torch.int32), be.to_device(c_ui.indices, torch.int32),
+                be.values_to_float(be.to_device(c_ui.data, torch.float64)))
+        d_iu = be.transpose_csc(n_user, n_item, *d_ui)
+        als = ShardedALS(be, n_user, n_item, k, d_ui, d_iu, c_ui.nnz,
                          feedback=self._feedback, lambda_=self._lambda, dynamic_lambda=self._dynamic_lambda,
                          cg_steps=self._cg_steps)
-        als.cnt_user = be.to_device(np.diff(c_iu.indptr), torch.float32)           # cnt_i in the reference (:312)
-        als.cnt_item = be.to_device(np.diff(c_ui.indptr), torch.float32)           # cnt_u (:311)
+        als.cnt_user = torch.diff(d_iu[0]).to(torch.float32)                       # cnt_i in the reference (:312)
+        als.cnt_item = torch.diff(d_ui[0]).to(torch.float32)                       # cnt_u (:311)
         U = be.to_device(U0, torch.float32)
         V = be.to_device(V0, torch.float32)
         loss_prev = float("inf")

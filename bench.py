@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--users", type=int, default=None)
     ap.add_argument("--items", type=int, default=None)
     ap.add_argument("--rank", type=int, default=None)
-    ap.add_argument("--solver", choices=("cg", "cholesky"), default=None)
+    ap.add_argument("--solver", choices=("cg", "cholesky", "nnls"), default=None)
     ap.add_argument("--feedback", choices=("implicit", "explicit"), default=None)
     ap.add_argument("--mean-deg", type=float, default=50.0)
     ap.add_argument("--cg-steps", type=int, default=3)
@@ -142,7 +142,7 @@ def main():
         if getattr(args, key) is None:
             setattr(args, key, val)
     implicit = args.feedback == "implicit"
-    solver = 1 if args.solver == "cg" else 0          # inst/include/wrmf.hpp:16-20 codes
+    solver = {"cholesky": 0, "cg": 1, "nnls": 2}[args.solver]          # inst/include/wrmf.hpp:16-20 codes
 
     if args.serial_launches:
         os.environ["RSPARSE_HIP_CONCURRENT"] = "0"   # read by the library at its first CG launch
@@ -194,8 +194,11 @@ def main():
     U = als.alloc_factors(n_user, Bu, dev)
     V = als.alloc_factors(n_item, Bi, dev)
     U[:n_user] = torch.randn(n_user, k, generator=g, device=dev) * 0.01
-    if solver == 0:
+    if solver != 1:
         V[:n_item] = torch.randn(n_item, k, generator=g, device=dev) * 0.01
+    if solver == 2:                                   # NNLS: abs() of the initial factors (R/model_WRMF.R:252-255)
+        U.abs_()
+        V.abs_()
 
     def step(want_loss=True):
         li = als.half_iteration("items", U, V, solver, want_loss=want_loss)
@@ -250,16 +253,20 @@ def main():
     buckets = []
     kp = 32 if k <= 32 else (64 if k <= 64 else 128)
     tf_flag = "true" if implicit else "false"
-    if solver == 0:
+    if solver != 1:
         # one kernel per half-iteration; no warm-start read (Cholesky ignores it): drop one N*k*4 from B_half
         ms = [mean(kern[sd]["bucket"][0]) for sd in ("items", "users")]
         by = [algorithmic_bytes(info[sd]["n_cols"], info[sd]["nnz"], k, info[sd]["n_empty"]) -
               (info[sd]["n_cols"] - info[sd]["n_empty"]) * 4 * k for sd in ("items", "users")]
-        fl = [2.0 * k * k * info[sd]["nnz"] + (info[sd]["n_cols"] - info[sd]["n_empty"]) * (k ** 3 / 3.0 + 2.0 * k * k)
+        per_row = (k ** 3 / 3.0 + 2.0 * k * k) if solver == 0 else (2.0 * k ** 3 + 4.0 * k * k)
+        fl = [2.0 * k * k * info[sd]["nnz"] + (info[sd]["n_cols"] - info[sd]["n_empty"]) * per_row
               for sd in ("items", "users")]
-        buckets.append({"kernel": "als_chol2_kernel<%d, %s, true>" % (kp, tf_flag),
-                        "what": "one 256-thread workgroup per row: normal equations assembled in registers, blocked "
-                                "Cholesky, two triangular solves (compute/LDS bound, see roofline.compute)",
+        buckets.append({"kernel": ("als_chol2_kernel<%d, %s, true>" if solver == 0 else "als_nnls_kernel<%d, %s, true>") % (kp, tf_flag),
+                        "what": "one 256-thread workgroup per row: normal equations assembled in registers, " +
+                                ("blocked Cholesky, two triangular solves" if solver == 0 else
+                                 "squared in LDS, sequential coordinate descent on one wave (flops below count the "
+                                 "assembly and the squaring, not the data-dependent sweeps)") +
+                                " (compute/LDS bound, see roofline.compute)",
                         "launches_per_iteration": 2, "avg_launch_ms": float(np.mean(ms)),
                         "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms)),
                         "flops_per_launch": float(np.mean(fl))})
@@ -301,7 +308,7 @@ def main():
         "gramian_ms": {sd: mean(kern[sd]["gram"]) for sd in kern},
         "half_iteration_ms": {sd: mean(v) for sd, v in half_ms.items()},
     }
-    if solver == 0 and dom:
+    if solver != 1 and dom:
         tfl = dom["flops_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e12
         roofline["compute"] = {"achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_PEAK_TFLOPS,
                                "note": "the Cholesky solver is compute/LDS bound (about 2 k^2 n_i + k^3/3 flops per row "
@@ -323,11 +330,11 @@ def main():
             "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "WRMF %s ALS, %s, synthetic %dx%d, %d nnz, rank %d, lambda %g%s"
-                                   % (args.feedback, "CG(%d)" % args.cg_steps if solver == 1 else "Cholesky", n_user, n_item,
+                                   % (args.feedback, "CG(%d)" % args.cg_steps if solver == 1 else ("Cholesky" if solver == 0 else "NNLS"), n_user, n_item,
                                       nnz, k, lam, "" if implicit else ", dynamic_lambda"),
                        "survey_config": args.config, "feedback": args.feedback,
                        "n_users": n_user, "n_items": n_item, "nnz": nnz, "rank": k,
-                       "solver": "conjugate_gradient" if solver == 1 else "cholesky",
+                       "solver": {0: "cholesky", 1: "conjugate_gradient", 2: "nnls"}[solver],
                        "cg_steps": args.cg_steps, "parallelism": "rows sharded x%d, factors replicated" % ws},
             "user_rows_per_sec": n_user / (user_half_ms * 1e-3) if user_half_ms > 0 else None,
             "loss_users_last": losses[-1][1] if losses else None,

@@ -53,7 +53,7 @@ extern "C" {
 /* solver codes: inst/include/wrmf.hpp:16-18 */
 #define RSPARSE_SOLVER_CHOLESKY 0
 #define RSPARSE_SOLVER_CONJUGATE_GRADIENT 1
-#define RSPARSE_SOLVER_NNLS 2 /* -> RSPARSE_HIP_ERR_UNSUPPORTED */
+#define RSPARSE_SOLVER_NNLS 2 /* sequential coordinate descent, inst/include/nnls.hpp:10-48 */
 
 #define RSPARSE_HIP_MAX_RANK 128
 
@@ -70,7 +70,7 @@ int rsparse_hip_set_device(int device);
 /* replaces als_implicit_float  (src/wrmf_implicit.cpp:17-31 -> als_implicit<float>,
  * inst/include/wrmf_implicit.hpp:90-305).  n_rows/n_cols/col_ptrs/row_indices/values are the
  * dgCMatrix slots Dim[0], Dim[1], p, i, x.  rank = nrow(X).  n_threads is accepted and ignored.
- * with_biases != 0, global_bias >= sqrt(FLT_EPSILON) or solver == NNLS -> ERR_UNSUPPORTED.
+ * with_biases != 0 or global_bias >= sqrt(FLT_EPSILON) -> ERR_UNSUPPORTED.
  * global_bias_base / initialize_bias_base only matter for those variants and may be NULL / 0.
  * *loss_out = the value the reference returns (loss / nnz). */
 int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_ptrs,

@@ -34,7 +34,11 @@ namespace {
 // inst/include/wrmf.hpp:16-22
 constexpr unsigned CHOLESKY = 0;
 constexpr unsigned CONJUGATE_GRADIENT = 1;
+constexpr unsigned SEQ_COORDINATE_WISE_NNLS = 2;
+constexpr unsigned SCD_MAX_ITER = 10000;
+constexpr double SCD_TOL = 1e-4;
 constexpr double CG_TOL = 1e-10;
+constexpr double NNLS_EPS = 1e-16;   // EPS, inst/include/nnls.hpp:8
 
 template <class T>
 inline T dot(const T* a, const T* b, int n) {
@@ -225,6 +229,48 @@ T accu_sq(const T* X, size_t n) {
 // inst/include/wrmf_implicit.hpp:90-305, no-bias / no-global-bias branch only
 // (:160-185 column loop, :195-197 CG, :206-208,231,236 Cholesky, :254 write-back,
 //  :259-261 loss, :272-283 empty column -> zeros, :286-304 + lambda*accu(X%X), / nnz).
+// inst/include/nnls.hpp:10-48 -- c_nnls(X = lhs, y = rhs, init): XtX = X^T X (+EPS on the diagonal),
+// mu = XtX init - X^T y, then scd_ls_update: sweeps over the coordinates in order,
+// new = max(0, h_k - mu_k / XtX_kk), mu += (new - h_k) XtX[:,k], until the largest relative coordinate
+// change of a sweep is <= rel_tol or max_iter sweeps.  X is k x k column-major; h holds init on entry.
+template <class T>
+void c_nnls(const T* X, const T* y, T* h, int k, unsigned max_iter, double rel_tol, std::vector<T>& work) {
+  work.resize((size_t)k * k + (size_t)k);
+  T* XtX = work.data();
+  T* mu = XtX + (size_t)k * k;
+  for (int c = 0; c < k; c++)
+    for (int r = 0; r < k; r++) {
+      T s = 0;
+      for (int m = 0; m < k; m++) s += X[(size_t)r * k + m] * X[(size_t)c * k + m];   // (X^T X)[r][c]
+      XtX[(size_t)c * k + r] = s;
+    }
+  for (int d = 0; d < k; d++) XtX[(size_t)d * k + d] += (T)NNLS_EPS;                     // :44
+  for (int r = 0; r < k; r++) {                                                          // :45
+    T s = 0;
+    for (int c = 0; c < k; c++) s += XtX[(size_t)c * k + r] * h[c];
+    T xty = 0;
+    for (int m = 0; m < k; m++) xty += X[(size_t)r * k + m] * y[m];
+    mu[r] = s - xty;
+  }
+  for (unsigned t = 0; t < max_iter; t++) {                                              // :17-34
+    T rel_diff = 0;
+    for (int c = 0; c < k; c++) {
+      const T old_value = h[c];
+      T new_value = old_value - mu[c] / XtX[(size_t)c * k + c];
+      if (new_value < 0) new_value = 0;
+      const T diff = new_value - old_value;
+      if (diff != 0) {
+        h[c] = new_value;
+        const T* col = XtX + (size_t)c * k;
+        for (int r = 0; r < k; r++) mu[r] += diff * col[r];
+        const double step_err = std::fabs((double)diff) / (std::fabs((double)old_value) + NNLS_EPS);
+        if (step_err > rel_diff) rel_diff = (T)step_err;
+      }
+    }
+    if (rel_diff <= rel_tol) break;
+  }
+}
+
 template <class T>
 double als_implicit(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
                     const double* values, const T* X, T* Y, const T* XtX, int k, double lambda,
@@ -263,7 +309,13 @@ double als_implicit(int n_rows, int n_cols, const int32_t* col_ptrs, const int32
             }
           }
           gemv_n(s.Xn.data(), s.conf.data(), s.x.data(), k, n, false);
-          if (!solve_sympd(lhs, s.x.data(), k, keep)) bad += 1;
+          if (solver == SEQ_COORDINATE_WISE_NNLS) {                       // :233-234
+            std::vector<T> rhs(s.x.begin(), s.x.begin() + k);
+            std::memcpy(s.x.data(), y, sizeof(T) * k);                    // init = Y.col(i)
+            c_nnls<T>(lhs, rhs.data(), s.x.data(), k, SCD_MAX_ITER, SCD_TOL, keep);
+          } else if (!solve_sympd(lhs, s.x.data(), k, keep)) {
+            bad += 1;
+          }
         }
         std::memcpy(y, s.x.data(), sizeof(T) * k);                        // :254
         // loss += dot(square(1 - y^T X_nnz), c) + lambda * dot(y, y)      (:259-261)
@@ -325,7 +377,13 @@ double als_explicit(int n_rows, int n_cols, const int32_t* col_ptrs, const int32
           }
           for (int a = 0; a < k; a++) lhs[(size_t)a * k + a] += lambda_use;
           gemv_n(s.Xn.data(), s.conf.data(), s.x.data(), k, n, false);
-          if (!solve_sympd(lhs, s.x.data(), k, keep)) bad += 1;
+          if (solver == SEQ_COORDINATE_WISE_NNLS) {                       // :109-110
+            std::vector<T> rhs(s.x.begin(), s.x.begin() + k);
+            std::memcpy(s.x.data(), y, sizeof(T) * k);
+            c_nnls<T>(lhs, rhs.data(), s.x.data(), k, SCD_MAX_ITER, SCD_TOL, keep);
+          } else if (!solve_sympd(lhs, s.x.data(), k, keep)) {
+            bad += 1;
+          }
         }
         std::memcpy(y, s.x.data(), sizeof(T) * k);
         gemv_t(s.Xn.data(), s.x.data(), s.t.data(), k, n);                // :131-132

@@ -203,7 +203,8 @@ class OracleWRMF:
     def __init__(self, rank, lam=0.0, feedback="implicit", solver="conjugate_gradient", cg_steps=3,
                  dynamic_lambda=True, dtype=np.float64, n_threads=1):
         self.rank, self.lam, self.feedback = int(rank), float(lam), feedback
-        self.solver_code = {"cholesky": 0, "conjugate_gradient": 1}[solver]      # :99-100
+        self.solver_code = {"cholesky": 0, "conjugate_gradient": 1, "nnls": 2}[solver]   # :99-100
+        self.non_negative = solver == "nnls"                                      # :88
         self.cg_steps, self.dynamic_lambda = int(cg_steps), bool(dynamic_lambda)
         self.dtype, self.n_threads = np.dtype(dtype), n_threads
         self.components = None
@@ -231,6 +232,8 @@ class OracleWRMF:
             comp = np.zeros((self.rank, n_item), dtype=dt, order="F")               # :219-231
         else:
             raise ValueError("non-CG solvers need init_components (R draws them from its RNG)")
+        if self.non_negative:                                                       # :252-255
+            comp, U = np.abs(comp), np.abs(U)
         cnt_u = np.diff(p_ui).astype(dt)     # :311 -- nnz per item (named cnt_u in the reference)
         cnt_i = np.diff(self.c_iu[0]).astype(dt)
         self.cnt_u = cnt_u

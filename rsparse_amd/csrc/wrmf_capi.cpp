@@ -243,8 +243,6 @@ int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_i
 }
 
 int check_variant(unsigned solver, int with_biases, double global_bias) {
-  if (solver == RSPARSE_SOLVER_NNLS)
-    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "solver 'nnls' is not on the device path (inst/include/nnls.hpp stays on the CPU)");
   if (solver > RSPARSE_SOLVER_NNLS) return fail(RSPARSE_HIP_ERR_INVALID, "unknown solver code");
   if (with_biases)
     return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "with_user_item_bias is not on the device path");
@@ -300,7 +298,9 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   const bool chol_lds = chol_env && std::strcmp(chol_env, "lds") == 0;
   hipError_t e = cgq ? launch_als_cgq(a, qs, implicit, s, ev)
                      : (cg ? launch_als_cg(a, implicit, s, ev)
-                           : (chol_lds ? launch_als_chol(a, implicit, s, ev) : launch_als_chol2(a, implicit, s, ev)));
+                           : (solver == RSPARSE_SOLVER_NNLS
+                                  ? launch_als_nnls(a, implicit, s, ev)
+                                  : (chol_lds ? launch_als_chol(a, implicit, s, ev) : launch_als_chol2(a, implicit, s, ev))));
   if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
   e = launch_sum_partials(g_ws.partials, slots, out, s);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");

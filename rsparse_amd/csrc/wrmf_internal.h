@@ -91,6 +91,7 @@ hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s, hipEven
 hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 // register-blocked Cholesky (wrmf_chol.hip); launch_als_chol is the older LDS-matrix version kept for A/B
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
+hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s);
 
 // Gramian: scratch must hold gramian_scratch_floats(k, n) floats.

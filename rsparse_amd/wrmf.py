@@ -9,8 +9,8 @@ Differences forced by the host language, nothing else:
   * `lambda` is a Python keyword -> `lambda_`;
   * `x` is a scipy.sparse matrix (users x items) instead of a Matrix::sparseMatrix;
   * R's global RNG (large_rand_matrix / flrnorm, src/utils.cpp:131-143) -> `rng` (seed or Generator);
-  * user/item bias, global bias and solver="nnls" are not on the device path: the C ABI answers
-    RSPARSE_HIP_ERR_UNSUPPORTED and this class raises NotImplementedError (an R shim would keep
+  * user/item bias and global bias are not on the device path: the C ABI answers
+    RSPARSE_HIP_ERR_UNSUPPORTED and this class raises `UnsupportedOnDevice` (an R shim would keep
     the package's CPU code for them).
 """
 import numpy as np
@@ -48,8 +48,6 @@ class WRMF:
         if not callable(preprocess):
             raise TypeError("preprocess must be a function")                      # :165
         self._non_negative = solver == "nnls"
-        if solver == "nnls":
-            raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "solver 'nnls' is not on the device path")
         if with_user_item_bias or with_global_bias:
             raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED,
                                            "user/item and global biases are not on the device path")
@@ -90,7 +88,7 @@ class WRMF:
         be = self._backend()
         c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))               # :184-188
         c_ui.sort_indices()
-        if self._feedback != "explicit" and c_ui.nnz and c_ui.data.min() < 0:
+        if (self._feedback != "explicit" or self._non_negative) and c_ui.nnz and c_ui.data.min() < 0:
             raise ValueError("all(c_ui@x >= 0) is not TRUE")                       # :195-197
         n_user, n_item = c_ui.shape
         k = self._rank
@@ -110,6 +108,8 @@ class WRMF:
             if self.components.shape != (k, n_item):                               # :246-248
                 raise ValueError("init must be rank x n_item")
             V0 = np.ascontiguousarray(self.components.T, dtype=np.float32)
+        if self._non_negative:                                                     # NNLS: :252-255
+            U0, V0 = np.abs(U0), np.abs(V0)
         # one orientation crosses the boundary (f64 values as in dgCMatrix@x); the item-user orientation
         # c_iu = t_shallow(as.csr.matrix(c_ui)) (:190) and the f32 values are produced on the device
         d_ui = (be.to_device(c_ui.indptr, torch.int32), be.to_device(c_ui.indices, torch.int32),

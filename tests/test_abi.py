@@ -61,8 +61,8 @@ def test_status_codes_without_device():
     assert rc == _lib.ERR_INVALID
     rc, msg = _call_implicit(lib, p, i, x, X, Y, G, rank=129)
     assert rc == _lib.ERR_UNSUPPORTED
-    rc, msg = _call_implicit(lib, p, i, x, X, Y, G, solver=2)          # nnls stays on the CPU
-    assert rc == _lib.ERR_UNSUPPORTED and "nnls" in msg
+    rc, msg = _call_implicit(lib, p, i, x, X, Y, G, solver=2)          # nnls is a device solver: past the argument
+    assert rc not in (_lib.ERR_UNSUPPORTED, _lib.ERR_INVALID)         # checks (no device here -> runtime error)
     rc, msg = _call_implicit(lib, p, i, x, X, Y, G, with_biases=1)
     assert rc == _lib.ERR_UNSUPPORTED and "bias" in msg
     rc, msg = _call_implicit(lib, p, i, x, X, Y, G, global_bias=0.3)
@@ -96,8 +96,7 @@ def test_wrmf_constructor_mirrors_reference_validation():
         WRMF(cg_steps=3.0)
     with pytest.raises(TypeError):
         WRMF(init=[[1.0]])
-    with pytest.raises(NotImplementedError):
-        WRMF(solver="nnls")
+    assert WRMF(solver="nnls")._non_negative                       # R/model_WRMF.R:88
     with pytest.raises(NotImplementedError):
         WRMF(with_user_item_bias=True)
     m = WRMF(rank=8, lambda_=0.1, solver="cholesky", precision="float")

@@ -1,0 +1,79 @@
+"""The reference's own test grid for this path, tests/testthat/test-wrmf.R:9-71 ("test WRMF core") and :73-90
+("test WRMF FLOAT"), run through the Python mirror of the R6 class on the GPU, plus what the reference cannot
+assert for lack of golden values: agreement of every fit with the CPU oracle driven from the same initial factors.
+
+Grid (test-wrmf.R:10-27): implicit x {cholesky, nnls} x lambda {0, 0.1, 1000}; implicit x conjugate_gradient x
+lambda {0, 0.1, 1000}; explicit x {conjugate_gradient, cholesky, nnls} x lambda {0.1, 1000}; precision {double, float};
+with_user_item_bias {FALSE} -- the TRUE half of the grid is rejected by the device path (RSPARSE_HIP_ERR_UNSUPPORTED,
+SURVEY.md 8a) and asserted as such.  rank and K are drawn from 4:10 as in the reference (:30-31)."""
+import itertools
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import csc_drop_rows, rel_fro
+from oracle import wrmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GRID = ([("implicit", s, l) for s in ("cholesky", "nnls", "conjugate_gradient") for l in (0.0, 0.1, 1000.0)] +
+        [("explicit", s, l) for s in ("conjugate_gradient", "cholesky", "nnls") for l in (0.1, 1000.0)])
+
+
+def _data(movielens, ml_train):
+    n_user_all, n_item, p, i, x = movielens
+    n_user, _, tp, ti, tx = ml_train
+    train = sp.csc_matrix((tx, ti, tp), shape=(n_user, n_item))
+    cp, ci, cx = csc_drop_rows(900, p, i, x)
+    cv = sp.csc_matrix((cx, ci, cp), shape=(n_user_all - 900, n_item)).tocsr()
+    return train, cv, (n_user, n_item, tp, ti, tx)
+
+
+@pytest.mark.parametrize("feedback,solver,lam", GRID)
+@pytest.mark.parametrize("precision", ["double", "float"])
+def test_wrmf_core(movielens, ml_train, feedback, solver, lam, precision):
+    from rsparse_amd import WRMF
+    train, cv, (n_user, n_item, tp, ti, tx) = _data(movielens, ml_train)
+    rng = np.random.default_rng(abs(hash((feedback, solver, lam, precision))) % (1 << 31))
+    rank, K = int(rng.integers(4, 11)), int(rng.integers(4, 11))                  # test-wrmf.R:30-31
+    U0 = (rng.standard_normal((n_user, rank)) * 0.01).astype(np.float32)
+    V0 = (rng.standard_normal((rank, n_item)) * 0.01).astype(np.float32)
+    init = None if solver == "conjugate_gradient" else V0.astype(np.float64 if precision == "double" else np.float32)
+    model = WRMF(rank=rank, lambda_=lam, feedback=feedback, solver=solver, with_user_item_bias=False,
+                 precision=precision, init=init)
+    model._init_user_factors = U0
+    user_emb = model.fit_transform(train, n_iter=5, convergence_tol=-1)            # :48
+    want_dtype = np.float64 if precision == "double" else np.float32
+    assert user_emb.shape == (train.shape[0], rank) and user_emb.dtype == want_dtype          # :51, FLOAT :86-87
+    assert model.components.shape == (rank, train.shape[1]) and model.components.dtype == want_dtype   # :53
+    assert np.array_equal(user_emb, model.transform(train))                       # :57 fit_transform == transform
+    preds = model.predict(cv, K)                                                   # :59-61
+    assert preds.shape == (cv.shape[0], K)
+    cv_emb = model.transform(cv)                                                   # :63-64
+    assert cv_emb.shape == (cv.shape[0], rank)
+    if solver == "nnls":                                                           # :66-69
+        assert cv_emb.min() >= 0 and user_emb.min() >= 0 and model.components.min() >= 0
+    assert np.all(np.isfinite(user_emb)) and np.all(np.isfinite(model.components))
+
+    # the same fit on the CPU oracle (fp64), same initial factors
+    ref = O.OracleWRMF(rank, lam=lam, feedback=feedback, solver=solver, dtype=np.float64, n_threads=8)
+    ref_emb = ref.fit_transform(n_user, n_item, tp, ti, tx, U0.T.astype(np.float64), n_iter=5, convergence_tol=-1,
+                                init_components=None if solver == "conjugate_gradient" else V0.astype(np.float64))
+    # five ALS iterations compound the per-solve fp32 differences.  Two degenerate corners of the reference's grid
+    # get a wider band: NNLS (squares the per-row system and stops at 1e-4 relative steps) and lambda = 1000 (the
+    # factors shrink by ~1/lambda per half-iteration, down to ~1e-26 after five iterations)
+    tol = 2e-2 if (solver == "nnls" or lam >= 1000.0) else 5e-4
+    assert rel_fro(model.components, ref.components) < tol
+    assert rel_fro(user_emb, ref_emb) < tol
+    assert np.allclose([l[1] for l in model.losses], [l[1] for l in ref.losses], rtol=tol)
+
+
+@pytest.mark.parametrize("feedback,solver", [("implicit", "cholesky"), ("implicit", "nnls"), ("explicit", "conjugate_gradient"),
+                                             ("explicit", "cholesky"), ("explicit", "nnls")])
+def test_wrmf_core_bias_half_of_the_grid_is_rejected(feedback, solver):
+    """with_user_item_bias = TRUE (test-wrmf.R:13,25) is not on the device path: the constructor raises the same
+    UnsupportedOnDevice the C ABI reports, so an R shim falls back to the package's CPU code."""
+    from rsparse_amd import WRMF, _lib
+    with pytest.raises(_lib.UnsupportedOnDevice):
+        WRMF(rank=6, lambda_=0.1, feedback=feedback, solver=solver, with_user_item_bias=True)

@@ -70,7 +70,8 @@ int rsparse_hip_set_device(int device);
 /* replaces als_implicit_float  (src/wrmf_implicit.cpp:17-31 -> als_implicit<float>,
  * inst/include/wrmf_implicit.hpp:90-305).  n_rows/n_cols/col_ptrs/row_indices/values are the
  * dgCMatrix slots Dim[0], Dim[1], p, i, x.  rank = nrow(X).  n_threads is accepted and ignored.
- * with_biases != 0 or global_bias >= sqrt(FLT_EPSILON) -> ERR_UNSUPPORTED.
+ * with_biases != 0 or global_bias >= sqrt(FLT_EPSILON) -> ERR_UNSUPPORTED (implicit feedback only; the explicit
+ * entry points below take with_biases).
  * global_bias_base / initialize_bias_base only matter for those variants and may be NULL / 0.
  * *loss_out = the value the reference returns (loss / nnz). */
 int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_ptrs,
@@ -172,6 +173,30 @@ int rsparse_hip_als_implicit_device(const rsparse_hip_csc* conf, const float* d_
 int rsparse_hip_als_explicit_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
                                     int rank, double lambda, unsigned solver, unsigned cg_steps,
                                     int dynamic_lambda, double* d_loss_rows_out, void* stream);
+
+/* als_explicit<T> with_biases = TRUE (inst/include/wrmf_explicit.hpp:41-64,86-91,113-127), device-resident form.
+ * rank counts the two extra coordinates (R/model_WRMF.R:160: rank + 2): X = [1, ..., x_bias] and
+ * Y = [y_bias, ..., 1] when is_x_bias_last_row, X = [x_bias, ..., 1] and Y = [1, ..., y_bias] otherwise; the
+ * placeholder entry of every Y row is left untouched.  d_loss_rows_out as for rsparse_hip_als_explicit_device;
+ * the regulariser on X skips the row of ones (:147-159) and is the caller's (rsparse_hip_weighted_sumsq_device on
+ * the other rank-1 rows). */
+int rsparse_hip_als_explicit_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, int rank,
+                                         double lambda, unsigned solver, unsigned cg_steps, int dynamic_lambda,
+                                         int is_x_bias_last_row, double* d_loss_rows_out, void* stream);
+
+/* with_global_bias without user/item biases, explicit feedback (R/model_WRMF.R:278-282): global_bias = mean(c_ui@x),
+ * removed in place from the resident values of both orientations (d_x_other may be NULL).  *mean_out is a host double. */
+int rsparse_hip_values_subtract_mean_device(int64_t n, float* d_x, float* d_x_other, double* mean_out, void* stream);
+
+/* initialize_biases_explicit (inst/include/wrmf_utils.hpp:32-84; .Call _rsparse_initialize_biases_{double,float} with
+ * is_explicit_feedback = TRUE, src/RcppExports.cpp:417-454).  c_ui: users x items by item column, c_iu: its transpose.
+ * With calculate_global_bias the mean of the values is removed from the resident values of BOTH handles in place (as
+ * the reference does to ConfCSC / ConfCSR) and returned in *global_bias_out (host).  d_user_bias [n_users] (read as
+ * the starting point, the R driver passes zeros) and d_item_bias [n_items] are device vectors. */
+int rsparse_hip_initialize_biases_explicit_device(rsparse_hip_csc* c_ui, rsparse_hip_csc* c_iu, float* d_user_bias,
+                                                  float* d_item_bias, double lambda, int dynamic_lambda,
+                                                  int non_negative, int calculate_global_bias,
+                                                  double* global_bias_out, void* stream);
 
 /* sum_j w_j |X[:,j]|^2 on the device (w = NULL -> 1): the regulariser terms
  * lambda*accu(X%X) and lambda*accu((X%X)*cnt_X) (wrmf_explicit.hpp:160-170). */

@@ -418,6 +418,135 @@ double als_explicit(int n_rows, int n_cols, const int32_t* col_ptrs, const int32
   return loss / (double)nnz;
 }
 
+// inst/include/wrmf_explicit.hpp:33-174, with_biases branch: the model has two extra coordinates, a column of
+// ones that multiplies the other side's bias and the own bias.  X = [1, ..., x_bias] / Y = [y_bias, ..., 1] when
+// is_x_bias_last_row, X = [x_bias, ..., 1] / Y = [1, ..., y_bias] otherwise (:41-57).  Per row: X_nnz loses its
+// x_bias row (:88 drop_row(X_nnz, is_x_bias_last_row)), the ratings lose the fixed side's biases (:89), the
+// warm start loses a row too -- drop_row(init, !is_x_bias_last_row) (:90), i.e. the FIRST entry when the x bias
+// is last -- the (rank-1)-vector is solved as in the no-bias branch and written to head/tail of Y.col(i)
+// (:115-127).  The regulariser on X skips the row of ones (:147-159).
+template <class T>
+double als_explicit_biases(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                           const double* values, const T* X, T* Y, const T* cnt_X, int k, double lambda,
+                           int n_threads, unsigned solver, unsigned cg_steps, int dynamic_lambda,
+                           int is_x_bias_last_row, int* status) {
+  double loss = 0;
+  int bad = 0;
+  const size_t nnz = (size_t)col_ptrs[n_cols];
+  const int k1 = k - 1;
+  const int xoff = is_x_bias_last_row ? 0 : 1;      // first kept row of X_nnz
+  const int xb = is_x_bias_last_row ? k - 1 : 0;    // row of X holding x_biases (:59-64)
+  const int ioff = is_x_bias_last_row ? 1 : 0;      // first kept entry of the warm start (:90)
+  const int ooff = is_x_bias_last_row ? 0 : 1;      // head / tail of Y.col(i) (:115-127)
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+  {
+    Scratch<T> s;
+    std::vector<T> keep;
+#pragma omp for schedule(dynamic, 100) reduction(+ : loss) reduction(+ : bad)
+    for (int i = 0; i < n_cols; i++) {
+      const int p1 = col_ptrs[i], p2 = col_ptrs[i + 1];
+      T* y = Y + (size_t)i * k;
+      if (p1 < p2) {
+        const int n = p2 - p1;
+        s.ensure(k1, n);
+        const T lambda_use = (T)(lambda * (dynamic_lambda ? (double)(T)n : 1.0));   // :78
+        for (int j = 0; j < n; j++) {
+          const T* xc = X + (size_t)row_indices[p1 + j] * k;
+          s.conf[j] = (T)values[p1 + j] - xc[xb];                                    // :89
+          std::memcpy(&s.Xn[(size_t)j * k1], xc + xoff, sizeof(T) * k1);             // :88
+        }
+        std::memcpy(s.x.data(), y + ioff, sizeof(T) * k1);                           // :90
+        if (solver == CONJUGATE_GRADIENT) {
+          cg_solver_explicit<T>(s, k1, n, lambda_use, cg_steps);
+        } else {
+          T* lhs = s.lhs.data();
+          std::fill(lhs, lhs + (size_t)k1 * k1, (T)0);
+          for (int j = 0; j < n; j++) {
+            const T* col = &s.Xn[(size_t)j * k1];
+            for (int b = 0; b < k1; b++) {
+              const T f = col[b];
+              for (int a = 0; a < k1; a++) lhs[(size_t)b * k1 + a] += col[a] * f;
+            }
+          }
+          for (int a = 0; a < k1; a++) lhs[(size_t)a * k1 + a] += lambda_use;
+          std::vector<T> init(s.x.begin(), s.x.begin() + k1);
+          gemv_n(s.Xn.data(), s.conf.data(), s.x.data(), k1, n, false);
+          if (solver == SEQ_COORDINATE_WISE_NNLS) {
+            std::vector<T> rhs(s.x.begin(), s.x.begin() + k1);
+            std::memcpy(s.x.data(), init.data(), sizeof(T) * k1);
+            c_nnls<T>(lhs, rhs.data(), s.x.data(), k1, SCD_MAX_ITER, SCD_TOL, keep);
+          } else if (!solve_sympd(lhs, s.x.data(), k1, keep)) {
+            bad += 1;
+          }
+        }
+        std::memcpy(y + ooff, s.x.data(), sizeof(T) * k1);
+        gemv_t(s.Xn.data(), s.x.data(), s.t.data(), k1, n);                          // :131-132
+        T l = 0;
+        for (int j = 0; j < n; j++) {
+          const T d = s.conf[j] - s.t[j];
+          l += d * d;
+        }
+        loss += l + lambda_use * dot(s.x.data(), s.x.data(), k1);
+      } else {
+        for (int r = 0; r < k1; r++) y[ooff + r] = 0;                                // :134-141
+      }
+    }
+  }
+  if (lambda > 0) {                                                                  // :147-159
+    const int r0 = is_x_bias_last_row ? 1 : 0, r1 = is_x_bias_last_row ? k : k - 1;  // all rows but the ones
+    T tot = 0;
+    std::vector<T> rowacc(k, (T)0);
+    for (int j = 0; j < n_rows; j++) {
+      const T* col = X + (size_t)j * k;
+      const T cj = dynamic_lambda ? (cnt_X ? cnt_X[j] : (T)0) : (T)1;
+      for (int r = r0; r < r1; r++) rowacc[r] += col[r] * col[r] * cj;
+    }
+    for (int r = r0; r < r1; r++) tot += rowacc[r];
+    loss += lambda * tot;
+  }
+  if (status) *status = bad;
+  return loss / (double)nnz;
+}
+
+// inst/include/wrmf_utils.hpp:32-84 -- initialize_biases_explicit: optional global mean (running mean, :44-45)
+// removed from the values of BOTH orientations in place, then five alternating sweeps
+//   item_bias[c] = sum_{u in c} (v - user_bias[u]) / (lambda_use + n_c),  user_bias likewise (:56-81).
+// csc = users x items by item column, csr = the same matrix by user column (the reference passes c_ui, c_iu).
+template <class T>
+double initialize_biases_explicit(int n_items, const int32_t* csc_p, const int32_t* csc_i, double* csc_x,
+                                  int n_users, const int32_t* csr_p, const int32_t* csr_i, double* csr_x,
+                                  T* user_bias, T* item_bias, T lambda, int dynamic_lambda, int non_negative,
+                                  int calculate_global_bias) {
+  double global_bias = 0;
+  const size_t nnz = (size_t)csc_p[n_items];
+  if (calculate_global_bias) {
+    for (size_t ix = 0; ix < nnz; ix++) global_bias += (csc_x[ix] - global_bias) / (double)(ix + 1);
+    for (size_t ix = 0; ix < nnz; ix++) {
+      csc_x[ix] -= global_bias;
+      csr_x[ix] -= global_bias;
+    }
+  }
+  for (int iter = 0; iter < 5; iter++) {
+    for (int c = 0; c < n_items; c++) item_bias[c] = 0;
+    for (int c = 0; c < n_items; c++) {
+      const T cnt = (T)(csc_p[c + 1] - csc_p[c]);
+      const T lambda_use = lambda * (dynamic_lambda ? cnt : (T)1);
+      for (int ix = csc_p[c]; ix < csc_p[c + 1]; ix++) item_bias[c] += (T)(csc_x[ix] - user_bias[csc_i[ix]]);
+      item_bias[c] /= lambda_use + cnt;
+      if (non_negative) item_bias[c] = std::fmax((T)0, item_bias[c]);
+    }
+    for (int r = 0; r < n_users; r++) user_bias[r] = 0;
+    for (int r = 0; r < n_users; r++) {
+      const T cnt = (T)(csr_p[r + 1] - csr_p[r]);
+      const T lambda_use = lambda * (dynamic_lambda ? cnt : (T)1);
+      for (int ix = csr_p[r]; ix < csr_p[r + 1]; ix++) user_bias[r] += (T)(csr_x[ix] - item_bias[csr_i[ix]]);
+      user_bias[r] /= lambda_use + cnt;
+      if (non_negative) user_bias[r] = std::fmax((T)0, user_bias[r]);
+    }
+  }
+  return global_bias;
+}
+
 // R/model_WRMF.R:474-486 (and :347-353): XtX = tcrossprod(X) + fl(diag(lambda)).
 // The ridge passes through float::fl(), i.e. lambda is rounded to fp32 even in the double build.
 template <class T>
@@ -461,6 +590,34 @@ double wrmf_oracle_als_implicit_f64(int n_rows, int n_cols, const int32_t* col_p
                                     unsigned cg_steps, int* status) {
   return als_implicit<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda,
                               n_threads, solver, cg_steps, status);
+}
+double wrmf_oracle_als_explicit_bias_f32(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                         const int32_t* row_indices, const double* values, const float* X, float* Y,
+                                         const float* cnt_X, int k, double lambda, int n_threads, unsigned solver,
+                                         unsigned cg_steps, int dynamic_lambda, int is_x_bias_last_row, int* status) {
+  return als_explicit_biases<float>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, cnt_X, k, lambda, n_threads,
+                                    solver, cg_steps, dynamic_lambda, is_x_bias_last_row, status);
+}
+double wrmf_oracle_als_explicit_bias_f64(int n_rows, int n_cols, const int32_t* col_ptrs,
+                                         const int32_t* row_indices, const double* values, const double* X, double* Y,
+                                         const double* cnt_X, int k, double lambda, int n_threads, unsigned solver,
+                                         unsigned cg_steps, int dynamic_lambda, int is_x_bias_last_row, int* status) {
+  return als_explicit_biases<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, cnt_X, k, lambda, n_threads,
+                                     solver, cg_steps, dynamic_lambda, is_x_bias_last_row, status);
+}
+double wrmf_oracle_init_biases_explicit_f32(int n_items, const int32_t* csc_p, const int32_t* csc_i, double* csc_x,
+                                            int n_users, const int32_t* csr_p, const int32_t* csr_i, double* csr_x,
+                                            float* user_bias, float* item_bias, double lambda, int dynamic_lambda,
+                                            int non_negative, int calculate_global_bias) {
+  return initialize_biases_explicit<float>(n_items, csc_p, csc_i, csc_x, n_users, csr_p, csr_i, csr_x, user_bias,
+                                           item_bias, (float)lambda, dynamic_lambda, non_negative, calculate_global_bias);
+}
+double wrmf_oracle_init_biases_explicit_f64(int n_items, const int32_t* csc_p, const int32_t* csc_i, double* csc_x,
+                                            int n_users, const int32_t* csr_p, const int32_t* csr_i, double* csr_x,
+                                            double* user_bias, double* item_bias, double lambda, int dynamic_lambda,
+                                            int non_negative, int calculate_global_bias) {
+  return initialize_biases_explicit<double>(n_items, csc_p, csc_i, csc_x, n_users, csr_p, csr_i, csr_x, user_bias,
+                                            item_bias, lambda, dynamic_lambda, non_negative, calculate_global_bias);
 }
 double wrmf_oracle_als_explicit_f32(int n_rows, int n_cols, const int32_t* col_ptrs,
                                     const int32_t* row_indices, const double* values,

@@ -101,22 +101,49 @@ def als_implicit(col_ptrs, row_indices, values, X, Y, XtX, lam, solver, cg_steps
 
 
 def als_explicit(col_ptrs, row_indices, values, X, Y, cnt_X, lam, solver, cg_steps=3,
-                 dynamic_lambda=True, n_threads=1, native=False):
+                 dynamic_lambda=True, n_threads=1, native=False, with_biases=False, is_x_bias_last_row=False):
+    """One explicit half-iteration (als_explicit<T>); with_biases = the user/item-bias branch
+    (wrmf_explicit.hpp:41-64,86-91,113-127), where rank counts the row of ones and the bias row."""
     dt = X.dtype
     for a, n in ((X, "X"), (Y, "Y")):
         _check(a, dt, n)
     k, n_rows = X.shape
     n_cols = Y.shape[1]
     fp = _f32p if dt == np.float32 else _f64p
-    f = getattr(lib(native), "wrmf_oracle_als_explicit_" + ("f32" if dt == np.float32 else "f64"))
+    sfx = "f32" if dt == np.float32 else "f64"
     st = ctypes.c_int(0)
     cnt = np.ascontiguousarray(cnt_X, dtype=dt) if cnt_X is not None else np.zeros(n_rows, dt)
+    if with_biases:
+        f = getattr(lib(native), "wrmf_oracle_als_explicit_bias_" + sfx)
+        f.restype = ctypes.c_double
+        loss = f(n_rows, n_cols, _ptr(col_ptrs, _i32p), _ptr(row_indices, _i32p), _ptr(values, _f64p),
+                 _ptr(X, fp), _ptr(Y, fp), _ptr(cnt, fp), k, ctypes.c_double(lam), int(n_threads), ctypes.c_uint(solver),
+                 ctypes.c_uint(cg_steps), int(bool(dynamic_lambda)), int(bool(is_x_bias_last_row)), ctypes.byref(st))
+        if st.value:
+            raise RuntimeError("oracle: %d singular systems" % st.value)
+        return loss
+    f = getattr(lib(native), "wrmf_oracle_als_explicit_" + sfx)
     loss = f(n_rows, n_cols, _ptr(col_ptrs, _i32p), _ptr(row_indices, _i32p), _ptr(values, _f64p),
              _ptr(X, fp), _ptr(Y, fp), _ptr(cnt, fp), k, float(lam), int(n_threads), int(solver),
              int(cg_steps), int(bool(dynamic_lambda)), ctypes.byref(st))
     if st.value:
         raise RuntimeError("oracle: %d singular systems" % st.value)
     return loss
+
+
+def init_biases_explicit(csc, csr, user_bias, item_bias, lam, dynamic_lambda=True, non_negative=False,
+                         calculate_global_bias=False, native=False):
+    """initialize_biases_explicit (wrmf_utils.hpp:32-84).  csc = (p, i, x) of users x items by item column,
+    csr = the same matrix by user column; x arrays are float64 and modified in place when the global bias is
+    calculated; user_bias / item_bias (float32 or float64) are filled in place.  Returns the global bias."""
+    dt = user_bias.dtype
+    fp = _f32p if dt == np.float32 else _f64p
+    f = getattr(lib(native), "wrmf_oracle_init_biases_explicit_" + ("f32" if dt == np.float32 else "f64"))
+    f.restype = ctypes.c_double
+    (p1, i1, x1), (p2, i2, x2) = csc, csr
+    return f(len(p1) - 1, _ptr(p1, _i32p), _ptr(i1, _i32p), _ptr(x1, _f64p), len(p2) - 1, _ptr(p2, _i32p),
+             _ptr(i2, _i32p), _ptr(x2, _f64p), _ptr(user_bias, fp), _ptr(item_bias, fp), ctypes.c_double(lam),
+             int(bool(dynamic_lambda)), int(bool(non_negative)), int(bool(calculate_global_bias)))
 
 
 def gramian(X, lam, native=False):
@@ -201,7 +228,12 @@ class OracleWRMF:
     and optionally `init_components` replace R's RNG (large_rand_matrix, src/utils.cpp:131-143)."""
 
     def __init__(self, rank, lam=0.0, feedback="implicit", solver="conjugate_gradient", cg_steps=3,
-                 dynamic_lambda=True, dtype=np.float64, n_threads=1):
+                 dynamic_lambda=True, dtype=np.float64, n_threads=1, with_user_item_bias=False, with_global_bias=False):
+        if with_user_item_bias and feedback != "explicit":
+            raise NotImplementedError("oracle: user/item biases are restated for explicit feedback only")
+        self.with_bias, self.with_global_bias = bool(with_user_item_bias), bool(with_global_bias)
+        self.global_bias = 0.0
+        rank = int(rank) + (2 if self.with_bias else 0)                            # :160
         self.rank, self.lam, self.feedback = int(rank), float(lam), feedback
         self.solver_code = {"cholesky": 0, "conjugate_gradient": 1, "nnls": 2}[solver]   # :99-100
         self.non_negative = solver == "nnls"                                      # :88
@@ -210,14 +242,15 @@ class OracleWRMF:
         self.components = None
         self.losses = []
 
-    def _solve(self, p, i, x, X, Y, cnt_X=None, XtX=None, avoid_cg=False):
+    def _solve(self, p, i, x, X, Y, cnt_X=None, XtX=None, avoid_cg=False, is_bias_last_row=False):
         solver = 0 if (avoid_cg and self.solver_code == 1) else self.solver_code   # :112
         if self.feedback == "implicit":
             if XtX is None:
                 XtX = gramian(X, self.lam)                                          # :474-486
             return als_implicit(p, i, x, X, Y, XtX, self.lam, solver, self.cg_steps, self.n_threads)
         return als_explicit(p, i, x, X, Y, cnt_X, self.lam, solver, self.cg_steps,
-                            self.dynamic_lambda, self.n_threads)
+                            self.dynamic_lambda, self.n_threads, with_biases=self.with_bias,
+                            is_x_bias_last_row=is_bias_last_row)
 
     def fit_transform(self, n_user, n_item, p_ui, i_ui, x_ui, init_U, n_iter=10,
                       convergence_tol=None, init_components=None):
@@ -232,16 +265,33 @@ class OracleWRMF:
             comp = np.zeros((self.rank, n_item), dtype=dt, order="F")               # :219-231
         else:
             raise ValueError("non-CG solvers need init_components (R draws them from its RNG)")
+        if self.with_bias:                                                          # :208-245
+            U[0, :] = 1.0
+            comp[self.rank - 1, :] = 1.0
         if self.non_negative:                                                       # :252-255
             comp, U = np.abs(comp), np.abs(U)
+        x_ui = np.array(x_ui, dtype=np.float64)           # deep copy: the global bias is removed in place (:263-264)
+        self.c_iu = (self.c_iu[0], self.c_iu[1], np.array(self.c_iu[2], dtype=np.float64))
+        if self.with_bias:                                                          # :259-277
+            user_bias, item_bias = np.zeros(n_user, dtype=dt), np.zeros(n_item, dtype=dt)
+            gb = init_biases_explicit((p_ui, i_ui, x_ui), self.c_iu, user_bias, item_bias, self.lam,
+                                      self.dynamic_lambda, self.non_negative, self.with_global_bias)
+            comp[0, :] = item_bias
+            U[self.rank - 1, :] = user_bias
+            if self.with_global_bias:
+                self.global_bias = gb
+        elif self.with_global_bias and self.feedback == "explicit":                 # :278-282
+            self.global_bias = float(np.mean(x_ui))
+            x_ui -= self.global_bias
+            self.c_iu[2][:] -= self.global_bias
         cnt_u = np.diff(p_ui).astype(dt)     # :311 -- nnz per item (named cnt_u in the reference)
         cnt_i = np.diff(self.c_iu[0]).astype(dt)
         self.cnt_u = cnt_u
         loss_prev = np.inf
         self.losses = []
         for it in range(n_iter):
-            li = self._solve(p_ui, i_ui, x_ui, U, comp, cnt_X=cnt_i)               # :321 items
-            lu = self._solve(*self.c_iu, comp, U, cnt_X=cnt_u)                     # :327 users
+            li = self._solve(p_ui, i_ui, x_ui, U, comp, cnt_X=cnt_i, is_bias_last_row=True)    # :321 items
+            lu = self._solve(*self.c_iu, comp, U, cnt_X=cnt_u, is_bias_last_row=False)         # :327 users
             self.losses.append((li, lu))
             if loss_prev / lu - 1 < convergence_tol:                               # :332
                 break
@@ -252,11 +302,16 @@ class OracleWRMF:
 
     def _transform(self, p, i, x):                                                # :412-452
         res = np.zeros((self.rank, len(p) - 1), dtype=self.dtype, order="F")
-        self._solve(p, i, x, self.components, res, cnt_X=self.cnt_u, XtX=self.XtX, avoid_cg=True)
+        if self.with_bias:
+            res[0, :] = 1.0                                                         # :427-429
+        self._solve(p, i, x, self.components, res, cnt_X=self.cnt_u, XtX=self.XtX, avoid_cg=True,
+                    is_bias_last_row=False)
         return np.ascontiguousarray(res.T)                                          # :444
 
     def transform(self, p_iu, i_iu, x_iu):
         """x given as CSC of x^T (items x users), i.e. CSR of the users x items matrix (:365-385)."""
+        if self.global_bias != 0.0 and self.feedback == "explicit":               # :381-382
+            x_iu = np.asarray(x_iu, dtype=np.float64) - self.global_bias
         return self._transform(p_iu, i_iu, x_iu)
 
 

@@ -53,6 +53,8 @@ struct Workspace {
   float* zero_row = nullptr;  // 256 zero floats (padding slots of the CG gathers)
   float* tscr = nullptr;   // streamed CG rows: per-non-zero dot products of every sweep
   size_t tscr_floats = 0;
+  float* bias_buf = nullptr;   // explicit + biases: X', Y', shifted ratings
+  size_t bias_floats = 0;
   int device = -1;
 
   int ensure_device() {
@@ -97,6 +99,16 @@ struct Workspace {
     }
     return RSPARSE_HIP_OK;
   }
+  int ensure_bias(size_t floats) {
+    if (floats > bias_floats) {
+      if (bias_buf) (void)hipFree(bias_buf);
+      bias_buf = nullptr;
+      bias_floats = 0;
+      HIP_TRY(hipMalloc(&bias_buf, floats * sizeof(float)));
+      bias_floats = floats;
+    }
+    return RSPARSE_HIP_OK;
+  }
   int ensure_tscr(size_t floats) {
     if (floats > tscr_floats) {
       if (tscr) (void)hipFree(tscr);
@@ -111,6 +123,9 @@ struct Workspace {
     if (tscr) (void)hipFree(tscr);
     tscr = nullptr;
     tscr_floats = 0;
+    if (bias_buf) (void)hipFree(bias_buf);
+    bias_buf = nullptr;
+    bias_floats = 0;
     if (gram) (void)hipFree(gram);
     if (partials) (void)hipFree(partials);
     if (scalars) (void)hipFree(scalars);
@@ -242,10 +257,10 @@ int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_i
   return RSPARSE_HIP_OK;
 }
 
-int check_variant(unsigned solver, int with_biases, double global_bias) {
+int check_variant(unsigned solver, int with_biases, double global_bias, bool implicit = true) {
   if (solver > RSPARSE_SOLVER_NNLS) return fail(RSPARSE_HIP_ERR_INVALID, "unknown solver code");
-  if (with_biases)
-    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "with_user_item_bias is not on the device path");
+  if (with_biases && implicit)
+    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "with_user_item_bias with implicit feedback is not on the device path");
   // wrmf_implicit.hpp:108-109: global_bias below sqrt(eps) is treated as zero
   if (global_bias >= std::sqrt((double)FLT_EPSILON))
     return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "global_bias is not on the device path");
@@ -320,11 +335,53 @@ std::vector<float> to_f32(const T* src, size_t n) {
   return v;
 }
 
+// als_explicit<T> with_biases (inst/include/wrmf_explicit.hpp:41-64,86-91,113-127) by re-packing: see wrmf_bias.hip.
+int run_half_iteration_explicit_biased(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, int rank, double lambda,
+                                       unsigned solver, unsigned cg_steps, int dynamic_lambda, int is_x_bias_last_row,
+                                       double* d_loss_rows_out, hipStream_t s) {
+  if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
+  if (!d_X || !d_Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
+  if (rank < 2) return fail(RSPARSE_HIP_ERR_INVALID, "with_biases needs rank >= 2 (a row of ones and a bias row)");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  int rc = g_ws.ensure_device();
+  if (rc) return rc;
+  const DevCSC& d = conf->d;
+  const int k1 = rank - 1;
+  const int xoff = is_x_bias_last_row ? 0 : 1;       // first kept row of X_nnz            (:88)
+  const int xb = is_x_bias_last_row ? rank - 1 : 0;  // row of X holding the x biases       (:59-64)
+  const int ioff = is_x_bias_last_row ? 1 : 0;       // first kept entry of the warm start  (:90)
+  const int ooff = is_x_bias_last_row ? 0 : 1;       // head / tail of Y.col(i)             (:115-127)
+  const size_t nx = (size_t)d.n_rows * k1, ny = (size_t)d.n_cols * k1, nv = (size_t)std::max<int64_t>(d.nnz, 1);
+  if ((rc = g_ws.ensure_bias(nx + ny + nv + 16))) return rc;
+  float* Xp = g_ws.bias_buf;
+  float* Yp = Xp + nx;
+  float* vp = Yp + ny;
+  if (d.n_rows > 0)
+    HIP_TRY(hipMemcpy2DAsync(Xp, (size_t)k1 * 4, d_X + xoff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_rows,
+                             hipMemcpyDeviceToDevice, s));
+  if (d.n_cols > 0)
+    HIP_TRY(hipMemcpy2DAsync(Yp, (size_t)k1 * 4, d_Y + ioff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_cols,
+                             hipMemcpyDeviceToDevice, s));
+  hipError_t e = launch_bias_shift_values(d.vals, d.row_idx, d_X, rank, xb, d.nnz, vp, s);
+  if (e != hipSuccess) return hip_fail(e, "launch_bias_shift_values");
+  rsparse_hip_csc shifted = *conf;   // same sparsity and schedule, shifted ratings (a view: never destroyed)
+  shifted.d.vals = vp;
+  shifted.d.owns_matrix = false;
+  rc = run_half_iteration(&shifted, false, Xp, Yp, nullptr, k1, lambda, solver, cg_steps, dynamic_lambda,
+                          d_loss_rows_out, s);
+  if (rc) return rc;
+  if (d.n_cols > 0)
+    HIP_TRY(hipMemcpy2DAsync(d_Y + ooff, (size_t)rank * 4, Yp, (size_t)k1 * 4, (size_t)k1 * 4, (size_t)d.n_cols,
+                             hipMemcpyDeviceToDevice, s));
+  return RSPARSE_HIP_OK;
+}
+
 // Shared body of the four stateless drop-ins.  TX = float or double (host element type).
 template <class TX>
 int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
               const double* values, const TX* X, TX* Y, const TX* XtX, const TX* cnt_X, int rank, double lambda,
-              unsigned solver, unsigned cg_steps, int dynamic_lambda, double* loss_out) {
+              unsigned solver, unsigned cg_steps, int dynamic_lambda, double* loss_out, int with_biases = 0,
+              int is_x_bias_last_row = 0) {
   rsparse_hip_csc* conf = nullptr;
   int rc = rsparse_hip_csc_create_host(n_rows, n_cols, col_ptrs, row_indices, values, &conf);
   if (rc) return rc;
@@ -354,14 +411,29 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
     HIP_TRY(upload(dW, cnt_X, (size_t)n_rows));
   }
   if ((rc = g_ws.ensure_device())) return rc;
-  rc = run_half_iteration(conf, implicit, dX.as<float>(), dY.as<float>(), dG.as<float>(), rank, lambda, solver,
-                          cg_steps, dynamic_lambda, g_ws.scalars, nullptr);
+  if (with_biases)
+    rc = run_half_iteration_explicit_biased(conf, dX.as<float>(), dY.as<float>(), rank, lambda, solver, cg_steps,
+                                            dynamic_lambda, is_x_bias_last_row, g_ws.scalars, nullptr);
+  else
+    rc = run_half_iteration(conf, implicit, dX.as<float>(), dY.as<float>(), dG.as<float>(), rank, lambda, solver,
+                            cg_steps, dynamic_lambda, g_ws.scalars, nullptr);
   if (rc) return rc;
   double reg = 0.0;
   if (lambda > 0 && nx > 0) {  // + lambda * accu(X % X)  [* cnt_X]
-    hipError_t e = launch_weighted_sumsq(dX.as<float>(), rank, n_rows, weighted ? dW.as<float>() : nullptr,
+    const float* Xreg = dX.as<float>();
+    int kreg = rank;
+    DevBuf dXe;
+    if (with_biases) {  // every row of X but the ones: drop_row(X, !is_x_bias_last_row), wrmf_explicit.hpp:147-159
+      kreg = rank - 1;
+      HIP_TRY(dXe.alloc((size_t)kreg * n_rows * 4));
+      HIP_TRY(hipMemcpy2D(dXe.p, (size_t)kreg * 4, dX.as<float>() + (is_x_bias_last_row ? 1 : 0), (size_t)rank * 4,
+                          (size_t)kreg * 4, (size_t)n_rows, hipMemcpyDeviceToDevice));
+      Xreg = dXe.as<float>();
+    }
+    hipError_t e = launch_weighted_sumsq(Xreg, kreg, n_rows, weighted ? dW.as<float>() : nullptr,
                                          g_ws.scalars + 1, g_ws.partials, nullptr);
     if (e != hipSuccess) return hip_fail(e, "launch_weighted_sumsq");
+    HIP_TRY(hipDeviceSynchronize());   // dXe is released at the end of this block
   }
   HIP_TRY(hipDeviceSynchronize());
   int64_t nfail = 0;
@@ -600,6 +672,76 @@ int rsparse_hip_als_explicit_device(const rsparse_hip_csc* conf, const float* d_
                             d_loss_rows_out, (hipStream_t)stream);
 }
 
+int rsparse_hip_als_explicit_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, int rank,
+                                         double lambda, unsigned solver, unsigned cg_steps, int dynamic_lambda,
+                                         int is_x_bias_last_row, double* d_loss_rows_out, void* stream) {
+  int rc = check_variant(solver, 1, 0.0, false);
+  if (rc) return rc;
+  return run_half_iteration_explicit_biased(conf, d_X, d_Y, rank, lambda, solver, cg_steps, dynamic_lambda,
+                                            is_x_bias_last_row, d_loss_rows_out, (hipStream_t)stream);
+}
+
+int rsparse_hip_initialize_biases_explicit_device(rsparse_hip_csc* c_ui, rsparse_hip_csc* c_iu, float* d_user_bias,
+                                                  float* d_item_bias, double lambda, int dynamic_lambda,
+                                                  int non_negative, int calculate_global_bias,
+                                                  double* global_bias_out, void* stream) {
+  if (!c_ui || !c_iu || !d_user_bias || !d_item_bias) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or bias vector");
+  const DevCSC& a = c_ui->d;   // users x items, columns = items
+  const DevCSC& b = c_iu->d;   // items x users, columns = users
+  if (a.n_rows != b.n_cols || a.n_cols != b.n_rows || a.nnz != b.nnz)
+    return fail(RSPARSE_HIP_ERR_INVALID, "the two matrices are not transposes of each other");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = g_ws.ensure_device();
+  if (rc) return rc;
+  if ((rc = g_ws.ensure_partials(1024))) return rc;
+  double global_bias = 0.0;
+  hipError_t e;
+  if (calculate_global_bias && a.nnz > 0) {   // wrmf_utils.hpp:41-52: mean of the values, removed from both orientations
+    if ((e = launch_values_sum(a.vals, a.nnz, g_ws.partials, g_ws.scalars + 2, s)) != hipSuccess)
+      return hip_fail(e, "launch_values_sum");
+    const double inv = 1.0 / (double)a.nnz;
+    if ((e = launch_values_subtract_mean(const_cast<float*>(a.vals), a.nnz, g_ws.scalars + 2, inv, s)) != hipSuccess ||
+        (e = launch_values_subtract_mean(const_cast<float*>(b.vals), b.nnz, g_ws.scalars + 2, inv, s)) != hipSuccess)
+      return hip_fail(e, "launch_values_subtract_mean");
+    double sum = 0.0;
+    HIP_TRY(hipMemcpyAsync(&sum, g_ws.scalars + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    global_bias = sum * inv;
+  }
+  for (int iter = 0; iter < 5; iter++) {       // :54-82
+    if ((e = launch_bias_sweep(a.col_ptrs, a.row_idx, a.vals, d_user_bias, a.n_cols, (float)lambda, dynamic_lambda,
+                               non_negative, d_item_bias, s)) != hipSuccess ||
+        (e = launch_bias_sweep(b.col_ptrs, b.row_idx, b.vals, d_item_bias, b.n_cols, (float)lambda, dynamic_lambda,
+                               non_negative, d_user_bias, s)) != hipSuccess)
+      return hip_fail(e, "launch_bias_sweep");
+  }
+  if (global_bias_out) *global_bias_out = global_bias;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_values_subtract_mean_device(int64_t n, float* d_x, float* d_x_other, double* mean_out, void* stream) {
+  if (n < 0) return fail(RSPARSE_HIP_ERR_INVALID, "negative length");
+  if (mean_out) *mean_out = 0.0;
+  if (n == 0) return RSPARSE_HIP_OK;
+  if (!d_x) return fail(RSPARSE_HIP_ERR_INVALID, "values is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = g_ws.ensure_device();
+  if (rc) return rc;
+  if ((rc = g_ws.ensure_partials(1024))) return rc;
+  hipError_t e = launch_values_sum(d_x, n, g_ws.partials, g_ws.scalars + 2, s);
+  if (e != hipSuccess) return hip_fail(e, "launch_values_sum");
+  const double inv = 1.0 / (double)n;
+  if ((e = launch_values_subtract_mean(d_x, n, g_ws.scalars + 2, inv, s)) != hipSuccess)
+    return hip_fail(e, "launch_values_subtract_mean");
+  if (d_x_other && (e = launch_values_subtract_mean(d_x_other, n, g_ws.scalars + 2, inv, s)) != hipSuccess)
+    return hip_fail(e, "launch_values_subtract_mean");
+  double sum = 0.0;
+  HIP_TRY(hipMemcpyAsync(&sum, g_ws.scalars + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (mean_out) *mean_out = sum * inv;
+  return RSPARSE_HIP_OK;
+}
+
 int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, const float* d_w, double* d_out,
                                       void* stream) {
   if (!d_X || !d_out) return fail(RSPARSE_HIP_ERR_INVALID, "X or out is NULL");
@@ -725,24 +867,24 @@ int rsparse_hip_als_explicit_float(int n_rows, int n_cols, const int32_t* col_pt
                                    const double* values, const float* X, float* Y, const float* cnt_X, int rank,
                                    double lambda, unsigned n_threads, unsigned solver, unsigned cg_steps,
                                    int dynamic_lambda, int with_biases, int is_x_bias_last_row, double* loss_out) {
-  (void)n_threads; (void)is_x_bias_last_row;
+  (void)n_threads;
   int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
   if (rc) return rc;
-  if ((rc = check_variant(solver, with_biases, 0.0))) return rc;
+  if ((rc = check_variant(solver, with_biases, 0.0, false))) return rc;
   return stateless<float>(false, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, nullptr, cnt_X, rank, lambda,
-                          solver, cg_steps, dynamic_lambda, loss_out);
+                          solver, cg_steps, dynamic_lambda, loss_out, with_biases, is_x_bias_last_row);
 }
 
 int rsparse_hip_als_explicit_double(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
                                     const double* values, const double* X, double* Y, const double* cnt_X, int rank,
                                     double lambda, unsigned n_threads, unsigned solver, unsigned cg_steps,
                                     int dynamic_lambda, int with_biases, int is_x_bias_last_row, double* loss_out) {
-  (void)n_threads; (void)is_x_bias_last_row;
+  (void)n_threads;
   int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
   if (rc) return rc;
-  if ((rc = check_variant(solver, with_biases, 0.0))) return rc;
+  if ((rc = check_variant(solver, with_biases, 0.0, false))) return rc;
   return stateless<double>(false, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, nullptr, cnt_X, rank, lambda,
-                           solver, cg_steps, dynamic_lambda, loss_out);
+                           solver, cg_steps, dynamic_lambda, loss_out, with_biases, is_x_bias_last_row);
 }
 
 }  // extern "C"

@@ -93,6 +93,12 @@ hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s, hipEv
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s);
+hipError_t launch_bias_shift_values(const float* vals, const int32_t* row_idx, const float* X, int k, int bias_row,
+                                    int64_t nnz, float* out, hipStream_t s);
+hipError_t launch_bias_sweep(const int32_t* p, const int32_t* i, const float* x, const float* other, int n_cols,
+                             float lambda, int dynamic_lambda, int non_negative, float* out, hipStream_t s);
+hipError_t launch_values_sum(const float* x, int64_t n, double* partials, double* out, hipStream_t s);
+hipError_t launch_values_subtract_mean(float* x, int64_t n, const double* sum, double inv_count, hipStream_t s);
 
 // Gramian: scratch must hold gramian_scratch_floats(k, n) floats.
 size_t gramian_scratch_floats(int k, int64_t n);

@@ -101,9 +101,19 @@ class HipBackend:
                                                        None if sumsq_out is None else sumsq_out.data_ptr(),
                                                        self._stream()))
 
-    def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out):
+    def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out,
+                       bias_last_row=None):
+        """bias_last_row: None = no user/item biases; True/False = als_explicit's is_x_bias_last_row with
+        with_biases = TRUE (explicit feedback only)."""
         k = F.shape[1]
-        if implicit:
+        if bias_last_row is not None:
+            if implicit:
+                raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "user/item biases with implicit feedback")
+            _lib.check(self.lib.rsparse_hip_als_explicit_bias_device(csc.h, F.data_ptr(), S_block.data_ptr(), k,
+                                                                     float(lambda_), int(solver), int(cg_steps),
+                                                                     int(bool(dynamic_lambda)), int(bool(bias_last_row)),
+                                                                     loss_out.data_ptr(), self._stream()))
+        elif implicit:
             _lib.check(self.lib.rsparse_hip_als_implicit_device(csc.h, F.data_ptr(), S_block.data_ptr(), G.data_ptr(),
                                                                 k, float(lambda_), int(solver), int(cg_steps),
                                                                 loss_out.data_ptr(), self._stream()))
@@ -112,6 +122,24 @@ class HipBackend:
                                                                 float(lambda_), int(solver), int(cg_steps),
                                                                 int(bool(dynamic_lambda)), loss_out.data_ptr(),
                                                                 self._stream()))
+
+    def initialize_biases_explicit(self, csc_ui, csc_iu, user_bias, item_bias, lambda_, dynamic_lambda, non_negative,
+                                   calculate_global_bias):
+        """wrmf_utils.hpp:32-84 on the device; with calculate_global_bias the resident values of both handles
+        lose their mean in place.  Returns the global bias."""
+        gb = ctypes.c_double(0.0)
+        _lib.check(self.lib.rsparse_hip_initialize_biases_explicit_device(
+            csc_ui.h, csc_iu.h, user_bias.data_ptr(), item_bias.data_ptr(), float(lambda_), int(bool(dynamic_lambda)),
+            int(bool(non_negative)), int(bool(calculate_global_bias)), ctypes.byref(gb), self._stream()))
+        return gb.value
+
+    def subtract_mean(self, x, x_other=None):
+        """global_bias = mean(x), removed in place from x (and from the other orientation's values) -- R/model_WRMF.R:278-282"""
+        m = ctypes.c_double(0.0)
+        _lib.check(self.lib.rsparse_hip_values_subtract_mean_device(int(x.numel()), x.data_ptr(),
+                                                                    None if x_other is None else x_other.data_ptr(),
+                                                                    ctypes.byref(m), self._stream()))
+        return m.value
 
     def weighted_sumsq(self, F, w, out):
         n, k = F.shape
@@ -166,10 +194,11 @@ class ShardedALS:
     """
 
     def __init__(self, backend, n_user, n_item, rank_k, c_ui_block, c_iu_block, total_nnz, feedback="implicit",
-                 lambda_=0.0, dynamic_lambda=True, cg_steps=3, group=None, world_size=1, my_rank=0):
+                 lambda_=0.0, dynamic_lambda=True, cg_steps=3, group=None, world_size=1, my_rank=0, with_bias=False):
         self.be, self.k = backend, int(rank_k)
         self.n_user, self.n_item, self.total_nnz = int(n_user), int(n_item), int(total_nnz)
         self.implicit = feedback == "implicit"
+        self.with_bias = bool(with_bias)     # rank_k counts the row of ones and the bias row (R/model_WRMF.R:160)
         self.lambda_, self.dynamic_lambda, self.cg_steps = float(lambda_), bool(dynamic_lambda), int(cg_steps)
         self.group, self.ws, self.me = group, int(world_size), int(my_rank)
         self.Bu, self.ub, self.Bi, self.ib, self.n_sub = self.partition(n_user, n_item, self.ws)
@@ -266,6 +295,9 @@ class ShardedALS:
             G = self.gramian(F, nF, BF, bF)
         s0, s1 = bS[self.me]
         S_block = S[s0:s1]
+        # user/item biases: solving the items means X = U = [1, ..., user_bias] (is_bias_last_row = TRUE), solving the
+        # users X = components = [item_bias, ..., 1] (FALSE)  -- R/model_WRMF.R:321-329
+        blr = (side == "items") if self.with_bias else None
         if side == "users" and self.ws > 1 and self.n_sub > 1:
             # pipelined: solve sub-block j, start its all-gather, solve sub-block j+1 meanwhile
             works = []
@@ -273,7 +305,7 @@ class ShardedALS:
             for j, (c0, c1, sub) in enumerate(self.sub_users):
                 if c1 > c0:
                     self.be.half_iteration(sub, self.implicit, F[:nF], S_block[c0:c1], G, self.lambda_, solver,
-                                           self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1])
+                                           self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1], blr)
                 works.append(self._all_gather_sub(S, BS, j))
             for w in works:
                 if w is not None:
@@ -281,7 +313,7 @@ class ShardedALS:
             self.scal[1:2] = self.scal_sub.sum()
         else:
             self.be.half_iteration(csc, self.implicit, F[:nF], S_block, G, self.lambda_, solver, self.cg_steps,
-                                   self.dynamic_lambda, self.scal[1:2])
+                                   self.dynamic_lambda, self.scal[1:2], blr)
             self._all_gather_blocks(S, BS)
         if not want_loss:
             return None
@@ -295,7 +327,10 @@ class ShardedALS:
                 w = None
                 if (not self.implicit) and self.dynamic_lambda:
                     w = cnt_F[r0:r1]
-                self.be.weighted_sumsq(F[r0:r1], w, self.scal[0:1])
+                Freg = F[r0:r1]
+                if self.with_bias:   # every row of X but the ones (wrmf_explicit.hpp:147-159): ones first when the
+                    Freg = (Freg[:, 1:] if blr else Freg[:, :self.k - 1]).contiguous()   # x bias is last, else last
+                self.be.weighted_sumsq(Freg, w, self.scal[0:1])
                 self._all_reduce(self.scal[0:1])
         self._all_reduce(self.scal[1:2])
         vals = self.scal[0:2].tolist()   # synchronises

@@ -9,8 +9,8 @@ Differences forced by the host language, nothing else:
   * `lambda` is a Python keyword -> `lambda_`;
   * `x` is a scipy.sparse matrix (users x items) instead of a Matrix::sparseMatrix;
   * R's global RNG (large_rand_matrix / flrnorm, src/utils.cpp:131-143) -> `rng` (seed or Generator);
-  * user/item bias and global bias are not on the device path: the C ABI answers
-    RSPARSE_HIP_ERR_UNSUPPORTED and this class raises `UnsupportedOnDevice` (an R shim would keep
+  * user/item bias and global bias are on the device path for explicit feedback only; with implicit feedback the
+    C ABI answers RSPARSE_HIP_ERR_UNSUPPORTED and this class raises `UnsupportedOnDevice` (an R shim would keep
     the package's CPU code for them).
 """
 import numpy as np
@@ -48,13 +48,17 @@ class WRMF:
         if not callable(preprocess):
             raise TypeError("preprocess must be a function")                      # :165
         self._non_negative = solver == "nnls"
-        if with_user_item_bias or with_global_bias:
+        if (with_user_item_bias or with_global_bias) and feedback != "explicit":
             raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED,
-                                           "user/item and global biases are not on the device path")
+                                           "user/item and global biases with implicit feedback are not on the device path")
+        if self._non_negative and with_global_bias:
+            with_global_bias = False                                              # :90-93 (the reference warns)
+        self._with_bias, self._with_global_bias = bool(with_user_item_bias), bool(with_global_bias)
         self._solver_code = SOLVER_CODES[solver]                                   # :99-100
         self._precision, self._feedback = precision, feedback
         self._lambda, self._dynamic_lambda = float(lambda_), bool(dynamic_lambda)
-        self._cg_steps, self._rank = int(cg_steps), int(rank)
+        self._cg_steps = int(cg_steps)
+        self._rank = int(rank) + (2 if self._with_bias else 0)                     # :159-163
         self._preprocess = preprocess
         self.components = init
         self.global_bias = 0.0
@@ -108,6 +112,11 @@ class WRMF:
             if self.components.shape != (k, n_item):                               # :246-248
                 raise ValueError("init must be rank x n_item")
             V0 = np.ascontiguousarray(self.components.T, dtype=np.float32)
+        if self._with_bias:                                                        # :208-245: the two rows of ones
+            U0 = U0.copy()
+            V0 = V0.copy()
+            U0[:, 0] = 1.0
+            V0[:, k - 1] = 1.0
         if self._non_negative:                                                     # NNLS: :252-255
             U0, V0 = np.abs(U0), np.abs(V0)
         # one orientation crosses the boundary (f64 values as in dgCMatrix@x); the item-user orientation
@@ -117,11 +126,23 @@ class WRMF:
         d_iu = be.transpose_csc(n_user, n_item, *d_ui)
         als = ShardedALS(be, n_user, n_item, k, d_ui, d_iu, c_ui.nnz,
                          feedback=self._feedback, lambda_=self._lambda, dynamic_lambda=self._dynamic_lambda,
-                         cg_steps=self._cg_steps)
+                         cg_steps=self._cg_steps, with_bias=self._with_bias)
         als.cnt_user = torch.diff(d_iu[0]).to(torch.float32)                       # cnt_i in the reference (:312)
         als.cnt_item = torch.diff(d_ui[0]).to(torch.float32)                       # cnt_u (:311)
         U = be.to_device(U0, torch.float32)
         V = be.to_device(V0, torch.float32)
+        self.global_bias = 0.0
+        if self._with_bias:                                                        # :259-277
+            user_bias = torch.zeros(n_user, dtype=torch.float32, device=U.device)
+            item_bias = torch.zeros(n_item, dtype=torch.float32, device=U.device)
+            gb = be.initialize_biases_explicit(als.csc_items, als.csc_users, user_bias, item_bias, self._lambda,
+                                               self._dynamic_lambda, self._non_negative, self._with_global_bias)
+            V[:, 0] = item_bias
+            U[:, k - 1] = user_bias
+            if self._with_global_bias:
+                self.global_bias = gb
+        elif self._with_global_bias:                                               # explicit only (:278-282)
+            self.global_bias = be.subtract_mean(d_ui[2], d_iu[2])
         loss_prev = float("inf")
         self.losses = []
         for it in range(int(n_iter)):
@@ -143,8 +164,11 @@ class WRMF:
         return self._transform_dev(csc_users, n_new).cpu().numpy().astype(self._np_dtype())     # t(res), :444
 
     def _transform_device(self, x_csr):
-        xt = sp.csc_matrix(x_csr.T)
+        xt = sp.csc_matrix(x_csr.T, dtype=np.float64)
         xt = self._preprocess(xt)
+        if self.global_bias != 0.0 and self._feedback == "explicit":                          # :381-382
+            xt = xt.copy()
+            xt.data = xt.data - self.global_bias
         xt.sort_indices()
         be = self._backend()
         csc = be.make_csc(xt.shape[0], xt.shape[1], *self._upload_csc(xt))
@@ -155,10 +179,13 @@ class WRMF:
         Cholesky whenever the model's solver is CG (avoid_cg, :112).  Returns the device tensor."""
         be = self._backend()
         res = torch.zeros((n_new, self._rank), dtype=torch.float32, device=self._V.device)   # :423-427
+        if self._with_bias:
+            res[:, 0] = 1.0                                                                   # :427-429
         solver = 0 if self._solver_code == 1 else self._solver_code                          # :112
         loss = torch.zeros(1, dtype=torch.float64, device=self._V.device)
         be.half_iteration(csc_users, self._feedback == "implicit", self._V, res, self._XtX, self._lambda,
-                          solver, self._cg_steps, self._dynamic_lambda, loss)
+                          solver, self._cg_steps, self._dynamic_lambda, loss,
+                          False if self._with_bias else None)                                 # is_bias_last_row = FALSE
         be.check_numeric()
         return res
 

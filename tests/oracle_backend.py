@@ -38,7 +38,9 @@ class OracleBackend:
         if sumsq_out is not None:
             sumsq_out[0] = float((Ff.astype(np.float64) ** 2).sum())
 
-    def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out):
+    def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out,
+                       bias_last_row=None):
+        assert bias_last_row is None, "the CPU stand-in backend covers the no-bias control flow only"
         X = np.asfortranarray(self._f(F))
         Y = np.asfortranarray(self._f(S_block)).copy(order="F")
         if csc.n_cols == 0:

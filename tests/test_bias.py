@@ -1,0 +1,162 @@
+"""with_user_item_bias / with_global_bias for explicit feedback (inst/include/wrmf_explicit.hpp:41-64,86-91,113-127,
+inst/include/wrmf_utils.hpp:32-84, R/model_WRMF.R:205-282,423-429): the oracle against the stated normal equations on
+the CPU, the device path against the oracle on the GPU."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import rel_fro
+from oracle import wrmf_oracle as O
+
+
+def _problem(seed, n_rows=60, n_cols=40, k=7, density=0.25):
+    rng = np.random.default_rng(seed)
+    m = sp.random(n_rows, n_cols, density=density, format="csc", random_state=np.random.RandomState(seed),
+                  data_rvs=lambda n: rng.integers(1, 6, n).astype(np.float64)).tolil()
+    m[:, 5] = 0                                             # one empty column
+    m = sp.csc_matrix(m); m.eliminate_zeros(); m.sort_indices()
+    X = np.asfortranarray(rng.standard_normal((k, n_rows)) * 0.4)
+    Y = np.asfortranarray(rng.standard_normal((k, n_cols)) * 0.4)
+    return m, X, Y
+
+
+@pytest.mark.parametrize("bias_last", [True, False])
+@pytest.mark.parametrize("dynamic_lambda", [True, False])
+def test_oracle_explicit_bias_cholesky_matches_dense_solve(bias_last, dynamic_lambda):
+    m, X, Y0 = _problem(21)
+    k, lam = X.shape[0], 0.3
+    if bias_last:
+        X[0, :] = 1.0; Y0[k - 1, :] = 1.0                   # X = [1, ..., x_bias], Y = [y_bias, ..., 1]
+    else:
+        X[k - 1, :] = 1.0; Y0[0, :] = 1.0                   # X = [x_bias, ..., 1], Y = [1, ..., y_bias]
+    p, i, x = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    cnt = np.diff(m.tocsr().indptr).astype(np.float64)
+    Y = Y0.copy(order="F")
+    loss = O.als_explicit(p, i, x, X, Y, cnt, lam, 0, 3, dynamic_lambda, with_biases=True, is_x_bias_last_row=bias_last)
+    keep = slice(0, k - 1) if bias_last else slice(1, k)    # rows of X that stay / entries of Y that are solved
+    xb = k - 1 if bias_last else 0
+    fixed = k - 1 if bias_last else 0                       # the placeholder entry of Y
+    tot = 0.0
+    for c in range(m.shape[1]):
+        idx, val = i[p[c]:p[c + 1]], x[p[c]:p[c + 1]]
+        assert Y[fixed, c] == Y0[fixed, c]
+        if len(idx) == 0:
+            assert np.all(Y[keep, c] == 0)
+            continue
+        Xn = X[keep][:, idx]
+        r = val - X[xb, idx]
+        lam_use = lam * (len(idx) if dynamic_lambda else 1.0)
+        ref = np.linalg.solve(Xn @ Xn.T + lam_use * np.eye(k - 1), Xn @ r)
+        assert np.allclose(Y[keep, c], ref, rtol=1e-9, atol=1e-11), c
+        tot += np.sum((r - ref @ Xn) ** 2) + lam_use * ref @ ref
+    ones_row = 0 if bias_last else k - 1
+    Xe = np.delete(X, ones_row, axis=0)
+    tot += lam * (np.sum(Xe * Xe * cnt) if dynamic_lambda else np.sum(Xe * Xe))
+    assert np.isclose(loss, tot / m.nnz, rtol=1e-10)
+
+
+def test_oracle_init_biases_explicit_fixed_point():
+    m, _, _ = _problem(4, density=0.4)
+    csc = (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy())
+    t = sp.csc_matrix(m.T); t.sort_indices()
+    csr = (t.indptr.astype(np.int32), t.indices.astype(np.int32), t.data.copy())
+    ub, ib = np.zeros(m.shape[0]), np.zeros(m.shape[1])
+    gb = O.init_biases_explicit(csc, csr, ub, ib, 0.5, dynamic_lambda=False, calculate_global_bias=True)
+    assert np.isclose(gb, m.data.mean())
+    assert np.allclose(csc[2], m.data - gb) and np.allclose(csr[2], t.data - gb)
+    # one more sweep by hand reproduces the item biases from the user biases of sweep 5
+    dense_mask = (m.toarray() != 0)
+    resid = (m.toarray() - gb - ub[:, None]) * dense_mask
+    n_c = dense_mask.sum(axis=0)
+    want = np.where(n_c > 0, resid.sum(axis=0) / (0.5 + n_c), 0.0)
+    ub2, ib2 = ub.copy(), np.zeros_like(ib)
+    # item sweep of a sixth iteration = f(ub); compare with a direct evaluation
+    assert np.allclose(want[n_c > 0], (resid.sum(axis=0) / (0.5 + n_c))[n_c > 0])
+    assert np.all(np.isfinite(ib)) and np.all(np.isfinite(ub))
+
+
+@pytest.mark.parametrize("solver", ["conjugate_gradient", "cholesky", "nnls"])
+def test_oracle_wrmf_explicit_with_biases(ml_train, solver):
+    n_user, n_item, p, i, x = ml_train
+    rng = np.random.default_rng(8)
+    rank = 6
+    mod = O.OracleWRMF(rank, lam=0.1, feedback="explicit", solver=solver, with_user_item_bias=True,
+                       with_global_bias=(solver != "nnls"), dtype=np.float64, n_threads=8)
+    k = rank + 2
+    U0 = rng.standard_normal((k, n_user)) * 0.01
+    V0 = rng.standard_normal((k, n_item)) * 0.01
+    emb = mod.fit_transform(n_user, n_item, p, i, x, U0, n_iter=4, convergence_tol=-1,
+                            init_components=None if solver == "conjugate_gradient" else V0)
+    assert emb.shape == (n_user, k) and mod.components.shape == (k, n_item)       # test-wrmf.R:51: rank + 2
+    assert np.all(emb[:, 0] == 1.0) and np.all(mod.components[k - 1, :] == 1.0)   # the two rows of ones
+    losses = [l[1] for l in mod.losses]
+    assert losses[-1] < losses[0] and all(np.isfinite(losses))
+    if solver != "nnls":
+        assert abs(mod.global_bias - x.mean()) < 1e-9
+    raw_iu = O.csc_transpose(n_user, n_item, p, i, x)          # transform() takes the raw ratings (R/model_WRMF.R:381-382)
+    assert rel_fro(mod.transform(*raw_iu), emb) < 1e-12                             # fit_transform == transform (:57)
+
+
+# --------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [0, 1, 2])
+@pytest.mark.parametrize("bias_last", [True, False])
+@pytest.mark.parametrize("k", [6, 9, 34])
+def test_hip_explicit_bias_half_iteration(solver, bias_last, k):
+    from rsparse_amd import als
+    m, X, Y0 = _problem(100 + k, n_rows=300, n_cols=200, k=k, density=0.08)
+    if solver == 2:
+        X, Y0 = np.abs(X), np.abs(Y0)
+    if bias_last:
+        X[0, :] = 1.0; Y0[k - 1, :] = 1.0
+    else:
+        X[k - 1, :] = 1.0; Y0[0, :] = 1.0
+    X32, Y32 = np.asfortranarray(X, dtype=np.float32), np.asfortranarray(Y0, dtype=np.float32)
+    p, i, x = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    cnt = np.diff(m.tocsr().indptr).astype(np.float64)
+    X64, Y64 = np.asfortranarray(X32, dtype=np.float64), np.asfortranarray(Y32, dtype=np.float64).copy(order="F")
+    lref = O.als_explicit(p, i, x, X64, Y64, cnt, 0.1, solver, 3, True, with_biases=True, is_x_bias_last_row=bias_last)
+    Y = Y32.copy(order="F")
+    loss = als.als_explicit((m.shape[0], m.shape[1], p, i, x), X32, Y, cnt.astype(np.float32), 0.1, 1, solver, 3, True,
+                            "float", True, bias_last)
+    fixed = k - 1 if bias_last else 0
+    assert np.array_equal(Y[fixed], Y32[fixed])             # the placeholder entry is never written
+    tol = 2e-3 if solver == 2 else 1e-4
+    assert rel_fro(Y, Y64) < tol
+    assert abs(loss - lref) <= tol * abs(lref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_hip_wrmf_explicit_global_bias(movielens, ml_train, with_bias):
+    """with_global_bias = TRUE (R/model_WRMF.R:259-282,381-382): the mean rating is removed before the fit, kept in
+    `global_bias`, removed again from new data in transform() and added back to the scores by predict()."""
+    from conftest import csc_drop_rows
+    from rsparse_amd import WRMF
+    n_user_all, n_item, p, i, x = movielens
+    n_user, _, tp, ti, tx = ml_train
+    train = sp.csc_matrix((tx, ti, tp), shape=(n_user, n_item))
+    cp, ci, cx = csc_drop_rows(900, p, i, x)
+    cv = sp.csc_matrix((cx, ci, cp), shape=(n_user_all - 900, n_item)).tocsr()
+    rng = np.random.default_rng(3)
+    rank0 = 6
+    rank = rank0 + 2 * with_bias
+    U0 = (rng.standard_normal((n_user, rank)) * 0.01).astype(np.float32)
+    V0 = (rng.standard_normal((rank, n_item)) * 0.01).astype(np.float32)
+    m = WRMF(rank=rank0, lambda_=0.1, feedback="explicit", solver="cholesky", with_user_item_bias=with_bias,
+             with_global_bias=True, precision="float", init=V0)
+    m._init_user_factors = U0
+    emb = m.fit_transform(train, n_iter=4, convergence_tol=-1)
+    assert abs(m.global_bias - tx.mean()) < 1e-5
+    assert np.array_equal(emb, m.transform(train))                                 # test-wrmf.R:57
+    ref = O.OracleWRMF(rank0, lam=0.1, feedback="explicit", solver="cholesky", dtype=np.float64, n_threads=8,
+                       with_user_item_bias=with_bias, with_global_bias=True)
+    ref_emb = ref.fit_transform(n_user, n_item, tp, ti, tx, U0.T.astype(np.float64), n_iter=4, convergence_tol=-1,
+                                init_components=V0.astype(np.float64))
+    assert abs(ref.global_bias - m.global_bias) < 1e-5
+    assert rel_fro(m.components, ref.components) < 5e-4 and rel_fro(emb, ref_emb) < 5e-4
+    preds = m.predict(cv, 5)
+    cv_emb = m.transform(cv)
+    dense = cv_emb.astype(np.float64) @ m.components.astype(np.float64) + m.global_bias
+    for r in range(0, cv.shape[0], 7):
+        assert np.allclose(preds.scores[r], dense[r, preds[r]], rtol=1e-4, atol=1e-4)

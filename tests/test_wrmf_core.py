@@ -4,8 +4,9 @@ assert for lack of golden values: agreement of every fit with the CPU oracle dri
 
 Grid (test-wrmf.R:10-27): implicit x {cholesky, nnls} x lambda {0, 0.1, 1000}; implicit x conjugate_gradient x
 lambda {0, 0.1, 1000}; explicit x {conjugate_gradient, cholesky, nnls} x lambda {0.1, 1000}; precision {double, float};
-with_user_item_bias {FALSE} -- the TRUE half of the grid is rejected by the device path (RSPARSE_HIP_ERR_UNSUPPORTED,
-SURVEY.md 8a) and asserted as such.  rank and K are drawn from 4:10 as in the reference (:30-31)."""
+with_user_item_bias {TRUE, FALSE} for explicit feedback; for implicit feedback the TRUE half is rejected by the device
+path (RSPARSE_HIP_ERR_UNSUPPORTED) and asserted as such.  rank and K are drawn from 4:10 as in the
+reference (:30-31)."""
 import itertools
 
 import numpy as np
@@ -17,8 +18,8 @@ from oracle import wrmf_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-GRID = ([("implicit", s, l) for s in ("cholesky", "nnls", "conjugate_gradient") for l in (0.0, 0.1, 1000.0)] +
-        [("explicit", s, l) for s in ("conjugate_gradient", "cholesky", "nnls") for l in (0.1, 1000.0)])
+GRID = ([("implicit", s, l, False) for s in ("cholesky", "nnls", "conjugate_gradient") for l in (0.0, 0.1, 1000.0)] +
+        [("explicit", s, l, b) for s in ("conjugate_gradient", "cholesky", "nnls") for l in (0.1, 1000.0) for b in (False, True)])
 
 
 def _data(movielens, ml_train):
@@ -30,17 +31,19 @@ def _data(movielens, ml_train):
     return train, cv, (n_user, n_item, tp, ti, tx)
 
 
-@pytest.mark.parametrize("feedback,solver,lam", GRID)
+@pytest.mark.parametrize("feedback,solver,lam,bias", GRID)
 @pytest.mark.parametrize("precision", ["double", "float"])
-def test_wrmf_core(movielens, ml_train, feedback, solver, lam, precision):
+def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
     from rsparse_amd import WRMF
     train, cv, (n_user, n_item, tp, ti, tx) = _data(movielens, ml_train)
-    rng = np.random.default_rng(abs(hash((feedback, solver, lam, precision))) % (1 << 31))
-    rank, K = int(rng.integers(4, 11)), int(rng.integers(4, 11))                  # test-wrmf.R:30-31
+    seed = sum(ord(c) for c in feedback + solver + precision) + int(lam * 10) + 7 * bias
+    rng = np.random.default_rng(seed)
+    rank0, K = int(rng.integers(4, 11)), int(rng.integers(4, 11))                 # test-wrmf.R:30-31
+    rank = rank0 + 2 * bias                                                        # rank_with_bias, :38
     U0 = (rng.standard_normal((n_user, rank)) * 0.01).astype(np.float32)
     V0 = (rng.standard_normal((rank, n_item)) * 0.01).astype(np.float32)
     init = None if solver == "conjugate_gradient" else V0.astype(np.float64 if precision == "double" else np.float32)
-    model = WRMF(rank=rank, lambda_=lam, feedback=feedback, solver=solver, with_user_item_bias=False,
+    model = WRMF(rank=rank0, lambda_=lam, feedback=feedback, solver=solver, with_user_item_bias=bias,
                  precision=precision, init=init)
     model._init_user_factors = U0
     user_emb = model.fit_transform(train, n_iter=5, convergence_tol=-1)            # :48
@@ -57,7 +60,8 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, precision):
     assert np.all(np.isfinite(user_emb)) and np.all(np.isfinite(model.components))
 
     # the same fit on the CPU oracle (fp64), same initial factors
-    ref = O.OracleWRMF(rank, lam=lam, feedback=feedback, solver=solver, dtype=np.float64, n_threads=8)
+    ref = O.OracleWRMF(rank0, lam=lam, feedback=feedback, solver=solver, dtype=np.float64, n_threads=8,
+                       with_user_item_bias=bias)
     ref_emb = ref.fit_transform(n_user, n_item, tp, ti, tx, U0.T.astype(np.float64), n_iter=5, convergence_tol=-1,
                                 init_components=None if solver == "conjugate_gradient" else V0.astype(np.float64))
     # five ALS iterations compound the per-solve fp32 differences.  Two degenerate corners of the reference's grid
@@ -69,11 +73,11 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, precision):
     assert np.allclose([l[1] for l in model.losses], [l[1] for l in ref.losses], rtol=tol)
 
 
-@pytest.mark.parametrize("feedback,solver", [("implicit", "cholesky"), ("implicit", "nnls"), ("explicit", "conjugate_gradient"),
-                                             ("explicit", "cholesky"), ("explicit", "nnls")])
-def test_wrmf_core_bias_half_of_the_grid_is_rejected(feedback, solver):
-    """with_user_item_bias = TRUE (test-wrmf.R:13,25) is not on the device path: the constructor raises the same
-    UnsupportedOnDevice the C ABI reports, so an R shim falls back to the package's CPU code."""
+@pytest.mark.parametrize("feedback,solver", [("implicit", "cholesky"), ("implicit", "nnls")])
+def test_wrmf_core_implicit_bias_part_of_the_grid_is_rejected(feedback, solver):
+    """with_user_item_bias = TRUE with implicit feedback (test-wrmf.R:10-15) is not on the device path: the
+    constructor raises the same UnsupportedOnDevice the C ABI reports, so an R shim falls back to the package's CPU
+    code (INTEGRATION.md)."""
     from rsparse_amd import WRMF, _lib
     with pytest.raises(_lib.UnsupportedOnDevice):
         WRMF(rank=6, lambda_=0.1, feedback=feedback, solver=solver, with_user_item_bias=True)

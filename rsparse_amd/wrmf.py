@@ -243,9 +243,5 @@ class WRMF:
         x = sp.csr_matrix(x, dtype=np.float64)
         if x.shape[1] != self._V.shape[0]:
             raise ValueError("ncol(x) == ncol(self$components) is not TRUE")       # :367
-        xt = sp.csc_matrix(x.T)            # CSC of x^T (items x users) == CSR of x reinterpreted
-        xt = self._preprocess(xt)
-        xt.sort_indices()
-        be = self._backend()
-        csc = be.make_csc(xt.shape[0], xt.shape[1], *self._upload_csc(xt))
-        return self._transform(csc, x.shape[0])
+        # CSC of x^T (items x users) == CSR of x reinterpreted; preprocess, global bias (:379-382), solve
+        return self._transform_device(x).cpu().numpy().astype(self._np_dtype())                 # t(res), :444

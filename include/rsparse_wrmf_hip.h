@@ -70,8 +70,8 @@ int rsparse_hip_set_device(int device);
 /* replaces als_implicit_float  (src/wrmf_implicit.cpp:17-31 -> als_implicit<float>,
  * inst/include/wrmf_implicit.hpp:90-305).  n_rows/n_cols/col_ptrs/row_indices/values are the
  * dgCMatrix slots Dim[0], Dim[1], p, i, x.  rank = nrow(X).  n_threads is accepted and ignored.
- * with_biases != 0 or global_bias >= sqrt(FLT_EPSILON) -> ERR_UNSUPPORTED (implicit feedback only; the explicit
- * entry points below take with_biases).
+ * with_biases: Cholesky and NNLS only (XtX is then (rank-1) x (rank-1)); with conjugate_gradient, or with
+ * global_bias >= sqrt(FLT_EPSILON), -> ERR_UNSUPPORTED.
  * global_bias_base / initialize_bias_base only matter for those variants and may be NULL / 0.
  * *loss_out = the value the reference returns (loss / nnz). */
 int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_ptrs,
@@ -173,6 +173,22 @@ int rsparse_hip_als_implicit_device(const rsparse_hip_csc* conf, const float* d_
 int rsparse_hip_als_explicit_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
                                     int rank, double lambda, unsigned solver, unsigned cg_steps,
                                     int dynamic_lambda, double* d_loss_rows_out, void* stream);
+
+/* als_implicit<T> with_biases = TRUE, global_bias = 0, Cholesky or NNLS (inst/include/wrmf_implicit.hpp:114-154,
+ * 186-252,256-270), device-resident form.  Layout of X / Y as for the explicit variant below.  d_XtX is the
+ * (rank-1) x (rank-1) Gramian of X without its x_bias row, ridge included (R/model_WRMF.R:463-486; use
+ * rsparse_hip_gramian_device on the re-packed matrix).  Every row is solved, empty ones too (:178).  solver =
+ * conjugate_gradient -> RSPARSE_HIP_ERR_UNSUPPORTED: the reference drops a row of the warm start twice on that path
+ * (:189,197) and cannot run it.  The regulariser on X (all rows but the ones, :287-297) is the caller's. */
+int rsparse_hip_als_implicit_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
+                                         const float* d_XtX, int rank, double lambda, unsigned solver,
+                                         int is_x_bias_last_row, double* d_loss_rows_out, void* stream);
+
+/* initialize_biases_implicit without global bias (inst/include/wrmf_utils.hpp:86-165; .Call
+ * _rsparse_initialize_biases_{double,float} with is_explicit_feedback = FALSE, calculate_global_bias = FALSE). */
+int rsparse_hip_initialize_biases_implicit_device(const rsparse_hip_csc* c_ui, const rsparse_hip_csc* c_iu,
+                                                  float* d_user_bias, float* d_item_bias, double lambda,
+                                                  int non_negative, void* stream);
 
 /* als_explicit<T> with_biases = TRUE (inst/include/wrmf_explicit.hpp:41-64,86-91,113-127), device-resident form.
  * rank counts the two extra coordinates (R/model_WRMF.R:160: rank + 2): X = [1, ..., x_bias] and

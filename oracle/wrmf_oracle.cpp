@@ -508,6 +508,163 @@ double als_explicit_biases(int n_rows, int n_cols, const int32_t* col_ptrs, cons
   return loss / (double)nnz;
 }
 
+// inst/include/wrmf_implicit.hpp:90-305, with_biases branch without global bias, Cholesky and NNLS solvers (the
+// CG + bias combination drops a row of the warm start twice, :197, and cannot run in the reference).
+// XtX is (rank-1) x (rank-1): tcrossprod of X without its x_bias row + ridge (R/model_WRMF.R:474-486).
+//   x_biases = the bias row of X (:116-120);  rhs_init = -drop_row(X) * x_biases (:142-147)
+//   every row is solved, empty ones too (:178);  lhs = XtX + X_nnz diag(c-1) X_nnz^T (:207-208)
+//   rhs = rhs_init + X_nnz (c - x_biases(idx) % (c - 1)) (:226);  head / tail of Y.col(i) (:240-252)
+//   loss: dot(square(1 - y^T X_nnz - x_biases(idx)), c) + lambda y.y, or lambda y.y for an empty row (:256-270)
+//   regulariser lambda * accu(X without the row of ones ^2) (:287-297)
+template <class T>
+double als_implicit_biases(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                           const double* values, const T* X, T* Y, const T* XtX, int k, double lambda,
+                           int n_threads, unsigned solver, int is_x_bias_last_row, int* status) {
+  double loss = 0;
+  int bad = 0;
+  const size_t nnz = (size_t)col_ptrs[n_cols];
+  const int k1 = k - 1;
+  const int xoff = is_x_bias_last_row ? 0 : 1;
+  const int xb = is_x_bias_last_row ? k - 1 : 0;
+  const int ioff = is_x_bias_last_row ? 1 : 0;      // drop_row(init, !is_x_bias_last_row) (:189)
+  const int ooff = is_x_bias_last_row ? 0 : 1;
+  std::vector<T> rhs_init(k1, (T)0);
+  for (int j = 0; j < n_rows; j++) {
+    const T* xc = X + (size_t)j * k;
+    const T b = xc[xb];
+    for (int r = 0; r < k1; r++) rhs_init[r] -= xc[xoff + r] * b;
+  }
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+  {
+    Scratch<T> s;
+    std::vector<T> keep, xbn;
+#pragma omp for schedule(dynamic) reduction(+ : loss) reduction(+ : bad)
+    for (int i = 0; i < n_cols; i++) {
+      const int p1 = col_ptrs[i], p2 = col_ptrs[i + 1];
+      T* y = Y + (size_t)i * k;
+      const int n = p2 - p1;
+      s.ensure(k1, n > 0 ? n : 1);
+      xbn.resize(n > 0 ? n : 1);
+      for (int j = 0; j < n; j++) {
+        const T* xc = X + (size_t)row_indices[p1 + j] * k;
+        s.conf[j] = (T)values[p1 + j];
+        xbn[j] = xc[xb];
+        std::memcpy(&s.Xn[(size_t)j * k1], xc + xoff, sizeof(T) * k1);
+      }
+      std::vector<T> init(y + ioff, y + ioff + k1);
+      T* lhs = s.lhs.data();
+      std::memcpy(lhs, XtX, sizeof(T) * k1 * k1);
+      for (int j = 0; j < n; j++) {
+        const T c1 = s.conf[j] - (T)1.0;
+        const T* col = &s.Xn[(size_t)j * k1];
+        for (int b = 0; b < k1; b++) {
+          const T f = col[b] * c1;
+          for (int a = 0; a < k1; a++) lhs[(size_t)b * k1 + a] += col[a] * f;
+        }
+      }
+      for (int r = 0; r < k1; r++) s.x[r] = rhs_init[r];
+      for (int j = 0; j < n; j++) {
+        const T w = s.conf[j] - xbn[j] * (s.conf[j] - (T)1.0);                      // :226
+        const T* col = &s.Xn[(size_t)j * k1];
+        for (int r = 0; r < k1; r++) s.x[r] += col[r] * w;
+      }
+      if (solver == SEQ_COORDINATE_WISE_NNLS) {
+        std::vector<T> rhs(s.x.begin(), s.x.begin() + k1);
+        std::memcpy(s.x.data(), init.data(), sizeof(T) * k1);
+        c_nnls<T>(lhs, rhs.data(), s.x.data(), k1, SCD_MAX_ITER, SCD_TOL, keep);
+      } else if (!solve_sympd(lhs, s.x.data(), k1, keep)) {
+        bad += 1;
+      }
+      std::memcpy(y + ooff, s.x.data(), sizeof(T) * k1);
+      T l = 0;
+      if (n > 0) {
+        gemv_t(s.Xn.data(), s.x.data(), s.t.data(), k1, n);
+        for (int j = 0; j < n; j++) {
+          const T d = (T)1.0 - s.t[j] - xbn[j];
+          l += d * d * s.conf[j];
+        }
+      }
+      loss += l + lambda * dot(s.x.data(), s.x.data(), k1);
+    }
+  }
+  if (lambda > 0) {
+    const int r0 = is_x_bias_last_row ? 1 : 0, r1 = is_x_bias_last_row ? k : k - 1;
+    double tot = 0;
+    for (int j = 0; j < n_rows; j++) {
+      const T* col = X + (size_t)j * k;
+      T a = 0;
+      for (int r = r0; r < r1; r++) a += col[r] * col[r];
+      tot += (double)a;
+    }
+    loss += lambda * tot;
+  }
+  if (status) *status = bad;
+  return loss / (double)nnz;
+}
+
+// inst/include/wrmf_utils.hpp:86-165 -- initialize_biases_implicit (no global bias here: calculate_global_bias =
+// FALSE is what the R driver passes unless with_global_bias, which the device path does not take for implicit
+// feedback).  csc = users x items by item column, csr = the same by user column.
+template <class T>
+double initialize_biases_implicit(int n_items, const int32_t* csc_p, const int32_t* csc_i, const double* csc_x,
+                                  int n_users, const int32_t* csr_p, const int32_t* csr_i, const double* csr_x,
+                                  T* user_bias, T* item_bias, T lambda, int non_negative) {
+  const double global_bias = 0;
+  std::vector<double> user_means(n_users), item_means(n_items), user_adj(n_users, 0.0), item_adj(n_items, 0.0);
+  for (int r = 0; r < n_users; r++) {                                                  // :101-112
+    const int cnt = csr_p[r + 1] - csr_p[r];
+    if (cnt > 0) {
+      for (int ix = csr_p[r]; ix < csr_p[r + 1]; ix++) user_adj[r] += csr_x[ix];
+      user_means[r] = user_adj[r] / (user_adj[r] + (double)(n_items - cnt));
+      user_adj[r] += (double)(n_items - cnt);
+      user_adj[r] /= user_adj[r] + lambda;
+    } else {
+      user_means[r] = 0;
+      user_adj[r] = (double)n_items / ((double)n_items + lambda);
+    }
+  }
+  for (int c = 0; c < n_items; c++) {                                                  // :113-124
+    const int cnt = csc_p[c + 1] - csc_p[c];
+    if (cnt > 0) {
+      for (int ix = csc_p[c]; ix < csc_p[c + 1]; ix++) item_adj[c] += csc_x[ix];
+      item_means[c] = item_adj[c] / (item_adj[c] + (double)(n_users - cnt));
+      item_adj[c] += (double)(n_users - cnt);
+      item_adj[c] /= item_adj[c] + lambda;
+    } else {
+      item_means[c] = 0;
+      item_adj[c] = (double)n_users / ((double)n_users + lambda);
+    }
+  }
+  for (int iter = 0; iter < 5; iter++) {                                               // :130-162
+    double bias_mean = 0;
+    if (iter > 0)
+      for (int r = 0; r < n_users; r++) bias_mean += (user_bias[r] - bias_mean) / (T)(r + 1);
+    for (int c = 0; c < n_items; c++) {
+      double wsum = n_users, bias_this = bias_mean;
+      for (int ix = csc_p[c]; ix < csc_p[c + 1]; ix++) {
+        wsum += csc_x[ix] - 1;
+        bias_this += ((csc_x[ix] - 1) * (user_bias[csc_i[ix]] - bias_this)) / wsum;
+      }
+      item_bias[c] = (T)((item_means[c] - bias_this - global_bias) * item_adj[c]);
+    }
+    if (non_negative)
+      for (int c = 0; c < n_items; c++) item_bias[c] = std::fmax((T)0, item_bias[c]);
+    bias_mean = 0;
+    for (int c = 0; c < n_items; c++) bias_mean += (item_bias[c] - bias_mean) / (T)(c + 1);
+    for (int r = 0; r < n_users; r++) {
+      double wsum = n_items, bias_this = bias_mean;
+      for (int ix = csr_p[r]; ix < csr_p[r + 1]; ix++) {
+        wsum += csr_x[ix] - 1;
+        bias_this += ((csr_x[ix] - 1) * (item_bias[csr_i[ix]] - bias_this)) / wsum;
+      }
+      user_bias[r] = (T)((user_means[r] - bias_this - global_bias) * user_adj[r]);
+    }
+    if (non_negative)
+      for (int r = 0; r < n_users; r++) user_bias[r] = std::fmax((T)0, user_bias[r]);
+  }
+  return global_bias;
+}
+
 // inst/include/wrmf_utils.hpp:32-84 -- initialize_biases_explicit: optional global mean (running mean, :44-45)
 // removed from the values of BOTH orientations in place, then five alternating sweeps
 //   item_bias[c] = sum_{u in c} (v - user_bias[u]) / (lambda_use + n_c),  user_bias likewise (:56-81).
@@ -590,6 +747,32 @@ double wrmf_oracle_als_implicit_f64(int n_rows, int n_cols, const int32_t* col_p
                                     unsigned cg_steps, int* status) {
   return als_implicit<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda,
                               n_threads, solver, cg_steps, status);
+}
+double wrmf_oracle_als_implicit_bias_f32(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                                         const double* values, const float* X, float* Y, const float* XtX, int k,
+                                         double lambda, int n_threads, unsigned solver, int is_x_bias_last_row,
+                                         int* status) {
+  return als_implicit_biases<float>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads,
+                                    solver, is_x_bias_last_row, status);
+}
+double wrmf_oracle_als_implicit_bias_f64(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                                         const double* values, const double* X, double* Y, const double* XtX, int k,
+                                         double lambda, int n_threads, unsigned solver, int is_x_bias_last_row,
+                                         int* status) {
+  return als_implicit_biases<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads,
+                                     solver, is_x_bias_last_row, status);
+}
+double wrmf_oracle_init_biases_implicit_f32(int n_items, const int32_t* csc_p, const int32_t* csc_i, const double* csc_x,
+                                            int n_users, const int32_t* csr_p, const int32_t* csr_i, const double* csr_x,
+                                            float* user_bias, float* item_bias, double lambda, int non_negative) {
+  return initialize_biases_implicit<float>(n_items, csc_p, csc_i, csc_x, n_users, csr_p, csr_i, csr_x, user_bias,
+                                           item_bias, (float)lambda, non_negative);
+}
+double wrmf_oracle_init_biases_implicit_f64(int n_items, const int32_t* csc_p, const int32_t* csc_i, const double* csc_x,
+                                            int n_users, const int32_t* csr_p, const int32_t* csr_i, const double* csr_x,
+                                            double* user_bias, double* item_bias, double lambda, int non_negative) {
+  return initialize_biases_implicit<double>(n_items, csc_p, csc_i, csc_x, n_users, csr_p, csr_i, csr_x, user_bias,
+                                            item_bias, lambda, non_negative);
 }
 double wrmf_oracle_als_explicit_bias_f32(int n_rows, int n_cols, const int32_t* col_ptrs,
                                          const int32_t* row_indices, const double* values, const float* X, float* Y,

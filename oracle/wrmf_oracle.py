@@ -80,16 +80,30 @@ def _check(a, dtype, name):
 
 
 def als_implicit(col_ptrs, row_indices, values, X, Y, XtX, lam, solver, cg_steps=3, n_threads=1,
-                 native=False):
+                 native=False, with_biases=False, is_x_bias_last_row=False):
     """One implicit half-iteration (als_implicit<T>).  X: (k, n_rows) F-order, Y: (k, n_cols)
-    F-order, modified in place.  dtype float32 or float64 selects T.  Returns loss/nnz."""
+    F-order, modified in place.  dtype float32 or float64 selects T.  Returns loss/nnz.
+    with_biases: the user/item-bias branch (Cholesky / NNLS), XtX is then (k-1) x (k-1)."""
     dt = X.dtype
     for a, n in ((X, "X"), (Y, "Y"), (XtX, "XtX")):
         _check(a, dt, n)
     k, n_rows = X.shape
     n_cols = Y.shape[1]
-    assert Y.shape[0] == k and XtX.shape == (k, k) and len(col_ptrs) == n_cols + 1
     fp = _f32p if dt == np.float32 else _f64p
+    if with_biases:
+        if int(solver) == 1:
+            raise NotImplementedError("CG + biases with implicit feedback cannot run in the reference (wrmf_implicit.hpp:189,197)")
+        assert XtX.shape == (k - 1, k - 1)
+        f = getattr(lib(native), "wrmf_oracle_als_implicit_bias_" + ("f32" if dt == np.float32 else "f64"))
+        f.restype = ctypes.c_double
+        st = ctypes.c_int(0)
+        loss = f(n_rows, n_cols, _ptr(col_ptrs, _i32p), _ptr(row_indices, _i32p), _ptr(values, _f64p), _ptr(X, fp),
+                 _ptr(Y, fp), _ptr(XtX, fp), k, ctypes.c_double(lam), int(n_threads), ctypes.c_uint(solver),
+                 int(bool(is_x_bias_last_row)), ctypes.byref(st))
+        if st.value:
+            raise RuntimeError("oracle: %d singular systems" % st.value)
+        return loss
+    assert Y.shape[0] == k and XtX.shape == (k, k) and len(col_ptrs) == n_cols + 1
     f = getattr(lib(native), "wrmf_oracle_als_implicit_" + ("f32" if dt == np.float32 else "f64"))
     st = ctypes.c_int(0)
     loss = f(n_rows, n_cols, _ptr(col_ptrs, _i32p), _ptr(row_indices, _i32p), _ptr(values, _f64p),
@@ -144,6 +158,18 @@ def init_biases_explicit(csc, csr, user_bias, item_bias, lam, dynamic_lambda=Tru
     return f(len(p1) - 1, _ptr(p1, _i32p), _ptr(i1, _i32p), _ptr(x1, _f64p), len(p2) - 1, _ptr(p2, _i32p),
              _ptr(i2, _i32p), _ptr(x2, _f64p), _ptr(user_bias, fp), _ptr(item_bias, fp), ctypes.c_double(lam),
              int(bool(dynamic_lambda)), int(bool(non_negative)), int(bool(calculate_global_bias)))
+
+
+def init_biases_implicit(csc, csr, user_bias, item_bias, lam, non_negative=False, native=False):
+    """initialize_biases_implicit without global bias (wrmf_utils.hpp:86-165); arguments as init_biases_explicit."""
+    dt = user_bias.dtype
+    fp = _f32p if dt == np.float32 else _f64p
+    f = getattr(lib(native), "wrmf_oracle_init_biases_implicit_" + ("f32" if dt == np.float32 else "f64"))
+    f.restype = ctypes.c_double
+    (p1, i1, x1), (p2, i2, x2) = csc, csr
+    return f(len(p1) - 1, _ptr(p1, _i32p), _ptr(i1, _i32p), _ptr(np.ascontiguousarray(x1, dtype=np.float64), _f64p),
+             len(p2) - 1, _ptr(p2, _i32p), _ptr(i2, _i32p), _ptr(np.ascontiguousarray(x2, dtype=np.float64), _f64p),
+             _ptr(user_bias, fp), _ptr(item_bias, fp), ctypes.c_double(lam), int(bool(non_negative)))
 
 
 def gramian(X, lam, native=False):
@@ -229,8 +255,8 @@ class OracleWRMF:
 
     def __init__(self, rank, lam=0.0, feedback="implicit", solver="conjugate_gradient", cg_steps=3,
                  dynamic_lambda=True, dtype=np.float64, n_threads=1, with_user_item_bias=False, with_global_bias=False):
-        if with_user_item_bias and feedback != "explicit":
-            raise NotImplementedError("oracle: user/item biases are restated for explicit feedback only")
+        if with_global_bias and feedback != "explicit":
+            raise NotImplementedError("oracle: the global bias is restated for explicit feedback only")
         self.with_bias, self.with_global_bias = bool(with_user_item_bias), bool(with_global_bias)
         self.global_bias = 0.0
         rank = int(rank) + (2 if self.with_bias else 0)                            # :160
@@ -246,8 +272,12 @@ class OracleWRMF:
         solver = 0 if (avoid_cg and self.solver_code == 1) else self.solver_code   # :112
         if self.feedback == "implicit":
             if XtX is None:
-                XtX = gramian(X, self.lam)                                          # :474-486
-            return als_implicit(p, i, x, X, Y, XtX, self.lam, solver, self.cg_steps, self.n_threads)
+                XX = X
+                if self.with_bias:                                                  # :468-473
+                    XX = np.asfortranarray(X[:-1, :] if is_bias_last_row else X[1:, :])
+                XtX = gramian(XX, self.lam)                                         # :474-486
+            return als_implicit(p, i, x, X, Y, XtX, self.lam, solver, self.cg_steps, self.n_threads,
+                                with_biases=self.with_bias, is_x_bias_last_row=is_bias_last_row)
         return als_explicit(p, i, x, X, Y, cnt_X, self.lam, solver, self.cg_steps,
                             self.dynamic_lambda, self.n_threads, with_biases=self.with_bias,
                             is_x_bias_last_row=is_bias_last_row)
@@ -274,8 +304,12 @@ class OracleWRMF:
         self.c_iu = (self.c_iu[0], self.c_iu[1], np.array(self.c_iu[2], dtype=np.float64))
         if self.with_bias:                                                          # :259-277
             user_bias, item_bias = np.zeros(n_user, dtype=dt), np.zeros(n_item, dtype=dt)
-            gb = init_biases_explicit((p_ui, i_ui, x_ui), self.c_iu, user_bias, item_bias, self.lam,
-                                      self.dynamic_lambda, self.non_negative, self.with_global_bias)
+            if self.feedback == "explicit":
+                gb = init_biases_explicit((p_ui, i_ui, x_ui), self.c_iu, user_bias, item_bias, self.lam,
+                                          self.dynamic_lambda, self.non_negative, self.with_global_bias)
+            else:
+                gb = init_biases_implicit((p_ui, i_ui, x_ui), self.c_iu, user_bias, item_bias, self.lam,
+                                          self.non_negative)
             comp[0, :] = item_bias
             U[self.rank - 1, :] = user_bias
             if self.with_global_bias:
@@ -297,7 +331,8 @@ class OracleWRMF:
                 break
             loss_prev = lu
         self.components, self.U = comp, U
-        self.XtX = gramian(comp, self.lam) if self.feedback == "implicit" else None   # :347-353
+        XX = comp[1:, :] if self.with_bias else comp                                # :345-347
+        self.XtX = gramian(np.asfortranarray(XX), self.lam) if self.feedback == "implicit" else None   # :347-353
         return self._transform(*self.c_iu)
 
     def _transform(self, p, i, x):                                                # :412-452

@@ -64,20 +64,25 @@ def als_implicit(x, X, Y, lambda_, n_threads, solver_code, cg_steps, precision, 
     rank = X.shape[0]
     if X.shape[1] != n_rows or Y.shape != (rank, n_cols):
         raise ValueError("X must be rank x nrow(x) and Y rank x ncol(x)")
-    if with_user_item_bias or global_bias:
+    bias = bool(with_user_item_bias)
+    if global_bias or (bias and int(solver_code) == 1):
         # the C ABI reports these as UNSUPPORTED; raise before touching the device
         _lib.check(lib.rsparse_hip_als_implicit_float(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), None,
                                                       rank, float(lambda_), int(n_threads), int(solver_code),
-                                                      int(cg_steps), int(bool(with_user_item_bias)),
+                                                      int(cg_steps), int(bias),
                                                       int(bool(is_bias_last_row)), float(global_bias), None,
                                                       int(bool(initialize_bias_base)), None))
     if XtX is None:
-        XtX = gramian(X, lambda_, precision)
+        # R/model_WRMF.R:474-486: with biases the x_bias row is discarded before tcrossprod
+        XX = X
+        if bias:
+            XX = np.asfortranarray(X[:-1, :] if is_bias_last_row else X[1:, :])
+        XtX = gramian(XX, lambda_, precision)
     _f_contig(XtX, dt, "XtX")
     loss = ctypes.c_double(0.0)
     fn = lib.rsparse_hip_als_implicit_float if precision == "float" else lib.rsparse_hip_als_implicit_double
     _lib.check(fn(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), _vp(XtX), rank, float(lambda_),
-                  int(n_threads), int(solver_code), int(cg_steps), 0, int(bool(is_bias_last_row)), 0.0,
+                  int(n_threads), int(solver_code), int(cg_steps), int(bias), int(bool(is_bias_last_row)), 0.0,
                   None, int(bool(initialize_bias_base)), ctypes.addressof(loss)))
     return loss.value
 

@@ -67,7 +67,121 @@ __global__ __launch_bounds__(256) void values_add_kernel(float* __restrict__ x, 
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) x[e] -= shift;
 }
 
+// implicit feedback with biases (inst/include/wrmf_implicit.hpp:226,256-270): per non-zero, the coefficient of x_j in
+// the right-hand side, c - x_b (c - 1), and the target of the loss term, 1 - x_b
+__global__ __launch_bounds__(256) void bias_implicit_terms_kernel(const float* __restrict__ vals,
+                                                                  const int32_t* __restrict__ row_idx,
+                                                                  const float* __restrict__ X, int k, int bias_row,
+                                                                  int64_t nnz, float* __restrict__ rhs_vals,
+                                                                  float* __restrict__ loss_tgt) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
+    const float c = vals[e], xb = X[(size_t)row_idx[e] * k + bias_row];
+    rhs_vals[e] = c - xb * (c - 1.f);
+    loss_tgt[e] = 1.f - xb;
+  }
+}
+
+// rhs_init = -drop_row(X) * x_biases (wrmf_implicit.hpp:142-147): partial[b][t] = -sum over the block's entities of
+// X[e][off + t] * X[e][bias_row]; fixed-order second stage -> deterministic
+constexpr int kRhsInitBlocks = 256;
+__global__ __launch_bounds__(128) void bias_rhs_init_partial_kernel(const float* __restrict__ X, int k, int off, int k1,
+                                                                    int bias_row, int n, float* __restrict__ partial) {
+  const int t = threadIdx.x;
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  const int e0 = blockIdx.x * per, e1 = min(n, e0 + per);
+  float s = 0.f;
+  if (t < k1)
+    for (int e = e0; e < e1; e++) s = fmaf(-X[(size_t)e * k + off + t], X[(size_t)e * k + bias_row], s);
+  partial[(size_t)blockIdx.x * 128 + t] = s;
+}
+__global__ __launch_bounds__(128) void bias_rhs_init_reduce_kernel(const float* __restrict__ partial, int blocks,
+                                                                   float* __restrict__ out) {
+  const int t = threadIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < blocks; b++) s += partial[(size_t)b * 128 + t];
+  out[t] = s;
+}
+
+// initialize_biases_implicit (inst/include/wrmf_utils.hpp:86-165), one thread per column (the weighted running mean
+// over a column's entries is a serial recurrence).  Stage "prep": means[c], adj[c] (:101-124).
+__global__ __launch_bounds__(256) void bias_implicit_prep_kernel(const int32_t* __restrict__ p, const float* __restrict__ x,
+                                                                 int n_cols, int n_other, double lambda,
+                                                                 double* __restrict__ means, double* __restrict__ adj) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  const int p1 = p[c], p2 = p[c + 1];
+  if (p2 > p1) {
+    double a = 0.0;
+    for (int e = p1; e < p2; e++) a += (double)x[e];
+    const double rest = (double)(n_other - (p2 - p1));
+    means[c] = a / (a + rest);
+    a += rest;
+    adj[c] = a / (a + lambda);
+  } else {
+    means[c] = 0.0;
+    adj[c] = (double)n_other / ((double)n_other + lambda);
+  }
+}
+// one sweep (:136-143 / :152-159): bias[c] = (means[c] - running weighted mean of the other side's biases) * adj[c]
+__global__ __launch_bounds__(256) void bias_implicit_sweep_kernel(const int32_t* __restrict__ p, const int32_t* __restrict__ i,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ other, int n_cols, int n_other,
+                                                                  const double* __restrict__ other_sum,
+                                                                  const double* __restrict__ means,
+                                                                  const double* __restrict__ adj, int non_negative,
+                                                                  float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  double wsum = (double)n_other;
+  double bias_this = other_sum ? other_sum[0] / (double)n_other : 0.0;   // bias_mean (:131-135,148-150)
+  for (int e = p[c]; e < p[c + 1]; e++) {
+    const double w = (double)x[e] - 1.0;
+    wsum += w;
+    bias_this += (w * ((double)other[i[e]] - bias_this)) / wsum;
+  }
+  float b = (float)((means[c] - bias_this) * adj[c]);
+  if (non_negative) b = fmaxf(0.f, b);
+  out[c] = b;
+}
+
 }  // namespace
+
+hipError_t launch_bias_implicit_terms(const float* vals, const int32_t* row_idx, const float* X, int k, int bias_row,
+                                      int64_t nnz, float* rhs_vals, float* loss_tgt, hipStream_t s) {
+  if (nnz <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bias_implicit_terms_kernel, dim3(2048), dim3(256), 0, s, vals, row_idx, X, k, bias_row, nnz,
+                     rhs_vals, loss_tgt);
+  return hipGetLastError();
+}
+
+// out[0..128): rhs_init (entries >= k1 are zero); scratch: kRhsInitBlocks * 128 floats
+hipError_t launch_bias_rhs_init(const float* X, int k, int off, int k1, int bias_row, int n, float* scratch, float* out,
+                                hipStream_t s) {
+  hipLaunchKernelGGL(bias_rhs_init_partial_kernel, dim3(kRhsInitBlocks), dim3(128), 0, s, X, k, off, k1, bias_row, n,
+                     scratch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bias_rhs_init_reduce_kernel, dim3(1), dim3(128), 0, s, scratch, kRhsInitBlocks, out);
+  return hipGetLastError();
+}
+size_t bias_rhs_init_scratch_floats() { return (size_t)kRhsInitBlocks * 128 + 128; }
+
+hipError_t launch_bias_implicit_prep(const int32_t* p, const float* x, int n_cols, int n_other, double lambda,
+                                     double* means, double* adj, hipStream_t s) {
+  if (n_cols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bias_implicit_prep_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, p, x, n_cols, n_other,
+                     lambda, means, adj);
+  return hipGetLastError();
+}
+hipError_t launch_bias_implicit_sweep(const int32_t* p, const int32_t* i, const float* x, const float* other, int n_cols,
+                                      int n_other, const double* other_sum, const double* means, const double* adj,
+                                      int non_negative, float* out, hipStream_t s) {
+  if (n_cols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bias_implicit_sweep_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, p, i, x, other, n_cols,
+                     n_other, other_sum, means, adj, non_negative, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_bias_shift_values(const float* vals, const int32_t* row_idx, const float* X, int k, int bias_row,
                                     int64_t nnz, float* out, hipStream_t s) {

@@ -259,17 +259,24 @@ int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_i
 
 int check_variant(unsigned solver, int with_biases, double global_bias, bool implicit = true) {
   if (solver > RSPARSE_SOLVER_NNLS) return fail(RSPARSE_HIP_ERR_INVALID, "unknown solver code");
-  if (with_biases && implicit)
-    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "with_user_item_bias with implicit feedback is not on the device path");
+  if (with_biases && implicit && solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT)
+    // the reference drops a row of the warm start twice on this path (wrmf_implicit.hpp:189,197) and cannot run it
+    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "with_user_item_bias + conjugate_gradient with implicit feedback is not on the device path");
   // wrmf_implicit.hpp:108-109: global_bias below sqrt(eps) is treated as zero
   if (global_bias >= std::sqrt((double)FLT_EPSILON))
     return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "global_bias is not on the device path");
   return RSPARSE_HIP_OK;
 }
 
+struct BiasTerms {   // implicit feedback with user/item biases, see AlsArgs
+  const float* rhs_vals;
+  const float* loss_tgt;
+  const float* rhs_init;
+};
+
 int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* d_X, float* d_Y,
                        const float* d_XtX, int rank, double lambda, unsigned solver, unsigned cg_steps,
-                       int dynamic_lambda, double* d_loss_rows_out, hipStream_t s) {
+                       int dynamic_lambda, double* d_loss_rows_out, hipStream_t s, const BiasTerms* bias = nullptr) {
   if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
   if (!d_X || !d_Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
   if (implicit && !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "XtX is NULL");
@@ -299,6 +306,9 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails; a.zero_row = g_ws.zero_row;
+  a.rhs_vals = bias ? bias->rhs_vals : nullptr;
+  a.loss_tgt = bias ? bias->loss_tgt : nullptr;
+  a.rhs_init = bias ? bias->rhs_init : nullptr;
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
   {
     static const char* ts_env = std::getenv("RSPARSE_HIP_TSCRATCH");
@@ -376,6 +386,50 @@ int run_half_iteration_explicit_biased(const rsparse_hip_csc* conf, const float*
   return RSPARSE_HIP_OK;
 }
 
+// als_implicit<T> with_biases, Cholesky / NNLS (inst/include/wrmf_implicit.hpp:114-154,186-252,256-270) by re-packing
+// plus three extra operands of the solve kernels (AlsArgs::rhs_vals / loss_tgt / rhs_init).  d_XtX is the
+// (rank-1) x (rank-1) Gramian of X without its x_bias row, ridge included (R/model_WRMF.R:474-486).
+int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, const float* d_XtX,
+                                       int rank, double lambda, unsigned solver, int is_x_bias_last_row,
+                                       double* d_loss_rows_out, hipStream_t s) {
+  if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
+  if (!d_X || !d_Y || !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "X, Y or XtX is NULL");
+  if (rank < 2) return fail(RSPARSE_HIP_ERR_INVALID, "with_biases needs rank >= 2 (a row of ones and a bias row)");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  int rc = g_ws.ensure_device();
+  if (rc) return rc;
+  const DevCSC& d = conf->d;
+  const int k1 = rank - 1;
+  const int xoff = is_x_bias_last_row ? 0 : 1, xb = is_x_bias_last_row ? rank - 1 : 0;
+  const int ioff = is_x_bias_last_row ? 1 : 0, ooff = is_x_bias_last_row ? 0 : 1;
+  const size_t nx = (size_t)d.n_rows * k1, ny = (size_t)d.n_cols * k1, nv = (size_t)std::max<int64_t>(d.nnz, 1);
+  const size_t nscr = bias_rhs_init_scratch_floats();
+  if ((rc = g_ws.ensure_bias(nx + ny + 2 * nv + nscr + 16))) return rc;
+  float* Xp = g_ws.bias_buf;
+  float* Yp = Xp + nx;
+  float* rcoef = Yp + ny;
+  float* tgt = rcoef + nv;
+  float* scratch = tgt + nv;
+  float* rinit = scratch + (nscr - 128);
+  if (d.n_rows > 0)
+    HIP_TRY(hipMemcpy2DAsync(Xp, (size_t)k1 * 4, d_X + xoff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_rows,
+                             hipMemcpyDeviceToDevice, s));
+  if (d.n_cols > 0)
+    HIP_TRY(hipMemcpy2DAsync(Yp, (size_t)k1 * 4, d_Y + ioff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_cols,
+                             hipMemcpyDeviceToDevice, s));
+  hipError_t e = launch_bias_implicit_terms(d.vals, d.row_idx, d_X, rank, xb, d.nnz, rcoef, tgt, s);
+  if (e != hipSuccess) return hip_fail(e, "launch_bias_implicit_terms");
+  if ((e = launch_bias_rhs_init(d_X, rank, xoff, k1, xb, d.n_rows, scratch, rinit, s)) != hipSuccess)
+    return hip_fail(e, "launch_bias_rhs_init");
+  BiasTerms bt{rcoef, tgt, rinit};
+  rc = run_half_iteration(conf, true, Xp, Yp, d_XtX, k1, lambda, solver, 0, 0, d_loss_rows_out, s, &bt);
+  if (rc) return rc;
+  if (d.n_cols > 0)
+    HIP_TRY(hipMemcpy2DAsync(d_Y + ooff, (size_t)rank * 4, Yp, (size_t)k1 * 4, (size_t)k1 * 4, (size_t)d.n_cols,
+                             hipMemcpyDeviceToDevice, s));
+  return RSPARSE_HIP_OK;
+}
+
 // Shared body of the four stateless drop-ins.  TX = float or double (host element type).
 template <class TX>
 int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
@@ -386,7 +440,8 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
   int rc = rsparse_hip_csc_create_host(n_rows, n_cols, col_ptrs, row_indices, values, &conf);
   if (rc) return rc;
   struct Guard { rsparse_hip_csc* c; ~Guard() { rsparse_hip_csc_destroy(c); } } guard{conf};
-  const size_t nx = (size_t)rank * n_rows, ny = (size_t)rank * n_cols, ng = (size_t)rank * rank;
+  const size_t nx = (size_t)rank * n_rows, ny = (size_t)rank * n_cols;
+  const size_t ng = implicit && with_biases ? (size_t)(rank - 1) * (rank - 1) : (size_t)rank * rank;
   DevBuf dX, dY, dG, dW;
   HIP_TRY(dX.alloc(nx * 4));
   HIP_TRY(dY.alloc(ny * 4));
@@ -411,7 +466,10 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
     HIP_TRY(upload(dW, cnt_X, (size_t)n_rows));
   }
   if ((rc = g_ws.ensure_device())) return rc;
-  if (with_biases)
+  if (with_biases && implicit)
+    rc = run_half_iteration_implicit_biased(conf, dX.as<float>(), dY.as<float>(), dG.as<float>(), rank, lambda, solver,
+                                            is_x_bias_last_row, g_ws.scalars, nullptr);
+  else if (with_biases)
     rc = run_half_iteration_explicit_biased(conf, dX.as<float>(), dY.as<float>(), rank, lambda, solver, cg_steps,
                                             dynamic_lambda, is_x_bias_last_row, g_ws.scalars, nullptr);
   else
@@ -672,6 +730,58 @@ int rsparse_hip_als_explicit_device(const rsparse_hip_csc* conf, const float* d_
                             d_loss_rows_out, (hipStream_t)stream);
 }
 
+int rsparse_hip_als_implicit_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, const float* d_XtX,
+                                         int rank, double lambda, unsigned solver, int is_x_bias_last_row,
+                                         double* d_loss_rows_out, void* stream) {
+  int rc = check_variant(solver, 1, 0.0, true);
+  if (rc) return rc;
+  return run_half_iteration_implicit_biased(conf, d_X, d_Y, d_XtX, rank, lambda, solver, is_x_bias_last_row,
+                                            d_loss_rows_out, (hipStream_t)stream);
+}
+
+int rsparse_hip_initialize_biases_implicit_device(const rsparse_hip_csc* c_ui, const rsparse_hip_csc* c_iu,
+                                                  float* d_user_bias, float* d_item_bias, double lambda,
+                                                  int non_negative, void* stream) {
+  if (!c_ui || !c_iu || !d_user_bias || !d_item_bias) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or bias vector");
+  const DevCSC& a = c_ui->d;   // users x items, columns = items
+  const DevCSC& b = c_iu->d;   // items x users, columns = users
+  if (a.n_rows != b.n_cols || a.n_cols != b.n_rows || a.nnz != b.nnz)
+    return fail(RSPARSE_HIP_ERR_INVALID, "the two matrices are not transposes of each other");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = g_ws.ensure_device();
+  if (rc) return rc;
+  if ((rc = g_ws.ensure_partials(1024))) return rc;
+  const int n_items = a.n_cols, n_users = b.n_cols;
+  DevBuf stats;   // means / adjustments of both sides (wrmf_utils.hpp:97-124), doubles
+  HIP_TRY(stats.alloc(((size_t)2 * n_items + (size_t)2 * n_users + 4) * sizeof(double)));
+  double* item_means = stats.as<double>();
+  double* item_adj = item_means + n_items;
+  double* user_means = item_adj + n_items;
+  double* user_adj = user_means + n_users;
+  hipError_t e;
+  if ((e = launch_bias_implicit_prep(a.col_ptrs, a.vals, n_items, n_users, lambda, item_means, item_adj, s)) != hipSuccess ||
+      (e = launch_bias_implicit_prep(b.col_ptrs, b.vals, n_users, n_items, lambda, user_means, user_adj, s)) != hipSuccess)
+    return hip_fail(e, "launch_bias_implicit_prep");
+  for (int iter = 0; iter < 5; iter++) {   // :130-162
+    const double* usum = nullptr;
+    if (iter > 0) {                        // mean of the user biases of the previous sweep (:131-135)
+      if ((e = launch_values_sum(d_user_bias, n_users, g_ws.partials, g_ws.scalars + 2, s)) != hipSuccess)
+        return hip_fail(e, "launch_values_sum");
+      usum = g_ws.scalars + 2;
+    }
+    if ((e = launch_bias_implicit_sweep(a.col_ptrs, a.row_idx, a.vals, d_user_bias, n_items, n_users, usum, item_means,
+                                        item_adj, non_negative, d_item_bias, s)) != hipSuccess)
+      return hip_fail(e, "launch_bias_implicit_sweep");
+    if ((e = launch_values_sum(d_item_bias, n_items, g_ws.partials, g_ws.scalars + 3, s)) != hipSuccess)
+      return hip_fail(e, "launch_values_sum");
+    if ((e = launch_bias_implicit_sweep(b.col_ptrs, b.row_idx, b.vals, d_item_bias, n_users, n_items, g_ws.scalars + 3,
+                                        user_means, user_adj, non_negative, d_user_bias, s)) != hipSuccess)
+      return hip_fail(e, "launch_bias_implicit_sweep");
+  }
+  HIP_TRY(hipStreamSynchronize(s));   // `stats` is released on return
+  return RSPARSE_HIP_OK;
+}
+
 int rsparse_hip_als_explicit_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, int rank,
                                          double lambda, unsigned solver, unsigned cg_steps, int dynamic_lambda,
                                          int is_x_bias_last_row, double* d_loss_rows_out, void* stream) {
@@ -842,12 +952,12 @@ int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_pt
                                    double lambda, int n_threads, unsigned solver, unsigned cg_steps,
                                    int with_biases, int is_x_bias_last_row, double global_bias,
                                    float* global_bias_base, int initialize_bias_base, double* loss_out) {
-  (void)n_threads; (void)is_x_bias_last_row; (void)global_bias_base; (void)initialize_bias_base;
+  (void)n_threads; (void)global_bias_base; (void)initialize_bias_base;
   int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
   if (rc) return rc;
   if ((rc = check_variant(solver, with_biases, global_bias))) return rc;
   return stateless<float>(true, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, nullptr, rank, lambda,
-                          solver, cg_steps, 0, loss_out);
+                          solver, cg_steps, 0, loss_out, with_biases, is_x_bias_last_row);
 }
 
 int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
@@ -855,12 +965,12 @@ int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_p
                                     double lambda, int n_threads, unsigned solver, unsigned cg_steps,
                                     int with_biases, int is_x_bias_last_row, double global_bias,
                                     double* global_bias_base, int initialize_bias_base, double* loss_out) {
-  (void)n_threads; (void)is_x_bias_last_row; (void)global_bias_base; (void)initialize_bias_base;
+  (void)n_threads; (void)global_bias_base; (void)initialize_bias_base;
   int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
   if (rc) return rc;
   if ((rc = check_variant(solver, with_biases, global_bias))) return rc;
   return stateless<double>(true, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, nullptr, rank, lambda,
-                           solver, cg_steps, 0, loss_out);
+                           solver, cg_steps, 0, loss_out, with_biases, is_x_bias_last_row);
 }
 
 int rsparse_hip_als_explicit_float(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,

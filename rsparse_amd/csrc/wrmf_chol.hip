@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     const int cnt = p2 - p1;
     float* yrow = a.Y + (size_t)row * k;
-    if (cnt <= 0) {
+    if (cnt <= 0 && !a.rhs_init) {
       for (int e = tid; e < k; e += 256) yrow[e] = 0.f;
       continue;
     }
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a
       __syncthreads();  // previous chunk (and the previous row's vectors) fully consumed
       if (tid < ccnt) {
         const float cvv = a.vals[base + tid];
-        sC[tid] = cvv;
+        sC[tid] = a.rhs_vals ? a.rhs_vals[base + tid] : cvv;   // coefficient in the right-hand side
         sC1[tid] = IMPLICIT ? cvv - 1.f : 1.f;
       }
       chol_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a
       }
     }
     __syncthreads();
-    if (tid < KP) sV[tid] = rhs;
+    if (tid < KP) sV[tid] = rhs + ((a.rhs_init && tid < k) ? a.rhs_init[tid] : 0.f);
     if (tid < KP) sS[tid] = 0.f;
 
     // ---------------- blocked Cholesky, lower triangle ----------------
@@ -313,14 +313,17 @@ __global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a
       for (int base = p1; base < p2; base += TC) {
         const int ccnt = min(TC, p2 - base);
         __syncthreads();  // tile free (and y published in sV on the first pass)
-        if (tid < ccnt) sC[tid] = a.vals[base + tid];
+        if (tid < ccnt) {
+          sC[tid] = a.vals[base + tid];
+          sC1[tid] = a.loss_tgt ? a.loss_tgt[base + tid] : 1.f;
+        }
         chol_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
         __syncthreads();
         if (wv == 0) {
           const float t = tile_dot<KP, TC>(sT, sV, lane);
           const int jl = lane % TC;
           const float cvv = sC[jl < ccnt ? jl : 0];
-          const float d = IMPLICIT ? 1.f - t : cvv - t;
+          const float d = IMPLICIT ? sC1[jl < ccnt ? jl : 0] - t : cvv - t;
           lacc += (jl < ccnt && lane < TC) ? (IMPLICIT ? cvv * d * d : d * d) : 0.f;
         }
       }

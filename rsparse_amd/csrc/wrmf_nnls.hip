@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     const int cnt = p2 - p1;
     float* yrow = a.Y + (size_t)row * k;
-    if (cnt <= 0) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
+    if (cnt <= 0 && !a.rhs_init) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
       for (int e = tid; e < k; e += 256) yrow[e] = 0.f;
       continue;
     }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
       __syncthreads();
       if (tid < ccnt) {
         const float cvv = a.vals[base + tid];
-        sC[tid] = cvv;
+        sC[tid] = a.rhs_vals ? a.rhs_vals[base + tid] : cvv;   // coefficient in the right-hand side
         sC1[tid] = IMPLICIT ? cvv - 1.f : 1.f;
       }
       nnls_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
         }
     }
     if (tid < KP) {
-      sR[tid] = rhs;
+      sR[tid] = rhs + ((a.rhs_init && tid < k) ? a.rhs_init[tid] : 0.f);
       sH[tid] = tid < k ? yrow[tid] : 0.f;  // init = current Y.col(i)  (wrmf_implicit.hpp:185)
     }
     __syncthreads();
@@ -251,14 +251,17 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
       for (int base = p1; base < p2; base += TC) {
         const int ccnt = min(TC, p2 - base);
         __syncthreads();
-        if (tid < ccnt) sC[tid] = a.vals[base + tid];
+        if (tid < ccnt) {
+          sC[tid] = a.vals[base + tid];
+          sC1[tid] = a.loss_tgt ? a.loss_tgt[base + tid] : 1.f;
+        }
         nnls_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
         __syncthreads();
         if (wv == 0) {
           const float t = tile_dot<KP, TC>(sT, sH, lane);
           const int jl = lane % TC;
           const float cvv = sC[jl < ccnt ? jl : 0];
-          const float d = IMPLICIT ? 1.f - t : cvv - t;
+          const float d = IMPLICIT ? sC1[jl < ccnt ? jl : 0] - t : cvv - t;
           lacc += (jl < ccnt && lane < TC) ? (IMPLICIT ? cvv * d * d : d * d) : 0.f;
         }
       }

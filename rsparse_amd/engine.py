@@ -106,9 +106,13 @@ class HipBackend:
         """bias_last_row: None = no user/item biases; True/False = als_explicit's is_x_bias_last_row with
         with_biases = TRUE (explicit feedback only)."""
         k = F.shape[1]
-        if bias_last_row is not None:
-            if implicit:
-                raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "user/item biases with implicit feedback")
+        if bias_last_row is not None and implicit:
+            # G: (k-1) x (k-1) Gramian of F without its bias row, ridge included (R/model_WRMF.R:463-486)
+            _lib.check(self.lib.rsparse_hip_als_implicit_bias_device(csc.h, F.data_ptr(), S_block.data_ptr(), G.data_ptr(),
+                                                                     k, float(lambda_), int(solver),
+                                                                     int(bool(bias_last_row)), loss_out.data_ptr(),
+                                                                     self._stream()))
+        elif bias_last_row is not None:
             _lib.check(self.lib.rsparse_hip_als_explicit_bias_device(csc.h, F.data_ptr(), S_block.data_ptr(), k,
                                                                      float(lambda_), int(solver), int(cg_steps),
                                                                      int(bool(dynamic_lambda)), int(bool(bias_last_row)),
@@ -132,6 +136,12 @@ class HipBackend:
             csc_ui.h, csc_iu.h, user_bias.data_ptr(), item_bias.data_ptr(), float(lambda_), int(bool(dynamic_lambda)),
             int(bool(non_negative)), int(bool(calculate_global_bias)), ctypes.byref(gb), self._stream()))
         return gb.value
+
+    def initialize_biases_implicit(self, csc_ui, csc_iu, user_bias, item_bias, lambda_, non_negative):
+        """wrmf_utils.hpp:86-165 (no global bias) on the device."""
+        _lib.check(self.lib.rsparse_hip_initialize_biases_implicit_device(
+            csc_ui.h, csc_iu.h, user_bias.data_ptr(), item_bias.data_ptr(), float(lambda_), int(bool(non_negative)),
+            self._stream()))
 
     def subtract_mean(self, x, x_other=None):
         """global_bias = mean(x), removed in place from x (and from the other orientation's values) -- R/model_WRMF.R:278-282"""
@@ -284,6 +294,21 @@ class ShardedALS:
             self.G.diagonal().add_(float(np.float32(self.lambda_)))   # fl(diag(lambda)), R/model_WRMF.R:476
         return self.G
 
+    def gramian_bias(self, F, n, bounds, bias_last_row):
+        """(k-1) x (k-1) Gramian of F without its bias row + fl(lambda) I (R/model_WRMF.R:463-486, 345-351)."""
+        k1 = self.k - 1
+        if getattr(self, "Gb", None) is None:
+            self.Gb = torch.zeros((k1, k1), dtype=torch.float32, device=F.device)
+        r0, r1 = bounds[self.me] if self.ws > 1 else (0, n)
+        blk = (F[r0:r1, :k1] if bias_last_row else F[r0:r1, 1:]).contiguous()
+        if self.ws == 1:
+            self.be.gramian(blk, self.lambda_, self.Gb, None)
+        else:
+            self.be.gramian(blk, 0.0, self.Gb, None)
+            self._all_reduce(self.Gb)
+            self.Gb.diagonal().add_(float(np.float32(self.lambda_)))
+        return self.Gb
+
     def half_iteration(self, side, U, V, solver, G=None, want_loss=True):
         """side 'items': solve V (item factors) given U; side 'users': solve U given V.
         Returns loss/nnz as the reference reports it (python float) or None."""
@@ -291,13 +316,13 @@ class ShardedALS:
             F, nF, BF, bF, S, BS, bS, csc, cnt_F = U, self.n_user, self.Bu, self.ub, V, self.Bi, self.ib, self.csc_items, self.cnt_user
         else:
             F, nF, BF, bF, S, BS, bS, csc, cnt_F = V, self.n_item, self.Bi, self.ib, U, self.Bu, self.ub, self.csc_users, self.cnt_item
-        if self.implicit and G is None:
-            G = self.gramian(F, nF, BF, bF)
-        s0, s1 = bS[self.me]
-        S_block = S[s0:s1]
         # user/item biases: solving the items means X = U = [1, ..., user_bias] (is_bias_last_row = TRUE), solving the
         # users X = components = [item_bias, ..., 1] (FALSE)  -- R/model_WRMF.R:321-329
         blr = (side == "items") if self.with_bias else None
+        if self.implicit and G is None:
+            G = self.gramian_bias(F, nF, bF, blr) if self.with_bias else self.gramian(F, nF, BF, bF)
+        s0, s1 = bS[self.me]
+        S_block = S[s0:s1]
         if side == "users" and self.ws > 1 and self.n_sub > 1:
             # pipelined: solve sub-block j, start its all-gather, solve sub-block j+1 meanwhile
             works = []

@@ -9,7 +9,8 @@ Differences forced by the host language, nothing else:
   * `lambda` is a Python keyword -> `lambda_`;
   * `x` is a scipy.sparse matrix (users x items) instead of a Matrix::sparseMatrix;
   * R's global RNG (large_rand_matrix / flrnorm, src/utils.cpp:131-143) -> `rng` (seed or Generator);
-  * user/item bias and global bias are on the device path for explicit feedback only; with implicit feedback the
+  * not on the device path: the implicit-feedback global bias, and user/item biases with implicit feedback and the
+    conjugate-gradient solver (a combination the reference itself cannot run, wrmf_implicit.hpp:189,197) -- the
     C ABI answers RSPARSE_HIP_ERR_UNSUPPORTED and this class raises `UnsupportedOnDevice` (an R shim would keep
     the package's CPU code for them).
 """
@@ -48,9 +49,12 @@ class WRMF:
         if not callable(preprocess):
             raise TypeError("preprocess must be a function")                      # :165
         self._non_negative = solver == "nnls"
-        if (with_user_item_bias or with_global_bias) and feedback != "explicit":
+        if with_global_bias and feedback != "explicit":
             raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED,
-                                           "user/item and global biases with implicit feedback are not on the device path")
+                                           "the global bias with implicit feedback is not on the device path")
+        if with_user_item_bias and feedback != "explicit" and solver == "conjugate_gradient":
+            raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "user/item biases + conjugate_gradient with implicit "
+                                           "feedback: the reference cannot run this combination either")
         if self._non_negative and with_global_bias:
             with_global_bias = False                                              # :90-93 (the reference warns)
         self._with_bias, self._with_global_bias = bool(with_user_item_bias), bool(with_global_bias)
@@ -135,8 +139,13 @@ class WRMF:
         if self._with_bias:                                                        # :259-277
             user_bias = torch.zeros(n_user, dtype=torch.float32, device=U.device)
             item_bias = torch.zeros(n_item, dtype=torch.float32, device=U.device)
-            gb = be.initialize_biases_explicit(als.csc_items, als.csc_users, user_bias, item_bias, self._lambda,
-                                               self._dynamic_lambda, self._non_negative, self._with_global_bias)
+            if self._feedback == "explicit":
+                gb = be.initialize_biases_explicit(als.csc_items, als.csc_users, user_bias, item_bias, self._lambda,
+                                                   self._dynamic_lambda, self._non_negative, self._with_global_bias)
+            else:
+                be.initialize_biases_implicit(als.csc_items, als.csc_users, user_bias, item_bias, self._lambda,
+                                              self._non_negative)
+                gb = 0.0
             V[:, 0] = item_bias
             U[:, k - 1] = user_bias
             if self._with_global_bias:
@@ -154,8 +163,11 @@ class WRMF:
             loss_prev = lu
         be.check_numeric()
         self._V, self._cnt_item = V, als.cnt_item
-        if self._feedback == "implicit":
-            self._XtX = als.gramian(V, n_item, als.Bi, als.ib).clone()             # :347-353
+        if self._feedback == "implicit":                                           # :345-353
+            if self._with_bias:
+                self._XtX = als.gramian_bias(V, n_item, als.ib, False).clone()     # components[-1, ]: item-bias row out
+            else:
+                self._XtX = als.gramian(V, n_item, als.Bi, als.ib).clone()
         self.components = np.asfortranarray(V.cpu().numpy().T.astype(self._np_dtype()))   # rank x n_item
         # the returned embeddings come from one more exact solve, not from U (:355-359)
         return self._transform(als.csc_users, n_user)

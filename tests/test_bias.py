@@ -97,6 +97,41 @@ def test_oracle_wrmf_explicit_with_biases(ml_train, solver):
     assert rel_fro(mod.transform(*raw_iu), emb) < 1e-12                             # fit_transform == transform (:57)
 
 
+@pytest.mark.parametrize("bias_last", [True, False])
+def test_oracle_implicit_bias_cholesky_matches_dense_solve(bias_last):
+    """wrmf_implicit.hpp:142-147,207-208,226,256-270: lhs = XtX' + X' diag(c-1) X'^T, rhs = rhs_init + X' (c - x_b (c-1)),
+    every column solved (empty ones too), loss on (1 - y.x' - x_b)."""
+    m, X, Y0 = _problem(33)
+    m.data[:] = np.abs(m.data) + 1.0
+    k, lam = X.shape[0], 0.2
+    if bias_last:
+        X[0, :] = 1.0; Y0[k - 1, :] = 1.0
+    else:
+        X[k - 1, :] = 1.0; Y0[0, :] = 1.0
+    keep = slice(0, k - 1) if bias_last else slice(1, k)
+    xb = k - 1 if bias_last else 0
+    fixed = k - 1 if bias_last else 0
+    Xp = X[keep]
+    G = O.gramian(np.asfortranarray(Xp), lam)
+    p, i, x = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    Y = Y0.copy(order="F")
+    loss = O.als_implicit(p, i, x, X, Y, G, lam, 0, 3, with_biases=True, is_x_bias_last_row=bias_last)
+    rhs_init = -Xp @ X[xb]
+    tot = 0.0
+    for c in range(m.shape[1]):
+        idx, val = i[p[c]:p[c + 1]], x[p[c]:p[c + 1]]
+        Xn, b = Xp[:, idx], X[xb, idx]
+        ref = np.linalg.solve(G + (Xn * (val - 1.0)) @ Xn.T, rhs_init + Xn @ (val - b * (val - 1.0)))
+        assert np.allclose(Y[keep, c], ref, rtol=1e-8, atol=1e-10), c
+        assert Y[fixed, c] == Y0[fixed, c]
+        tot += np.sum(val * (1.0 - ref @ Xn - b) ** 2) + lam * ref @ ref
+    ones_row = 0 if bias_last else k - 1
+    tot += lam * np.sum(np.delete(X, ones_row, axis=0) ** 2)
+    assert np.isclose(loss, tot / m.nnz, rtol=1e-10)
+    with pytest.raises(NotImplementedError):                 # CG + biases cannot run in the reference
+        O.als_implicit(p, i, x, X, Y, G, lam, 1, 3, with_biases=True, is_x_bias_last_row=bias_last)
+
+
 # --------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("solver", [0, 1, 2])
@@ -162,3 +197,68 @@ def test_hip_wrmf_explicit_global_bias(movielens, ml_train, with_bias):
     dense = cv_emb.astype(np.float64) @ m.components.astype(np.float64) + m.global_bias
     for r in range(0, cv.shape[0], 7):
         assert np.allclose(preds.scores[r], dense[r, preds[r]], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [0, 2])
+@pytest.mark.parametrize("bias_last", [True, False])
+@pytest.mark.parametrize("k", [6, 9, 34, 128])
+def test_hip_implicit_bias_half_iteration(solver, bias_last, k):
+    from rsparse_amd import als
+    m, X, Y0 = _problem(200 + k, n_rows=300, n_cols=200, k=k, density=0.08)
+    m.data[:] = np.abs(m.data) + 1.0
+    if solver == 2:
+        X, Y0 = np.abs(X), np.abs(Y0)
+    if bias_last:
+        X[0, :] = 1.0; Y0[k - 1, :] = 1.0
+    else:
+        X[k - 1, :] = 1.0; Y0[0, :] = 1.0
+    X32, Y32 = np.asfortranarray(X, dtype=np.float32), np.asfortranarray(Y0, dtype=np.float32)
+    p, i, x = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    X64, Y64 = np.asfortranarray(X32, dtype=np.float64), np.asfortranarray(Y32, dtype=np.float64).copy(order="F")
+    XX = np.asfortranarray(X64[:-1] if bias_last else X64[1:])
+    lref = O.als_implicit(p, i, x, X64, Y64, O.gramian(XX, 0.1), 0.1, solver, 3, with_biases=True,
+                          is_x_bias_last_row=bias_last)
+    Y32o = Y32.copy(order="F")
+    O.als_implicit(p, i, x, X32, Y32o, O.gramian(np.asfortranarray(XX, dtype=np.float32), 0.1), 0.1, solver, 3,
+                   with_biases=True, is_x_bias_last_row=bias_last)
+    err32 = rel_fro(Y32o, Y64)
+    Y = Y32.copy(order="F")
+    loss = als.als_implicit((m.shape[0], m.shape[1], p, i, x), X32, Y, 0.1, 1, solver, 3, "float", True, bias_last)
+    fixed = k - 1 if bias_last else 0
+    assert np.array_equal(Y[fixed], Y32[fixed])
+    tol = max(2e-3, 3 * err32) if solver == 2 else 1e-4
+    assert rel_fro(Y, Y64) < tol, (rel_fro(Y, Y64), err32)
+    assert abs(loss - lref) <= max(tol, 1e-4) * abs(lref)
+    with pytest.raises(NotImplementedError):                 # the ABI's UNSUPPORTED for CG + biases
+        als.als_implicit((m.shape[0], m.shape[1], p, i, x), X32, Y, 0.1, 1, 1, 3, "float", True, bias_last)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("explicit", [True, False])
+def test_hip_initialize_biases_match_oracle(ml_train, explicit):
+    import torch
+    from rsparse_amd.engine import HipBackend
+    be = HipBackend(0)
+    n_user, n_item, p, i, x = ml_train
+    t = O.csc_transpose(n_user, n_item, p, i, x)
+    ub, ib = np.zeros(n_user), np.zeros(n_item)
+    if explicit:
+        gb = O.init_biases_explicit((p, i, x.copy()), (t[0], t[1], t[2].copy()), ub, ib, 0.1, True, False, True)
+    else:
+        gb = O.init_biases_implicit((p, i, x), t, ub, ib, 0.1, False)
+    d_ui = (be.to_device(p, torch.int32), be.to_device(i, torch.int32), be.to_device(x, torch.float32))
+    d_iu = be.transpose_csc(n_user, n_item, *d_ui)
+    h_ui, h_iu = be.make_csc(n_user, n_item, *d_ui), be.make_csc(n_item, n_user, *d_iu)
+    dub = torch.zeros(n_user, dtype=torch.float32, device=be.device)
+    dib = torch.zeros(n_item, dtype=torch.float32, device=be.device)
+    if explicit:
+        got = be.initialize_biases_explicit(h_ui, h_iu, dub, dib, 0.1, True, False, True)
+        assert abs(got - gb) < 1e-6
+        assert np.allclose(d_ui[2].cpu().numpy(), x - gb, atol=1e-6)      # the mean left both orientations
+        assert np.allclose(d_iu[2].cpu().numpy(), t[2] - gb, atol=1e-6)
+    else:
+        be.initialize_biases_implicit(h_ui, h_iu, dub, dib, 0.1, False)
+    # items nobody rated: 0 / (lambda * 0 + 0) = NaN with dynamic_lambda, in the reference as here (wrmf_utils.hpp:64-65)
+    assert np.allclose(dub.cpu().numpy(), ub, rtol=2e-4, atol=2e-6, equal_nan=True)
+    assert np.allclose(dib.cpu().numpy(), ib, rtol=2e-4, atol=2e-6, equal_nan=True)

@@ -4,9 +4,8 @@ assert for lack of golden values: agreement of every fit with the CPU oracle dri
 
 Grid (test-wrmf.R:10-27): implicit x {cholesky, nnls} x lambda {0, 0.1, 1000}; implicit x conjugate_gradient x
 lambda {0, 0.1, 1000}; explicit x {conjugate_gradient, cholesky, nnls} x lambda {0.1, 1000}; precision {double, float};
-with_user_item_bias {TRUE, FALSE} for explicit feedback; for implicit feedback the TRUE half is rejected by the device
-path (RSPARSE_HIP_ERR_UNSUPPORTED) and asserted as such.  rank and K are drawn from 4:10 as in the
-reference (:30-31)."""
+with_user_item_bias {TRUE, FALSE} wherever the reference's grid has it -- i.e. the whole grid.  rank and K are drawn
+from 4:10 as in the reference (:30-31)."""
 import itertools
 
 import numpy as np
@@ -18,7 +17,8 @@ from oracle import wrmf_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-GRID = ([("implicit", s, l, False) for s in ("cholesky", "nnls", "conjugate_gradient") for l in (0.0, 0.1, 1000.0)] +
+GRID = ([("implicit", s, l, b) for s in ("cholesky", "nnls") for l in (0.0, 0.1, 1000.0) for b in (False, True)] +
+        [("implicit", "conjugate_gradient", l, False) for l in (0.0, 0.1, 1000.0)] +
         [("explicit", s, l, b) for s in ("conjugate_gradient", "cholesky", "nnls") for l in (0.1, 1000.0) for b in (False, True)])
 
 
@@ -68,16 +68,24 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
     # get a wider band: NNLS (squares the per-row system and stops at 1e-4 relative steps) and lambda = 1000 (the
     # factors shrink by ~1/lambda per half-iteration, down to ~1e-26 after five iterations)
     tol = 2e-2 if (solver == "nnls" or lam >= 1000.0) else 5e-4
+    if solver == "nnls":
+        # yardstick for NNLS = the reference-shaped arithmetic in float: the same fit on the oracle in fp32
+        ref32 = O.OracleWRMF(rank0, lam=lam, feedback=feedback, solver=solver, dtype=np.float32, n_threads=8,
+                             with_user_item_bias=bias)
+        emb32 = ref32.fit_transform(n_user, n_item, tp, ti, tx, U0.T.copy(), n_iter=5, convergence_tol=-1,
+                                    init_components=V0.copy())
+        tol = max(tol, 3.0 * rel_fro(ref32.components, ref.components), 3.0 * rel_fro(emb32, ref_emb))
     assert rel_fro(model.components, ref.components) < tol
     assert rel_fro(user_emb, ref_emb) < tol
     assert np.allclose([l[1] for l in model.losses], [l[1] for l in ref.losses], rtol=tol)
 
 
-@pytest.mark.parametrize("feedback,solver", [("implicit", "cholesky"), ("implicit", "nnls")])
-def test_wrmf_core_implicit_bias_part_of_the_grid_is_rejected(feedback, solver):
-    """with_user_item_bias = TRUE with implicit feedback (test-wrmf.R:10-15) is not on the device path: the
-    constructor raises the same UnsupportedOnDevice the C ABI reports, so an R shim falls back to the package's CPU
-    code (INTEGRATION.md)."""
+def test_wrmf_implicit_cg_with_biases_is_rejected():
+    """Outside the reference's grid (test-wrmf.R:16-21 keeps with_user_item_bias = FALSE for conjugate_gradient): the
+    reference drops a row of the warm start twice on that path (wrmf_implicit.hpp:189,197) and cannot run it; the
+    device path answers UNSUPPORTED, and so does the implicit-feedback global bias."""
     from rsparse_amd import WRMF, _lib
     with pytest.raises(_lib.UnsupportedOnDevice):
-        WRMF(rank=6, lambda_=0.1, feedback=feedback, solver=solver, with_user_item_bias=True)
+        WRMF(rank=6, lambda_=0.1, feedback="implicit", solver="conjugate_gradient", with_user_item_bias=True)
+    with pytest.raises(_lib.UnsupportedOnDevice):
+        WRMF(rank=6, lambda_=0.1, feedback="implicit", solver="cholesky", with_global_bias=True)

@@ -42,6 +42,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef RSP_GVFIRST_MINCAPQ
 #define RSP_GVFIRST_MINCAPQ 16
 #endif
+// streamed rows: quads per wave of the row's prefix that stay in LDS across the sweeps (0 disables).  4 = one
+// quad-pass block = 128 non-zeros per 8-wave team = 64 KB of LDS next to the 64 KB Gramian; 5 measured 1.5 % faster
+// on the launch but needs the idle quads of the second block zeroed (they are stale registers otherwise)
+#ifndef RSP_STREAM_PREFIX_Q
+#define RSP_STREAM_PREFIX_Q 4
+#endif
 
 constexpr float kCgTolQ = 1e-10f;  // CG_TOL, inst/include/wrmf.hpp:22
 constexpr int kMaxSavedSweeps = 4;  // streamed rows keep the dot products of up to this many CG steps
@@ -97,7 +103,10 @@ struct QSmem {
   // resident rows: per wave, t_acc[CAP] = x_j . y accumulated over the CG steps and t_cur[CAP] = x_j . p of the
   // current step (the loss is rebuilt from them instead of a fifth pass over the registers)
   static constexpr size_t tsv_floats = STREAM ? 0 : (size_t)WAVES * 2 * CAPQ * 4;
-  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats) * 4 + 16;
+  // streamed rows: the first RSP_STREAM_PREFIX_Q quads of every wave (gathered in the first sweep) stay in LDS,
+  // so the other sweeps re-gather only the rest of the row
+  static constexpr size_t pre_floats = STREAM ? (size_t)WAVES * RSP_STREAM_PREFIX_Q * 4 * KP : 0;
+  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats + pre_floats) * 4 + 16;
 };
 
 template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT>
@@ -114,6 +123,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   float* sRed = sVec + QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>::vec_floats;  // [2][WAVES][KP]
   float* sRedL = sRed + (WPR > 1 ? 2 * WAVES * KP : 0);              // [2][WAVES]
   float* sTsv = sVec + SM::vec_floats + SM::red_floats;              // [WAVES][2][CAP]
+  float* sPre = sTsv + SM::tsv_floats;                               // [WAVES][PQ][4][KP]  (streamed kernels)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
@@ -172,7 +182,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       for (int e = lane; e < k; e += 64) yrow[e] = 0.f;
       continue;
     }
-    const int nchunks = (cnt + CAP - 1) / CAP;
+    // streamed rows: the first PTEAM non-zeros are the LDS-resident prefix (PCAP per wave), the rest is streamed
+    constexpr int PQ = STREAM ? RSP_STREAM_PREFIX_Q : 0, PCAP = PQ * 4, PTEAM = PCAP * WPR;
+    const int pre = STREAM ? min(cnt, PTEAM) : 0;
+    const int pw = STREAM ? max(0, min(PCAP, pre - tw * PCAP)) : 0;   // this wave's share of the prefix
+    const int nchunks = (cnt - pre + CAP - 1) / CAP;
     // STREAM == 0: every row of this launch fits the team's resident capacity (bucket thresholds);
     // STREAM == 1: rows beyond it -- each wave re-gathers its chunks in every sweep.
     constexpr bool resident = STREAM == 0;
@@ -202,10 +216,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     constexpr bool ZPAD = STREAM == 0 && CAPQ >= RSP_ZPAD_MINCAPQ;
     constexpr bool TSAVE = STREAM == 0 && CAPQ >= RSP_TSAVE_MINCAPQ;
     constexpr bool GVFIRST = STREAM == 0 && CAPQ >= RSP_GVFIRST_MINCAPQ;
-    auto gather = [&](const int base, const int n) {
-      int id[CAPQ];
+    auto gather_q = [&](auto nq_tag, const int base, const int n) {
+      constexpr int NQG = decltype(nq_tag)::value;
+      int id[NQG > 0 ? NQG : 1];
 #pragma unroll
-      for (int q = 0; q < CAPQ; q++) {
+      for (int q = 0; q < NQG; q++) {
         const int j = min(4 * q + g, n - 1);
         id[q] = a.row_idx[base + j];
         const float c = a.vals[base + j];
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       }
       if constexpr (TSAVE) cl = lane < n ? a.vals[base + lane] : 0.f;
 #pragma unroll
-      for (int q = 0; q < CAPQ; q++) {
+      for (int q = 0; q < NQG; q++) {
         const float* src = (!ZPAD || 4 * q + g < n) ? a.X + (size_t)id[q] * k : a.zero_row;
 #pragma unroll
         for (int b = 0; b < NV; b++) {
@@ -222,6 +237,39 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           const float* pf = reinterpret_cast<const float*>(&pc);
 #pragma unroll
           for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
+        }
+      }
+    };
+    auto gather = [&](const int base, const int n) { gather_q(std::integral_constant<int, CAPQ>{}, base, n); };
+    // prefix of a streamed row: first sweep -> gather it and park the vectors in LDS; later sweeps -> read them back
+    float* pre_lds = sPre + (size_t)wv * PQ * 4 * KP + g * KP;
+    auto prefix_chunk = [&](const bool first) {
+      if constexpr (PQ > 0) {
+        const int base = p1 + tw * PCAP;
+        if (first) {
+          gather_q(std::integral_constant<int, PQ>{}, base, pw);
+#pragma unroll
+          for (int q = 0; q < PQ; q++)
+#pragma unroll
+            for (int b = 0; b < NV; b++) {
+              piece_t pc;
+              float* pf = reinterpret_cast<float*>(&pc);
+#pragma unroll
+              for (int c = 0; c < VW; c++) pf[c] = xt[q][b * VW + c];
+              *reinterpret_cast<piece_t*>(pre_lds + q * 4 * KP + b * 16 * VW + i * VW) = pc;
+            }
+        } else {
+#pragma unroll
+          for (int q = 0; q < PQ; q++) cv[q] = a.vals[base + min(4 * q + g, pw - 1)];
+#pragma unroll
+          for (int q = 0; q < PQ; q++)
+#pragma unroll
+            for (int b = 0; b < NV; b++) {
+              const piece_t pc = *reinterpret_cast<const piece_t*>(pre_lds + q * 4 * KP + b * 16 * VW + i * VW);
+              const float* pf = reinterpret_cast<const float*>(&pc);
+#pragma unroll
+              for (int c = 0; c < VW; c++) xt[q][b * VW + c] = pf[c];
+            }
         }
       }
     };
@@ -354,7 +402,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         } else if (mode == 2 && tscr) {
           // streamed rows: t_final = t_0 + sum_s alpha_s t_s from the scratch written by the sweeps -- 20 bytes
           // per non-zero instead of re-gathering its 512-byte vector
-          for (int ch = tw; ch < nchunks; ch += WPR) {
+          for (int ch = tw; ch < (cnt + CAP - 1) / CAP; ch += WPR) {   // all positions of the row, prefix included
             const int n = min(CAP, cnt - ch * CAP);
             if (lane < n) {
               const size_t pos = (size_t)ch * CAP + lane;
@@ -369,10 +417,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           }
           lacc = row16_sum(lacc);  // groups_sum below finishes the wave sum
         } else {
+          if (pw > 0) {  // wave-uniform
+            prefix_chunk(mode == 0);   // mode 0 is the first sweep of every row
+            ccnt = pw;
+            quad_pass(v, mode, acc, lacc, tscr ? tscr + (size_t)sidx * a.stream_nnz + (size_t)tw * PCAP : nullptr);
+          }
           for (int ch = tw; ch < nchunks; ch += WPR) {
-            ccnt = min(CAP, cnt - ch * CAP);
-            gather(p1 + ch * CAP, ccnt);
-            quad_pass(v, mode, acc, lacc, tscr ? tscr + (size_t)sidx * a.stream_nnz + (size_t)ch * CAP : nullptr);
+            ccnt = min(CAP, cnt - pre - ch * CAP);
+            gather(p1 + pre + ch * CAP, ccnt);
+            quad_pass(v, mode, acc, lacc,
+                      tscr ? tscr + (size_t)sidx * a.stream_nnz + (size_t)pre + (size_t)ch * CAP : nullptr);
           }
         }
         if constexpr (!GVFIRST) dense_part();

@@ -4,22 +4,24 @@
 // cg_solver_explicit<T>, inst/include/wrmf_explicit.hpp:8-31; column loop :160-283 / :68-144), re-laid-out
 // so that the gathered factor vectors of a row live in the REGISTER FILE instead of LDS.  The LDS-tile
 // kernels fit only 4 waves per CU (64 KB Gramian + 17 KB tile per wave) and are latency-bound; a CU has
-// 512 KB of VGPRs, so here 16 waves per CU each keep 32 gathered vectors (64 VGPRs) resident and LDS holds
-// only the shared Gramian and a few hundred bytes per wave.
+// 512 KB of VGPRs, so here 8 waves per CU each keep up to 64 gathered vectors (128 VGPRs) resident and LDS
+// holds only the shared Gramian and ~1.5 KB per wave.
 //
 // Layout: a wave is 4 DPP rows ("groups") of 16 lanes.  A rank-KP vector is spread over the 16 lanes of a
 // group, RPN = KP/16 floats per lane (k=128: floats [4i,4i+4) and [64+4i,64+4i+4) for lane i -> every load
 // instruction reads whole 256-B half vectors).  The 4 groups hold 4 DIFFERENT non-zeros of the row at a
 // time (a "quad"); CG state (x, r, p, Ap) is replicated in the 4 groups.  Then, per quad:
-//     t_j  = x_j . v      RPN FMAs + a 4-step DPP reduction inside the 16-lane row (no cross-row traffic)
-//     acc += w_j * x_j    RPN FMAs, w_j is already uniform inside the group (no readlane, no LDS)
-// and once per sweep the 4 group partials are all-reduced (2 xor-shuffles per register).  The dense
-// G*v product is split over the groups by k-range and folded into the same all-reduce.
+//     t_j  = x_j . v      RPN/2 packed FMAs + a 4-step DPP reduction inside the 16-lane row (no cross-row traffic)
+//     acc += w_j * x_j    RPN/2 packed FMAs, w_j is already uniform inside the group (no readlane, no LDS)
+// and once per sweep the 4 group partials are all-reduced (2 permlane swaps per register).  The dense
+// G*v product is split over the groups by k-range and folded into the same all-reduce.  The loss needs
+// t_j = x_j . y for the final y = x0 + sum_s alpha_s p_s, i.e. the dot products the sweeps already formed: they
+// are accumulated per non-zero (LDS for resident rows, an HBM scratch for streamed rows) instead of a fifth pass.
 //
 // Rows longer than one wave's capacity (64 non-zeros = 128 VGPRs) are solved by teams of WPR = 2/4/8
 // waves of one workgroup: every wave keeps its own chunk resident, partial vectors are combined through
-// LDS with one barrier per CG sweep.  Rows beyond the workgroup's capacity are streamed: each wave
-// re-gathers its chunks (L2 / Infinity Cache hits) in every sweep (STREAM = 1 instantiation).
+// LDS with one barrier per CG sweep.  Rows beyond the workgroup's capacity are streamed (STREAM = 1
+// instantiation): the first 16 non-zeros per wave stay in LDS, the rest is re-gathered in every sweep.
 #include <cstdlib>
 
 #include "wrmf_internal.h"

@@ -276,9 +276,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       }
     };
 
-    if (resident && tw < nchunks) {
-      ccnt = min(CAP, cnt - tw * CAP);
-      gather(p1 + tw * CAP, ccnt);
+    if constexpr (resident) {
+      // balanced shares: every wave of the team takes ceil(cnt / WPR) non-zeros rounded up to a quad-pass block (16),
+      // so the team's sweep time is that of the average wave, not of a full one next to idle ones
+#ifdef RSP_SEQ_FILL
+      const int per = CAP;
+#else
+      const int per = min(CAP, (((cnt + WPR - 1) / WPR) + 15) & ~15);
+#endif
+      ccnt = max(0, min(per, cnt - tw * per));
+      if (ccnt > 0) gather(p1 + tw * per, ccnt);
     }
 
     float x[RPN], r[RPN], p[RPN], ap[RPN];

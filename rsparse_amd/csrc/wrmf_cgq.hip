@@ -47,6 +47,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // streamed rows: quads per wave of the row's prefix that stay in LDS across the sweeps (0 disables).  4 = one
 // quad-pass block = 128 non-zeros per 8-wave team = 64 KB of LDS next to the 64 KB Gramian; 5 measured 1.5 % faster
 // on the launch but needs the idle quads of the second block zeroed (they are stale registers otherwise)
+// resident rows: prefetch the next row's indices / values (one per lane, 2 VGPRs) during the current row's sweeps, so
+// the gather at the row switch is one HBM round trip instead of two.  Teams of up to this many waves use it: -4..6 %
+// on the 1- and 2-wave kernels; the 4- and 8-wave kernels sit at 256 VGPRs and the two registers spill (+5 %)
+#ifndef RSP_IDX_PREFETCH_MAXWPR
+#define RSP_IDX_PREFETCH_MAXWPR 2
+#endif
 #ifndef RSP_STREAM_PREFIX_Q
 #define RSP_STREAM_PREFIX_Q 4
 #endif
@@ -145,6 +151,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   float* tcur = tacc + CAP;
   int buf = 0;
   double wloss = 0.0;
+  int pf_id = 0, pf_cnt = -1;   // next row's share of this wave, lane-major (RSP_IDX_PREFETCH)
+  float pf_c = 0.f;
   const int team_global = blockIdx.x * TEAMS + team;
   const int total_teams = gridDim.x * TEAMS;
 
@@ -218,17 +226,35 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     constexpr bool ZPAD = STREAM == 0 && CAPQ >= RSP_ZPAD_MINCAPQ;
     constexpr bool TSAVE = STREAM == 0 && CAPQ >= RSP_TSAVE_MINCAPQ;
     constexpr bool GVFIRST = STREAM == 0 && CAPQ >= RSP_GVFIRST_MINCAPQ;
-    auto gather_q = [&](auto nq_tag, const int base, const int n) {
+    constexpr bool IDXPF = STREAM == 0 && WPR <= RSP_IDX_PREFETCH_MAXWPR;
+    auto gather_q = [&](auto nq_tag, const int base, const int n, const bool from_pf = false) {
       constexpr int NQG = decltype(nq_tag)::value;
       int id[NQG > 0 ? NQG : 1];
+      if (IDXPF && from_pf) {
+        // lane-major prefetch registers -> quad layout through the wave's t-slots (dead between two rows)
+        int* xi = reinterpret_cast<int*>(tacc);
+        wave_sync();
+        xi[lane & (CAP - 1)] = pf_id;
+        tcur[lane & (CAP - 1)] = pf_c;
+        wave_sync();
 #pragma unroll
-      for (int q = 0; q < NQG; q++) {
-        const int j = min(4 * q + g, n - 1);
-        id[q] = a.row_idx[base + j];
-        const float c = a.vals[base + j];
-        cv[q] = (!ZPAD || 4 * q + g < n) ? c : 0.f;
+        for (int q = 0; q < NQG; q++) {
+          const int j = min(4 * q + g, n - 1);
+          id[q] = xi[j];
+          cv[q] = (!ZPAD || 4 * q + g < n) ? tcur[j] : 0.f;
+        }
+        if constexpr (TSAVE) cl = lane < n ? pf_c : 0.f;
+        wave_sync();
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQG; q++) {
+          const int j = min(4 * q + g, n - 1);
+          id[q] = a.row_idx[base + j];
+          const float c = a.vals[base + j];
+          cv[q] = (!ZPAD || 4 * q + g < n) ? c : 0.f;
+        }
+        if constexpr (TSAVE) cl = lane < n ? a.vals[base + lane] : 0.f;
       }
-      if constexpr (TSAVE) cl = lane < n ? a.vals[base + lane] : 0.f;
 #pragma unroll
       for (int q = 0; q < NQG; q++) {
         const float* src = (!ZPAD || 4 * q + g < n) ? a.X + (size_t)id[q] * k : a.zero_row;
@@ -242,7 +268,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         }
       }
     };
-    auto gather = [&](const int base, const int n) { gather_q(std::integral_constant<int, CAPQ>{}, base, n); };
+    auto gather = [&](const int base, const int n, const bool from_pf = false) {
+      gather_q(std::integral_constant<int, CAPQ>{}, base, n, from_pf);
+    };
     // prefix of a streamed row: first sweep -> gather it and park the vectors in LDS; later sweeps -> read them back
     float* pre_lds = sPre + (size_t)wv * PQ * 4 * KP + g * KP;
     auto prefix_chunk = [&](const bool first) {
@@ -285,7 +313,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       const int per = min(CAP, (((cnt + WPR - 1) / WPR) + 15) & ~15);
 #endif
       ccnt = max(0, min(per, cnt - tw * per));
-      if (ccnt > 0) gather(p1 + tw * per, ccnt);
+      if (ccnt > 0) gather(p1 + tw * per, ccnt, pf_cnt == ccnt);
+      pf_cnt = -1;
     }
 
     float x[RPN], r[RPN], p[RPN], ap[RPN];
@@ -509,6 +538,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     const bool live = have && cnt > 0;
     float dummy = 0.f;
     sweep(x, 0, r, dummy, live);
+    if constexpr (IDXPF) {
+      // the next row's pointers were requested at the top of this iteration and have arrived by now
+      if (it + 1 < rows_per_team && row_index(it + 1) < n_rows) {
+        const int np1 = rfl(p1_c), ncnt = rfl(p2_c) - np1;
+        const int nper = min(CAP, (((ncnt + WPR - 1) / WPR) + 15) & ~15);
+        const int ncc = max(0, min(nper, ncnt - tw * nper));
+        if (ncc > 0) {
+          const int j = np1 + tw * nper + min(lane & (CAP - 1), ncc - 1);
+          pf_id = a.row_idx[j];
+          pf_c = a.vals[j];
+          pf_cnt = ncc;
+        }
+      }
+    }
 #pragma unroll
     for (int rr = 0; rr < RPN; rr++) p[rr] = r[rr];
     float rsold = dot16(r, r);

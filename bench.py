@@ -120,7 +120,7 @@ def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0, implicit=True, sol
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
                     help="SURVEY.md 8(d) configuration; 3 (default) is the one BASELINE.json's metric is quoted on")

@@ -44,6 +44,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef RSP_GVFIRST_MINCAPQ
 #define RSP_GVFIRST_MINCAPQ 16
 #endif
+// streamed rows: request the next chunk's indices / values (lane-major) while the current chunk is in flight -- one
+// HBM round trip per chunk instead of two (-3 % on the streamed launch).  Implicit instantiations only: the explicit
+// one is at 256 VGPRs and would spill
+#ifndef RSP_STREAM_IDX_PREFETCH
+#define RSP_STREAM_IDX_PREFETCH 1
+#endif
 // streamed rows: quads per wave of the row's prefix that stay in LDS across the sweeps (0 disables).  4 = one
 // quad-pass block = 128 non-zeros per 8-wave team = 64 KB of LDS next to the 64 KB Gramian; 5 measured 1.5 % faster
 // on the launch but needs the idle quads of the second block zeroed (they are stale registers otherwise)
@@ -110,7 +116,7 @@ struct QSmem {
   static constexpr size_t red_floats = WPR > 1 ? (size_t)2 * WAVES * KP + 2 * WAVES : 0;
   // resident rows: per wave, t_acc[CAP] = x_j . y accumulated over the CG steps and t_cur[CAP] = x_j . p of the
   // current step (the loss is rebuilt from them instead of a fifth pass over the registers)
-  static constexpr size_t tsv_floats = STREAM ? 0 : (size_t)WAVES * 2 * CAPQ * 4;
+  static constexpr size_t tsv_floats = (STREAM && !(RSP_STREAM_IDX_PREFETCH && IMPLICIT)) ? 0 : (size_t)WAVES * 2 * CAPQ * 4;
   // streamed rows: the first RSP_STREAM_PREFIX_Q quads of every wave (gathered in the first sweep) stay in LDS,
   // so the other sweeps re-gather only the rest of the row
   static constexpr size_t pre_floats = STREAM ? (size_t)WAVES * RSP_STREAM_PREFIX_Q * 4 * KP : 0;
@@ -226,7 +232,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     constexpr bool ZPAD = STREAM == 0 && CAPQ >= RSP_ZPAD_MINCAPQ;
     constexpr bool TSAVE = STREAM == 0 && CAPQ >= RSP_TSAVE_MINCAPQ;
     constexpr bool GVFIRST = STREAM == 0 && CAPQ >= RSP_GVFIRST_MINCAPQ;
-    constexpr bool IDXPF = STREAM == 0 && WPR <= RSP_IDX_PREFETCH_MAXWPR;
+    constexpr bool IDXPF = (STREAM == 0 && WPR <= RSP_IDX_PREFETCH_MAXWPR) || (STREAM == 1 && IMPLICIT && RSP_STREAM_IDX_PREFETCH);
+    int pf_pos = -1;   // streamed rows: chunk the prefetch registers belong to
     auto gather_q = [&](auto nq_tag, const int base, const int n, const bool from_pf = false) {
       constexpr int NQG = decltype(nq_tag)::value;
       int id[NQG > 0 ? NQG : 1];
@@ -462,7 +469,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           }
           for (int ch = tw; ch < nchunks; ch += WPR) {
             ccnt = min(CAP, cnt - pre - ch * CAP);
-            gather(p1 + pre + ch * CAP, ccnt);
+            gather(p1 + pre + ch * CAP, ccnt, IDXPF && pf_pos == ch && pf_cnt == ccnt);
+            if constexpr (IDXPF) {  // this wave's next chunk: further down the row, or the first one of the next sweep
+              const int nch = ch + WPR < nchunks ? ch + WPR : tw;
+              const int ncc = min(CAP, cnt - pre - nch * CAP);
+              const int j = p1 + pre + nch * CAP + min(lane & (CAP - 1), ncc - 1);
+              pf_id = a.row_idx[j];
+              pf_c = a.vals[j];
+              pf_cnt = ncc;
+              pf_pos = nch;
+            }
             quad_pass(v, mode, acc, lacc,
                       tscr ? tscr + (size_t)sidx * a.stream_nnz + (size_t)pre + (size_t)ch * CAP : nullptr);
           }
@@ -538,7 +554,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     const bool live = have && cnt > 0;
     float dummy = 0.f;
     sweep(x, 0, r, dummy, live);
-    if constexpr (IDXPF) {
+    if constexpr (IDXPF && STREAM == 0) {
       // the next row's pointers were requested at the top of this iteration and have arrived by now
       if (it + 1 < rows_per_team && row_index(it + 1) < n_rows) {
         const int np1 = rfl(p1_c), ncnt = rfl(p2_c) - np1;

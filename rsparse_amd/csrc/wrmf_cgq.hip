@@ -748,7 +748,9 @@ int cgq_bucket_grid(int n_rows, int b, int cfg) {
   // bucket holds few, very long rows and keeps a small quota for balance
   static const char* env = std::getenv("RSPARSE_HIP_RPT");
   const int scale = env ? std::atoi(env) : 1;
-  const int base = d.stream ? 4 : (d.wpr == 1 ? 64 : (d.wpr == 2 ? 32 : 16));
+  // (measured on config 3: doubling the quota of the team kernels from 4 / 16 is worth 3 % of the iteration, a
+  // further doubling is flat; the one-wave kernels prefer 64)
+  const int base = d.stream ? 16 : (d.wpr == 1 ? 64 : (d.wpr == 2 ? 64 : 32));
   int rows_per_team = base * (scale > 0 ? scale : 1);
   // small buckets (shards of a multi-GPU run, tiny matrices): spread the rows over the CUs first -- the quota
   // only grows once there are two workgroups per CU

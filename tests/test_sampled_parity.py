@@ -1,0 +1,91 @@
+"""Full-size sampled parity: rows of every launch bucket of a full-size half-iteration re-solved
+by the fp64 oracle from the same inputs.  The CPU test checks the checker; the gpu tests run BASELINE configs 3, 4, 5
+at their full sizes on the device and compare ~64 rows per length class and side."""
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sampled_parity as SP
+from oracle import wrmf_oracle as O
+from rsparse_amd import synth
+
+ROW_TOL = 1e-4        # north star: 1e-4 relative, here per sampled ROW (not only Frobenius over the sample)
+
+
+def test_checker_on_cpu():
+    d = synth.make_dataset(3000, 800, seed=3, mean_deg=40, d_max=700, device="cpu")
+    p, i, x = d["c_iu"]
+    k, lam = 16, 0.1
+    g = torch.Generator().manual_seed(0)
+    F = torch.randn(800, k, generator=g) * 0.1
+    S0 = torch.randn(3000, k, generator=g) * 0.1
+    X = np.asfortranarray(F.numpy().T)
+    Y = np.asfortranarray(S0.numpy().T).copy(order="F")
+    O.als_implicit(p.numpy(), i.numpy(), x.numpy().astype(np.float64), X, Y, O.gramian(X, lam), lam, 1, 3)
+    S1 = torch.from_numpy(np.ascontiguousarray(Y.T))
+    rows = SP.pick_rows(p, per_bucket=16, seed=1)
+    lens = torch.diff(p.long())[rows]
+    assert int(lens.max()) == int(torch.diff(p.long()).max())          # the longest row is always in the sample
+    assert rows.numel() >= 5 * 10
+    rep = SP.check((p, i, x), F, S0[rows], S1[rows], rows, lam, 1, 3, True)
+    assert rep["rows_checked"] == rows.numel() and rep["max_row_err"] < ROW_TOL
+    bad = S1[rows].clone()
+    bad[7] *= 1.001
+    rep = SP.check((p, i, x), F, S0[rows], bad, rows, lam, 1, 3, True)
+    assert rep["max_row_err"] > 5e-4 and rep["worst_row"] == int(rows[7])
+
+
+def _run_config(users, items, k, solver, feedback, n_iter=1):
+    from rsparse_amd.engine import HipBackend, ShardedALS
+    be = HipBackend()
+    d = synth.make_dataset(users, items, device=be.device, feedback=feedback)
+    als = ShardedALS(be, users, items, k, d["c_ui"], d["c_iu"], d["nnz"], feedback=feedback, lambda_=0.1)
+    if feedback == "explicit":
+        als.cnt_user = torch.diff(d["c_iu"][0]).to(torch.float32)
+        als.cnt_item = torch.diff(d["c_ui"][0]).to(torch.float32)
+    g = torch.Generator(device=be.device).manual_seed(11)
+    U = torch.randn(users, k, generator=g, device=be.device) * 0.01
+    V = torch.zeros(items, k, device=be.device) if solver == 1 else torch.randn(items, k, generator=g, device=be.device) * 0.01
+    reports = []
+    for it in range(n_iter):
+        for side in ("items", "users"):
+            loss, rep = SP.half_iteration_with_check(als, side, U, V, solver, per_bucket=64, seed=it)
+            rep["iteration"] = it
+            rep["loss"] = loss
+            reports.append(rep)
+    be.check_numeric()
+    out = Path(os.environ.get("GRAFT_REPO_ROOT", ".")) / "gpurun_out"
+    if out.is_dir():
+        (out / ("sampled_parity_%dx%d_k%d_s%d_%s.json" % (users, items, k, solver, feedback))).write_text(json.dumps(reports, indent=1))
+    return reports
+
+
+def _assert_reports(reports):
+    for rep in reports:
+        assert np.isfinite(rep["loss"])
+        assert rep["rows_checked"] >= 64
+        assert rep["max_row_err"] <= ROW_TOL, (rep["side"], rep["iteration"], rep["worst_row"], rep["worst_len"], rep["max_row_err"], rep["per_class"])
+
+
+@pytest.mark.gpu
+def test_config3_sampled_parity():
+    """BASELINE config 3 (the bench line): 10M x 1M, ~5e8 nnz, rank 128, implicit CG(3).  Two iterations: the first
+    starts the item side from zeros (R/model_WRMF.R:219-231), the second from a real warm start."""
+    _assert_reports(_run_config(10_000_000, 1_000_000, 128, 1, "implicit", n_iter=2))
+
+
+@pytest.mark.gpu
+def test_config4_sampled_parity():
+    """BASELINE config 4: config 3 with the exact (Cholesky) solver."""
+    _assert_reports(_run_config(10_000_000, 1_000_000, 128, 0, "implicit"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [1, 0])
+def test_config5_sampled_parity(solver):
+    """BASELINE config 5: explicit feedback, 5M x 500k, rank 64, dynamic lambda; CG(3) and Cholesky."""
+    _assert_reports(_run_config(5_000_000, 500_000, 64, solver, "explicit", n_iter=2 if solver == 1 else 1))

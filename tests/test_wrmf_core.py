@@ -7,15 +7,29 @@ lambda {0, 0.1, 1000}; explicit x {conjugate_gradient, cholesky, nnls} x lambda 
 with_user_item_bias {TRUE, FALSE} wherever the reference's grid has it -- i.e. the whole grid.  rank and K are drawn
 from 4:10 as in the reference (:30-31)."""
 import itertools
+import json
+import os
+from pathlib import Path
 
 import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import csc_drop_rows, rel_fro
+from conftest import GOLDEN, csc_drop_rows, rel_fro
 from oracle import wrmf_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+_TOL_FILE = GOLDEN / "wrmf_core_tolerances.json"
+_TOLERANCES = json.loads(_TOL_FILE.read_text())["cells"] if _TOL_FILE.exists() else {}
+
+
+def _record(cell, errs):
+    """achieved errors of this run -> gpurun_out/wrmf_core_errors.jsonl (input of tools/make_core_tolerances.py)"""
+    out = Path(os.environ.get("GRAFT_REPO_ROOT", ".")) / "gpurun_out"
+    if out.is_dir():
+        with open(out / "wrmf_core_errors.jsonl", "a") as f:
+            f.write(json.dumps({"cell": cell, **errs}) + "\n")
 
 GRID = ([("implicit", s, l, b) for s in ("cholesky", "nnls") for l in (0.0, 0.1, 1000.0) for b in (False, True)] +
         [("implicit", "conjugate_gradient", l, False) for l in (0.0, 0.1, 1000.0)] +
@@ -64,10 +78,20 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
                        with_user_item_bias=bias)
     ref_emb = ref.fit_transform(n_user, n_item, tp, ti, tx, U0.T.astype(np.float64), n_iter=5, convergence_tol=-1,
                                 init_components=None if solver == "conjugate_gradient" else V0.astype(np.float64))
-    # five ALS iterations compound the per-solve fp32 differences.  Two degenerate corners of the reference's grid
-    # get a wider band: NNLS (squares the per-row system and stops at 1e-4 relative steps) and lambda = 1000 (the
-    # factors shrink by ~1/lambda per half-iteration, down to ~1e-26 after five iterations)
-    tol = 2e-2 if (solver == "nnls" or lam >= 1000.0) else 5e-4
+    # Five ALS iterations compound the per-solve fp32 differences, so the bound is per cell: tests/golden/
+    # wrmf_core_tolerances.json holds, for every cell of the grid, the error the device path achieved against the fp64
+    # oracle when the table was made (tools/make_core_tolerances.py) and the bound asserted here (the achieved error with
+    # a 3x margin, never below the north star's 1e-4).  The cells above 1e-4 are the two degenerate corners of the
+    # reference's grid: lambda = 1000 (the factors shrink by ~1/lambda per half-iteration, to ~1e-26 after five
+    # iterations, where fp32 loses relative accuracy to underflow) and NNLS (which squares the per-row system and
+    # stops at 1e-4 relative steps).
+    cell = "%s|%s|%g|%d|%s" % (feedback, solver, lam, bias, precision)
+    errs = {"components": rel_fro(model.components, ref.components), "user_emb": rel_fro(user_emb, ref_emb),
+            "loss": float(np.max(np.abs(np.array([l[1] for l in model.losses]) / np.array([l[1] for l in ref.losses]) - 1.0)))}
+    _record(cell, errs)
+    tol = _TOLERANCES.get(cell, {}).get("bound", 1e-4)
+    if os.environ.get("RSPARSE_CORE_RECORD"):      # table-making run: record, do not judge
+        tol = 1.0
     if solver == "nnls":
         # yardstick for NNLS = the reference-shaped arithmetic in float: the same fit on the oracle in fp32
         ref32 = O.OracleWRMF(rank0, lam=lam, feedback=feedback, solver=solver, dtype=np.float32, n_threads=8,
@@ -75,9 +99,9 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
         emb32 = ref32.fit_transform(n_user, n_item, tp, ti, tx, U0.T.copy(), n_iter=5, convergence_tol=-1,
                                     init_components=V0.copy())
         tol = max(tol, 3.0 * rel_fro(ref32.components, ref.components), 3.0 * rel_fro(emb32, ref_emb))
-    assert rel_fro(model.components, ref.components) < tol
-    assert rel_fro(user_emb, ref_emb) < tol
-    assert np.allclose([l[1] for l in model.losses], [l[1] for l in ref.losses], rtol=tol)
+    assert errs["components"] < tol, (cell, errs, tol)
+    assert errs["user_emb"] < tol, (cell, errs, tol)
+    assert errs["loss"] < tol, (cell, errs, tol)
 
 
 def test_wrmf_implicit_cg_with_biases_is_rejected():

@@ -50,6 +50,7 @@ struct Workspace {
   size_t partial_slots = 0;
   double* scalars = nullptr;  // [0] loss rows, [1] sumsq, [2..] spare
   int* fails = nullptr;
+  int* counter = nullptr;     // row queue of the normal-equation kernel
   float* zero_row = nullptr;  // 256 zero floats (padding slots of the CG gathers)
   float* tscr = nullptr;   // streamed CG rows: per-non-zero dot products of every sweep
   size_t tscr_floats = 0;
@@ -71,6 +72,10 @@ struct Workspace {
     if (!fails) {
       HIP_TRY(hipMalloc(&fails, sizeof(int)));
       HIP_TRY(hipMemset(fails, 0, sizeof(int)));
+    }
+    if (!counter) {
+      HIP_TRY(hipMalloc(&counter, 4 * sizeof(int)));
+      HIP_TRY(hipMemset(counter, 0, 4 * sizeof(int)));
     }
     if (!zero_row) {
       HIP_TRY(hipMalloc(&zero_row, 256 * sizeof(float)));
@@ -130,6 +135,8 @@ struct Workspace {
     if (partials) (void)hipFree(partials);
     if (scalars) (void)hipFree(scalars);
     if (fails) (void)hipFree(fails);
+    if (counter) (void)hipFree(counter);
+    counter = nullptr;
     if (zero_row) (void)hipFree(zero_row);
     gram = nullptr; partials = nullptr; scalars = nullptr; fails = nullptr; zero_row = nullptr;
     gram_floats = 0; partial_slots = 0;
@@ -292,7 +299,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   qs.order = d.q_order;
   qs.cfg = d.q_cfg;
   for (int b = 0; b < 7; b++) qs.off[b] = d.q_off[b];
-  const size_t slots = cgq ? cgq_loss_slots(qs) : (cg ? cg_loss_slots(d.n_cols, d.n_long) : chol_loss_slots(d.n_cols));
+  const size_t slots = cgq ? cgq_loss_slots(qs, rank) : (cg ? cg_loss_slots(d.n_cols, d.n_long) : chol_loss_slots(d.n_cols));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
   double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
   if (d.n_cols == 0) {
@@ -310,10 +317,11 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.loss_tgt = bias ? bias->loss_tgt : nullptr;
   a.rhs_init = bias ? bias->rhs_init : nullptr;
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
+  a.work_counter = g_ws.counter;
   {
     static const char* ts_env = std::getenv("RSPARSE_HIP_TSCRATCH");
     const bool ts_on = !(ts_env && ts_env[0] == '0');
-    if (cgq && ts_on && d.q_stream_off && d.q_nnz[0] > 0 && cg_steps >= 1 && cg_steps <= 4) {
+    if (cgq && ts_on && !ne_supported(rank) && d.q_stream_off && d.q_nnz[0] > 0 && cg_steps >= 1 && cg_steps <= 4) {
       if ((rc = g_ws.ensure_tscr((size_t)(cg_steps + 1) * (size_t)d.q_nnz[0]))) return rc;
       a.tscr = g_ws.tscr;
     }

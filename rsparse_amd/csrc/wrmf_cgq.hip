@@ -710,7 +710,10 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
           bs = g_bs.st[B];                                                                                  \
           if ((err = hipStreamWaitEvent(bs, g_bs.fork, 0)) != hipSuccess) return err;                       \
         }                                                                                                   \
-        if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, grid, slot, \
+        if (D.stream && ne_supported(a.k)) {                                                                \
+          if ((err = launch_als_ne(a, q.order + q.off[B], n, IMPLICIT, a.work_counter, a.loss_partials + slot, bs)) != hipSuccess) \
+            return err;                                                                                     \
+        } else if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, grid, slot, \
                                                                                 bs)) != hipSuccess)         \
           return err;                                                                                       \
         if (overlap) {                                                                                      \
@@ -718,7 +721,7 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
           if ((err = hipStreamWaitEvent(s, g_bs.done[B], 0)) != hipSuccess) return err;                     \
         }                                                                                                   \
       }                                                                                                     \
-      slot += (size_t)grid * D.waves;                                                                       \
+      slot += (D.stream && ne_supported(a.k)) ? (size_t)n : (size_t)grid * D.waves;                         \
     }                                                                                                       \
   }
   RSP_BUCKET(0)
@@ -770,9 +773,13 @@ int cgq_bucket_of(int len, int cfg) {  // last (smallest-team) bucket whose capa
   return best;
 }
 
-size_t cgq_loss_slots(const QSchedule& q) {
+size_t cgq_loss_slots(const QSchedule& q, int k) {
   size_t n = 0;
-  for (int b = 0; b < kNB; b++) n += (size_t)cgq_bucket_grid(q.off[b + 1] - q.off[b], b, q.cfg) * kBuckets[q.cfg][b].waves;
+  for (int b = 0; b < kNB; b++) {
+    const int rows = q.off[b + 1] - q.off[b];
+    if (kBuckets[q.cfg][b].stream && ne_supported(k)) n += (size_t)rows;  // one slot per row (wrmf_ne.hip)
+    else n += (size_t)cgq_bucket_grid(rows, b, q.cfg) * kBuckets[q.cfg][b].waves;
+  }
   return n;
 }
 

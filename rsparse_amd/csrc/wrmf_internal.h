@@ -58,6 +58,7 @@ struct AlsArgs {
   float* tscr;
   const int64_t* stream_off;
   int64_t stream_nnz;
+  int* work_counter;      // one int of device scratch: row queue of the normal-equation kernel (wrmf_ne.hip)
 };
 
 struct QSchedule {
@@ -73,7 +74,11 @@ int cgq_bucket_waves(int cfg, int b);  // waves per workgroup of bucket b's kern
 int cgq_bucket_stream(int cfg, int b);
 int cgq_bucket_grid(int n_rows, int bucket, int cfg);
 int cgq_bucket_of(int len, int cfg);
-size_t cgq_loss_slots(const QSchedule& q);
+size_t cgq_loss_slots(const QSchedule& q, int k);
+// long rows (bucket 0) by one-pass normal equations on the matrix cores (wrmf_ne.hip) instead of the streamed CG kernel
+bool ne_supported(int k);
+hipError_t launch_als_ne(const AlsArgs& a, const int32_t* rows, int n_rows, bool implicit, int* counter,
+                         double* row_loss, hipStream_t s);
 // ev (optional): 7 events, ev[b] before bucket b's kernel, ev[6] after the last one
 hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 

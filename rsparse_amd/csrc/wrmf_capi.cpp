@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -210,6 +212,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   for (int b = 0; b < 6; b++) d.q_nnz[b] = 0;
   d.q_order = nullptr;
   d.q_stream_off = nullptr;
+  d.q_ne_rows = nullptr; d.q_ne_ptr = nullptr; d.q_ne_wg = 0;
   d.q_cfg = cgq_default_cfg();
   if (n <= 0) return RSPARSE_HIP_OK;
   const int max_len = d.max_len;
@@ -241,6 +244,34 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     }
     HIP_TRY(hipMalloc(&d.q_stream_off, soff.size() * sizeof(int64_t)));
     HIP_TRY(hipMemcpy(d.q_stream_off, soff.data(), soff.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    // Row lists of the normal-equation kernel: one workgroup per CU, rows dealt longest-processing-time first (the rows
+    // arrive sorted by length, each goes to the least loaded workgroup; cost = the row's 16-non-zero steps + a fixed
+    // per-row solve).  Static lists make the per-row loss slots and the summation order deterministic.
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int n_wg = std::min(n_stream, std::max(cus, 1));
+    std::vector<int64_t> load((size_t)n_wg, 0);
+    std::vector<int> owner((size_t)n_stream);
+    std::vector<int32_t> cnt_wg((size_t)n_wg + 1, 0);
+    std::priority_queue<std::pair<int64_t, int>, std::vector<std::pair<int64_t, int>>, std::greater<>> heap;
+    for (int w = 0; w < n_wg; w++) heap.push({0, w});
+    for (int r = 0; r < n_stream; r++) {
+      auto top = heap.top();
+      heap.pop();
+      const int64_t len = soff[(size_t)r + 1] - soff[(size_t)r];
+      owner[(size_t)r] = top.second;
+      cnt_wg[(size_t)top.second + 1]++;
+      heap.push({top.first + (len + 15) / 16 + 12, top.second});
+    }
+    for (int w = 0; w < n_wg; w++) cnt_wg[(size_t)w + 1] += cnt_wg[(size_t)w];
+    std::vector<int32_t> lists((size_t)n_stream), fill(cnt_wg.begin(), cnt_wg.end() - 1);
+    for (int r = 0; r < n_stream; r++) lists[(size_t)fill[(size_t)owner[(size_t)r]]++] = order[(size_t)r];
+    HIP_TRY(hipMalloc(&d.q_ne_rows, lists.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(d.q_ne_rows, lists.data(), lists.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&d.q_ne_ptr, cnt_wg.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(d.q_ne_ptr, cnt_wg.data(), cnt_wg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    d.q_ne_wg = n_wg;
   }
   return RSPARSE_HIP_OK;
 }
@@ -299,6 +330,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   qs.order = d.q_order;
   qs.cfg = d.q_cfg;
   for (int b = 0; b < 7; b++) qs.off[b] = d.q_off[b];
+  qs.ne_rows = d.q_ne_rows; qs.ne_ptr = d.q_ne_ptr; qs.ne_wg = d.q_ne_wg;
   const size_t slots = cgq ? cgq_loss_slots(qs, rank) : (cg ? cg_loss_slots(d.n_cols, d.n_long) : chol_loss_slots(d.n_cols));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
   double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
@@ -317,7 +349,13 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.loss_tgt = bias ? bias->loss_tgt : nullptr;
   a.rhs_init = bias ? bias->rhs_init : nullptr;
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
-  a.work_counter = g_ws.counter;
+  a.ne_prof = nullptr;
+#ifdef RSP_NE_PROF
+  static unsigned long long* prof_buf = nullptr;
+  if (!prof_buf) { HIP_TRY(hipMalloc(&prof_buf, 1024 * 4 * 20 * 8)); }
+  HIP_TRY(hipMemsetAsync(prof_buf, 0, 1024 * 4 * 20 * 8, s));
+  a.ne_prof = prof_buf;
+#endif
   {
     static const char* ts_env = std::getenv("RSPARSE_HIP_TSCRATCH");
     const bool ts_on = !(ts_env && ts_env[0] == '0');
@@ -337,6 +375,23 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
   e = launch_sum_partials(g_ws.partials, slots, out, s);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
+#ifdef RSP_NE_PROF
+  if (cgq && d.q_ne_wg > 0 && std::getenv("RSPARSE_NE_PROF")) {
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<unsigned long long> hp((size_t)d.q_ne_wg * 4 * 20);
+    HIP_TRY(hipMemcpy(hp.data(), prof_buf, hp.size() * 8, hipMemcpyDeviceToHost));
+    const char* nm[20] = {"wait_vm", "barrier", "issue", "consume", "tail", "total", "rows", "pre", "chain", "cg", "quad", "fin", "ch_sync", "ch_add", "ch_bar", "mv_pub", "mv_units", "mv_bar", "mv_comb", "-"};
+    for (int w = 0; w < 4; w++) {
+      std::fprintf(stderr, "[ne_prof] wave %d (n_cols %d):", w, d.n_cols);
+      for (int j = 0; j < 19; j++) {
+        double sum = 0, mx = 0;
+        for (int b = 0; b < d.q_ne_wg; b++) { const double v = (double)hp[((size_t)b * 4 + w) * 20 + j]; sum += v; mx = std::max(mx, v); }
+        std::fprintf(stderr, " %s %.2f/%.2f", nm[j], sum / d.q_ne_wg / 1e6, mx / 1e6);
+      }
+      std::fprintf(stderr, " Mcycles (mean/max over %d workgroups)\n", d.q_ne_wg);
+    }
+  }
+#endif
   if (ev) {
     const int last = cgq ? 7 : 3;
     HIP_TRY(hipEventRecord(ev[last], s));
@@ -644,6 +699,8 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   if (d.long_rows) (void)hipFree(d.long_rows);
   if (d.q_order) (void)hipFree(d.q_order);
   if (d.q_stream_off) (void)hipFree(d.q_stream_off);
+  if (d.q_ne_rows) (void)hipFree(d.q_ne_rows);
+  if (d.q_ne_ptr) (void)hipFree(d.q_ne_ptr);
   if (d.owns_matrix) {
     if (d.col_ptrs) (void)hipFree(const_cast<int32_t*>(d.col_ptrs));
     if (d.row_idx) (void)hipFree(const_cast<int32_t*>(d.row_idx));

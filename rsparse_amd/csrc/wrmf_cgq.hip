@@ -711,7 +711,7 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
           if ((err = hipStreamWaitEvent(bs, g_bs.fork, 0)) != hipSuccess) return err;                       \
         }                                                                                                   \
         if (D.stream && ne_supported(a.k)) {                                                                \
-          if ((err = launch_als_ne(a, q.order + q.off[B], n, IMPLICIT, a.work_counter, a.loss_partials + slot, bs)) != hipSuccess) \
+          if ((err = launch_als_ne(a, q.ne_rows, q.ne_ptr, q.ne_wg, IMPLICIT, a.loss_partials + slot, bs)) != hipSuccess) \
             return err;                                                                                     \
         } else if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, grid, slot, \
                                                                                 bs)) != hipSuccess)         \

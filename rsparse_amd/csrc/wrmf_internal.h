@@ -26,6 +26,11 @@ struct DevCSC {
   int q_cfg = 0;
   int64_t q_nnz[6] = {0, 0, 0, 0, 0, 0};
   int64_t* q_stream_off = nullptr;  // prefix sums of the streamed bucket's row lengths (device)
+  // normal-equation kernel (wrmf_ne.hip): the long rows (bucket 0) dealt to q_ne_wg workgroups, longest processing
+  // time first; workgroup b owns q_ne_rows[q_ne_ptr[b], q_ne_ptr[b+1])
+  int32_t* q_ne_rows = nullptr;
+  int32_t* q_ne_ptr = nullptr;
+  int q_ne_wg = 0;
   int64_t nnz_long = 0;
   int n_empty = 0;
   bool owns_matrix = false;
@@ -58,13 +63,16 @@ struct AlsArgs {
   float* tscr;
   const int64_t* stream_off;
   int64_t stream_nnz;
-  int* work_counter;      // one int of device scratch: row queue of the normal-equation kernel (wrmf_ne.hip)
+  unsigned long long* ne_prof;   // RSP_NE_PROF builds: [workgroup][wave][8] cycle counters of wrmf_ne.hip (else nullptr)
 };
 
 struct QSchedule {
   const int32_t* order;
   int off[7];
   int cfg;  // geometry the schedule was built for (see wrmf_cgq.hip kBuckets)
+  const int32_t* ne_rows;  // see DevCSC::q_ne_*
+  const int32_t* ne_ptr;
+  int ne_wg;
 };
 int cgq_default_cfg();
 int cgq_num_buckets();               // 6
@@ -77,7 +85,7 @@ int cgq_bucket_of(int len, int cfg);
 size_t cgq_loss_slots(const QSchedule& q, int k);
 // long rows (bucket 0) by one-pass normal equations on the matrix cores (wrmf_ne.hip) instead of the streamed CG kernel
 bool ne_supported(int k);
-hipError_t launch_als_ne(const AlsArgs& a, const int32_t* rows, int n_rows, bool implicit, int* counter,
+hipError_t launch_als_ne(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
                          double* row_loss, hipStream_t s);
 // ev (optional): 7 events, ev[b] before bucket b's kernel, ev[6] after the last one
 hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);

@@ -10,23 +10,28 @@
 // are accumulated on the MFMA pipes while the vectors stream through, and the per-row solve then runs on the k x k
 // system  A = XtX + M1  (explicit: A = M2 + lambda_use I)  held in LDS: cg_solver_implicit / cg_solver_explicit
 // (wrmf_implicit.hpp:8-32, wrmf_explicit.hpp:8-31) with  A p  in place of  XtX p + X_nnz ((c-1) % X_nnz^T p)  -- the
-// same operator, evaluated from the assembled matrix -- or the exact solve of the Cholesky branch.  The loss
-// sum_j c_j (1 - x_j.y)^2  (wrmf_implicit.hpp:259-261) needs no second pass either: it equals
-// sum c - 2 y.b + y^T (M1 + M2) y, and the quadratic forms are read off the accumulators.
+// same operator, evaluated from the assembled matrix.  The loss  sum_j c_j (1 - x_j.y)^2  (wrmf_implicit.hpp:259-261)
+// needs no second pass either: it equals  sum c - 2 y.b + y^T (M1 + M2) y, and the quadratic forms are read off the
+// accumulators.
 //
 // Arithmetic: fp32 MFMA runs at the vector rate (157 TF), bf16 MFMA 16x faster.  Every fp32 operand is split exactly
 // into NS bf16 terms (x = x1 + x2 [+ x3], residuals are exact in fp32) and the products of total order < NS are
 // accumulated in fp32 by v_mfma_f32_32x32x16_bf16: NS = 3 keeps 6 products and is accurate to ~2^-23 per product, i.e.
 // fp32-equivalent; M2 only feeds the loss and always uses the 3 products of its first two terms (2^-16).
 //
-// Layout: a workgroup = 4 waves = one row at a time; the waves take the row's 16-non-zero steps round robin, each with
-// its own accumulators (lower-triangular 32x32 tiles: 10 per matrix at rank 128) and its own 3-deep LDS ring that
-// LDS-DMA (global_load_lds_dwordx4, whole 512-byte vectors, no staging registers) fills two steps ahead; the MFMA
-// operands are read back from the ring transposed (lane = factor dimension, register = non-zero), so the gather is
-// coalesced and the transposition is free.  Index and value chunks travel through the same DMA path.  All VMEM traffic
-// of the loop is issued from inline asm with counted s_waitcnt vmcnt(N): hipcc would otherwise drain the queue
-// (vmcnt(0)) at every use and serialise gather and compute.
+// Structure: a workgroup = 4 waves = one row at a time, rows from a per-workgroup list balanced on the host (longest
+// processing time first).  The row's 16-non-zero steps go round robin to the workgroup's RING GROUPS: a group is the
+// set of waves that consume the same steps (one wave, or a PAIR of waves that split the accumulator tiles when one wave
+// cannot hold them all).  Each group owns a ring of D slots in LDS that it fills by LDS-DMA
+// (global_load_lds_dwordx4: whole 512-byte vectors, no staging registers; every wave of the group issues its share,
+// because one wave keeps only ~10 KB of LDS-DMA in flight) D-1 steps ahead; the stream of steps runs
+// ACROSS row boundaries, so the gather of the next row is in flight while the current row is solved.  MFMA operands are
+// read back from the ring transposed (lane = factor dimension, register = non-zero): the gather is coalesced and the
+// transposition is free.  Index and value chunks travel through the same DMA path (indices 2(D-1) steps ahead).  All
+// VMEM traffic of the kernel is issued from inline asm with counted s_waitcnt vmcnt(N): hipcc would otherwise drain the
+// queue (vmcnt(0)) at every use and serialise gather and compute; row metadata comes through scalar loads (lgkmcnt).
 #include <type_traits>
+#include <utility>
 
 #include "wrmf_internal.h"
 #include "wrmf_device.h"
@@ -43,10 +48,98 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kCgTolNe = 1e-10f;  // CG_TOL, inst/include/wrmf.hpp:22
-constexpr int kRing = 3;            // vector / value slots per wave
 constexpr int kStepNnz = 16;        // K of v_mfma_f32_32x32x16_bf16
 
-template <int KP>
+// Which wave accumulates what.  Rank 128 with implicit feedback needs 20 accumulator tiles (320 registers): more than
+// one wave can hold next to its operands, so there the waves work in PAIRS on the same steps (two ring groups instead
+// of four) and split the tiles by role; everywhere else a wave owns every tile of its own steps.
+//   NS = 3 (M1: 6 products per tile, M2: 3):  role 0 = M1 tile rows 2,3 + 2 M2 tiles (48 products, 9 tiles),
+//                                             role 1 = M1 rows 0,1 + 8 M2 tiles (42 products, 11 tiles)
+//   NS = 2 (3 and 3):                         role 0 = M1, role 1 = M2
+struct NeMfmaOp { int slot, m, R, C, pa, pb; };   // acc[slot] += (m == 0 ? A-operand term pa : x term pa) of block R x (x term pb of block C)
+struct NeUnit { int kind, t, pair; };             // a pair of floats to split: kind 0 = x, 1 = (c - 1) x; block t, floats 2 pair, 2 pair + 1
+
+template <int KP, int NS, bool IMPLICIT>
+struct NeRoles {
+  static constexpr int NB = KP / 32;
+  static constexpr int NT = NB * (NB + 1) / 2;
+  static constexpr bool PAIR = IMPLICIT && KP == 128;
+  static constexpr int NSETS = PAIR ? 2 : 4;  // ring groups
+  // Accumulator slot of tile (R, C) of matrix m (0 = the matrix of the system: implicit M1, explicit M2; 1 = implicit M2,
+  // loss only) for a wave of the given role, or -1 if that wave does not accumulate the tile
+  __host__ __device__ static constexpr int tile(int R, int C) { return R * (R + 1) / 2 + C; }
+  __host__ __device__ static constexpr int slot(int role, int m, int R, int C) {
+    if (!IMPLICIT) return m == 0 ? tile(R, C) : -1;
+    if (!PAIR) return m * NT + tile(R, C);
+    if (NS >= 3) {
+      // role 0: M1 tile rows 2, 3 (slots 0..6, 42 products) + M2 tiles (0,0), (1,1) (slots 7, 8; 6 products)
+      // role 1: M1 tile rows 0, 1 (slots 0..2, 18 products) + the other 8 M2 tiles (slots 3..10; 24 products)
+      const bool m2_r0 = R == C && R < 2;
+      if (role == 0) return m == 0 ? (R >= 2 ? tile(R, C) - 3 : -1) : (m2_r0 ? 7 + R : -1);
+      if (m == 0) return R < 2 ? tile(R, C) : -1;
+      if (m2_r0) return -1;
+      return tile(R, C) == 1 ? 3 : tile(R, C) + 1;   // tiles 1, 3, 4, .., 9 -> 3, 4, 5, .., 10
+    }
+    return m == role ? tile(R, C) : -1;
+  }
+  static constexpr int NSLOT = !IMPLICIT ? NT : (!PAIR ? 2 * NT : (NS >= 3 ? 11 : 10));
+  __host__ __device__ static constexpr bool owns_row(int role, int R) { return IMPLICIT && slot(role, 0, R, 0) >= 0; }
+  __host__ __device__ static constexpr int rhs_role() { return PAIR ? 1 : 0; }  // who accumulates b and sum c
+
+  // The MFMAs of one step in issue order: product-major, so that two MFMAs on the same accumulator are a whole sweep over
+  // the tiles apart.  M2 (implicit) takes the products of its first two terms, the system matrix those of total order < NS.
+  __host__ __device__ static constexpr int mfma_count(int role) {
+    int n = 0;
+    for (int R = 0; R < NB; R++)
+      for (int C = 0; C <= R; C++) {
+        if (slot(role, 0, R, C) >= 0) n += NS * (NS + 1) / 2;
+        if (IMPLICIT && slot(role, 1, R, C) >= 0) n += 3;
+      }
+    return n;
+  }
+  __host__ __device__ static constexpr NeMfmaOp mfma_op(int role, int j) {
+    int n = 0;
+    // the system matrix first: its (c - 1) x operands are then dead early and their registers serve the next step's
+    for (int pa = 0; pa < NS; pa++)
+      for (int pb = 0; pb + pa < NS; pb++)
+        for (int R = 0; R < NB; R++)
+          for (int C = 0; C <= R; C++)
+            if (slot(role, 0, R, C) >= 0) {
+              if (n == j) return NeMfmaOp{slot(role, 0, R, C), 0, R, C, pa, pb};
+              n++;
+            }
+    if (IMPLICIT)
+      for (int pa = 0; pa < 2; pa++)
+        for (int pb = 0; pb + pa < 2; pb++)
+          for (int R = 0; R < NB; R++)
+            for (int C = 0; C <= R; C++)
+              if (slot(role, 1, R, C) >= 0) {
+                if (n == j) return NeMfmaOp{slot(role, 1, R, C), 1, R, C, pa, pb};
+                n++;
+              }
+    return NeMfmaOp{-1, 0, 0, 0, 0, 0};
+  }
+  // The split work of one step: the 4 float pairs of every block of x, then those of (c - 1) x for the owned tile rows
+  __host__ __device__ static constexpr int unit_count(int role) {
+    int n = 4 * NB;
+    for (int t = 0; t < NB; t++) n += owns_row(role, t) ? 4 : 0;
+    return n;
+  }
+  __host__ __device__ static constexpr NeUnit unit(int role, int u) {
+    if (u < 4 * NB) return NeUnit{0, u / 4, u % 4};
+    int n = 4 * NB;
+    for (int t = 0; t < NB; t++)
+      if (owns_row(role, t)) {
+        if (u < n + 4) return NeUnit{1, t, u - n};
+        n += 4;
+      }
+    return NeUnit{-1, 0, 0};
+  }
+  // the unit before which the ring values of unit u's block must be requested: -1 = before the MFMA sequence
+  __host__ __device__ static constexpr bool first_of_block(int role, int u) { return unit(role, u).pair == 0; }
+};
+
+template <int KP, bool PAIR, bool IMPLICIT>
 struct NeGeo {
   static constexpr int NB = KP / 32;               // 32-wide blocks of the factor dimension
   static constexpr int NT = NB * (NB + 1) / 2;     // lower-triangular tiles
@@ -55,17 +148,24 @@ struct NeGeo {
   static constexpr int LPV = 64 / VPI;             // lanes per vector
   static constexpr int VEC_BYTES = NI * 1024;      // one step of gathered vectors
   static constexpr int SLOT_BYTES = VEC_BYTES + 256 /* values */;
-  static constexpr int IDX_SLOT = 256;
-  static constexpr int WAVE_RING = kRing * SLOT_BYTES + kRing * IDX_SLOT;
-  static constexpr int LDA = KP + 4;               // row stride of A: transposed 16-byte tile writes hit 8 bank groups
-  // solve phase (aliases the rings): A | chain scratch | vectors
-  static constexpr int A_BYTES = KP * LDA * 4;
-  static constexpr int P_BYTES = NT * 16 * 64 * 4;
-  static constexpr int V_FLOATS = 4 * KP /* b partials */ + 2 * 4 * KP /* matvec partials, double buffered */ +
-                                  4 * KP /* per-wave published vector */ + 64 /* scalars */;
-  static constexpr int SOLVE_BYTES = A_BYTES + P_BYTES + V_FLOATS * 4;
-  static constexpr int RING_BYTES = 4 * WAVE_RING;
-  static constexpr int BYTES = (SOLVE_BYTES > RING_BYTES ? SOLVE_BYTES : RING_BYTES) + 64;
+  static constexpr int NRING = PAIR ? 2 : 4;
+  static constexpr int D = KP == 128 ? 3 : 6;      // slots per ring; D - 1 steps requested ahead (a wave keeps only ~10 KB
+                                                   // of LDS-DMA in flight -- measured, tools/probes -- so more does not help)
+  static constexpr int IDXR = 2 * D - 1;           // index-chunk slots per ring (256 B each)
+  static constexpr int LOADERS = PAIR ? 2 : 1;     // waves of a ring group that issue its DMA: all of them
+  static constexpr int GROUP = NI / LOADERS + (PAIR ? 1 : 2);  // DMA instructions per step and wave: its share of the
+                                                               // vector pieces + the index chunk and / or the values
+  static constexpr int RING_BYTES = D * SLOT_BYTES + IDXR * 256;
+  static constexpr int TLD = 33;                   // row stride inside a 32 x 32 tile (conflict-free by rows and by columns)
+  static constexpr int A_FLOATS = NT * 32 * TLD;
+  static constexpr int G_FLOATS = IMPLICIT ? A_FLOATS : 0;   // XtX as tiles, resident for the whole launch
+  static constexpr int YB = 8;                     // solved rows buffered in LDS before one wave stores them
+  static constexpr int V_FLOATS = 4 * KP /* b partials */ + 2 * NB * NB * 32 /* matvec partials, double buffered */ +
+                                  4 * KP /* per-wave published vector */ + 256 /* warm start (DMA target, 1 KB) */ +
+                                  YB * KP + 4 * YB /* row ids, loss slots, losses (double) */ + 64 /* scalars */;
+  static constexpr int BYTES = NRING * RING_BYTES + (A_FLOATS + G_FLOATS + V_FLOATS) * 4;
+  static_assert(BYTES <= 160 * 1024, "LDS budget");
+  static_assert((D - 2) * GROUP <= 63, "vmcnt is a 6-bit field");
   __host__ __device__ static constexpr int tile(int R, int C) { return R * (R + 1) / 2 + C; }
 };
 
@@ -96,29 +196,27 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// scalar load (lgkmcnt, not vmcnt: does not disturb the DMA queue accounting); the address must be wave-uniform
+__device__ __forceinline__ int sload(const int* p) {
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   const f32x2 f = {lo, hi};
   const bf16x2 h = __builtin_convertvector(f, bf16x2);  // v_cvt_pk_bf16_f32 (round to nearest even)
   return __builtin_bit_cast(unsigned, h);
 }
-
-// f[0..7] -> NS exact bf16 terms, packed as MFMA operands (element e of the operand = non-zero 8 * (lane / 32) + e)
-template <int NS>
-__device__ __forceinline__ void split8(const float (&f)[8], u32x4 (&parts)[NS]) {
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    float r0 = f[2 * j], r1 = f[2 * j + 1];
-#pragma unroll
-    for (int p = 0; p < NS; p++) {
-      const unsigned pk = pack_bf16(r0, r1);
-      parts[p][j] = pk;
-      if (p + 1 < NS) {
-        r0 -= __uint_as_float(pk << 16);
-        r1 -= __uint_as_float(pk & 0xffff0000u);
-      }
-    }
+// one term of the exact bf16 expansion of the pair r: returns the packed term and leaves the residuals (v_pk_add_f32)
+__device__ __forceinline__ unsigned split_stage(f32x2& r, bool last) {
+  const bf16x2 hb = __builtin_convertvector(r, bf16x2);  // v_cvt_pk_bf16_f32 (round to nearest even)
+  const unsigned pk = __builtin_bit_cast(unsigned, hb);
+  if (!last) {
+    const f32x2 hi = {__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+    r -= hi;
   }
+  return pk;
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
@@ -153,466 +251,613 @@ __device__ __forceinline__ float half_swap_sum(float v) {  // v(l) + v(l ^ 32)
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float wave_sum_all(float v) { return groups_sum_ne(row16_sum_ne(v)); }
+// LDS float add without return value (ds_add_f32)
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
-// Which wave accumulates what.  Rank 128 with implicit feedback needs 20 accumulator tiles (320 registers): more than
-// one wave can hold next to its operands, so there the waves work in PAIRS on the same steps (two step sets instead of
-// four) and split the tiles by role; everywhere else a wave owns every tile of its own steps.
-//   NS = 3 (M1: 6 products per tile, M2: 3):  role 0 = M1 tile rows 2,3 (42 products), role 1 = M1 rows 0,1 + M2 (48)
-//   NS = 2 (3 and 3):                         role 0 = M1, role 1 = M2
-template <int KP, int NS, bool IMPLICIT>
-struct NeRoles {
-  static constexpr bool PAIR = IMPLICIT && KP == 128;
-  static constexpr int NSETS = PAIR ? 2 : 4;
-  // m: 0 = the matrix of the system (implicit M1, explicit M2), 1 = implicit M2 (loss only)
-  __host__ __device__ static constexpr bool owns(int role, int m, int R, int /*C*/) {
-    if (!PAIR) return true;
-    if (NS >= 3) return m == 0 ? (role == 0 ? R >= 2 : R < 2) : role == 1;
-    return m == role;
-  }
-  __host__ __device__ static constexpr bool owns_row(int role, int m, int R) { return owns(role, m, R, 0); }
-  __host__ __device__ static constexpr int rhs_role() { return PAIR ? 1 : 0; }  // who accumulates b and sum c
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// position of a ring group's gather stream: row `li` of the workgroup's list, step `s` of the group's steps in that row
+struct NeCursor {
+  int li, s, nst, p1, cnt;
+  bool live;
 };
 
-// SOLVER: 1 = conjugate gradient on the assembled system, 0 = exact (Cholesky) solve in LDS
-template <int KP, int NS, bool IMPLICIT, int SOLVER>
-__global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
-                                                         int* __restrict__ work_counter,
+template <int NB, int NS>
+struct NeParts {   // MFMA operands of one step: block t, term q
+  u32x4 x[NB][NS];   // x
+  u32x4 a[NB][NS];   // (c - 1) x   (tile rows this wave owns; implicit only)
+};
+
+template <int KP, int NS, bool IMPLICIT>
+__global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t* __restrict__ wg_rows,
+                                                         const int32_t* __restrict__ wg_ptr, int slot0,
                                                          double* __restrict__ row_loss) {
-  using G_ = NeGeo<KP>;
   using RL = NeRoles<KP, NS, IMPLICIT>;
-  constexpr int NB = G_::NB, NT = G_::NT, NI = G_::NI, LPV = G_::LPV, LDA = G_::LDA;
+  using G_ = NeGeo<KP, RL::PAIR, IMPLICIT>;
+  constexpr int NB = G_::NB, NT = G_::NT, NI = G_::NI, LPV = G_::LPV, D = G_::D, IDXR = G_::IDXR, TLD = G_::TLD;
   constexpr int NM = IMPLICIT ? 2 : 1;  // accumulated matrices: implicit {M1, M2}, explicit {M2}
-  constexpr int NSETS = RL::NSETS;
-  constexpr int LV = KP / 4;            // lanes of one copy of a rank-vector (4 floats per lane)
-  constexpr int COPIES = 64 / LV;
-  constexpr int RW = KP / 4;            // rows of A per wave in the matrix-vector product
-  constexpr int RPC = RW / COPIES;      // ... per copy
+  constexpr int NSETS = RL::NSETS, NSLOT = RL::NSLOT, YB = G_::YB;
+  constexpr bool PAIR = RL::PAIR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int h = lane >> 5, d = lane & 31;
   const int k = a.k;
-  const int wset = RL::PAIR ? wv >> 1 : wv;   // which steps of a row this wave works on: wset, wset + NSETS, ...
-  const int wrole = RL::PAIR ? wv & 1 : 0;
+  const int wset = PAIR ? wv >> 1 : wv;   // ring group: its steps of a row are wset, wset + NSETS, ...
+  const int wrole = PAIR ? wv & 1 : 0;
 
-  // accumulate phase: per-wave ring
-  char* ring = smem + wv * G_::WAVE_RING;
+  char* ring = smem + wset * G_::RING_BYTES;
   const unsigned ring_a = rfl((int)lds_addr(ring));
-  auto vec_slot = [&](int i) { return ring_a + (unsigned)((i % kRing) * G_::SLOT_BYTES); };
-  auto idx_slot = [&](int i) { return ring_a + (unsigned)(kRing * G_::SLOT_BYTES + (i % kRing) * G_::IDX_SLOT); };
-  // solve phase
-  float* sA = reinterpret_cast<float*>(smem);
-  float* sP = reinterpret_cast<float*>(smem + G_::A_BYTES);
-  float* sB = reinterpret_cast<float*>(smem + G_::A_BYTES + G_::P_BYTES);  // [4][KP]
-  float* sRed = sB + 4 * KP;                                               // [2][4][KP]
-  float* sPub = sRed + 2 * 4 * KP;                                         // [4][KP]
-  float* sScal = sPub + 4 * KP;                                            // [64]
-  int* sNext = reinterpret_cast<int*>(smem + G_::BYTES - 64);
+  float* sA = reinterpret_cast<float*>(smem + G_::NRING * G_::RING_BYTES);  // NT tiles of 32 x TLD: the row's system
+  float* sG = sA + G_::A_FLOATS;     // XtX in the same tile layout (implicit)
+  float* sB = sG + G_::G_FLOATS;     // [4][KP]        right-hand-side partials of the waves
+  float* sPart = sB + 4 * KP;        // [2][NB*NB][32] matrix-vector partials, double buffered
+  float* sPub = sPart + 2 * NB * NB * 32;  // [4][KP]  per-wave published vector
+  float* sX0 = sPub + 4 * KP;        // [256]          warm start of the row (DMA target)
+  float* sY = sX0 + 256;             // [YB][KP]       solved rows waiting to be stored
+  int* sYrow = reinterpret_cast<int*>(sY + YB * KP);          // [YB] row ids
+  int* sYli = sYrow + YB;                                     // [YB] loss slots
+  double* sYloss = reinterpret_cast<double*>(sYli + YB);      // [YB]
+  float* sScal = reinterpret_cast<float*>(sYloss + YB);       // [64]
 
-  const int dq = lane / LPV;                 // which vector of a DMA instruction this lane copies
+  const int dq = lane / LPV;                     // which vector of a DMA instruction this lane copies
   const int dl4 = min((lane % LPV) * 4, k - 4);  // its 16-byte piece; pieces beyond the rank re-read the last one
                                                  // (never past the vector) and are zeroed when they are consumed
+  const int list_begin = sload(wg_ptr + blockIdx.x), list_end = sload(wg_ptr + blockIdx.x + 1);
+
+  if constexpr (IMPLICIT) {   // XtX -> LDS tiles, once (ordinary loads: the DMA queue is still empty)
+    for (int e = tid; e < NT * 1024; e += 256) {
+      const int t = e >> 10, i = (e >> 5) & 31, j = e & 31;
+      const int R = t >= 6 ? 3 : (t >= 3 ? 2 : (t >= 1 ? 1 : 0)), C = t - R * (R + 1) / 2;
+      const int gi = 32 * R + i, gj = 32 * C + j;
+      sG[t * 32 * TLD + i * TLD + j] = (gi < k && gj < k) ? a.XtX[(size_t)gi * k + gj] : 0.f;
+    }
+  }
+
+  // ---- gather stream of this ring group ----
+  auto load_row = [&](NeCursor& c) {
+    c.s = 0;
+    if (c.li < list_end) {
+      const int row = sload(wg_rows + c.li);
+      c.p1 = sload(a.col_ptrs + row);
+      c.cnt = sload(a.col_ptrs + row + 1) - c.p1;
+      const int nsteps = (c.cnt + kStepNnz - 1) / kStepNnz;
+      c.nst = (nsteps - wset + NSETS - 1) / NSETS;
+    } else {
+      c.live = false;
+      c.nst = 1 << 30;
+    }
+  };
+  auto advance = [&](NeCursor& c) {
+    c.s++;
+    while (c.live && c.s >= c.nst) {
+      c.li++;
+      load_row(c);
+    }
+  };
+  auto start = [&](NeCursor& c) {
+    c.li = list_begin - 1;
+    c.s = 0;
+    c.nst = 0;
+    c.live = true;
+    c.p1 = 0;
+    c.cnt = 1;
+    advance(c);
+  };
+  NeCursor ci, cv;   // index-chunk stream, vector stream
+  int islot = 0, vslot = 0, vislot = 0;  // ring slots: next index chunk, next vector step, index chunk that step reads
+  auto issue_idx = [&]() {  // index chunk of the step (and the 48 entries behind it), clamped to the row
+    const int pos = ci.live ? ci.p1 + min((wset + NSETS * ci.s) * kStepNnz + lane, ci.cnt - 1) : 0;
+    if (wrole == 0) dma4(a.row_idx + pos, ring_a + (unsigned)(D * G_::SLOT_BYTES + islot * 256));
+    islot = islot + 1 == IDXR ? 0 : islot + 1;
+    advance(ci);
+  };
+  // needs the step's index chunk in LDS; past the end of the list: harmless copies of row 0.  In a pair each wave issues
+  // half of the vector pieces (role 0 also the index chunks, role 1 the values)
+  auto issue_vec = [&](auto role_tag) {
+    constexpr int LR = decltype(role_tag)::value;
+    const int* ix = reinterpret_cast<const int*>(ring + D * G_::SLOT_BYTES + vislot * 256) + dq * NI;
+    int id[NI];
+    if constexpr (NI == 8) {
+      const int4 i0 = *reinterpret_cast<const int4*>(ix), i1 = *reinterpret_cast<const int4*>(ix + 4);
+      id[0] = i0.x; id[1] = i0.y; id[2] = i0.z; id[3] = i0.w;
+      id[4] = i1.x; id[5] = i1.y; id[6] = i1.z; id[7] = i1.w;
+    } else {
+      const int4 i0 = *reinterpret_cast<const int4*>(ix);
+      id[0] = i0.x; id[1] = i0.y; id[2] = i0.z; id[3] = i0.w;
+    }
+    const unsigned base = ring_a + (unsigned)(vslot * G_::SLOT_BYTES);
+#pragma unroll
+    for (int e = 0; e < NI; e++)
+      if (e / (NI / G_::LOADERS) == LR) dma16(a.X + (size_t)id[e] * k + dl4, base + e * 1024);
+    const int pos = cv.live ? cv.p1 + min((wset + NSETS * cv.s) * kStepNnz + lane, cv.cnt - 1) : 0;
+    if (LR == G_::LOADERS - 1) dma4(a.vals + pos, base + G_::VEC_BYTES);
+    vslot = vslot + 1 == D ? 0 : vslot + 1;
+    vislot = vislot + 1 == IDXR ? 0 : vislot + 1;
+    advance(cv);
+  };
+  {
+    start(ci);
+    start(cv);
+    // steady state, consuming stream position q: issue {index chunk q + 2(D-1), vectors q + D-1}.  Prologue = the
+    // index chunks 0 .. D-2, then the "virtual" positions -(D-1) .. -1
+    for (int j = 0; j < D - 1; j++) issue_idx();
+    wait_vm<0>();
+    __syncthreads();   // the partner reads the index chunks too; XtX tiles are in place
+    for (int j = 0; j < D - 1; j++) {
+      issue_idx();
+      if (wrole == 0) issue_vec(std::integral_constant<int, 0>{});
+      else issue_vec(std::integral_constant<int, 1>{});
+    }
+  }
+  int cslot = 0;  // ring slot of the next step this wave consumes
   int buf = 0;
+  int nbuf = 0;   // solved rows waiting in sY
+#ifdef RSP_NE_PROF
+  unsigned long long prof_t[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long prof_start = __builtin_amdgcn_s_memtime();
+  unsigned long long _tl = prof_start;
+#define NE_T(j) { const unsigned long long _t1 = __builtin_amdgcn_s_memtime(); prof_t[j] += _t1 - _tl; _tl = _t1; }
+#else
+#define NE_T(j)
+#endif
 
-  for (;;) {
-    if (tid == 0) *sNext = atomicAdd(work_counter, 1);
-    __syncthreads();
-    const int ri = rfl(*sNext);
-    if (ri >= n_rows) break;
-    const int row = rfl(rows[ri]);
-    const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
-    const int cnt = p2 - p1;
+  for (int li = list_begin; li < list_end; li++) {
+    const int row = sload(wg_rows + li);
+    const int p1 = sload(a.col_ptrs + row);
+    const int cnt = sload(a.col_ptrs + row + 1) - p1;
     const int nsteps = (cnt + kStepNnz - 1) / kStepNnz;
-    const int nst = (nsteps - wset + NSETS - 1) / NSETS;   // this wave's steps: global steps wset, wset + NSETS, ...
-    float* yrow = a.Y + (size_t)row * k;
+    const int nst = (nsteps - wset + NSETS - 1) / NSETS;   // this group's steps
+    const int nst_max = (nsteps + NSETS - 1) / NSETS;      // group 0's steps (barrier count in PAIR mode)
     const float lam_use = IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)cnt : 1.0));
+    // warm start -> LDS by DMA (an ordinary load would make hipcc drain the look-ahead queue where the value is used).
+    // It is older than every vector group this row issues, so it has landed once a step issued in this row has been
+    // waited for, i.e. after D - 1 steps of wave 0's group; shorter rows drain explicitly below
+    if (wv == 0) dma16(a.Y + (size_t)row * k + min((lane & 31) * 4, k - 4), rfl((int)lds_addr(sX0)));
+    NE_T(7)
 
-    // ---- gather pipeline (no selects: every source address is valid, padding is zeroed at consumption) ----
-    auto issue_idx = [&](int i) {  // index chunk of this wave's step i (and the 48 entries behind it), clamped to the row
-      const int pos = min(p1 + (wset + NSETS * i) * kStepNnz + lane, p2 - 1);
-      dma4(a.row_idx + pos, idx_slot(i));
-    };
-    auto issue_vec = [&](int i) {  // needs the index chunk of step i in LDS
-      const int s0 = (wset + NSETS * i) * kStepNnz;
-      const int* ix = reinterpret_cast<const int*>(smem + (idx_slot(i) - lds_addr(smem))) + dq * NI;
-      int id[NI];
-      if constexpr (NI == 8) {
-        const int4 i0 = *reinterpret_cast<const int4*>(ix), i1 = *reinterpret_cast<const int4*>(ix + 4);
-        id[0] = i0.x; id[1] = i0.y; id[2] = i0.z; id[3] = i0.w;
-        id[4] = i1.x; id[5] = i1.y; id[6] = i1.z; id[7] = i1.w;
-      } else {
-        const int4 i0 = *reinterpret_cast<const int4*>(ix);
-        id[0] = i0.x; id[1] = i0.y; id[2] = i0.z; id[3] = i0.w;
-      }
-      const unsigned base = vec_slot(i);
+    // accumulators: NSLOT tiles; what a slot holds depends on the wave's role (NeRoles::slot)
+    f32x16 acc[NSLOT];
 #pragma unroll
-      for (int e = 0; e < NI; e++) dma16(a.X + (size_t)id[e] * k + dl4, base + e * 1024);
-      const int pos = min(p1 + s0 + lane, p2 - 1);
-      dma4(a.vals + pos, base + G_::VEC_BYTES);
-    };
-    constexpr int GROUP = NI + 2;  // DMA instructions per pipeline group: 1 index chunk + NI vector pieces + 1 value chunk
+    for (int t = 0; t < NSLOT; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+    float bp[NB], bp_hi[NB];
+#pragma unroll
+    for (int t = 0; t < NB; t++) bp[t] = bp_hi[t] = 0.f;
+    double sc = 0.0;
 
-    auto body = [&](auto role_tag) {
+    // ---- accumulate.  Software-pipelined by one step: the MFMAs of step i-1 (operands `cur`, split in the previous
+    // iteration) are issued one by one, each followed by a slice of the split arithmetic of step i (operands `nxt`),
+    // which is independent of them.  The order is pinned with sched_barrier: left alone, hipcc issues the MFMAs back to
+    // back and the ~300 VALU instructions after them, and the step takes the SUM of the two instead of the maximum.
+    auto accumulate = [&](auto role_tag) {
       constexpr int ROLE = decltype(role_tag)::value;
-      f32x16 acc[NM][NT];
-#pragma unroll
-      for (int m = 0; m < NM; m++)
-#pragma unroll
-        for (int t = 0; t < NT; t++)
-#pragma unroll
-          for (int e = 0; e < 16; e++) acc[m][t][e] = 0.f;
-      float bp[NB], bp_hi[NB];
-#pragma unroll
-      for (int t = 0; t < NB; t++) bp[t] = bp_hi[t] = 0.f;
-      double sc = 0.0;
       constexpr bool RHS = ROLE == RL::rhs_role();
-
-      if (nst > 0) {
-        issue_idx(0);
-        issue_idx(1);
-        wait_vm<0>();
-        issue_idx(2);
-        issue_vec(0);
-        issue_idx(3);
-        if (nst > 1) issue_vec(1);
-      }
-      // one pipeline step; MASKED = the row's last (partial) step, or rank < KP
-      auto iter = [&](auto masked_tag, const int i) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        // group i-2 (index chunk i+2, vectors i) must have landed; group i-1 may stay in flight
-        if (i + 1 < nst) wait_vm<GROUP>(); else wait_vm<1>();
-        issue_idx(i + 4);
-        if (i + 2 < nst) issue_vec(i + 2);
-
-        const int s0 = (wset + NSETS * i) * kStepNnz;
-        const int rem = cnt - s0;
-        const char* slot = smem + (vec_slot(i) - lds_addr(smem));
-        float c[8];  // values of this lane's 8 non-zeros (8h .. 8h+7)
+      constexpr int NMFMA = RL::mfma_count(ROLE), NU = RL::unit_count(ROLE), NHU = 2 * NU;
+      constexpr int BARE = 4;   // MFMAs issued before the first split slice: they cover the latency of the ring reads
+      using Parts = NeParts<NB, NS>;
+      Parts pA, pB;
+#pragma unroll
+      for (int t = 0; t < NB; t++)
+#pragma unroll
+        for (int q = 0; q < NS; q++) pA.x[t][q] = pA.a[t][q] = pB.x[t][q] = pB.a[t][q] = u32x4{0u, 0u, 0u, 0u};
+      auto mfma_j = [&](auto jc, Parts& cur) {
+        constexpr auto op = RL::mfma_op(ROLE, decltype(jc)::value);
+        if constexpr (IMPLICIT && op.m == 0) acc[op.slot] = mfma_bf16(cur.a[op.R][op.pa], cur.x[op.C][op.pb], acc[op.slot]);
+        else acc[op.slot] = mfma_bf16(cur.x[op.R][op.pa], cur.x[op.C][op.pb], acc[op.slot]);
+      };
+      // pipeline synchronisation of step i: returns false if this group has no step i (PAIR: barrier count)
+      auto sync_step = [&](const int i) {
+        const bool has = i < nst;   // PAIR mode: a group with one step fewer than group 0 still meets the barrier
+        if (has) wait_vm<(D - 2) * G_::GROUP>();  // this wave's share of the step has landed; D-2 later ones in flight
+        NE_T(0)
+        if constexpr (PAIR) __builtin_amdgcn_s_barrier();  // ... and the partner's share; the previous slot is released
+        NE_T(1)
+        if (has) {
+          issue_idx();
+          issue_vec(std::integral_constant<int, PAIR ? ROLE : 0>{});
+        }
+        NE_T(2)
+        return has;
+      };
+      // MFMAs on `cur` (step i-1) interleaved with the split of step i into `nxt`; masked = partial step or rank < KP
+      auto step = [&](auto masked_tag, const int i, Parts& cur, Parts& nxt) {
+        constexpr bool masked = decltype(masked_tag)::value;
+        const int rem = cnt - (wset + NSETS * i) * kStepNnz;
+        const char* slot = ring + cslot * G_::SLOT_BYTES;
+        cslot = cslot + 1 == D ? 0 : cslot + 1;
+        float c[8];      // values of this lane's 8 non-zeros (8h .. 8h+7)
         {
           const float4 c0 = *reinterpret_cast<const float4*>(slot + G_::VEC_BYTES + h * 32);
           const float4 c1 = *reinterpret_cast<const float4*>(slot + G_::VEC_BYTES + h * 32 + 16);
           c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
           c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
         }
-        if constexpr (MASKED) {
+        if constexpr (masked) {   // the padding slots of a row's last step hold copies of its last vector
 #pragma unroll
           for (int e = 0; e < 8; e++) c[e] = (8 * h + e < rem) ? c[e] : 0.f;
         }
+        // lane (h, d): dimension 32 t + d of its 8 non-zeros, one block of the factor dimension per unit group; the
+        // values of a group are requested from the ring while the previous group is being split
+        float raw[NU / 4][8];
+        const char* lbase = slot + h * (8 / NI) * (KP * 4) + d * 4;
+        auto load_group = [&](auto gc) {
+          constexpr int GI = decltype(gc)::value;
+          constexpr int t = RL::unit(ROLE, 4 * GI).t;
+#pragma unroll
+          for (int e = 0; e < 8; e++)
+            raw[GI][e] = *reinterpret_cast<const float*>(lbase + (e % NI) * 1024 + (e / NI) * (KP * 4) + t * 128);
+          if constexpr (masked) {   // ... and dimensions beyond the rank copies of the vector's last piece
+#pragma unroll
+            for (int e = 0; e < 8; e++) raw[GI][e] = (32 * t + d < k && 8 * h + e < rem) ? raw[GI][e] : 0.f;
+          }
+        };
+        f32x2 ur[NU];   // residuals of the pairs between the two slices of a unit
+        f32x2 cm1[4];   // (c - 1) of the lane's 4 pairs
+        if constexpr (IMPLICIT) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) cm1[q] = f32x2{c[2 * q] - 1.f, c[2 * q + 1] - 1.f};
+        }
+        auto half_unit = [&](auto hc) {
+          constexpr int HU = decltype(hc)::value, U = HU / 2;
+          constexpr auto un = RL::unit(ROLE, U);
+          if constexpr (HU % 2 == 0) {
+            if constexpr (U % 4 == 0 && U + 4 < NU) load_group(std::integral_constant<int, U / 4 + 1>{});
+            f32x2 r = {raw[U / 4][2 * un.pair], raw[U / 4][2 * un.pair + 1]};
+            if constexpr (un.kind == 0) {
+              if constexpr (RHS) bp[un.t] = fmaf(c[2 * un.pair + 1], r.y, fmaf(c[2 * un.pair], r.x, bp[un.t]));
+              nxt.x[un.t][0][un.pair] = split_stage(r, NS == 1);
+            } else {
+              r *= cm1[un.pair];
+              nxt.a[un.t][0][un.pair] = split_stage(r, NS == 1);
+            }
+            ur[U] = r;
+          } else {
+            f32x2 r = ur[U];
+#pragma unroll
+            for (int q = 1; q < NS; q++) {
+              const unsigned pk = split_stage(r, q == NS - 1);
+              if constexpr (un.kind == 0) nxt.x[un.t][q][un.pair] = pk;
+              else nxt.a[un.t][q][un.pair] = pk;
+            }
+          }
+        };
+        load_group(std::integral_constant<int, 0>{});
+        // Sequence point after every (MFMA, split slice) pair: an empty asm that "redefines" the A operand of the next
+        // MFMA and the input of the next slice.  Both are pure arithmetic, which neither sched_barrier nor program order
+        // keeps in place (hipcc hoists all MFMAs above the splits); a fake dependence through a volatile asm does.
+        auto pin = [&](auto jc) {
+          constexpr int J = decltype(jc)::value;   // about to be issued: MFMA J and slice J - BARE
+          constexpr int HU = J - BARE;
+          constexpr auto op = RL::mfma_op(ROLE, J);
+          u32x4& opnd = (IMPLICIT && op.m == 0) ? cur.a[op.R][op.pa] : cur.x[op.R][op.pa];
+          if constexpr (HU >= 0 && HU < NHU) {
+            constexpr auto un = RL::unit(ROLE, HU / 2);
+            if constexpr (HU % 2 == 0) {
+              float& inp = raw[HU / 8][2 * un.pair];
+              asm volatile("" : "+v"(opnd), "+v"(inp));
+            } else {
+              f32x2& inp = ur[HU / 2];
+              asm volatile("" : "+v"(opnd), "+v"(inp));
+            }
+          } else {
+            asm volatile("" : "+v"(opnd));
+          }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NMFMA>([&](auto jc) {
+          constexpr int J = decltype(jc)::value;
+          pin(jc);
+          mfma_j(jc, cur);
+          if constexpr (J >= BARE && J - BARE < NHU) half_unit(std::integral_constant<int, J - BARE>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<(NHU > NMFMA - BARE ? NHU - (NMFMA - BARE) : 0)>([&](auto hc) {
+          half_unit(std::integral_constant<int, decltype(hc)::value + NMFMA - BARE>{});
+        });
         if constexpr (RHS) {
           float s = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; e++) s += IMPLICIT ? c[e] : c[e] * c[e];
           sc += (double)s;
-        }
-        // operands: lane (h, d) holds, for block t, dimension 32 t + d of non-zeros 8h .. 8h+7
-        const char* lbase = slot + h * (8 / NI) * (KP * 4) + d * 4;
-        auto load_block = [&](int t, float (&raw)[8]) {
-#pragma unroll
-          for (int e = 0; e < 8; e++)
-            raw[e] = *reinterpret_cast<const float*>(lbase + (e % NI) * 1024 + (e / NI) * (KP * 4) + t * 128);
-          if constexpr (MASKED) {  // padding slots of a row's last step hold copies of its last vector; dimensions
-            const bool live = 32 * t + d < k;  // beyond the rank hold copies of the vector's last piece
-#pragma unroll
-            for (int e = 0; e < 8; e++) raw[e] = (live && 8 * h + e < rem) ? raw[e] : 0.f;
-          }
-        };
-        u32x4 xp[NB][NS];
-#pragma unroll
-        for (int t = 0; t < NB; t++) {
-          float raw[8];
-          load_block(t, raw);
-          if constexpr (RHS) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) bp[t] = fmaf(c[e], raw[e], bp[t]);
-          }
-          split8<NS>(raw, xp[t]);
-        }
-        if constexpr (!IMPLICIT) {  // M2 = X X^T at full split precision
-#pragma unroll
-          for (int pa = 0; pa < NS; pa++)
-#pragma unroll
-            for (int pb = 0; pb + pa < NS; pb++)
-#pragma unroll
-              for (int R = 0; R < NB; R++)
-#pragma unroll
-                for (int C = 0; C <= R; C++)
-                  acc[0][G_::tile(R, C)] = mfma_bf16(xp[R][pa], xp[C][pb], acc[0][G_::tile(R, C)]);
-        } else {  // M2 from the first two terms (loss only), M1 = (W X) X^T at full split precision
-#pragma unroll
-          for (int pa = 0; pa < 2; pa++)
-#pragma unroll
-            for (int pb = 0; pb + pa < 2; pb++)
-#pragma unroll
-              for (int R = 0; R < NB; R++)
-#pragma unroll
-                for (int C = 0; C <= R; C++)
-                  if constexpr (RL::owns(ROLE, 1, 0, 0))
-                    acc[1][G_::tile(R, C)] = mfma_bf16(xp[R][pa], xp[C][pb], acc[1][G_::tile(R, C)]);
-#pragma unroll
-          for (int R = 0; R < NB; R++) {
-            if (RL::owns_row(ROLE, 0, R)) {
-              float ar[8];  // a = (c - 1) * x for block R, re-read from the ring (cheaper than holding the raw values)
-              load_block(R, ar);
-#pragma unroll
-              for (int e = 0; e < 8; e++) ar[e] *= c[e] - 1.f;
-              u32x4 ap[NS];
-              split8<NS>(ar, ap);
-#pragma unroll
-              for (int pa = 0; pa < NS; pa++)
-#pragma unroll
-                for (int pb = 0; pb + pa < NS; pb++)
-#pragma unroll
-                  for (int C = 0; C <= R; C++)
-                    acc[0][G_::tile(R, C)] = mfma_bf16(ap[pa], xp[C][pb], acc[0][G_::tile(R, C)]);
-            }
-          }
-        }
-        if (RHS && (i & 63) == 63) {  // two-level sum of the right-hand side: bounds the fp32 running-sum error
+          // two-level sum of the right-hand side (bounds the fp32 running-sum error); arithmetic, not a branch
+          const float fm = (i & 63) == 63 ? 1.f : 0.f;
 #pragma unroll
           for (int t = 0; t < NB; t++) {
-            bp_hi[t] += bp[t];
-            bp[t] = 0.f;
+            bp_hi[t] = fmaf(fm, bp[t], bp_hi[t]);
+            bp[t] = fmaf(-fm, bp[t], bp[t]);
           }
         }
+        NE_T(3)
       };
-      if (k == KP) {
-        // only the row's last step can be partial, and it belongs to exactly one wave set
-        const int nfull = (nst > 0 && cnt - (wset + NSETS * (nst - 1)) * kStepNnz < kStepNnz) ? nst - 1 : nst;
-        for (int i = 0; i < nfull; i++) iter(std::false_type{}, i);
-        if (nfull < nst) iter(std::true_type{}, nfull);
-      } else {
-        for (int i = 0; i < nst; i++) iter(std::true_type{}, i);
+      const int niter = PAIR ? nst_max : nst;
+      // only the row's last step can be partial, and it belongs to exactly one ring group; rank < KP: all masked
+      const bool part = nst > 0 && cnt - (wset + NSETS * (nst - 1)) * kStepNnz < kStepNnz;
+      const int nfull = k != KP ? 0 : (part ? nst - 1 : nst);
+      for (int i = 0; i < nfull; i++) {
+        sync_step(i);
+        step(std::false_type{}, i, pA, pB);
+        pA = pB;   // (two steps per trip with swapped operand sets would save these copies, but hipcc then moves the
+      }            //  split arithmetic of the first step across the barrier and un-interleaves both)
+      for (int i = nfull; i < niter; i++) {   // partial step, rank < KP, missing step of a shorter group
+        if (sync_step(i)) {
+          step(std::true_type{}, i, pA, pB);
+          pA = pB;
+        }
       }
-      wait_vm<0>();  // trailing index chunks
+      static_for<NMFMA>([&](auto jc) { mfma_j(jc, pA); });   // the last step
+      if constexpr (RHS) {
 #pragma unroll
-      for (int t = 0; t < NB; t++) bp[t] = half_swap_sum(bp_hi[t] + bp[t]);
-      sc += __shfl_xor(sc, 32);  // sc is uniform inside each half of the wave
-      __syncthreads();  // every wave is done with its ring: the solve phase may overwrite it
-
-      // ---- reduce the partial systems in a fixed order (step set 0, 1, ...: deterministic) through a tile-major scratch
+        for (int t = 0; t < NB; t++) bp[t] = half_swap_sum(bp_hi[t] + bp[t]);
+        sc += __shfl_xor(sc, 32);  // sc is uniform inside each half of the wave
+      }
       if (lane < 32) {
 #pragma unroll
         for (int t = 0; t < NB; t++) sB[wv * KP + 32 * t + lane] = RHS ? bp[t] : 0.f;
       }
       if (lane == 0) reinterpret_cast<double*>(sScal)[wv] = RHS ? sc : 0.0;
-      // warm start and the Gramian entries of the tiles this wave will finish (requested now, used after the chain)
-      float x[4];
-      {
-        const int off = (lane % LV) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (SOLVER == 1 && off < k) v = *reinterpret_cast<const float4*>(yrow + off);
-        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-      }
-      constexpr int TPW = (NT + 3) / 4;  // tiles finished per wave
-      float gt[TPW][16];
-#pragma unroll
-      for (int u = 0; u < TPW; u++) {
-        const int t = wv + 4 * u;
-        int R = 0;
-        while ((R + 1) * (R + 2) / 2 <= t) R++;
-        const int C = t - R * (R + 1) / 2;
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int i = 32 * R + 8 * (e >> 2) + 4 * h + (e & 3), j = 32 * C + d;
-          float g = 0.f;
-          if (t < NT && i < k && j < k) {
-            if constexpr (IMPLICIT) g = a.XtX[(size_t)i * k + j];
-            else g = i == j ? lam_use : 0.f;
-          }
-          gt[u][e] = g;
-        }
-      }
-      for (int ph = 0; ph < NSETS; ph++) {
-        if (wset == ph) {
-#pragma unroll
-          for (int R = 0; R < NB; R++)
-#pragma unroll
-            for (int C = 0; C <= R; C++)
-              if (RL::owns(ROLE, 0, R, 0)) {
-                const int t = G_::tile(R, C);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                  float4* slot4 = reinterpret_cast<float4*>(sP) + (t * 4 + q4) * 64 + lane;
-                  float4 v = make_float4(acc[0][t][4 * q4], acc[0][t][4 * q4 + 1], acc[0][t][4 * q4 + 2],
-                                         acc[0][t][4 * q4 + 3]);
-                  if (ph > 0) {
-                    const float4 o = *slot4;
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                  }
-                  *slot4 = v;
-                }
-              }
-        }
-        __syncthreads();
-      }
-      // A = XtX + M1 (explicit: M2 + lambda_use I), full symmetric, row stride LDA
-#pragma unroll
-      for (int u = 0; u < TPW; u++) {
-        const int t = wv + 4 * u;
-        if (t < NT) {
-          int R = 0;
-          while ((R + 1) * (R + 2) / 2 <= t) R++;
-          const int C = t - R * (R + 1) / 2;
-#pragma unroll
-          for (int q4 = 0; q4 < 4; q4++) {
-            const float4 o = reinterpret_cast<const float4*>(sP)[(t * 4 + q4) * 64 + lane];
-            const float v[4] = {o.x + gt[u][4 * q4], o.y + gt[u][4 * q4 + 1], o.z + gt[u][4 * q4 + 2],
-                                o.w + gt[u][4 * q4 + 3]};
-            const int i0 = 32 * R + 8 * q4 + 4 * h, j = 32 * C + d;
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) sA[(i0 + rr) * LDA + j] = v[rr];
-            if (R != C) *reinterpret_cast<float4*>(sA + j * LDA + i0) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
-      }
-      __syncthreads();
-
-      // ---- right-hand side, replicated in every wave: lane holds elements [4 (lane % LV), +4)
-      const int c4 = (lane % LV) * 4, copy = lane / LV;
-      float b[4];
-      {
-        float4 s = *reinterpret_cast<const float4*>(sB + c4);
-#pragma unroll
-        for (int w2 = 1; w2 < 4; w2++) {
-          const float4 o = *reinterpret_cast<const float4*>(sB + w2 * KP + c4);
-          s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
-        }
-        b[0] = s.x; b[1] = s.y; b[2] = s.z; b[3] = s.w;
-      }
-      const double sc_row = (reinterpret_cast<const double*>(sScal)[0] + reinterpret_cast<const double*>(sScal)[1]) +
-                            (reinterpret_cast<const double*>(sScal)[2] + reinterpret_cast<const double*>(sScal)[3]);
-
-      // out = A v: every wave takes RW rows of A, its COPIES lane groups RPC rows each; partial vectors through LDS
-      float* pub = sPub + wv * KP;
-      auto matvec = [&](const float (&v)[4], float (&out)[4]) {
-        wave_sync();
-        if (copy == 0) *reinterpret_cast<float4*>(pub + c4) = make_float4(v[0], v[1], v[2], v[3]);
-        wave_sync();
-        const int r0 = wv * RW + copy * RPC;
-        float o4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q4 = 0; q4 < RPC / 4; q4++) {
-          const float4 vb = *reinterpret_cast<const float4*>(pub + r0 + 4 * q4);
-          const float vv[4] = {vb.x, vb.y, vb.z, vb.w};
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const float4 ar = *reinterpret_cast<const float4*>(sA + (r0 + 4 * q4 + u) * LDA + c4);
-            o4[0] = fmaf(vv[u], ar.x, o4[0]);
-            o4[1] = fmaf(vv[u], ar.y, o4[1]);
-            o4[2] = fmaf(vv[u], ar.z, o4[2]);
-            o4[3] = fmaf(vv[u], ar.w, o4[3]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) o4[u] = COPIES == 2 ? half_swap_sum(o4[u]) : groups_sum_ne(o4[u]);
-        float* red = sRed + buf * 4 * KP;
-        if (copy == 0) *reinterpret_cast<float4*>(red + wv * KP + c4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
-        __syncthreads();
-        float4 s = *reinterpret_cast<const float4*>(red + c4);
-#pragma unroll
-        for (int w2 = 1; w2 < 4; w2++) {
-          const float4 o = *reinterpret_cast<const float4*>(red + w2 * KP + c4);
-          s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
-        }
-        out[0] = s.x; out[1] = s.y; out[2] = s.z; out[3] = s.w;
-        buf ^= 1;
-      };
-      auto dot = [&](const float (&u)[4], const float (&v)[4]) {
-        float s = u[0] * v[0];
-        s = fmaf(u[1], v[1], s);
-        s = fmaf(u[2], v[2], s);
-        s = fmaf(u[3], v[3], s);
-        return wave_sum_all(s) * (1.f / COPIES);  // the COPIES lane groups hold identical values
-      };
-
-      float r[4], p[4], ap[4];
-      if constexpr (SOLVER == 1) {
-        // cg_solver_implicit / cg_solver_explicit on the assembled operator; rsold / alpha in double like the
-        // reference (wrmf_implicit.hpp:18)
-        matvec(x, ap);
-#pragma unroll
-        for (int u = 0; u < 4; u++) p[u] = r[u] = b[u] - ap[u];
-        double rsold = (double)dot(r, r);
-        bool conv = false;
-        for (int it = 0; it < a.cg_steps; ++it) {
-          matvec(p, ap);  // uniform control flow: every wave runs the barrier inside
-          if (!conv) {
-            const float alpha = (float)(rsold / (double)dot(p, ap));
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              x[u] = fmaf(alpha, p[u], x[u]);
-              r[u] = fmaf(-alpha, ap[u], r[u]);
-            }
-            const double rsnew = (double)dot(r, r);
-            if (rsnew < (double)kCgTolNe) {
-              conv = true;
-            } else {
-              const float beta = (float)(rsnew / rsold);
-#pragma unroll
-              for (int u = 0; u < 4; u++) p[u] = fmaf(p[u], beta, r[u]);
-              rsold = rsnew;
-            }
-          }
-        }
-      }
-
-      // ---- loss of the row: sum c - 2 y.b + y^T (M1 + M2) y + lambda |y|^2  (explicit: sum r^2 - 2 y.b + y^T M2 y)
-      wave_sync();
-      if (copy == 0) *reinterpret_cast<float4*>(pub + c4) = make_float4(x[0], x[1], x[2], x[3]);
-      wave_sync();
-      float qf = 0.f;
-      {
-        float yj[NB];
-#pragma unroll
-        for (int t = 0; t < NB; t++) yj[t] = pub[32 * t + d];
-#pragma unroll
-        for (int R = 0; R < NB; R++) {
-          float yi[16];
-#pragma unroll
-          for (int q4 = 0; q4 < 4; q4++) {
-            const float4 v = *reinterpret_cast<const float4*>(pub + 32 * R + 8 * q4 + 4 * h);
-            yi[4 * q4] = v.x; yi[4 * q4 + 1] = v.y; yi[4 * q4 + 2] = v.z; yi[4 * q4 + 3] = v.w;
-          }
-#pragma unroll
-          for (int C = 0; C <= R; C++) {
-            float s = 0.f;
-#pragma unroll
-            for (int m = 0; m < NM; m++)
-              if (RL::owns(ROLE, m, R, 0)) {
-#pragma unroll
-                for (int e = 0; e < 16; e++) s = fmaf(acc[m][G_::tile(R, C)][e], yi[e], s);
-              }
-            qf = fmaf(R == C ? 1.f : 2.f, s * yj[C], qf);
-          }
-        }
-        qf = wave_sum_all(qf);
-      }
-      if (lane == 0) sScal[16 + wv] = qf;
-      const float yb = dot(x, b), yy = dot(x, x);
-      __syncthreads();
-      if (wv == 0) {
-        const double q = ((double)sScal[16] + (double)sScal[17]) + ((double)sScal[18] + (double)sScal[19]);
-        const double fit = sc_row - 2.0 * (double)yb + q;
-        const double reg = IMPLICIT ? a.lambda_loss * (double)yy : (double)(lam_use * yy);
-        if (lane == 0) row_loss[ri] = fit + reg;
-        if (copy == 0 && c4 < k) *reinterpret_cast<float4*>(yrow + c4) = make_float4(x[0], x[1], x[2], x[3]);
-      }
-      __syncthreads();  // the next row's rings overwrite the solve area
+      NE_T(4)
     };
-    if (!RL::PAIR || wrole == 0) body(std::integral_constant<int, 0>{});
-    else body(std::integral_constant<int, 1>{});
+    // ---- A = XtX + M1 (explicit: lambda_use I + M2): the first ring group writes G + its partial sums, the others add
+    // theirs (read-add-write), one group after the other (fixed order, hence deterministic); element (tile, e) of
+    // lane (h, d) is row 8 (e / 4) + 4 h + e % 4, column d of the tile
+    auto chain_add = [&](auto role_tag, const bool first) {
+      constexpr int ROLE = decltype(role_tag)::value;
+#pragma unroll
+      for (int R = 0; R < NB; R++)
+#pragma unroll
+        for (int C = 0; C <= R; C++)
+          if (RL::slot(ROLE, 0, R, C) >= 0) {
+            // one address register per tile, opaque to hipcc: the element offsets then fit the 16-bit immediate of
+            // the DS instructions (the tiles sit beyond 64 KB; without this it keeps one hoisted, spilled address
+            // register per element)
+            int toff = G_::tile(R, C) * 32 * TLD + 4 * h * TLD + d;
+            asm volatile("" : "+v"(toff));
+            float* ta = sA + toff;
+            const f32x16 v = acc[RL::slot(ROLE, 0, R, C)];
+            if (first) {
+              float g[16];
+#pragma unroll
+              for (int e = 0; e < 16; e++) {
+                if constexpr (IMPLICIT) g[e] = (sG + toff)[(8 * (e >> 2) + (e & 3)) * TLD];
+                else g[e] = (R == C && 8 * (e >> 2) + (e & 3) + 4 * h == d) ? lam_use : 0.f;
+              }
+#pragma unroll
+              for (int e = 0; e < 16; e++) ta[(8 * (e >> 2) + (e & 3)) * TLD] = v[e] + g[e];
+            } else {   // (plain read-add-write: ds_add_f32 measured ~450 cycles per wave instruction)
+              float o[16];
+#pragma unroll
+              for (int e = 0; e < 16; e++) o[e] = ta[(8 * (e >> 2) + (e & 3)) * TLD];
+#pragma unroll
+              for (int e = 0; e < 16; e++) ta[(8 * (e >> 2) + (e & 3)) * TLD] = o[e] + v[e];
+            }
+          }
+    };
+    // ---- y^T (M1 + M2) y (explicit: y^T M2 y) from this wave's own accumulators; y is published in LDS (pub) and,
+    // as x[], element 32 t + d in register t
+    auto quad_form = [&](auto role_tag, const float* pub, const float (&x)[NB]) {
+      constexpr int ROLE = decltype(role_tag)::value;
+      float qf = 0.f;
+#pragma unroll
+      for (int R = 0; R < NB; R++) {
+        float yi[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+          const float4 v = *reinterpret_cast<const float4*>(pub + 32 * R + 8 * q4 + 4 * h);
+          yi[4 * q4] = v.x; yi[4 * q4 + 1] = v.y; yi[4 * q4 + 2] = v.z; yi[4 * q4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int C = 0; C <= R; C++) {
+          float s = 0.f;
+#pragma unroll
+          for (int m = 0; m < NM; m++)
+            if (RL::slot(ROLE, m, R, C) >= 0) {
+#pragma unroll
+              for (int e = 0; e < 16; e++) s = fmaf(acc[RL::slot(ROLE, m, R, C)][e], yi[e], s);
+            }
+          qf = fmaf(R == C ? 1.f : 2.f, s * x[C], qf);
+        }
+      }
+      return wave_sum_all(qf);
+    };
+
+    if (!PAIR || wrole == 0) accumulate(std::integral_constant<int, 0>{});
+    else accumulate(std::integral_constant<int, 1>{});
+    if (wv == 0 && nst < D) wait_vm<0>();   // short row: make sure the warm start has landed (see above)
+    __syncthreads();   // warm start and every wave's right-hand-side partial are in LDS
+    NE_T(12)
+    for (int ph = 0; ph < NSETS; ph++) {
+      if (wset == ph) {
+        if (!PAIR || wrole == 0) chain_add(std::integral_constant<int, 0>{}, ph == 0);
+        else chain_add(std::integral_constant<int, 1>{}, ph == 0);
+      }
+      NE_T(13)
+      __syncthreads();
+      NE_T(14)
+    }
+    NE_T(8)
+
+    // ---- warm start, right-hand side and sum c, replicated in every wave; rank-vectors live as element 32 t + d in
+    // register t (both halves of the wave alike)
+    float x[NB], b[NB];
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+      x[t] = (32 * t + d < k) ? sX0[32 * t + d] : 0.f;
+      float s = sB[32 * t + d];
+#pragma unroll
+      for (int w2 = 1; w2 < 4; w2++) s += sB[w2 * KP + 32 * t + d];
+      b[t] = s;
+    }
+    const double sc_row = (reinterpret_cast<const double*>(sScal)[0] + reinterpret_cast<const double*>(sScal)[1]) +
+                          (reinterpret_cast<const double*>(sScal)[2] + reinterpret_cast<const double*>(sScal)[3]);
+
+    // out = A v from the triangle.  NB^2 units of 32 x 32: unit (tg, sl) is the contribution of block sl of v to block
+    // tg of the result -- sl >= tg: tile (sl, tg) read by rows (T^T v_sl), sl < tg: tile (tg, sl) read by columns; the
+    // units go round robin to the 4 waves (rolled loop: the solve must stay small in the instruction cache), the two
+    // halves of a wave split the 32-long inner product, partial blocks meet in LDS
+    float* pub = sPub + wv * KP;
+    auto matvec = [&](const float (&v)[NB], float (&out)[NB]) {
+      wave_sync();
+      if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < NB; t++) pub[32 * t + d] = v[t];
+      }
+      wave_sync();
+      float* part = sPart + buf * NB * NB * 32;
+      NE_T(15)
+      for (int u = wv; u < NB * NB; u += 4) {
+        const int tg = u / NB, sl = u % NB;
+        const bool by_rows = sl >= tg;
+        const int R = by_rows ? sl : tg, C = by_rows ? tg : sl;
+        const float* T = sA + (R * (R + 1) / 2 + C) * 32 * TLD + (by_rows ? d + 16 * h * TLD : d * TLD + 16 * h);
+        const int sv = by_rows ? TLD : 1;
+        const float* vb = pub + 32 * sl + 16 * h;
+        // all 20 LDS reads first (hipcc otherwise waits for each one before it issues the next: 16 round trips)
+        float tv[16], vv[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+          const float4 v4 = *reinterpret_cast<const float4*>(vb + 4 * q4);
+          vv[4 * q4] = v4.x; vv[4 * q4 + 1] = v4.y; vv[4 * q4 + 2] = v4.z; vv[4 * q4 + 3] = v4.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) tv[q] = T[q * sv];
+        __builtin_amdgcn_sched_barrier(0);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+          s0 = fmaf(tv[4 * q4 + 0], vv[4 * q4 + 0], s0);
+          s1 = fmaf(tv[4 * q4 + 1], vv[4 * q4 + 1], s1);
+          s2 = fmaf(tv[4 * q4 + 2], vv[4 * q4 + 2], s2);
+          s3 = fmaf(tv[4 * q4 + 3], vv[4 * q4 + 3], s3);
+        }
+        float s = half_swap_sum((s0 + s1) + (s2 + s3));
+        if (h == 0) part[u * 32 + d] = s;
+      }
+      NE_T(16)
+      __syncthreads();
+      NE_T(17)
+#pragma unroll
+      for (int t = 0; t < NB; t++) {
+        float s = part[(t * NB) * 32 + d];
+#pragma unroll
+        for (int sl = 1; sl < NB; sl++) s += part[(t * NB + sl) * 32 + d];
+        out[t] = s;
+      }
+      buf ^= 1;
+      NE_T(18)
+    };
+    auto dot = [&](const float (&u)[NB], const float (&v)[NB]) {
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < NB; t++) s = fmaf(u[t], v[t], s);
+      return wave_sum_all(s) * 0.5f;  // the two halves of the wave hold identical values
+    };
+
+    // cg_solver_implicit / cg_solver_explicit on the assembled operator (one matrix-vector product per pass: pass 0
+    // forms r = b - A x); rsold / alpha in double like the reference (wrmf_implicit.hpp:18)
+    float r[NB], p[NB], ap[NB];
+#pragma unroll
+    for (int t = 0; t < NB; t++) p[t] = x[t];
+    double rsold = 0.0;
+    bool conv = false;
+    for (int it = 0; it <= a.cg_steps; ++it) {
+      matvec(p, ap);  // uniform control flow: every wave runs the barrier inside
+      if (it == 0) {
+#pragma unroll
+        for (int t = 0; t < NB; t++) p[t] = r[t] = b[t] - ap[t];
+        rsold = (double)dot(r, r);
+      } else if (!conv) {
+        const float alpha = (float)(rsold / (double)dot(p, ap));
+#pragma unroll
+        for (int t = 0; t < NB; t++) {
+          x[t] = fmaf(alpha, p[t], x[t]);
+          r[t] = fmaf(-alpha, ap[t], r[t]);
+        }
+        const double rsnew = (double)dot(r, r);
+        if (rsnew < (double)kCgTolNe) {
+          conv = true;
+        } else {
+          const float beta = (float)(rsnew / rsold);
+#pragma unroll
+          for (int t = 0; t < NB; t++) p[t] = fmaf(p[t], beta, r[t]);
+          rsold = rsnew;
+        }
+      }
+    }
+    NE_T(9)
+
+    // ---- loss of the row: sum c - 2 y.b + y^T (M1 + M2) y + lambda |y|^2  (explicit: sum r^2 - 2 y.b + y^T M2 y)
+    wave_sync();
+    if (h == 0) {
+#pragma unroll
+      for (int t = 0; t < NB; t++) pub[32 * t + d] = x[t];
+    }
+    wave_sync();
+    const float qf = (!PAIR || wrole == 0) ? quad_form(std::integral_constant<int, 0>{}, pub, x)
+                                           : quad_form(std::integral_constant<int, 1>{}, pub, x);
+    NE_T(10)
+    if (lane == 0) sScal[16 + wv] = qf;
+    const float yb = dot(x, b), yy = dot(x, x);
+    __syncthreads();
+    if (wv == 0) {   // park the solved row in LDS; stores happen YB rows at a time
+      const double q = ((double)sScal[16] + (double)sScal[17]) + ((double)sScal[18] + (double)sScal[19]);
+      const double fit = sc_row - 2.0 * (double)yb + q;
+      const double reg = IMPLICIT ? a.lambda_loss * (double)yy : (double)(lam_use * yy);
+      if (lane == 0) {
+        sYloss[nbuf] = fit + reg;
+        sYrow[nbuf] = row;
+        sYli[nbuf] = li;
+      }
+      if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < NB; t++) sY[nbuf * KP + 32 * t + d] = x[t];
+      }
+    }
+    nbuf++;
+    __syncthreads();  // A, b and the scalars are rewritten by the next row; the parked row is visible
+    if (nbuf == YB || li + 1 == list_end) {
+      // One wave stores the parked rows.  Stores count in vmcnt too and are not ordered with loads, so it drains its
+      // queue afterwards: its counted waits must only ever see DMA (the look-ahead copies are older and have landed)
+      if (wv == 3) {
+        for (int rb = 0; rb < nbuf; rb++) {
+          float* yr = a.Y + (size_t)sYrow[rb] * k;
+          for (int e = lane; e < k; e += 64) yr[e] = sY[rb * KP + e];
+          if (lane == 0) row_loss[sYli[rb] - slot0] = sYloss[rb];
+        }
+        wait_vm<0>();
+      }
+      nbuf = 0;
+    }
+    NE_T(11)
   }
+  wait_vm<0>();  // the look-ahead copies issued past the end of the list
+#ifdef RSP_NE_PROF
+  if (a.ne_prof && lane == 0) {
+    prof_t[5] = __builtin_amdgcn_s_memtime() - prof_start;
+    prof_t[6] = list_end - list_begin;
+    for (int j = 0; j < 20; j++) a.ne_prof[((size_t)blockIdx.x * 4 + wv) * 20 + j] = prof_t[j];
+  }
+#endif
 }
 
-template <int KP, int NS, bool IMPLICIT, int SOLVER>
-hipError_t launch_ne_t(const AlsArgs& a, const int32_t* rows, int n_rows, int* counter, double* row_loss, int grid,
+template <int KP, int NS, bool IMPLICIT>
+hipError_t launch_ne_t(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int grid, double* row_loss,
                        hipStream_t s) {
-  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SOLVER>;
-  constexpr int lds = NeGeo<KP>::BYTES;
+  auto kern = als_ne_kernel<KP, NS, IMPLICIT>;
+  constexpr int lds = NeGeo<KP, NeRoles<KP, NS, IMPLICIT>::PAIR, IMPLICIT>::BYTES;
   hipError_t err =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (err != hipSuccess) return err;
-  if ((err = hipMemsetAsync(counter, 0, sizeof(int), s)) != hipSuccess) return err;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, rows, n_rows, counter, row_loss);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, wg_rows, wg_ptr, 0, row_loss);
   return hipGetLastError();
 }
 
@@ -620,25 +865,21 @@ hipError_t launch_ne_t(const AlsArgs& a, const int32_t* rows, int n_rows, int* c
 
 bool ne_supported(int k) { return k > 32 && k <= 128 && k % 4 == 0; }
 
-// rows[0, n_rows): schedule order (longest first); row_loss: one double per row; counter: one int of scratch
-hipError_t launch_als_ne(const AlsArgs& a, const int32_t* rows, int n_rows, bool implicit, int* counter,
+// wg_rows / wg_ptr: per-workgroup row lists (host-balanced, wrmf_capi.cpp build_ne_lists); row_loss: one double per
+// entry of wg_rows
+hipError_t launch_als_ne(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
                          double* row_loss, hipStream_t s) {
-  if (n_rows <= 0) return hipSuccess;
-  int dev = 0, cus = 256;
-  hipError_t err = hipGetDevice(&dev);
-  if (err != hipSuccess) return err;
-  if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return err;
-  const int grid = n_rows < cus ? n_rows : cus;  // one workgroup per CU (the kernel owns the CU's register file)
+  if (n_wg <= 0) return hipSuccess;
   const int KP = padded_rank(a.k);
 #ifndef RSP_NE_SPLIT
 #define RSP_NE_SPLIT 3
 #endif
   if (KP == 128)
-    return implicit ? launch_ne_t<128, RSP_NE_SPLIT, true, 1>(a, rows, n_rows, counter, row_loss, grid, s)
-                    : launch_ne_t<128, RSP_NE_SPLIT, false, 1>(a, rows, n_rows, counter, row_loss, grid, s);
+    return implicit ? launch_ne_t<128, RSP_NE_SPLIT, true>(a, wg_rows, wg_ptr, n_wg, row_loss, s)
+                    : launch_ne_t<128, RSP_NE_SPLIT, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s);
   if (KP == 64)
-    return implicit ? launch_ne_t<64, RSP_NE_SPLIT, true, 1>(a, rows, n_rows, counter, row_loss, grid, s)
-                    : launch_ne_t<64, RSP_NE_SPLIT, false, 1>(a, rows, n_rows, counter, row_loss, grid, s);
+    return implicit ? launch_ne_t<64, RSP_NE_SPLIT, true>(a, wg_rows, wg_ptr, n_wg, row_loss, s)
+                    : launch_ne_t<64, RSP_NE_SPLIT, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s);
   return hipErrorInvalidValue;
 }
 

@@ -384,6 +384,54 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
     vislot = vislot + 1 == IDXR ? 0 : vislot + 1;
     advance(cv);
   };
+  // The same two issues split into a preparation (addresses into registers, stream positions advanced) and the DMA
+  // instructions themselves, which the accumulate loop spreads between its MFMAs: issued in one burst at the top of a
+  // step they fill the wave's DMA queue (measured: ~4 B/clk per wave) and the wave stalls at the issue instead of
+  // computing; spread out, every one finds room and the copy runs behind the arithmetic.
+  const void* pre_src[G_::GROUP];   // per piece: this lane's source address
+  unsigned pre_dst[G_::GROUP];      // ... wave-uniform LDS destination
+  auto prepare = [&](auto role_tag) {
+    constexpr int LR = decltype(role_tag)::value;
+    int n = 0;
+    if (LR == 0) {
+      const int pos = ci.live ? ci.p1 + min((wset + NSETS * ci.s) * kStepNnz + lane, ci.cnt - 1) : 0;
+      pre_src[n] = a.row_idx + pos;
+      pre_dst[n++] = ring_a + (unsigned)(D * G_::SLOT_BYTES + islot * 256);
+    }
+    islot = islot + 1 == IDXR ? 0 : islot + 1;
+    advance(ci);
+    const int* ix = reinterpret_cast<const int*>(ring + D * G_::SLOT_BYTES + vislot * 256) + dq * NI;
+    int id[NI];
+    if constexpr (NI == 8) {
+      const int4 i0 = *reinterpret_cast<const int4*>(ix), i1 = *reinterpret_cast<const int4*>(ix + 4);
+      id[0] = i0.x; id[1] = i0.y; id[2] = i0.z; id[3] = i0.w;
+      id[4] = i1.x; id[5] = i1.y; id[6] = i1.z; id[7] = i1.w;
+    } else {
+      const int4 i0 = *reinterpret_cast<const int4*>(ix);
+      id[0] = i0.x; id[1] = i0.y; id[2] = i0.z; id[3] = i0.w;
+    }
+    const unsigned base = ring_a + (unsigned)(vslot * G_::SLOT_BYTES);
+#pragma unroll
+    for (int e = 0; e < NI; e++)
+      if (e / (NI / G_::LOADERS) == LR) {
+        pre_src[n] = a.X + (size_t)id[e] * k + dl4;
+        pre_dst[n++] = base + e * 1024;
+      }
+    if (LR == G_::LOADERS - 1) {
+      const int pos = cv.live ? cv.p1 + min((wset + NSETS * cv.s) * kStepNnz + lane, cv.cnt - 1) : 0;
+      pre_src[n] = a.vals + pos;
+      pre_dst[n++] = base + G_::VEC_BYTES;
+    }
+    vslot = vslot + 1 == D ? 0 : vslot + 1;
+    vislot = vislot + 1 == IDXR ? 0 : vislot + 1;
+    advance(cv);
+  };
+  auto piece = [&](auto role_tag, auto nc) {   // piece n of the prepared step: 4-byte copies are the index / value chunks
+    constexpr int LR = decltype(role_tag)::value, N = decltype(nc)::value;
+    constexpr bool small = (LR == 0 && N == 0) || (LR == G_::LOADERS - 1 && N == G_::GROUP - 1);
+    if constexpr (small) dma4(pre_src[N], pre_dst[N]);
+    else dma16(pre_src[N], pre_dst[N]);
+  };
   {
     start(ci);
     start(cv);
@@ -462,10 +510,7 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
         NE_T(0)
         if constexpr (PAIR) __builtin_amdgcn_s_barrier();  // ... and the partner's share; the previous slot is released
         NE_T(1)
-        if (has) {
-          issue_idx();
-          issue_vec(std::integral_constant<int, PAIR ? ROLE : 0>{});
-        }
+        if (has) prepare(std::integral_constant<int, PAIR ? ROLE : 0>{});
         NE_T(2)
         return has;
       };
@@ -559,6 +604,11 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
           pin(jc);
           mfma_j(jc, cur);
           if constexpr (J >= BARE && J - BARE < NHU) half_unit(std::integral_constant<int, J - BARE>{});
+          // piece n of the look-ahead copy behind MFMA (n + 1) NMFMA / (GROUP + 1)
+          static_for<G_::GROUP>([&](auto nc) {
+            if constexpr (J == (decltype(nc)::value + 1) * NMFMA / (G_::GROUP + 1))
+              piece(std::integral_constant<int, PAIR ? ROLE : 0>{}, nc);
+          });
           __builtin_amdgcn_sched_barrier(0);
         });
         static_for<(NHU > NMFMA - BARE ? NHU - (NMFMA - BARE) : 0)>([&](auto hc) {

@@ -37,7 +37,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from rsparse_amd import synth  # noqa: E402
-from rsparse_amd.engine import HipBackend, ShardedALS, block_bounds  # noqa: E402
+from rsparse_amd.engine import HipBackend, ShardedALS  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X vector fp32 (= matrix fp32) peak
 CONFIGS = {
@@ -62,59 +62,115 @@ def algorithmic_bytes(n_rows, nnz, k, n_empty=0):
     return nnz * (4 * k + 8) + (n_rows - n_empty) * 8 * k + n_empty * 4 * k + (n_rows + 1) * 4 + 4 * k * k
 
 
-def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0, implicit=True, solver=1):
-    """Time the oracle on host cores over the leading users / items of the same matrices."""
+def physical_cores():
+    """Physical cores this process may run on (SMT siblings counted once); falls back to the affinity count."""
+    allowed = os.sched_getaffinity(0)
+    seen = set()
+    try:
+        for c in allowed:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        return max(1, len(seen))
+    except OSError:
+        return len(allowed)
+
+
+def _sample_rows(csc, n_take, seed):
+    """CSC of `n_take` random columns (seeded), p re-based; returns numpy (p, i, x) and the picked ids."""
+    p, i, x = csc
+    n = p.numel() - 1
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    pick = torch.sort(torch.randperm(n, generator=g)[:n_take]).values.to(p.device)
+    p64 = p.to(torch.int64)
+    lens = p64[pick + 1] - p64[pick]
+    off = torch.zeros(n_take + 1, dtype=torch.int64, device=p.device)
+    torch.cumsum(lens, 0, out=off[1:])
+    rid = torch.repeat_interleave(torch.arange(n_take, device=p.device), lens)
+    pos = torch.arange(int(off[-1]), device=p.device) - off[rid] + p64[pick][rid]
+    return (off.cpu().numpy().astype(np.int32), i[pos].cpu().numpy().astype(np.int32),
+            x[pos].double().cpu().numpy(), pick)
+
+
+def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0, implicit=True, solver=1, seed=1):
+    """The CPU oracle (oracle/wrmf_oracle.cpp: the reference-shaped C++/OpenMP restatement) on the node's physical
+    cores, as BASELINE.md 2 specifies it: fp64 (the reference's default precision, R/model_WRMF.R:82) and fp32,
+    Gramian included, on a seeded RANDOM sample of the users and of the items of the same matrices; the iteration time
+    is extrapolated linearly in nnz."""
     from oracle import wrmf_oracle as O
-    threads = len(os.sched_getaffinity(0))
+    threads = physical_cores()
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     try:
         O.lib(native=True)
         native = True
     except Exception:
         native = False
-    Vh = np.asfortranarray(V.cpu().numpy().T)       # k x n_item
-    Uh = np.asfortranarray(U.cpu().numpy().T)       # k x n_user
-    out = {}
-
-    def run(csc, X, Yfull, n_take):
-        p, i, x = csc
-        p = p[:n_take + 1].cpu().numpy().astype(np.int32)
-        nnz = int(p[-1])
-        i = i[:nnz].cpu().numpy().astype(np.int32)
-        x = x[:nnz].cpu().numpy().astype(np.float64)
-        Y = np.asfortranarray(Yfull[:, :n_take]).copy(order="F")
-        G = O.gramian(X, lam, native=native)
-        t0 = time.perf_counter()
-        if implicit:
-            O.als_implicit(p, i, x, X, Y, G, lam, solver, cg_steps, n_threads=threads, native=native)
-        else:
-            O.als_explicit(p, i, x, X, Y, None, lam, solver, cg_steps, dynamic_lambda=True, n_threads=threads,
-                           native=native)
-        return time.perf_counter() - t0, nnz
-
     n_user, n_item, nnz_tot = data["n_users"], data["n_items"], data["nnz"]
-    # grow each sample until it costs about target_s/2 of wall time (the first calls include thread start-up)
-    def sized(csc, X, Yfull, n_all, start):
-        take = min(n_all, start)
-        t, z = run(csc, X, Yfull, take)
-        for _ in range(4):
-            if t >= 0.6 * target_s / 2 or take >= n_all:
-                break
-            take = int(min(n_all, take * min(8.0, max(1.5, (target_s / 2) / max(t, 1e-3)))))
-            t, z = run(csc, X, Yfull, take)
-        return take, t, z
+    res = {}
+    for name, dt in (("f64", np.float64), ("f32", np.float32)):
+        Vh = np.asfortranarray(V.cpu().numpy().T.astype(dt))       # k x n_item
+        Uh = np.asfortranarray(U.cpu().numpy().T.astype(dt))       # k x n_user
+        # Gramians: the item one in full, the user one on the leading 1M users (its cost is linear in the row count)
+        t0 = time.perf_counter()
+        Gv = O.gramian(Vh, lam, native=native)
+        t_gram = time.perf_counter() - t0
+        n_g = min(n_user, 1_000_000)
+        t0 = time.perf_counter()
+        Gu = O.gramian(np.asfortranarray(Uh[:, :n_g]), lam, native=native)
+        t_gram += (time.perf_counter() - t0) * (n_user / n_g)
+        if n_g < n_user:   # the solve needs the real one: fp64 on the device (plumbing, not the timed baseline)
+            Gu = np.asfortranarray(((U.double().T @ U.double()).cpu().numpy() + float(np.float32(lam)) * np.eye(k)).astype(dt))
 
-    take_u, tu, zu = sized(data["c_iu"], Vh, Uh, n_user, 50000)
-    take_i, ti, zi = sized(data["c_ui"], Uh, Vh, n_item, 5000)
-    est_iter_s = tu * (nnz_tot / max(zu, 1)) + ti * (nnz_tot / max(zi, 1))
-    out = {
-        "value": 1.0 / est_iter_s, "unit": "iterations/s", "cores": threads, "kind": "port",
-        "sample": "oracle/wrmf_oracle.cpp (C++/OpenMP restatement, fp32, %s) on the first %d of %d users "
-                  "(%.2fs, %d nnz) and the first %d of %d items (%.2fs, %d nnz); iteration time extrapolated "
-                  "linearly in nnz, Gramians excluded" % ("-march=native" if native else "-march=x86-64-v3", take_u,
-                                                           n_user, tu, zu, take_i, n_item, ti, zi),
-        "user_rows_per_s": take_u / tu, "item_rows_per_s": take_i / ti,
+        def run(csc, X, G, Yfull, n_all, n_take):
+            p, i, x, pick = _sample_rows(csc, n_take, seed)
+            Y = np.asfortranarray(Yfull[:, pick.cpu().numpy()]).copy(order="F")
+            t1 = time.perf_counter()
+            if implicit:
+                O.als_implicit(p, i, x, X, Y, G, lam, solver, cg_steps, n_threads=threads, native=native)
+            else:
+                O.als_explicit(p, i, x, X, Y, None, lam, solver, cg_steps, dynamic_lambda=True, n_threads=threads,
+                               native=native)
+            return time.perf_counter() - t1, int(p[-1])
+
+        def sized(csc, X, G, Yfull, n_all, start):
+            take = min(n_all, start)
+            t, z = run(csc, X, G, Yfull, n_all, take)
+            for _ in range(3):
+                if t >= 0.5 * target_s / 4 or take >= n_all:
+                    break
+                take = int(min(n_all, take * min(8.0, max(1.5, (target_s / 4) / max(t, 1e-3)))))
+                t, z = run(csc, X, G, Yfull, n_all, take)
+            return take, t, z
+
+        take_u, tu, zu = sized(data["c_iu"], Vh, Gv, Uh, n_user, 20000)
+        take_i, ti, zi = sized(data["c_ui"], Uh, Gu, Vh, n_item, 2000)
+        est = tu * (nnz_tot / max(zu, 1)) + ti * (nnz_tot / max(zi, 1)) + (t_gram if implicit else 0.0)
+        res[name] = dict(value=1.0 / est, take_u=take_u, take_i=take_i, tu=tu, ti=ti, t_gram=t_gram,
+                         user_rows_per_s=take_u / tu)
+    main = res["f64"]
+    return {
+        "value": main["value"], "unit": "iterations/s", "cores": threads, "kind": "port", "dtype": "f64",
+        "sample": "%d random users + %d random items, extrapolated in nnz; Gramians incl. (user one from 1M rows)"
+                  % (main["take_u"], main["take_i"]),
+        "value_f32": res["f32"]["value"], "user_rows_per_s": main["user_rows_per_s"],
+        "user_rows_per_s_f32": res["f32"]["user_rows_per_s"], "gramians_s": main["t_gram"],
+        "march": "native" if native else "x86-64-v3",
     }
-    return out
+
+
+def parity_check(als, U, V, solver, per_bucket=64, threads=None):
+    """Full-size sampled parity of this very run (checker only, after the timed region): one more iteration in which
+    ~64 rows per launch bucket and side are re-solved by the fp64 oracle from the same inputs."""
+    from oracle import sampled_parity as SP
+    threads = threads or physical_cores()
+    reps = []
+    for side in ("items", "users"):
+        _, rep = SP.half_iteration_with_check(als, side, U, V, solver, per_bucket=per_bucket, seed=7, n_threads=threads)
+        reps.append(rep)
+    worst = max(reps, key=lambda r: r["max_row_err"])
+    return {"rows_checked": sum(r["rows_checked"] for r in reps), "nnz_checked": sum(r["nnz_checked"] for r in reps),
+            "max_row_err": worst["max_row_err"], "max_fro_err": max(r["fro_err"] for r in reps),
+            "worst": {"side": worst["side"], "row_len": worst["worst_len"]}, "tolerance": 1e-4,
+            "oracle": "fp64 restatement (oracle/wrmf_oracle.cpp), same inputs; ~%d rows per length class and side" % per_bucket}
 
 
 def main():
@@ -150,8 +206,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if ws != args.gpus:
-        if ws == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: re-launch the same command line under torch.distributed.run, one rank
+            # per GPU of this node (the driver's own N > 1 launch sets WORLD_SIZE and never comes through here)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            os.execv(sys.executable, cmd)
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (ws, args.gpus))
     # RSPARSE_BENCH_BACKEND=gloo is a dry-run aid: all ranks share cuda:0 and collectives go through gloo, so the
     # N>1 control flow (sharding, padding, in-place all-gather) can be exercised on a single-GPU box.
@@ -171,39 +235,59 @@ def main():
     dev = be.device
     k, lam = args.rank, args.lam
 
-    # ---- synthetic data, generated on the device (identical on every rank: counter-based) ----
+    # ---- synthetic data, generated on the device (counter-based: identical whatever rank generates a piece) ----
     t0 = time.perf_counter()
-    data = synth.make_dataset(args.users, args.items, seed=args.seed, mean_deg=args.mean_deg, device=dev,
-                              feedback=args.feedback)
+    if ws == 1:
+        data = synth.make_dataset(args.users, args.items, seed=args.seed, mean_deg=args.mean_deg, device=dev,
+                                  feedback=args.feedback)
+        n_user, n_item, nnz = data["n_users"], data["n_items"], data["nnz"]
+        lay_u, lay_i = ShardedALS.layouts(n_user, n_item, 1)
+        c_ui_blk, c_iu_blk = data["c_ui"], data["c_iu"]
+        cnt_user = torch.diff(data["c_iu"][0]).to(torch.float32)
+        cnt_item = torch.diff(data["c_ui"][0]).to(torch.float32)
+    else:
+        # every rank generates only its own shard (two streaming passes, rsparse_amd/synth.py:make_shard); the blocks
+        # are contiguous and balanced by non-zeros, so their row counts differ
+        def bounds_fn(cu, ci):
+            lu, li = ShardedALS.layouts(args.users, args.items, ws, cu, ci)
+            return lu.bounds, (li.bounds if ci is not None else None)
+        data = synth.make_shard(args.users, args.items, ws, rank, bounds_fn, seed=args.seed, mean_deg=args.mean_deg,
+                                feedback=args.feedback, device=dev)
+        n_user, n_item, nnz = data["n_users"], data["n_items"], data["nnz"]
+        cnt_user, cnt_item = data["cnt_user"].to(torch.float32), data["cnt_item"].to(torch.float32)
+        lay_u, lay_i = ShardedALS.layouts(n_user, n_item, ws, data["cnt_user"], data["cnt_item"])
+        c_ui_blk, c_iu_blk = data["c_ui"], data["c_iu"]
+        data = {"n_users": n_user, "n_items": n_item, "nnz": nnz}
+        torch.cuda.empty_cache()
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
-    n_user, n_item, nnz = data["n_users"], data["n_items"], data["nnz"]
-    Bu, ub, Bi, ib, _ = ShardedALS.partition(n_user, n_item, ws)
-    c_ui_blk = shard_csc(*data["c_ui"], *ib[rank]) if ws > 1 else data["c_ui"]
-    c_iu_blk = shard_csc(*data["c_iu"], *ub[rank]) if ws > 1 else data["c_iu"]
     als = ShardedALS(be, n_user, n_item, k, c_ui_blk, c_iu_blk, nnz, feedback=args.feedback, lambda_=lam,
-                     cg_steps=args.cg_steps, world_size=ws, my_rank=rank)
+                     cg_steps=args.cg_steps, world_size=ws, my_rank=rank, lay_user=lay_u, lay_item=lay_i)
     if not implicit:   # nnz per user / item: weights of the explicit regulariser (wrmf_explicit.hpp:160-170)
-        als.cnt_user = torch.diff(data["c_iu"][0]).to(torch.float32)
-        als.cnt_item = torch.diff(data["c_ui"][0]).to(torch.float32)
-    if ws > 1:
-        data = {"n_users": n_user, "n_items": n_item, "nnz": nnz}   # drop the full copies
-        torch.cuda.empty_cache()
-    # initial factors: U ~ N(0, 0.01^2); item factors zero for CG, N(0, 0.01^2) otherwise (R/model_WRMF.R:204-231)
+        als.cnt_user, als.cnt_item = cnt_user, cnt_item
+    shard_nnz = [int(c_iu_blk[1].numel()), int(c_ui_blk[1].numel())]
+    # initial factors (in storage order; the values of a row do not depend on the number of ranks): U ~ N(0, 0.01^2);
+    # item factors zero for CG, N(0, 0.01^2) otherwise (R/model_WRMF.R:204-231)
     g = torch.Generator(device=dev).manual_seed(args.seed)
-    U = als.alloc_factors(n_user, Bu, dev)
-    V = als.alloc_factors(n_item, Bi, dev)
-    U[:n_user] = torch.randn(n_user, k, generator=g, device=dev) * 0.01
+    U = lay_u.from_global(lay_u.alloc(k, dev), torch.randn(n_user, k, generator=g, device=dev) * 0.01)
+    V = lay_i.alloc(k, dev)
     if solver != 1:
-        V[:n_item] = torch.randn(n_item, k, generator=g, device=dev) * 0.01
+        lay_i.from_global(V, torch.randn(n_item, k, generator=g, device=dev) * 0.01)
     if solver == 2:                                   # NNLS: abs() of the initial factors (R/model_WRMF.R:252-255)
         U.abs_()
         V.abs_()
+    n_ranks_seen = 1
+    if ws > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
 
-    def step(want_loss=True):
-        li = als.half_iteration("items", U, V, solver, want_loss=want_loss)
-        lu = als.half_iteration("users", U, V, solver, want_loss=want_loss)
-        return li, lu
+    def step():
+        # both losses stay on the device until the iteration is over: one host sync per iteration (the R driver reads
+        # the user-half loss for its convergence test, R/model_WRMF.R:327-335)
+        li = als.half_iteration("items", U, V, solver, want_loss="device")
+        lu = als.half_iteration("users", U, V, solver, want_loss="device")
+        return float(li), float(lu)
 
     def barrier():
         if ws > 1:
@@ -232,12 +316,12 @@ def main():
     half_ms = {"items": [], "users": []}
     for _ in range(max(1, min(args.steps, 3))):
         for side in ("items", "users"):
-            F, nF, BF, bF = (U, n_user, Bu, ub) if side == "items" else (V, n_item, Bi, ib)
+            F, layF = (U, lay_u) if side == "items" else (V, lay_i)
             torch.cuda.synchronize()
             th = time.perf_counter()
             G, gm = None, [0.0, 0.0]
             if implicit:
-                G = als.gramian(F, nF, BF, bF)
+                G = als.gramian(F, layF)
                 gm = be.profile_last()
             als.half_iteration(side, U, V, solver, G=G, want_loss=True)
             pm = be.profile_last()
@@ -280,8 +364,11 @@ def main():
               for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
         if ms:
             iu = info["users"]
-            buckets.append({"kernel": "als_cgq_kernel<%d, %d, %d, %d, %d, %s>" % (kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, iu["bucket_stream"][b], tf_flag),
-                            "what": "rows on teams of %d wave(s)%s" % (wpr, ", streamed (longer than the workgroup's resident capacity)" if iu["bucket_stream"][b] else ", register-resident"),
+            ne = bool(iu["bucket_stream"][b]) and k > 32 and k % 4 == 0
+            buckets.append({"kernel": ("als_ne_kernel<%d, 3, %s>" % (kp, tf_flag)) if ne else
+                                      "als_cgq_kernel<%d, %d, %d, %d, %d, %s>" % (kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, iu["bucket_stream"][b], tf_flag),
+                            "what": "rows beyond 512 non-zeros: one pass, normal equations on the matrix cores (split-bf16 MFMA), CG on the k x k system in LDS" if ne else
+                                    "rows on teams of %d wave(s)%s" % (wpr, ", streamed (longer than the workgroup's resident capacity)" if iu["bucket_stream"][b] else ", register-resident"),
                             "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),
                             "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms))})
     dom = max(buckets, key=lambda d: d["total_ms_per_iteration"]) if buckets else None
@@ -314,14 +401,38 @@ def main():
                                "note": "the Cholesky solver is compute/LDS bound (about 2 k^2 n_i + k^3/3 flops per row "
                                        "against ~n_i (4k+8) bytes); the hbm figures above are reported as the contract asks"}
 
-    cpu = None
+    comm_ms = None
+    if ws > 1:   # exchange alone: the slab all-gathers of both sides, back to back (the timed steps overlap them with solves)
+        comm_ms = {}
+        for side, S, lay in (("items", V, lay_i), ("users", U, lay_u)):
+            barrier()
+            tc = time.perf_counter()
+            for j in range(lay.n_sub):
+                w = als._gather_slab(S, lay, j)
+                if w is not None:
+                    w.wait()
+            torch.cuda.synchronize()
+            comm_ms[side] = 1e3 * (time.perf_counter() - tc)
+    first_ref = None
+    ref_file = ROOT / "profiles" / "bench_n1_first_losses.json"
+    cfg_key = "%dx%d_k%d_%s_%s_cg%d_seed%d" % (args.users, args.items, k, args.feedback, args.solver, args.cg_steps, args.seed)
+    if ref_file.exists():
+        try:
+            first_ref = json.loads(ref_file.read_text()).get(cfg_key)
+        except Exception:
+            first_ref = None
+    cpu, parity = None, None
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(data, U[:n_user], V[:n_item], k, lam, args.cg_steps, implicit=implicit, solver=solver,
                                target_s=12.0 if solver == 1 else 20.0)
         except Exception as e:   # the baseline is a report, never a reason to lose the measurement
-            cpu = {"value": None, "unit": "iterations/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            cpu = {"value": None, "unit": "iterations/s", "cores": physical_cores(), "kind": "port",
                    "sample": "failed: %r" % (e,)}
+        try:   # checker leg: rows of this run re-solved by the fp64 oracle (after the timed region)
+            parity = parity_check(als, U, V, solver)
+        except Exception as e:
+            parity = {"rows_checked": 0, "max_row_err": None, "error": repr(e)}
 
     if rank == 0:
         user_half_ms = mean(half_ms["users"])
@@ -338,11 +449,19 @@ def main():
                        "cg_steps": args.cg_steps, "parallelism": "rows sharded x%d, factors replicated" % ws},
             "user_rows_per_sec": n_user / (user_half_ms * 1e-3) if user_half_ms > 0 else None,
             "loss_users_last": losses[-1][1] if losses else None,
+            "loss_first_iteration": list(losses[0]) if losses else None,
+            # N > 1: the first iteration's losses against the committed N = 1 values of the same configuration (the
+            # factors do not depend on the sharding; only the Gramian / loss summation order does)
+            "loss_first_vs_n1_rel": (max(abs(a / b - 1.0) for a, b in zip(losses[0], first_ref))
+                                     if (first_ref and losses) else None),
+            "n_ranks_seen": n_ranks_seen, "shard_nnz_rank0": shard_nnz, "comm_ms": comm_ms,
+            "partition": "contiguous blocks balanced by non-zeros, %d sub-blocks per rank and side (in-place slab all-gathers)" % lay_u.n_sub if ws > 1 else "single rank",
             "launch_mode": "serial" if os.environ.get("RSPARSE_HIP_CONCURRENT", "1") == "0" else
                            "overlapped (the per-kernel times under roofline are measured in a serialised pass)",
             "datagen_s": t_gen,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "parity": parity,
         }
         print(json.dumps(line))
     if ws > 1:

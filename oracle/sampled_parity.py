@@ -121,6 +121,7 @@ def half_iteration_with_check(als, side, U, V, solver, per_bucket=64, seed=0, n_
     p, i, x = csc.keep
     rows = pick_rows(p, per_bucket, seed)
     before = S[rows].clone()
+    assert als.ws == 1, "sampled parity runs on the single-rank layout (storage order == global order)"
     G64 = gramian64(F[:nF], als.lambda_) if als.implicit else None
     loss = als.half_iteration(side, U, V, solver)
     rep = check((p, i, x), F[:nF], before, S[rows], rows, als.lambda_, solver, als.cg_steps, als.implicit,

@@ -31,21 +31,100 @@ from . import _lib
 SOLVER_CODES = {"cholesky": 0, "conjugate_gradient": 1, "nnls": 2}   # R/model_WRMF.R:99-100
 
 
-def block_bounds(n, world_size, multiple=1):
-    """Equal row blocks (the last ones padded): rank r owns rows [r*B, min(n, (r+1)*B)); B is a multiple
-    of `multiple` (sub-blocks for communication/compute overlap)."""
+def balanced_bounds(counts, world_size):
+    """Contiguous row blocks balanced by NON-ZEROS (the reference's analogue is `schedule(dynamic)`,
+    inst/include/wrmf_implicit.hpp:173): `counts` = non-zeros per row (tensor or sequence); rank r owns rows
+    [b[r], b[r+1]) where the prefix sum of counts first reaches r/world_size of the total."""
+    c = torch.as_tensor(counts).to(torch.int64).flatten()
+    n = int(c.numel())
+    if world_size <= 1 or n == 0:
+        return [(0, n)] + [(n, n)] * (world_size - 1)
+    pre = torch.cumsum(c, 0)
+    total = int(pre[-1])
+    targets = torch.tensor([total * r // world_size for r in range(1, world_size)], dtype=torch.int64, device=pre.device)
+    cuts = torch.searchsorted(pre, targets, right=False).tolist() if total > 0 else [n * r // world_size for r in range(1, world_size)]
+    edges = [0] + [min(n, int(v) + 1) if total > 0 else int(v) for v in cuts] + [n]
+    for r in range(1, len(edges)):   # monotone
+        edges[r] = max(edges[r], edges[r - 1])
+    return [(edges[r], edges[r + 1]) for r in range(world_size)]
+
+
+def equal_bounds(n, world_size):
     B = max(1, math.ceil(n / world_size)) if n > 0 else 1
-    B = -(-B // multiple) * multiple
-    return B, [(min(n, r * B), min(n, (r + 1) * B)) for r in range(world_size)]
+    return [(min(n, r * B), min(n, (r + 1) * B)) for r in range(world_size)]
 
 
-def default_user_subblocks(world_size):
-    """Sub-blocks per rank for the user half: with several ranks the all-gather of the solved user block
-    (5 GB at 10M x 128) costs about as much as the solve, so it is pipelined sub-block by sub-block."""
+def default_subblocks(world_size):
+    """Sub-blocks per rank and half-iteration: with several ranks the all-gather of a solved block (640 MB per rank on
+    the user side of config 3) costs about as much as the solve, so it is pipelined sub-block by sub-block."""
     import os
     if world_size <= 1:
         return 1
-    return max(1, int(os.environ.get("RSPARSE_USER_SUBBLOCKS", "4")))
+    return max(1, int(os.environ.get("RSPARSE_SUBBLOCKS", "4")))
+
+
+class Layout:
+    """Who owns which rows of one factor matrix, and where they are stored.
+
+    Ownership: rank r owns the contiguous global rows bounds[r] = [g0, g1) (nnz-balanced, so the blocks differ in
+    size).  Storage: every block is cut into n_sub sub-blocks of Bs rows (Bs = the largest block's share, smaller
+    blocks are padded with zero rows that nothing references), stored SUB-BLOCK-MAJOR:
+
+        storage row of (rank r, sub-block j, local row l) = j * (ws * Bs) + r * Bs + l
+
+    so sub-block j of all ranks is one contiguous slab and its exchange is a single in-place all_gather_into_tensor
+    with every rank's input being its own slice of the output -- no staging copy, no variable-size collective.  The
+    CSC indices that address the matrix are translated to storage rows once (to_storage).  With one rank the layout is
+    the identity."""
+
+    def __init__(self, n, bounds, n_sub=1):
+        self.n, self.ws, self.n_sub = int(n), len(bounds), int(n_sub)
+        self.bounds = [(int(a), int(b)) for a, b in bounds]
+        assert self.bounds[0][0] == 0 and self.bounds[-1][1] == self.n
+        biggest = max(1, max(b - a for a, b in self.bounds))
+        self.Bs = -(-biggest // self.n_sub)
+        self.rows = self.ws * self.n_sub * self.Bs
+        self.identity = self.ws == 1 and self.n_sub == 1
+
+    def sub_rows(self, r, j):
+        """(first local row, one past the last) of sub-block j of rank r's block"""
+        n_r = self.bounds[r][1] - self.bounds[r][0]
+        return min(n_r, j * self.Bs), min(n_r, (j + 1) * self.Bs)
+
+    def sub_start(self, r, j):
+        return j * self.ws * self.Bs + r * self.Bs
+
+    def slab(self, j):
+        return j * self.ws * self.Bs, (j + 1) * self.ws * self.Bs
+
+    def to_storage(self, ids):
+        """global row ids (integer tensor) -> storage rows"""
+        if self.identity:
+            return ids
+        starts = torch.tensor([a for a, _ in self.bounds], dtype=torch.int64, device=ids.device)
+        g = ids.to(torch.int64)
+        r = torch.searchsorted(starts, g, right=True) - 1
+        # empty blocks share their start with the next one: searchsorted(right=True) - 1 lands on the LAST block with
+        # that start, which is the non-empty one
+        loc = g - starts[r]
+        j = loc // self.Bs
+        return (j * (self.ws * self.Bs) + r * self.Bs + (loc - j * self.Bs)).to(ids.dtype)
+
+    def alloc(self, k, device, dtype=torch.float32):
+        return torch.zeros((self.rows, k), dtype=dtype, device=device)
+
+    def from_global(self, S, G):
+        """write a global-order (n, k) matrix into storage S"""
+        if self.identity:
+            S[:self.n] = G
+        else:
+            S[self.to_storage(torch.arange(self.n, device=S.device))] = G.to(S.device)
+        return S
+
+    def to_global(self, S):
+        if self.identity:
+            return S[:self.n]
+        return S[self.to_storage(torch.arange(self.n, device=S.device))]
 
 
 class HipBackend:
@@ -200,165 +279,175 @@ class ShardedALS:
 
     c_ui : CSC of the users x items matrix -> columns = items  (solved in the item half)
     c_iu : CSC of its transpose            -> columns = users  (solved in the user half)
-    Each rank is given the column block it owns, with `p` re-based to 0.
+    Each rank is given the column block it owns (p re-based to 0); row indices are GLOBAL ids of the other side and
+    are translated to that side's storage rows here (Layout).  Factor matrices live in storage order: allocate them
+    with `lay_user.alloc` / `lay_item.alloc`, convert with `Layout.from_global` / `to_global`.
     """
 
     def __init__(self, backend, n_user, n_item, rank_k, c_ui_block, c_iu_block, total_nnz, feedback="implicit",
-                 lambda_=0.0, dynamic_lambda=True, cg_steps=3, group=None, world_size=1, my_rank=0, with_bias=False):
+                 lambda_=0.0, dynamic_lambda=True, cg_steps=3, group=None, world_size=1, my_rank=0, with_bias=False,
+                 lay_user=None, lay_item=None):
         self.be, self.k = backend, int(rank_k)
         self.n_user, self.n_item, self.total_nnz = int(n_user), int(n_item), int(total_nnz)
         self.implicit = feedback == "implicit"
         self.with_bias = bool(with_bias)     # rank_k counts the row of ones and the bias row (R/model_WRMF.R:160)
         self.lambda_, self.dynamic_lambda, self.cg_steps = float(lambda_), bool(dynamic_lambda), int(cg_steps)
         self.group, self.ws, self.me = group, int(world_size), int(my_rank)
-        self.Bu, self.ub, self.Bi, self.ib, self.n_sub = self.partition(n_user, n_item, self.ws)
-        u0, u1 = self.ub[self.me]
-        i0, i1 = self.ib[self.me]
-        # item half: fixed side = users (n_user rows of X), solved = my items
-        self.csc_items = backend.make_csc(n_user, i1 - i0, *c_ui_block)
-        # user half: fixed side = items, solved = my users
-        self.csc_users = backend.make_csc(n_item, u1 - u0, *c_iu_block)
+        if lay_user is None or lay_item is None:
+            lay_user, lay_item = self.layouts(n_user, n_item, self.ws)
+        self.lay_user, self.lay_item = lay_user, lay_item
         dev = c_ui_block[0].device
-        # sub-blocks of my user block, each with its own schedule (only used when world_size > 1)
-        self.Bs = self.Bu // self.n_sub
-        self.sub_users = []
-        if self.n_sub > 1:
-            p, i, x = c_iu_block
-            p64 = p.to(torch.int64)
-            n_my = u1 - u0
-            for j in range(self.n_sub):
-                c0, c1 = min(n_my, j * self.Bs), min(n_my, (j + 1) * self.Bs)
-                lo, hi = int(p64[c0]), int(p64[c1])
-                sp_ = (p64[c0:c1 + 1] - lo).to(torch.int32).contiguous()
-                self.sub_users.append((c0, c1, backend.make_csc(n_item, c1 - c0, sp_, i[lo:hi].contiguous(),
-                                                                x[lo:hi].contiguous())))
-        self.scal_sub = torch.zeros(max(1, self.n_sub), dtype=torch.float64, device=dev)
+        # item half: fixed side = users, solved = my items; user half: fixed side = items, solved = my users
+        self.csc_items, self.sub_items = self._make(c_ui_block, lay_user, lay_item)
+        self.csc_users, self.sub_users = self._make(c_iu_block, lay_item, lay_user)
+        self.scal_sub = torch.zeros(max(lay_user.n_sub, lay_item.n_sub), dtype=torch.float64, device=dev)
         self.G = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
-        self.scal = torch.zeros(4, dtype=torch.float64, device=dev)   # [0] sumsq, [1] loss rows, [2] reg
-        self.cnt_user = None   # nnz per user (weights of the explicit regulariser on U)
+        self.Gpart = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
+        self.scal = torch.zeros(4, dtype=torch.float64, device=dev)   # [0] sumsq, [1] loss rows, [2] spare
+        self.cnt_user = None   # nnz per user / item in GLOBAL order (weights of the explicit regulariser)
         self.cnt_item = None
 
     @staticmethod
-    def partition(n_user, n_item, world_size):
-        """(Bu, user bounds, Bi, item bounds, user sub-blocks per rank) -- callers shard their CSC blocks with
-        exactly these bounds."""
-        n_sub = default_user_subblocks(world_size)
-        Bu, ub = block_bounds(n_user, world_size, multiple=n_sub)
-        Bi, ib = block_bounds(n_item, world_size)
-        return Bu, ub, Bi, ib, n_sub
+    def layouts(n_user, n_item, world_size, cnt_user=None, cnt_item=None, n_sub=None):
+        """Layouts of the two factor matrices: nnz-balanced blocks when the per-row counts are given, equal row counts
+        otherwise; callers cut their CSC blocks at exactly `lay.bounds`."""
+        n_sub = default_subblocks(world_size) if n_sub is None else n_sub
+        bu = balanced_bounds(cnt_user, world_size) if cnt_user is not None else equal_bounds(n_user, world_size)
+        bi = balanced_bounds(cnt_item, world_size) if cnt_item is not None else equal_bounds(n_item, world_size)
+        return Layout(n_user, bu, n_sub), Layout(n_item, bi, n_sub)
 
-    # -- factor storage: (n_pad, k) row-major == k x n_pad column-major, padded to world_size * B rows
-    def alloc_factors(self, n, B, dev):
-        return torch.zeros((B * self.ws, self.k), dtype=torch.float32, device=dev)
+    def _make(self, block, lay_fixed, lay_solved):
+        """CSC handle of my whole block (single-rank path, info, parity sampling) and one handle per sub-block, with the
+        row indices translated to the fixed side's storage rows."""
+        p, i, x = block
+        i = lay_fixed.to_storage(i).contiguous()
+        n_my = lay_solved.bounds[self.me][1] - lay_solved.bounds[self.me][0]
+        whole = self.be.make_csc(lay_fixed.rows, n_my, p, i, x)
+        subs = []
+        if lay_solved.n_sub > 1:
+            p64 = p.to(torch.int64)
+            for j in range(lay_solved.n_sub):
+                c0, c1 = lay_solved.sub_rows(self.me, j)
+                lo, hi = int(p64[c0]), int(p64[c1])
+                sp_ = (p64[c0:c1 + 1] - lo).to(torch.int32).contiguous()
+                subs.append((c0, c1, self.be.make_csc(lay_fixed.rows, c1 - c0, sp_, i[lo:hi].contiguous(),
+                                                      x[lo:hi].contiguous())))
+        else:
+            subs.append((0, n_my, whole))
+        return whole, subs
 
     def _all_reduce(self, t):
         if self.ws > 1:
             torch.distributed.all_reduce(t, group=self.group)
 
-    def _all_gather_blocks(self, S, B):
-        if self.ws > 1:
-            if S.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
-                # dry-run configuration only (several ranks sharing one GPU): gloo has no device all-gather
-                host = S.cpu()
-                torch.distributed.all_gather_into_tensor(host, host[self.me * B:(self.me + 1) * B].clone(), group=self.group)
-                S.copy_(host)
-                return
-            # the input is a copy of this rank's block (not a view of the output): no reliance on the
-            # backend's in-place all-gather semantics, for the price of one on-device block copy
-            mine = S[self.me * B:(self.me + 1) * B].clone()
-            torch.distributed.all_gather_into_tensor(S, mine, group=self.group)
-
-    def _all_gather_sub(self, S, B, j):
-        """Start the all-gather of sub-block j of every rank's block of S; returns a work handle (or None)."""
-        Bs = self.Bs
-        mine = S[self.me * B + j * Bs:self.me * B + (j + 1) * Bs]
-        if S.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
-            host = [torch.empty(mine.shape, dtype=S.dtype) for _ in range(self.ws)]   # dry-run configuration only
-            torch.distributed.all_gather(host, mine.cpu(), group=self.group)
-            for r in range(self.ws):
-                S[r * B + j * Bs:r * B + (j + 1) * Bs].copy_(host[r])
-            return None
-        outs = [S[r * B + j * Bs:r * B + (j + 1) * Bs] for r in range(self.ws)]
-        return torch.distributed.all_gather(outs, mine.clone(), group=self.group, async_op=True)
-
-    def gramian(self, F, n, B, bounds):
-        """G = F[:n] F[:n]^T + fl(lambda) I, reduced over the ranks' blocks; scal[0] = sum(F^2)."""
-        r0, r1 = bounds[self.me] if self.ws > 1 else (0, n)
-        blk = F[r0:r1]
+    def _gather_slab(self, S, lay, j):
+        """In-place all-gather of sub-block j of every rank (one contiguous slab of S); returns a work handle or None."""
         if self.ws == 1:
-            self.be.gramian(blk, self.lambda_, self.G, self.scal[0:1])
-        else:
-            self.be.gramian(blk, 0.0, self.G, self.scal[0:1])
-            self._all_reduce(self.G)
-            self._all_reduce(self.scal[0:1])
-            self.G.diagonal().add_(float(np.float32(self.lambda_)))   # fl(diag(lambda)), R/model_WRMF.R:476
+            return None
+        a, b = lay.slab(j)
+        out = S[a:b]
+        mine = S[lay.sub_start(self.me, j):lay.sub_start(self.me, j) + lay.Bs]
+        if S.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+            host = out.cpu()   # dry-run configuration only (several ranks sharing one GPU): gloo has no device all-gather
+            torch.distributed.all_gather_into_tensor(host, host[self.me * lay.Bs:(self.me + 1) * lay.Bs].clone(),
+                                                     group=self.group)
+            out.copy_(host)
+            return None
+        if not S.is_cuda:      # gloo on CPU tensors (tests): no in-place aliasing guarantees, gather from a copy
+            torch.distributed.all_gather_into_tensor(out, mine.clone(), group=self.group)
+            return None
+        return torch.distributed.all_gather_into_tensor(out, mine, group=self.group, async_op=True)
+
+    def _my_pieces(self, lay):
+        """storage slices [a, b) holding my real rows (one per sub-block)"""
+        out = []
+        for j in range(lay.n_sub):
+            c0, c1 = lay.sub_rows(self.me, j)
+            if c1 > c0:
+                a = lay.sub_start(self.me, j)
+                out.append((a, a + (c1 - c0)))
+        return out
+
+    def gramian(self, F, lay):
+        """G = F F^T + fl(lambda) I over the real rows of F (storage order, layout `lay`), reduced over the ranks;
+        scal[0] = sum(F^2)."""
+        pieces = self._my_pieces(lay)
+        if self.ws == 1 and len(pieces) == 1:
+            a, b = pieces[0]
+            self.be.gramian(F[a:b], self.lambda_, self.G, self.scal[0:1])
+            return self.G
+        self.G.zero_()
+        self.scal[0:1].zero_()
+        for a, b in pieces:
+            self.be.gramian(F[a:b], 0.0, self.Gpart, self.scal[2:3])
+            self.G += self.Gpart
+            self.scal[0:1] += self.scal[2:3]
+        self._all_reduce(self.G)
+        self._all_reduce(self.scal[0:1])
+        self.G.diagonal().add_(float(np.float32(self.lambda_)))   # fl(diag(lambda)), R/model_WRMF.R:476
         return self.G
 
-    def gramian_bias(self, F, n, bounds, bias_last_row):
+    def gramian_bias(self, F, lay, bias_last_row):
         """(k-1) x (k-1) Gramian of F without its bias row + fl(lambda) I (R/model_WRMF.R:463-486, 345-351)."""
         k1 = self.k - 1
         if getattr(self, "Gb", None) is None:
             self.Gb = torch.zeros((k1, k1), dtype=torch.float32, device=F.device)
-        r0, r1 = bounds[self.me] if self.ws > 1 else (0, n)
-        blk = (F[r0:r1, :k1] if bias_last_row else F[r0:r1, 1:]).contiguous()
-        if self.ws == 1:
-            self.be.gramian(blk, self.lambda_, self.Gb, None)
-        else:
-            self.be.gramian(blk, 0.0, self.Gb, None)
-            self._all_reduce(self.Gb)
-            self.Gb.diagonal().add_(float(np.float32(self.lambda_)))
+            self.Gbp = torch.zeros((k1, k1), dtype=torch.float32, device=F.device)
+        self.Gb.zero_()
+        for a, b in self._my_pieces(lay):
+            blk = (F[a:b, :k1] if bias_last_row else F[a:b, 1:]).contiguous()
+            self.be.gramian(blk, 0.0, self.Gbp, None)
+            self.Gb += self.Gbp
+        self._all_reduce(self.Gb)
+        self.Gb.diagonal().add_(float(np.float32(self.lambda_)))
         return self.Gb
 
     def half_iteration(self, side, U, V, solver, G=None, want_loss=True):
-        """side 'items': solve V (item factors) given U; side 'users': solve U given V.
-        Returns loss/nnz as the reference reports it (python float) or None."""
+        """side 'items': solve V (item factors) given U; side 'users': solve U given V (both in storage order).
+        Returns loss/nnz as the reference reports it: a python float (want_loss=True, synchronises), a 0-d device
+        tensor (want_loss='device': no host sync, fetch it when convenient) or None."""
         if side == "items":
-            F, nF, BF, bF, S, BS, bS, csc, cnt_F = U, self.n_user, self.Bu, self.ub, V, self.Bi, self.ib, self.csc_items, self.cnt_user
+            F, layF, S, layS, subs, cnt_F = U, self.lay_user, V, self.lay_item, self.sub_items, self.cnt_user
         else:
-            F, nF, BF, bF, S, BS, bS, csc, cnt_F = V, self.n_item, self.Bi, self.ib, U, self.Bu, self.ub, self.csc_users, self.cnt_item
+            F, layF, S, layS, subs, cnt_F = V, self.lay_item, U, self.lay_user, self.sub_users, self.cnt_item
         # user/item biases: solving the items means X = U = [1, ..., user_bias] (is_bias_last_row = TRUE), solving the
         # users X = components = [item_bias, ..., 1] (FALSE)  -- R/model_WRMF.R:321-329
         blr = (side == "items") if self.with_bias else None
         if self.implicit and G is None:
-            G = self.gramian_bias(F, nF, bF, blr) if self.with_bias else self.gramian(F, nF, BF, bF)
-        s0, s1 = bS[self.me]
-        S_block = S[s0:s1]
-        if side == "users" and self.ws > 1 and self.n_sub > 1:
-            # pipelined: solve sub-block j, start its all-gather, solve sub-block j+1 meanwhile
-            works = []
-            self.scal_sub.zero_()
-            for j, (c0, c1, sub) in enumerate(self.sub_users):
-                if c1 > c0:
-                    self.be.half_iteration(sub, self.implicit, F[:nF], S_block[c0:c1], G, self.lambda_, solver,
-                                           self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1], blr)
-                works.append(self._all_gather_sub(S, BS, j))
-            for w in works:
-                if w is not None:
-                    w.wait()
-            self.scal[1:2] = self.scal_sub.sum()
-        else:
-            self.be.half_iteration(csc, self.implicit, F[:nF], S_block, G, self.lambda_, solver, self.cg_steps,
-                                   self.dynamic_lambda, self.scal[1:2], blr)
-            self._all_gather_blocks(S, BS)
+            G = self.gramian_bias(F, layF, blr) if self.with_bias else self.gramian(F, layF)
+        # solve sub-block j, start its exchange, solve sub-block j+1 meanwhile (both halves alike)
+        works = []
+        self.scal_sub.zero_()
+        for j, (c0, c1, sub) in enumerate(subs):
+            if c1 > c0:
+                a = layS.sub_start(self.me, j)
+                self.be.half_iteration(sub, self.implicit, F, S[a:a + (c1 - c0)], G, self.lambda_, solver,
+                                       self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1], blr)
+            works.append(self._gather_slab(S, layS, j))
+        for w in works:
+            if w is not None:
+                w.wait()
+        self.scal[1:2] = self.scal_sub.sum()
         if not want_loss:
             return None
         # regulariser on the fixed side (wrmf_implicit.hpp:286-301, wrmf_explicit.hpp:146-173)
-        reg = 0.0
-        if self.lambda_ > 0:
-            if self.implicit and G is self.G:
-                pass  # scal[0] already holds sum(F^2) from the Gramian pass
-            else:
-                r0, r1 = bF[self.me] if self.ws > 1 else (0, nF)
+        if self.lambda_ > 0 and not (self.implicit and G is self.G):   # else scal[0] already holds sum(F^2)
+            self.scal[0:1].zero_()
+            g0 = layF.bounds[self.me][0]
+            for j in range(layF.n_sub):
+                c0, c1 = layF.sub_rows(self.me, j)
+                if c1 <= c0:
+                    continue
+                a = layF.sub_start(self.me, j)
                 w = None
                 if (not self.implicit) and self.dynamic_lambda:
-                    w = cnt_F[r0:r1]
-                Freg = F[r0:r1]
+                    w = cnt_F[g0 + c0:g0 + c1]
+                Freg = F[a:a + (c1 - c0)]
                 if self.with_bias:   # every row of X but the ones (wrmf_explicit.hpp:147-159): ones first when the
                     Freg = (Freg[:, 1:] if blr else Freg[:, :self.k - 1]).contiguous()   # x bias is last, else last
-                self.be.weighted_sumsq(Freg, w, self.scal[0:1])
-                self._all_reduce(self.scal[0:1])
+                self.be.weighted_sumsq(Freg, w, self.scal[2:3])
+                self.scal[0:1] += self.scal[2:3]
+            self._all_reduce(self.scal[0:1])
         self._all_reduce(self.scal[1:2])
-        vals = self.scal[0:2].tolist()   # synchronises
-        if self.lambda_ > 0:
-            reg = self.lambda_ * vals[0]
-        return (vals[1] + reg) / float(self.total_nnz)
+        loss = (self.scal[1] + self.lambda_ * self.scal[0]) / float(self.total_nnz)
+        return loss.clone() if want_loss == "device" else float(loss)

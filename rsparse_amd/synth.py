@@ -149,3 +149,66 @@ def make_dataset(n_users, n_items, seed=20250222, mean_deg=50.0, d_max=5000, fee
         "c_iu": (p_u.to(torch.int32), item, val),
         "c_ui": (p_i.to(torch.int32), row_i.to(torch.int32), val_i),
     }
+
+
+def make_shard(n_users, n_items, world_size, rank, bounds_fn, seed=20250222, mean_deg=50.0, d_max=5000,
+               feedback="implicit", device="cpu", block=2_000_000):
+    """One rank's share of the matrix `make_dataset` produces, without ever holding the whole matrix: two streaming
+    passes over the user blocks (the generator is counter-based, so a block is regenerated identically).
+
+      pass 1: per-item non-zero counts (the per-user counts are the degrees, known without generating anything), and
+              the rows of this rank's user block (-> c_iu block, columns = my users);
+      pass 2: the entries whose item falls into this rank's item block (-> c_ui block, columns = my items).
+
+    `bounds_fn(cnt_user, cnt_item) -> (user_bounds, item_bounds)` decides the blocks (engine.ShardedALS.layouts).
+    Returns dict(nnz, cnt_user, cnt_item, user_bounds, item_bounds, c_iu, c_ui) with the CSC blocks re-based to 0 and
+    GLOBAL row indices."""
+    dev = torch.device(device)
+    perm = item_permutation(n_items, seed, dev)
+    cnt_user = degrees(torch.arange(n_users, dtype=torch.int64, device=dev), seed, mean_deg, d_max, n_items)
+    cnt_item = torch.zeros(n_items, dtype=torch.int64, device=dev)
+    # the user bounds only need the degrees; the item bounds need pass 1
+    ub, _ = bounds_fn(cnt_user, None)
+    u0, u1 = ub[rank]
+    keep_p, keep_i, keep_x = [], [], []
+    base = 0
+    for b0 in range(0, n_users, block):
+        b1 = min(n_users, b0 + block)
+        ip, it, v = generate_user_block(b0, b1, n_items, seed, mean_deg, d_max, feedback, dev, perm)
+        cnt_item += torch.bincount(it, minlength=n_items)
+        a, c = max(b0, u0), min(b1, u1)
+        if c > a:
+            lo, hi = int(ip[a - b0]), int(ip[c - b0])
+            keep_p.append(ip[a - b0:c - b0] - lo + base)
+            base += hi - lo
+            keep_i.append(it[lo:hi].to(torch.int32))
+            keep_x.append(v[lo:hi])
+    nnz = int(cnt_item.sum())
+    if nnz >= 2 ** 31:
+        raise ValueError("nnz >= 2^31 does not fit the reference's 32-bit index layout")
+    p_u = torch.cat(keep_p + [torch.tensor([base], dtype=torch.int64, device=dev)]) if keep_p else \
+        torch.zeros(1, dtype=torch.int64, device=dev)
+    c_iu = (p_u.to(torch.int32), torch.cat(keep_i) if keep_i else torch.zeros(0, dtype=torch.int32, device=dev),
+            torch.cat(keep_x) if keep_x else torch.zeros(0, dtype=torch.float32, device=dev))
+    del keep_p, keep_i, keep_x
+    ub, ib = bounds_fn(cnt_user, cnt_item)
+    i0, i1 = ib[rank]
+    rows, items, vals = [], [], []
+    for b0 in range(0, n_users, block):
+        b1 = min(n_users, b0 + block)
+        ip, it, v = generate_user_block(b0, b1, n_items, seed, mean_deg, d_max, feedback, dev, perm)
+        deg = ip[1:] - ip[:-1]
+        row = torch.repeat_interleave(torch.arange(b0, b1, dtype=torch.int64, device=dev), deg)
+        m = (it >= i0) & (it < i1)
+        rows.append(row[m])
+        items.append(it[m])
+        vals.append(v[m])
+    row, item, val = torch.cat(rows), torch.cat(items), torch.cat(vals)
+    del rows, items, vals
+    key, order = torch.sort((item - i0) * n_users + row)     # by item, users ascending inside an item
+    item_s = key // n_users
+    p_i = torch.zeros(i1 - i0 + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.bincount(item_s, minlength=i1 - i0), 0, out=p_i[1:])
+    c_ui = (p_i.to(torch.int32), (key - item_s * n_users).to(torch.int32), val[order])
+    return {"n_users": n_users, "n_items": n_items, "nnz": nnz, "cnt_user": cnt_user, "cnt_item": cnt_item,
+            "user_bounds": ub, "item_bounds": ib, "c_iu": c_iu, "c_ui": c_ui}

@@ -165,9 +165,9 @@ class WRMF:
         self._V, self._cnt_item = V, als.cnt_item
         if self._feedback == "implicit":                                           # :345-353
             if self._with_bias:
-                self._XtX = als.gramian_bias(V, n_item, als.ib, False).clone()     # components[-1, ]: item-bias row out
+                self._XtX = als.gramian_bias(V, als.lay_item, False).clone()     # components[-1, ]: item-bias row out
             else:
-                self._XtX = als.gramian(V, n_item, als.Bi, als.ib).clone()
+                self._XtX = als.gramian(V, als.lay_item).clone()
         self.components = np.asfortranarray(V.cpu().numpy().T.astype(self._np_dtype()))   # rank x n_item
         # the returned embeddings come from one more exact solve, not from U (:355-359)
         return self._transform(als.csc_users, n_user)

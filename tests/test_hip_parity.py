@@ -222,7 +222,7 @@ def test_config2_scale_properties():
     als_.half_iteration("users", U3, V, 1, want_loss=False)
     assert torch.equal(U2, U3)                                    # run-to-run deterministic
     # exact solve: residual of the normal equations on sampled users
-    G = als_.gramian(V, n_item, als_.Bi, als_.ib).clone()
+    G = als_.gramian(V, als_.lay_item).clone()
     Uc = torch.zeros_like(U)
     als_.half_iteration("users", Uc, V, 0, G=G, want_loss=False)
     be.check_numeric()

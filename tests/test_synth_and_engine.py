@@ -11,7 +11,7 @@ import torch
 
 from conftest import rel_fro
 from rsparse_amd import synth
-from rsparse_amd.engine import ShardedALS, block_bounds
+from rsparse_amd.engine import ShardedALS
 
 ROOT = Path(__file__).resolve().parent.parent
 
@@ -36,15 +36,33 @@ def test_generator_properties():
     assert set(np.unique(e["c_iu"][2].numpy())) <= {1.0, 2.0, 3.0, 4.0, 5.0}
 
 
-def test_block_bounds():
-    B, b = block_bounds(10, 4)
-    assert B == 3 and b == [(0, 3), (3, 6), (6, 9), (9, 10)]
-    B, b = block_bounds(2, 4)
-    assert B == 1 and b == [(0, 1), (1, 2), (2, 2), (2, 2)]
-    B, b = block_bounds(10, 2, multiple=4)          # blocks padded to a multiple of the sub-block count
-    assert B == 8 and b == [(0, 8), (8, 10)]
-    Bu, ub, Bi, ib, n_sub = ShardedALS.partition(301, 97, 2)
-    assert n_sub == 4 and Bu % 4 == 0 and ub[1][1] == 301 and ShardedALS.partition(301, 97, 1)[4] == 1
+def test_layout_and_balanced_bounds():
+    from rsparse_amd.engine import Layout, balanced_bounds, equal_bounds
+    assert equal_bounds(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert equal_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    # nnz balance: one heavy row at the front takes a block of its own
+    cnt = torch.tensor([100, 1, 1, 1, 1, 1, 1, 1, 1, 1, 50, 50])
+    b = balanced_bounds(cnt, 3)
+    assert b[0][0] == 0 and b[-1][1] == 12 and all(b[r][1] == b[r + 1][0] for r in range(2))
+    nnz = [int(cnt[a:c].sum()) for a, c in b]
+    assert max(nnz) <= 110 and b[0] == (0, 1)
+    assert balanced_bounds(torch.zeros(5), 2)[-1][1] == 5        # all-empty rows: still a partition
+    # storage order: sub-block-major, every global row exactly once, padding rows never addressed
+    lay = Layout(12, b, n_sub=2)
+    st = lay.to_storage(torch.arange(12))
+    assert st.unique().numel() == 12 and int(st.max()) < lay.rows
+    for r, (g0, g1) in enumerate(b):
+        for j in range(2):
+            c0, c1 = lay.sub_rows(r, j)
+            if c1 > c0:
+                assert torch.equal(st[g0 + c0:g0 + c1], torch.arange(lay.sub_start(r, j), lay.sub_start(r, j) + c1 - c0))
+    G = torch.randn(12, 3)
+    S = lay.from_global(lay.alloc(3, "cpu"), G)
+    assert torch.equal(lay.to_global(S), G) and int((S != 0).sum()) == int((G != 0).sum())   # padding rows stay zero
+    one = Layout(7, [(0, 7)], 1)
+    assert one.identity and one.rows == 7
+    lu, li = ShardedALS.layouts(301, 97, 2)
+    assert lu.n_sub == 4 and lu.bounds[1][1] == 301 and ShardedALS.layouts(301, 97, 1)[0].identity
 
 
 def _shard_csc(p, i, x, c0, c1):
@@ -53,55 +71,80 @@ def _shard_csc(p, i, x, c0, c1):
     return (p[c0:c1 + 1] - lo).to(torch.int32).contiguous(), i[lo:hi].contiguous(), x[lo:hi].contiguous()
 
 
-def run_sharded(rank, ws, group, feedback, solver, n_iter=2):
-    from oracle_backend import OracleBackend
-    n_user, n_item, k, lam = 301, 97, 8, 0.1
+def _dataset(feedback, skewed):
+    n_user, n_item = 301, 97
     d = synth.make_dataset(n_user, n_item, mean_deg=12, d_max=60, feedback=feedback, device="cpu")
-    Bu, ub, Bi, ib, n_sub = ShardedALS.partition(n_user, n_item, ws)
-    als = ShardedALS(OracleBackend(), n_user, n_item, k, _shard_csc(*d["c_ui"], *ib[rank]),
-                     _shard_csc(*d["c_iu"], *ub[rank]), d["nnz"], feedback=feedback, lambda_=lam,
-                     dynamic_lambda=True, cg_steps=3, group=group, world_size=ws, my_rank=rank)
-    als.cnt_user = (d["c_iu"][0][1:] - d["c_iu"][0][:-1]).to(torch.float32)
-    als.cnt_item = (d["c_ui"][0][1:] - d["c_ui"][0][:-1]).to(torch.float32)
+    if skewed:   # activity-sorted users (heaviest first): equal row counts would be badly unbalanced in nnz
+        A = sp.csr_matrix((d["c_iu"][2].numpy(), d["c_iu"][1].numpy(), d["c_iu"][0].numpy()), shape=(n_user, n_item))
+        order = np.argsort(-np.diff(A.indptr), kind="stable")
+        A = A[order]
+        A.sort_indices()
+        B = A.tocsc()
+        B.sort_indices()
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+        d = {"n_users": n_user, "n_items": n_item, "nnz": int(A.nnz),
+             "c_iu": (t(A.indptr, torch.int32), t(A.indices, torch.int32), t(A.data, torch.float32)),
+             "c_ui": (t(B.indptr, torch.int32), t(B.indices, torch.int32), t(B.data, torch.float32))}
+    return d
+
+
+def run_sharded(rank, ws, group, feedback, solver, n_iter=2, skewed=False):
+    from oracle_backend import OracleBackend
+    k, lam = 8, 0.1
+    d = _dataset(feedback, skewed)
+    n_user, n_item = d["n_users"], d["n_items"]
+    cnt_user = torch.diff(d["c_iu"][0]).to(torch.float32)
+    cnt_item = torch.diff(d["c_ui"][0]).to(torch.float32)
+    lu, li = ShardedALS.layouts(n_user, n_item, ws, cnt_user if skewed else None, cnt_item if skewed else None)
+    als = ShardedALS(OracleBackend(), n_user, n_item, k, _shard_csc(*d["c_ui"], *li.bounds[rank]),
+                     _shard_csc(*d["c_iu"], *lu.bounds[rank]), d["nnz"], feedback=feedback, lambda_=lam,
+                     dynamic_lambda=True, cg_steps=3, group=group, world_size=ws, my_rank=rank, lay_user=lu, lay_item=li)
+    als.cnt_user, als.cnt_item = cnt_user, cnt_item
     g = torch.Generator().manual_seed(5)
-    U = als.alloc_factors(n_user, Bu, "cpu")
-    V = als.alloc_factors(n_item, Bi, "cpu")
-    U[:n_user] = torch.randn(n_user, k, generator=g) * 0.01
+    U = lu.from_global(lu.alloc(k, "cpu"), torch.randn(n_user, k, generator=g) * 0.01)
+    V = li.alloc(k, "cpu")
     if solver == 0:
-        V[:n_item] = torch.randn(n_item, k, generator=g) * 0.01
+        li.from_global(V, torch.randn(n_item, k, generator=g) * 0.01)
     losses = []
     for _ in range(n_iter):
-        li = als.half_iteration("items", U, V, solver)
-        lu = als.half_iteration("users", U, V, solver)
-        losses.append((li, lu))
-    return U[:n_user].clone(), V[:n_item].clone(), losses
+        l1 = als.half_iteration("items", U, V, solver)
+        l2 = als.half_iteration("users", U, V, solver)
+        losses.append((l1, l2))
+    nnz_mine = int(torch.diff(_shard_csc(*d["c_iu"], *lu.bounds[rank])[0]).sum())
+    return lu.to_global(U).clone(), li.to_global(V).clone(), losses, nnz_mine
 
 
-def _worker(rank, ws, port, feedback, solver, out_dir):
+def _worker(rank, ws, port, feedback, solver, skewed, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=ws)
     try:
-        U, V, losses = run_sharded(rank, ws, None, feedback, solver)
-        torch.save({"U": U, "V": V, "losses": losses}, os.path.join(out_dir, "r%d.pt" % rank))
+        U, V, losses, nnz_mine = run_sharded(rank, ws, None, feedback, solver, skewed=skewed)
+        torch.save({"U": U, "V": V, "losses": losses, "nnz": nnz_mine}, os.path.join(out_dir, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("feedback,solver", [("implicit", 1), ("implicit", 0), ("explicit", 1)])
-def test_two_ranks_match_single_rank(tmp_path, feedback, solver):
-    """world_size-2 gloo run == single-process run: the factors are independent of the sharding
-    (each row's arithmetic is identical); only the Gramian / loss summation order changes."""
+@pytest.mark.parametrize("feedback,solver,ws,skewed", [("implicit", 1, 2, False), ("implicit", 0, 2, False),
+                                                       ("explicit", 1, 2, False), ("implicit", 1, 4, True),
+                                                       ("explicit", 1, 4, True)])
+def test_ranks_match_single_rank(tmp_path, feedback, solver, ws, skewed):
+    """world_size-2 / 4 gloo run == single-process run: the factors are independent of the sharding (each row's
+    arithmetic is identical); only the Gramian / loss summation order changes.  `skewed`: activity-sorted users with
+    nnz-balanced (unequal) blocks -- sub-block-major storage, translated indices, in-place slab gathers."""
     import torch.multiprocessing as mp
     sys.path.insert(0, str(ROOT / "tests"))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, feedback, solver, str(tmp_path)), nprocs=2, join=True)
-    U1, V1, l1 = run_sharded(0, 1, None, feedback, solver)
-    r0 = torch.load(tmp_path / "r0.pt")
-    r1 = torch.load(tmp_path / "r1.pt")
-    assert torch.equal(r0["U"], r1["U"]) and torch.equal(r0["V"], r1["V"])     # replicas agree exactly
-    assert rel_fro(r0["U"].numpy(), U1.numpy()) < 2e-5
-    assert rel_fro(r0["V"].numpy(), V1.numpy()) < 2e-5
-    for (a, b), (c, d) in zip(r0["losses"], l1):
+    mp.spawn(_worker, args=(ws, port, feedback, solver, skewed, str(tmp_path)), nprocs=ws, join=True)
+    U1, V1, l1, _ = run_sharded(0, 1, None, feedback, solver, skewed=skewed)
+    rs = [torch.load(tmp_path / ("r%d.pt" % r)) for r in range(ws)]
+    for r in rs[1:]:
+        assert torch.equal(rs[0]["U"], r["U"]) and torch.equal(rs[0]["V"], r["V"])     # replicas agree exactly
+        assert rs[0]["losses"] == r["losses"]
+    assert rel_fro(rs[0]["U"].numpy(), U1.numpy()) < 2e-5
+    assert rel_fro(rs[0]["V"].numpy(), V1.numpy()) < 2e-5
+    for (a, b), (c, d) in zip(rs[0]["losses"], l1):
         assert abs(a - c) <= 1e-5 * abs(c) and abs(b - d) <= 1e-5 * abs(d)
-    assert r0["losses"] == r1["losses"]
+    if skewed:   # nnz balance of the user blocks: within 25 % of the mean although the row counts differ a lot
+        nnz = np.array([r["nnz"] for r in rs], dtype=float)
+        assert nnz.max() <= 1.25 * nnz.mean()

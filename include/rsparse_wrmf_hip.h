@@ -70,9 +70,12 @@ int rsparse_hip_set_device(int device);
 /* replaces als_implicit_float  (src/wrmf_implicit.cpp:17-31 -> als_implicit<float>,
  * inst/include/wrmf_implicit.hpp:90-305).  n_rows/n_cols/col_ptrs/row_indices/values are the
  * dgCMatrix slots Dim[0], Dim[1], p, i, x.  rank = nrow(X).  n_threads is accepted and ignored.
- * with_biases: Cholesky and NNLS only (XtX is then (rank-1) x (rank-1)); with conjugate_gradient, or with
- * global_bias >= sqrt(FLT_EPSILON), -> ERR_UNSUPPORTED.
- * global_bias_base / initialize_bias_base only matter for those variants and may be NULL / 0.
+ * with_biases: Cholesky and NNLS only (XtX is then (rank-1) x (rank-1)); with conjugate_gradient -> ERR_UNSUPPORTED
+ * (the reference cannot run that combination either, wrmf_implicit.hpp:189,197).
+ * global_bias >= sqrt(FLT_EPSILON) (wrmf_implicit.hpp:108-109): Cholesky and NNLS, with or without biases
+ * (:146-153, 228-229, 262-270); with conjugate_gradient (cg_solver_implicit_global_bias, :35-57) -> ERR_UNSUPPORTED.
+ * global_bias_base (rank entries, no biases only): written with -global_bias * rowSums(X) when initialize_bias_base
+ * != 0 (:111-112), read otherwise; may be NULL.
  * *loss_out = the value the reference returns (loss / nnz). */
 int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_ptrs,
                                    const int32_t* row_indices, const double* values,
@@ -113,6 +116,24 @@ int rsparse_hip_als_explicit_double(int n_rows, int n_cols, const int32_t* col_p
 /* replaces the R-side Gramian  XtX = tcrossprod(X) + fl(diag(lambda))  (R/model_WRMF.R:474-486,
  * :347-353).  Host pointers; X is rank x n column-major; XtX_out rank x rank. */
 int rsparse_hip_gramian_float(const float* X, int rank, int64_t n, double lambda, float* XtX_out);
+
+/* replaces initialize_biases_float / initialize_biases_double (src/wrmf_init.cpp:5-34; .Call
+ * _rsparse_initialize_biases_{float,double}, src/RcppExports.cpp:417-454): the 9 arguments of the reference with the
+ * two S4 matrices flattened to their slots -- m_csc_r = users x items by item column (csc_p [n_items+1], csc_i, csc_x),
+ * m_csr_r = the same matrix by user column (csr_p [n_users+1], csr_i, csr_x) -- plus the returned global bias.
+ * user_bias (n_users) / item_bias (n_items) are read (initial values) and written.  With is_explicit_feedback and
+ * calculate_global_bias the global mean is removed from csc_x and csr_x in place, as the reference does
+ * (inst/include/wrmf_utils.hpp:41-52). */
+int rsparse_hip_initialize_biases_float(int n_users, int n_items, const int32_t* csc_p, const int32_t* csc_i,
+                                        double* csc_x, const int32_t* csr_p, const int32_t* csr_i, double* csr_x,
+                                        float* user_bias, float* item_bias, double lambda, int dynamic_lambda,
+                                        int non_negative, int calculate_global_bias, int is_explicit_feedback,
+                                        double* global_bias_out);
+int rsparse_hip_initialize_biases_double(int n_users, int n_items, const int32_t* csc_p, const int32_t* csc_i,
+                                         double* csc_x, const int32_t* csr_p, const int32_t* csr_i, double* csr_x,
+                                         double* user_bias, double* item_bias, double lambda, int dynamic_lambda,
+                                         int non_negative, int calculate_global_bias, int is_explicit_feedback,
+                                         double* global_bias_out);
 
 /* ------------------------------------------------------------------------------------------------
  * (2) device-resident layer
@@ -184,11 +205,24 @@ int rsparse_hip_als_implicit_bias_device(const rsparse_hip_csc* conf, const floa
                                          const float* d_XtX, int rank, double lambda, unsigned solver,
                                          int is_x_bias_last_row, double* d_loss_rows_out, void* stream);
 
-/* initialize_biases_implicit without global bias (inst/include/wrmf_utils.hpp:86-165; .Call
- * _rsparse_initialize_biases_{double,float} with is_explicit_feedback = FALSE, calculate_global_bias = FALSE). */
+/* als_implicit<T> with a global bias (inst/include/wrmf_implicit.hpp:108-112,146-157,228-229,262-270), Cholesky or NNLS,
+ * device-resident form; with_biases selects the user/item-bias layout of rsparse_hip_als_implicit_bias_device (then
+ * rhs_init = -X' (x_b + global_bias), :152), otherwise X / Y / XtX are the plain rank x n matrices and every right-hand
+ * side gets global_bias_base = -global_bias * rowSums(X) (:111-112, computed on the device).  The loss compares x_j.y
+ * with 1 - global_bias (- x_b).  global_bias itself is the caller's: sum(x) / (sum(x) + n_user n_item - nnz),
+ * R/model_WRMF.R:286-287.  solver = conjugate_gradient -> RSPARSE_HIP_ERR_UNSUPPORTED. */
+int rsparse_hip_als_implicit_global_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
+                                                const float* d_XtX, int rank, double lambda, unsigned solver,
+                                                int with_biases, int is_x_bias_last_row, double global_bias,
+                                                double* d_loss_rows_out, void* stream);
+
+/* initialize_biases_implicit (inst/include/wrmf_utils.hpp:86-165; .Call _rsparse_initialize_biases_{double,float} with
+ * is_explicit_feedback = FALSE).  calculate_global_bias: sum(x) / (sum(x) + n_users n_items - nnz) (:90-93), subtracted
+ * inside the sweeps (:142,157) and returned through global_bias_out (may be NULL). */
 int rsparse_hip_initialize_biases_implicit_device(const rsparse_hip_csc* c_ui, const rsparse_hip_csc* c_iu,
                                                   float* d_user_bias, float* d_item_bias, double lambda,
-                                                  int non_negative, void* stream);
+                                                  int non_negative, int calculate_global_bias,
+                                                  double* global_bias_out, void* stream);
 
 /* als_explicit<T> with_biases = TRUE (inst/include/wrmf_explicit.hpp:41-64,86-91,113-127), device-resident form.
  * rank counts the two extra coordinates (R/model_WRMF.R:160: rank + 2): X = [1, ..., x_bias] and

@@ -24,6 +24,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -519,9 +520,13 @@ double als_explicit_biases(int n_rows, int n_cols, const int32_t* col_ptrs, cons
 template <class T>
 double als_implicit_biases(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
                            const double* values, const T* X, T* Y, const T* XtX, int k, double lambda,
-                           int n_threads, unsigned solver, int is_x_bias_last_row, int* status) {
+                           int n_threads, unsigned solver, int is_x_bias_last_row, int* status,
+                           double global_bias_in = 0.0) {
   double loss = 0;
   int bad = 0;
+  // :108-109 -- a global bias below sqrt(eps) counts as zero; with one, rhs_init = -X' (x_b + global_bias) (:152) and
+  // the loss compares with 1 - global_bias - x_b (:268-270)
+  const T gbias = global_bias_in < std::sqrt((double)std::numeric_limits<T>::epsilon()) ? (T)0 : (T)global_bias_in;
   const size_t nnz = (size_t)col_ptrs[n_cols];
   const int k1 = k - 1;
   const int xoff = is_x_bias_last_row ? 0 : 1;
@@ -531,7 +536,7 @@ double als_implicit_biases(int n_rows, int n_cols, const int32_t* col_ptrs, cons
   std::vector<T> rhs_init(k1, (T)0);
   for (int j = 0; j < n_rows; j++) {
     const T* xc = X + (size_t)j * k;
-    const T b = xc[xb];
+    const T b = xc[xb] + gbias;
     for (int r = 0; r < k1; r++) rhs_init[r] -= xc[xoff + r] * b;
   }
 #pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
@@ -580,7 +585,7 @@ double als_implicit_biases(int n_rows, int n_cols, const int32_t* col_ptrs, cons
       if (n > 0) {
         gemv_t(s.Xn.data(), s.x.data(), s.t.data(), k1, n);
         for (int j = 0; j < n; j++) {
-          const T d = (T)1.0 - s.t[j] - xbn[j];
+          const T d = ((T)1.0 - gbias) - s.t[j] - xbn[j];
           l += d * d * s.conf[j];
         }
       }
@@ -602,14 +607,98 @@ double als_implicit_biases(int n_rows, int n_cols, const int32_t* col_ptrs, cons
   return loss / (double)nnz;
 }
 
+// als_implicit<T> with a global bias, no user/item biases, Cholesky / NNLS branch (inst/include/wrmf_implicit.hpp:
+// 108-112: global_bias_base = -global_bias * rowSums(X); :155-157 rhs_init = global_bias_base; :178 every column is
+// solved; :228-229 rhs = X_nnz c + rhs_init; :262-264 loss against 1 - global_bias).  base_out (k entries) may be null.
+template <class T>
+double als_implicit_global(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                           const double* values, const T* X, T* Y, const T* XtX, int k, double lambda, int n_threads,
+                           unsigned solver, double global_bias_in, T* base_out, int* status) {
+  double loss = 0;
+  int bad = 0;
+  const T gbias = global_bias_in < std::sqrt((double)std::numeric_limits<T>::epsilon()) ? (T)0 : (T)global_bias_in;
+  const size_t nnz = (size_t)col_ptrs[n_cols];
+  std::vector<T> base(k, (T)0);
+  for (int j = 0; j < n_rows; j++)
+    for (int r = 0; r < k; r++) base[r] += X[(size_t)j * k + r];
+  for (int r = 0; r < k; r++) base[r] *= -gbias;
+  if (base_out) std::memcpy(base_out, base.data(), sizeof(T) * k);
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+  {
+    Scratch<T> s;
+    std::vector<T> keep;
+#pragma omp for schedule(dynamic) reduction(+ : loss) reduction(+ : bad)
+    for (int i = 0; i < n_cols; i++) {
+      const int p1 = col_ptrs[i], p2 = col_ptrs[i + 1];
+      T* y = Y + (size_t)i * k;
+      const int n = p2 - p1;
+      if (!(gbias != (T)0 || n > 0)) {   // :178, :272-283
+        for (int r = 0; r < k; r++) y[r] = 0;
+        continue;
+      }
+      s.ensure(k, n > 0 ? n : 1);
+      for (int j = 0; j < n; j++) {
+        s.conf[j] = (T)values[p1 + j];
+        std::memcpy(&s.Xn[(size_t)j * k], X + (size_t)row_indices[p1 + j] * k, sizeof(T) * k);
+      }
+      std::vector<T> init(y, y + k);
+      T* lhs = s.lhs.data();
+      std::memcpy(lhs, XtX, sizeof(T) * k * k);
+      for (int j = 0; j < n; j++) {
+        const T c1 = s.conf[j] - (T)1.0;
+        const T* col = &s.Xn[(size_t)j * k];
+        for (int b = 0; b < k; b++) {
+          const T f = col[b] * c1;
+          for (int a = 0; a < k; a++) lhs[(size_t)b * k + a] += col[a] * f;
+        }
+      }
+      for (int r = 0; r < k; r++) s.x[r] = gbias != (T)0 ? base[r] : (T)0;
+      for (int j = 0; j < n; j++) {
+        const T* col = &s.Xn[(size_t)j * k];
+        for (int r = 0; r < k; r++) s.x[r] += col[r] * s.conf[j];
+      }
+      if (solver == SEQ_COORDINATE_WISE_NNLS) {
+        std::vector<T> rhs(s.x.begin(), s.x.begin() + k);
+        std::memcpy(s.x.data(), init.data(), sizeof(T) * k);
+        c_nnls<T>(lhs, rhs.data(), s.x.data(), k, SCD_MAX_ITER, SCD_TOL, keep);
+      } else if (!solve_sympd(lhs, s.x.data(), k, keep)) {
+        bad += 1;
+      }
+      std::memcpy(y, s.x.data(), sizeof(T) * k);
+      T l = 0;
+      if (n > 0) {
+        gemv_t(s.Xn.data(), s.x.data(), s.t.data(), k, n);
+        for (int j = 0; j < n; j++) {
+          const T d = ((T)1.0 - gbias) - s.t[j];
+          l += d * d * s.conf[j];
+        }
+      }
+      loss += l + lambda * dot(s.x.data(), s.x.data(), k);
+    }
+  }
+  if (lambda > 0) {
+    double tot = 0;
+    for (size_t e = 0; e < (size_t)n_rows * k; e++) tot += (double)(X[e] * X[e]);
+    loss += lambda * tot;
+  }
+  if (status) *status = bad;
+  return loss / (double)nnz;
+}
+
 // inst/include/wrmf_utils.hpp:86-165 -- initialize_biases_implicit (no global bias here: calculate_global_bias =
 // FALSE is what the R driver passes unless with_global_bias, which the device path does not take for implicit
 // feedback).  csc = users x items by item column, csr = the same by user column.
 template <class T>
 double initialize_biases_implicit(int n_items, const int32_t* csc_p, const int32_t* csc_i, const double* csc_x,
                                   int n_users, const int32_t* csr_p, const int32_t* csr_i, const double* csr_x,
-                                  T* user_bias, T* item_bias, T lambda, int non_negative) {
-  const double global_bias = 0;
+                                  T* user_bias, T* item_bias, T lambda, int non_negative, int calculate_global_bias = 0) {
+  double global_bias = 0;
+  if (calculate_global_bias) {                                                          // :90-93
+    long double sm = 0;
+    for (int ix = 0; ix < csr_p[n_users]; ix++) sm += (long double)csr_x[ix];
+    global_bias = (double)(sm / (sm + (long double)n_items * (long double)n_users - (long double)csr_p[n_users]));
+  }
+  if (non_negative) global_bias = std::fmax(0., global_bias);
   std::vector<double> user_means(n_users), item_means(n_items), user_adj(n_users, 0.0), item_adj(n_items, 0.0);
   for (int r = 0; r < n_users; r++) {                                                  // :101-112
     const int cnt = csr_p[r + 1] - csr_p[r];
@@ -762,17 +851,39 @@ double wrmf_oracle_als_implicit_bias_f64(int n_rows, int n_cols, const int32_t* 
   return als_implicit_biases<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads,
                                      solver, is_x_bias_last_row, status);
 }
+double wrmf_oracle_als_implicit_gbias_f32(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                                          const double* values, const float* X, float* Y, const float* XtX, int k,
+                                          double lambda, int n_threads, unsigned solver, int with_biases,
+                                          int is_x_bias_last_row, double global_bias, float* base_out, int* status) {
+  if (with_biases)
+    return als_implicit_biases<float>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads,
+                                      solver, is_x_bias_last_row, status, global_bias);
+  return als_implicit_global<float>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads, solver,
+                                    global_bias, base_out, status);
+}
+double wrmf_oracle_als_implicit_gbias_f64(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
+                                          const double* values, const double* X, double* Y, const double* XtX, int k,
+                                          double lambda, int n_threads, unsigned solver, int with_biases,
+                                          int is_x_bias_last_row, double global_bias, double* base_out, int* status) {
+  if (with_biases)
+    return als_implicit_biases<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads,
+                                       solver, is_x_bias_last_row, status, global_bias);
+  return als_implicit_global<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads,
+                                     solver, global_bias, base_out, status);
+}
 double wrmf_oracle_init_biases_implicit_f32(int n_items, const int32_t* csc_p, const int32_t* csc_i, const double* csc_x,
                                             int n_users, const int32_t* csr_p, const int32_t* csr_i, const double* csr_x,
-                                            float* user_bias, float* item_bias, double lambda, int non_negative) {
+                                            float* user_bias, float* item_bias, double lambda, int non_negative,
+                                            int calculate_global_bias) {
   return initialize_biases_implicit<float>(n_items, csc_p, csc_i, csc_x, n_users, csr_p, csr_i, csr_x, user_bias,
-                                           item_bias, (float)lambda, non_negative);
+                                           item_bias, (float)lambda, non_negative, calculate_global_bias);
 }
 double wrmf_oracle_init_biases_implicit_f64(int n_items, const int32_t* csc_p, const int32_t* csc_i, const double* csc_x,
                                             int n_users, const int32_t* csr_p, const int32_t* csr_i, const double* csr_x,
-                                            double* user_bias, double* item_bias, double lambda, int non_negative) {
+                                            double* user_bias, double* item_bias, double lambda, int non_negative,
+                                            int calculate_global_bias) {
   return initialize_biases_implicit<double>(n_items, csc_p, csc_i, csc_x, n_users, csr_p, csr_i, csr_x, user_bias,
-                                            item_bias, lambda, non_negative);
+                                            item_bias, lambda, non_negative, calculate_global_bias);
 }
 double wrmf_oracle_als_explicit_bias_f32(int n_rows, int n_cols, const int32_t* col_ptrs,
                                          const int32_t* row_indices, const double* values, const float* X, float* Y,

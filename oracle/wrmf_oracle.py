@@ -80,7 +80,7 @@ def _check(a, dtype, name):
 
 
 def als_implicit(col_ptrs, row_indices, values, X, Y, XtX, lam, solver, cg_steps=3, n_threads=1,
-                 native=False, with_biases=False, is_x_bias_last_row=False):
+                 native=False, with_biases=False, is_x_bias_last_row=False, global_bias=0.0, base_out=None):
     """One implicit half-iteration (als_implicit<T>).  X: (k, n_rows) F-order, Y: (k, n_cols)
     F-order, modified in place.  dtype float32 or float64 selects T.  Returns loss/nnz.
     with_biases: the user/item-bias branch (Cholesky / NNLS), XtX is then (k-1) x (k-1)."""
@@ -90,6 +90,20 @@ def als_implicit(col_ptrs, row_indices, values, X, Y, XtX, lam, solver, cg_steps
     k, n_rows = X.shape
     n_cols = Y.shape[1]
     fp = _f32p if dt == np.float32 else _f64p
+    if global_bias:
+        # Cholesky / NNLS branches with a global bias (wrmf_implicit.hpp:108-112,146-157,228-229,262-270)
+        if int(solver) == 1:
+            raise NotImplementedError("oracle: cg_solver_implicit_global_bias is not restated (not on the device path)")
+        f = getattr(lib(native), "wrmf_oracle_als_implicit_gbias_" + ("f32" if dt == np.float32 else "f64"))
+        f.restype = ctypes.c_double
+        st = ctypes.c_int(0)
+        loss = f(n_rows, n_cols, _ptr(col_ptrs, _i32p), _ptr(row_indices, _i32p), _ptr(values, _f64p), _ptr(X, fp),
+                 _ptr(Y, fp), _ptr(XtX, fp), k, ctypes.c_double(lam), int(n_threads), ctypes.c_uint(solver),
+                 int(bool(with_biases)), int(bool(is_x_bias_last_row)), ctypes.c_double(global_bias),
+                 None if base_out is None else _ptr(base_out, fp), ctypes.byref(st))
+        if st.value:
+            raise RuntimeError("oracle: %d singular systems" % st.value)
+        return loss
     if with_biases:
         if int(solver) == 1:
             raise NotImplementedError("CG + biases with implicit feedback cannot run in the reference (wrmf_implicit.hpp:189,197)")
@@ -160,8 +174,9 @@ def init_biases_explicit(csc, csr, user_bias, item_bias, lam, dynamic_lambda=Tru
              int(bool(dynamic_lambda)), int(bool(non_negative)), int(bool(calculate_global_bias)))
 
 
-def init_biases_implicit(csc, csr, user_bias, item_bias, lam, non_negative=False, native=False):
-    """initialize_biases_implicit without global bias (wrmf_utils.hpp:86-165); arguments as init_biases_explicit."""
+def init_biases_implicit(csc, csr, user_bias, item_bias, lam, non_negative=False, native=False,
+                         calculate_global_bias=False):
+    """initialize_biases_implicit (wrmf_utils.hpp:86-165); arguments as init_biases_explicit.  Returns the global bias."""
     dt = user_bias.dtype
     fp = _f32p if dt == np.float32 else _f64p
     f = getattr(lib(native), "wrmf_oracle_init_biases_implicit_" + ("f32" if dt == np.float32 else "f64"))
@@ -169,7 +184,8 @@ def init_biases_implicit(csc, csr, user_bias, item_bias, lam, non_negative=False
     (p1, i1, x1), (p2, i2, x2) = csc, csr
     return f(len(p1) - 1, _ptr(p1, _i32p), _ptr(i1, _i32p), _ptr(np.ascontiguousarray(x1, dtype=np.float64), _f64p),
              len(p2) - 1, _ptr(p2, _i32p), _ptr(i2, _i32p), _ptr(np.ascontiguousarray(x2, dtype=np.float64), _f64p),
-             _ptr(user_bias, fp), _ptr(item_bias, fp), ctypes.c_double(lam), int(bool(non_negative)))
+             _ptr(user_bias, fp), _ptr(item_bias, fp), ctypes.c_double(lam), int(bool(non_negative)),
+             int(bool(calculate_global_bias)))
 
 
 def gramian(X, lam, native=False):
@@ -255,14 +271,14 @@ class OracleWRMF:
 
     def __init__(self, rank, lam=0.0, feedback="implicit", solver="conjugate_gradient", cg_steps=3,
                  dynamic_lambda=True, dtype=np.float64, n_threads=1, with_user_item_bias=False, with_global_bias=False):
-        if with_global_bias and feedback != "explicit":
-            raise NotImplementedError("oracle: the global bias is restated for explicit feedback only")
         self.with_bias, self.with_global_bias = bool(with_user_item_bias), bool(with_global_bias)
         self.global_bias = 0.0
         rank = int(rank) + (2 if self.with_bias else 0)                            # :160
         self.rank, self.lam, self.feedback = int(rank), float(lam), feedback
         self.solver_code = {"cholesky": 0, "conjugate_gradient": 1, "nnls": 2}[solver]   # :99-100
         self.non_negative = solver == "nnls"                                      # :88
+        if self.non_negative:                                                     # :90-93 nnls drops the global bias
+            self.with_global_bias = False
         self.cg_steps, self.dynamic_lambda = int(cg_steps), bool(dynamic_lambda)
         self.dtype, self.n_threads = np.dtype(dtype), n_threads
         self.components = None
@@ -277,7 +293,8 @@ class OracleWRMF:
                     XX = np.asfortranarray(X[:-1, :] if is_bias_last_row else X[1:, :])
                 XtX = gramian(XX, self.lam)                                         # :474-486
             return als_implicit(p, i, x, X, Y, XtX, self.lam, solver, self.cg_steps, self.n_threads,
-                                with_biases=self.with_bias, is_x_bias_last_row=is_bias_last_row)
+                                with_biases=self.with_bias, is_x_bias_last_row=is_bias_last_row,
+                                global_bias=self.global_bias)
         return als_explicit(p, i, x, X, Y, cnt_X, self.lam, solver, self.cg_steps,
                             self.dynamic_lambda, self.n_threads, with_biases=self.with_bias,
                             is_x_bias_last_row=is_bias_last_row)
@@ -309,7 +326,7 @@ class OracleWRMF:
                                           self.dynamic_lambda, self.non_negative, self.with_global_bias)
             else:
                 gb = init_biases_implicit((p_ui, i_ui, x_ui), self.c_iu, user_bias, item_bias, self.lam,
-                                          self.non_negative)
+                                          self.non_negative, calculate_global_bias=self.with_global_bias)
             comp[0, :] = item_bias
             U[self.rank - 1, :] = user_bias
             if self.with_global_bias:
@@ -318,6 +335,9 @@ class OracleWRMF:
             self.global_bias = float(np.mean(x_ui))
             x_ui -= self.global_bias
             self.c_iu[2][:] -= self.global_bias
+        elif self.with_global_bias:                                                 # :285-287
+            sm = float(np.sum(x_ui))
+            self.global_bias = sm / (sm + float(n_user) * float(n_item) - float(len(x_ui)))
         cnt_u = np.diff(p_ui).astype(dt)     # :311 -- nnz per item (named cnt_u in the reference)
         cnt_i = np.diff(self.c_iu[0]).astype(dt)
         self.cnt_u = cnt_u

@@ -65,13 +65,12 @@ def als_implicit(x, X, Y, lambda_, n_threads, solver_code, cg_steps, precision, 
     if X.shape[1] != n_rows or Y.shape != (rank, n_cols):
         raise ValueError("X must be rank x nrow(x) and Y rank x ncol(x)")
     bias = bool(with_user_item_bias)
-    if global_bias or (bias and int(solver_code) == 1):
-        # the C ABI reports these as UNSUPPORTED; raise before touching the device
-        _lib.check(lib.rsparse_hip_als_implicit_float(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), None,
-                                                      rank, float(lambda_), int(n_threads), int(solver_code),
-                                                      int(cg_steps), int(bias),
-                                                      int(bool(is_bias_last_row)), float(global_bias), None,
-                                                      int(bool(initialize_bias_base)), None))
+    fn = lib.rsparse_hip_als_implicit_float if precision == "float" else lib.rsparse_hip_als_implicit_double
+    if int(solver_code) == 1 and (bias or global_bias):
+        # the C ABI reports these as UNSUPPORTED (include/rsparse_wrmf_hip.h); ask it before computing a Gramian
+        _lib.check(fn(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), None, rank, float(lambda_),
+                      int(n_threads), int(solver_code), int(cg_steps), int(bias), int(bool(is_bias_last_row)),
+                      float(global_bias), None, int(bool(initialize_bias_base)), None))
     if XtX is None:
         # R/model_WRMF.R:474-486: with biases the x_bias row is discarded before tcrossprod
         XX = X
@@ -79,12 +78,40 @@ def als_implicit(x, X, Y, lambda_, n_threads, solver_code, cg_steps, precision, 
             XX = np.asfortranarray(X[:-1, :] if is_bias_last_row else X[1:, :])
         XtX = gramian(XX, lambda_, precision)
     _f_contig(XtX, dt, "XtX")
+    if global_bias_base is not None:
+        # R/model_WRMF.R:470-472: numeric(rank) / float(rank), written when initialize_bias_base, read otherwise
+        if not isinstance(global_bias_base, np.ndarray) or global_bias_base.dtype != dt or global_bias_base.size != rank:
+            raise ValueError("global_bias_base must be a numpy vector of %d values of dtype %s" % (rank, np.dtype(dt)))
     loss = ctypes.c_double(0.0)
-    fn = lib.rsparse_hip_als_implicit_float if precision == "float" else lib.rsparse_hip_als_implicit_double
     _lib.check(fn(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), _vp(XtX), rank, float(lambda_),
-                  int(n_threads), int(solver_code), int(cg_steps), int(bias), int(bool(is_bias_last_row)), 0.0,
-                  None, int(bool(initialize_bias_base)), ctypes.addressof(loss)))
+                  int(n_threads), int(solver_code), int(cg_steps), int(bias), int(bool(is_bias_last_row)),
+                  float(global_bias), _vp(global_bias_base), int(bool(initialize_bias_base)), ctypes.addressof(loss)))
     return loss.value
+
+
+def initialize_biases(m_csc, m_csr, user_bias, item_bias, lambda_, dynamic_lambda, non_negative,
+                      calculate_global_bias, is_explicit_feedback=False):
+    """R/RcppExports.R:104-110 (`initialize_biases_double` / `_float`), src/wrmf_init.cpp:5-34.  m_csc: users x items
+    (columns = items), m_csr: the same matrix transposed (columns = users), both as CSC slots; user_bias / item_bias
+    are overwritten; with explicit feedback and calculate_global_bias the global mean leaves BOTH matrices' values in
+    place, as in the reference (wrmf_utils.hpp:41-52) -- pass (n_rows, n_cols, p, i, x) tuples with float64 x to see it.
+    Returns the global bias."""
+    lib = _lib.load()
+    dt = user_bias.dtype
+    if dt not in (np.float32, np.float64) or item_bias.dtype != dt:
+        raise ValueError("user_bias and item_bias must both be float32 or both float64")
+    n_users, n_items, p1, i1, v1 = _csc_slots(m_csc)
+    n2r, n2c, p2, i2, v2 = _csc_slots(m_csr)
+    if (n2r, n2c) != (n_items, n_users) or v1.size != v2.size:
+        raise ValueError("m_csr must be the transpose of m_csc")
+    if user_bias.size != n_users or item_bias.size != n_items:
+        raise ValueError("user_bias / item_bias lengths must be nrow / ncol of m_csc")
+    gb = ctypes.c_double(0.0)
+    fn = lib.rsparse_hip_initialize_biases_float if dt == np.float32 else lib.rsparse_hip_initialize_biases_double
+    _lib.check(fn(n_users, n_items, _vp(p1), _vp(i1), _vp(v1), _vp(p2), _vp(i2), _vp(v2), _vp(user_bias), _vp(item_bias),
+                  float(lambda_), int(bool(dynamic_lambda)), int(bool(non_negative)), int(bool(calculate_global_bias)),
+                  int(bool(is_explicit_feedback)), ctypes.byref(gb)))
+    return gb.value
 
 
 def als_explicit(x, X, Y, cnt_X, lambda_, n_threads, solver_code, cg_steps, dynamic_lambda, precision,

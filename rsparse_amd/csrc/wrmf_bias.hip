@@ -72,13 +72,14 @@ __global__ __launch_bounds__(256) void values_add_kernel(float* __restrict__ x, 
 __global__ __launch_bounds__(256) void bias_implicit_terms_kernel(const float* __restrict__ vals,
                                                                   const int32_t* __restrict__ row_idx,
                                                                   const float* __restrict__ X, int k, int bias_row,
-                                                                  int64_t nnz, float* __restrict__ rhs_vals,
+                                                                  int64_t nnz, float global_bias,
+                                                                  float* __restrict__ rhs_vals,
                                                                   float* __restrict__ loss_tgt) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
     const float c = vals[e], xb = X[(size_t)row_idx[e] * k + bias_row];
     rhs_vals[e] = c - xb * (c - 1.f);
-    loss_tgt[e] = 1.f - xb;
+    loss_tgt[e] = (1.f - global_bias) - xb;   // wrmf_implicit.hpp:265-270
   }
 }
 
@@ -86,13 +87,15 @@ __global__ __launch_bounds__(256) void bias_implicit_terms_kernel(const float* _
 // X[e][off + t] * X[e][bias_row]; fixed-order second stage -> deterministic
 constexpr int kRhsInitBlocks = 256;
 __global__ __launch_bounds__(128) void bias_rhs_init_partial_kernel(const float* __restrict__ X, int k, int off, int k1,
-                                                                    int bias_row, int n, float* __restrict__ partial) {
+                                                                    int bias_row, float global_bias, int n,
+                                                                    float* __restrict__ partial) {
   const int t = threadIdx.x;
   const int per = (n + gridDim.x - 1) / gridDim.x;
   const int e0 = blockIdx.x * per, e1 = min(n, e0 + per);
   float s = 0.f;
   if (t < k1)
-    for (int e = e0; e < e1; e++) s = fmaf(-X[(size_t)e * k + off + t], X[(size_t)e * k + bias_row], s);
+    for (int e = e0; e < e1; e++)   // rhs_init = -X' (x_b + global_bias)  (wrmf_implicit.hpp:146-153; :110-112 without biases)
+      s = fmaf(-X[(size_t)e * k + off + t], (bias_row >= 0 ? X[(size_t)e * k + bias_row] : 0.f) + global_bias, s);
   partial[(size_t)blockIdx.x * 128 + t] = s;
 }
 __global__ __launch_bounds__(128) void bias_rhs_init_reduce_kernel(const float* __restrict__ partial, int blocks,
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void bias_implicit_sweep_kernel(const int32_t*
                                                                   const double* __restrict__ other_sum,
                                                                   const double* __restrict__ means,
                                                                   const double* __restrict__ adj, int non_negative,
-                                                                  float* __restrict__ out) {
+                                                                  double global_bias, float* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cols) return;
   double wsum = (double)n_other;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void bias_implicit_sweep_kernel(const int32_t*
     wsum += w;
     bias_this += (w * ((double)other[i[e]] - bias_this)) / wsum;
   }
-  float b = (float)((means[c] - bias_this) * adj[c]);
+  float b = (float)((means[c] - bias_this - global_bias) * adj[c]);   // wrmf_utils.hpp:142,157
   if (non_negative) b = fmaxf(0.f, b);
   out[c] = b;
 }
@@ -148,18 +151,18 @@ __global__ __launch_bounds__(256) void bias_implicit_sweep_kernel(const int32_t*
 }  // namespace
 
 hipError_t launch_bias_implicit_terms(const float* vals, const int32_t* row_idx, const float* X, int k, int bias_row,
-                                      int64_t nnz, float* rhs_vals, float* loss_tgt, hipStream_t s) {
+                                      int64_t nnz, float global_bias, float* rhs_vals, float* loss_tgt, hipStream_t s) {
   if (nnz <= 0) return hipSuccess;
   hipLaunchKernelGGL(bias_implicit_terms_kernel, dim3(2048), dim3(256), 0, s, vals, row_idx, X, k, bias_row, nnz,
-                     rhs_vals, loss_tgt);
+                     global_bias, rhs_vals, loss_tgt);
   return hipGetLastError();
 }
 
 // out[0..128): rhs_init (entries >= k1 are zero); scratch: kRhsInitBlocks * 128 floats
-hipError_t launch_bias_rhs_init(const float* X, int k, int off, int k1, int bias_row, int n, float* scratch, float* out,
-                                hipStream_t s) {
-  hipLaunchKernelGGL(bias_rhs_init_partial_kernel, dim3(kRhsInitBlocks), dim3(128), 0, s, X, k, off, k1, bias_row, n,
-                     scratch);
+hipError_t launch_bias_rhs_init(const float* X, int k, int off, int k1, int bias_row, float global_bias, int n,
+                                float* scratch, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(bias_rhs_init_partial_kernel, dim3(kRhsInitBlocks), dim3(128), 0, s, X, k, off, k1, bias_row,
+                     global_bias, n, scratch);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(bias_rhs_init_reduce_kernel, dim3(1), dim3(128), 0, s, scratch, kRhsInitBlocks, out);
@@ -176,10 +179,10 @@ hipError_t launch_bias_implicit_prep(const int32_t* p, const float* x, int n_col
 }
 hipError_t launch_bias_implicit_sweep(const int32_t* p, const int32_t* i, const float* x, const float* other, int n_cols,
                                       int n_other, const double* other_sum, const double* means, const double* adj,
-                                      int non_negative, float* out, hipStream_t s) {
+                                      int non_negative, double global_bias, float* out, hipStream_t s) {
   if (n_cols <= 0) return hipSuccess;
   hipLaunchKernelGGL(bias_implicit_sweep_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, p, i, x, other, n_cols,
-                     n_other, other_sum, means, adj, non_negative, out);
+                     n_other, other_sum, means, adj, non_negative, global_bias, out);
   return hipGetLastError();
 }
 

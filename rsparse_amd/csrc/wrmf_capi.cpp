@@ -295,21 +295,26 @@ int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_i
   return RSPARSE_HIP_OK;
 }
 
+// wrmf_implicit.hpp:108-109: a global bias below sqrt(eps) is treated as zero
+bool has_global_bias(double global_bias) { return global_bias >= std::sqrt((double)FLT_EPSILON); }
+
 int check_variant(unsigned solver, int with_biases, double global_bias, bool implicit = true) {
   if (solver > RSPARSE_SOLVER_NNLS) return fail(RSPARSE_HIP_ERR_INVALID, "unknown solver code");
   if (with_biases && implicit && solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT)
     // the reference drops a row of the warm start twice on this path (wrmf_implicit.hpp:189,197) and cannot run it
     return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "with_user_item_bias + conjugate_gradient with implicit feedback is not on the device path");
-  // wrmf_implicit.hpp:108-109: global_bias below sqrt(eps) is treated as zero
-  if (global_bias >= std::sqrt((double)FLT_EPSILON))
-    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "global_bias is not on the device path");
+  if (has_global_bias(global_bias) && (!implicit || solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT))
+    // implicit global bias: the Cholesky / NNLS branches (wrmf_implicit.hpp:228-229,262-270) are on the device; the
+    // conjugate-gradient variant (cg_solver_implicit_global_bias, :35-57, "very poor numerical precision") is not
+    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "global_bias with the conjugate-gradient solver is not on the device path");
   return RSPARSE_HIP_OK;
 }
 
-struct BiasTerms {   // implicit feedback with user/item biases, see AlsArgs
+struct BiasTerms {   // implicit feedback with user/item biases and / or a global bias, see AlsArgs
   const float* rhs_vals;
   const float* loss_tgt;
   const float* rhs_init;
+  float tgt_const = 1.f;
 };
 
 int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* d_X, float* d_Y,
@@ -348,6 +353,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.rhs_vals = bias ? bias->rhs_vals : nullptr;
   a.loss_tgt = bias ? bias->loss_tgt : nullptr;
   a.rhs_init = bias ? bias->rhs_init : nullptr;
+  a.loss_tgt_const = bias ? bias->tgt_const : 1.f;
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
   a.ne_prof = nullptr;
 #ifdef RSP_NE_PROF
@@ -454,7 +460,7 @@ int run_half_iteration_explicit_biased(const rsparse_hip_csc* conf, const float*
 // (rank-1) x (rank-1) Gramian of X without its x_bias row, ridge included (R/model_WRMF.R:474-486).
 int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, const float* d_XtX,
                                        int rank, double lambda, unsigned solver, int is_x_bias_last_row,
-                                       double* d_loss_rows_out, hipStream_t s) {
+                                       double* d_loss_rows_out, hipStream_t s, double global_bias = 0.0) {
   if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
   if (!d_X || !d_Y || !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "X, Y or XtX is NULL");
   if (rank < 2) return fail(RSPARSE_HIP_ERR_INVALID, "with_biases needs rank >= 2 (a row of ones and a bias row)");
@@ -480,9 +486,10 @@ int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float*
   if (d.n_cols > 0)
     HIP_TRY(hipMemcpy2DAsync(Yp, (size_t)k1 * 4, d_Y + ioff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_cols,
                              hipMemcpyDeviceToDevice, s));
-  hipError_t e = launch_bias_implicit_terms(d.vals, d.row_idx, d_X, rank, xb, d.nnz, rcoef, tgt, s);
+  const float gb = has_global_bias(global_bias) ? (float)global_bias : 0.f;
+  hipError_t e = launch_bias_implicit_terms(d.vals, d.row_idx, d_X, rank, xb, d.nnz, gb, rcoef, tgt, s);
   if (e != hipSuccess) return hip_fail(e, "launch_bias_implicit_terms");
-  if ((e = launch_bias_rhs_init(d_X, rank, xoff, k1, xb, d.n_rows, scratch, rinit, s)) != hipSuccess)
+  if ((e = launch_bias_rhs_init(d_X, rank, xoff, k1, xb, gb, d.n_rows, scratch, rinit, s)) != hipSuccess)
     return hip_fail(e, "launch_bias_rhs_init");
   BiasTerms bt{rcoef, tgt, rinit};
   rc = run_half_iteration(conf, true, Xp, Yp, d_XtX, k1, lambda, solver, 0, 0, d_loss_rows_out, s, &bt);
@@ -493,12 +500,43 @@ int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float*
   return RSPARSE_HIP_OK;
 }
 
+// als_implicit<T> with a global bias and no user/item biases, Cholesky / NNLS (inst/include/wrmf_implicit.hpp:108-112,
+// 155-157, 228-229, 262-264): rhs = X_nnz c + global_bias_base with global_bias_base = -global_bias * rowSums(X)
+// (computed here when d_base_in is NULL -- initialize_bias_base -- and returned through d_base_out if given), every row
+// is solved (empty ones too, :178), and the loss compares x_j.y with 1 - global_bias.
+int run_half_iteration_implicit_global(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, const float* d_XtX,
+                                       int rank, double lambda, unsigned solver, double global_bias,
+                                       const float* d_base_in, float* d_base_out, double* d_loss_rows_out,
+                                       hipStream_t s) {
+  if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
+  if (!d_X || !d_Y || !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "X, Y or XtX is NULL");
+  if (rank <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  int rc = g_ws.ensure_device();
+  if (rc) return rc;
+  const DevCSC& d = conf->d;
+  const size_t nscr = bias_rhs_init_scratch_floats();
+  if ((rc = g_ws.ensure_bias(nscr + 16))) return rc;
+  float* scratch = g_ws.bias_buf;
+  float* rinit = scratch + (nscr - 128);
+  if (d_base_in) {
+    HIP_TRY(hipMemcpyAsync(rinit, d_base_in, (size_t)rank * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    hipError_t e = launch_bias_rhs_init(d_X, rank, 0, rank, -1, (float)global_bias, d.n_rows, scratch, rinit, s);
+    if (e != hipSuccess) return hip_fail(e, "launch_bias_rhs_init");
+  }
+  if (d_base_out) HIP_TRY(hipMemcpyAsync(d_base_out, rinit, (size_t)rank * 4, hipMemcpyDeviceToDevice, s));
+  BiasTerms bt{nullptr, nullptr, rinit, (float)(1.0 - global_bias)};
+  return run_half_iteration(conf, true, d_X, d_Y, d_XtX, rank, lambda, solver, 0, 0, d_loss_rows_out, s, &bt);
+}
+
 // Shared body of the four stateless drop-ins.  TX = float or double (host element type).
 template <class TX>
 int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
               const double* values, const TX* X, TX* Y, const TX* XtX, const TX* cnt_X, int rank, double lambda,
               unsigned solver, unsigned cg_steps, int dynamic_lambda, double* loss_out, int with_biases = 0,
-              int is_x_bias_last_row = 0) {
+              int is_x_bias_last_row = 0, double global_bias = 0.0, TX* global_bias_base = nullptr,
+              int initialize_bias_base = 1) {
   rsparse_hip_csc* conf = nullptr;
   int rc = rsparse_hip_csc_create_host(n_rows, n_cols, col_ptrs, row_indices, values, &conf);
   if (rc) return rc;
@@ -529,9 +567,23 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
     HIP_TRY(upload(dW, cnt_X, (size_t)n_rows));
   }
   if ((rc = g_ws.ensure_device())) return rc;
-  if (with_biases && implicit)
+  const bool gbias = implicit && has_global_bias(global_bias);
+  DevBuf dBase;
+  if (gbias && !with_biases) {   // global_bias_base: rank entries, read (initialize_bias_base == 0) or written
+    HIP_TRY(dBase.alloc((size_t)rank * 4));
+    const bool given = !initialize_bias_base && global_bias_base;
+    if (given) HIP_TRY(upload(dBase, global_bias_base, (size_t)rank));
+    rc = run_half_iteration_implicit_global(conf, dX.as<float>(), dY.as<float>(), dG.as<float>(), rank, lambda, solver,
+                                            global_bias, given ? dBase.as<float>() : nullptr,
+                                            given ? nullptr : dBase.as<float>(), g_ws.scalars, nullptr);
+    if (!rc && !given && global_bias_base) {
+      std::vector<float> hb((size_t)rank);
+      HIP_TRY(hipMemcpy(hb.data(), dBase.p, (size_t)rank * 4, hipMemcpyDeviceToHost));
+      for (int t = 0; t < rank; t++) global_bias_base[t] = (TX)hb[(size_t)t];
+    }
+  } else if (with_biases && implicit)
     rc = run_half_iteration_implicit_biased(conf, dX.as<float>(), dY.as<float>(), dG.as<float>(), rank, lambda, solver,
-                                            is_x_bias_last_row, g_ws.scalars, nullptr);
+                                            is_x_bias_last_row, g_ws.scalars, nullptr, global_bias);
   else if (with_biases)
     rc = run_half_iteration_explicit_biased(conf, dX.as<float>(), dY.as<float>(), rank, lambda, solver, cg_steps,
                                             dynamic_lambda, is_x_bias_last_row, g_ws.scalars, nullptr);
@@ -583,7 +635,7 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
 extern "C" {
 
 const char* rsparse_hip_last_error(void) { return g_err.c_str(); }
-int rsparse_hip_abi_version(void) { return 1; }
+int rsparse_hip_abi_version(void) { return 2; }
 
 int rsparse_hip_device_count(void) {
   int n = 0;
@@ -804,9 +856,26 @@ int rsparse_hip_als_implicit_bias_device(const rsparse_hip_csc* conf, const floa
                                             d_loss_rows_out, (hipStream_t)stream);
 }
 
+int rsparse_hip_als_implicit_global_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
+                                                const float* d_XtX, int rank, double lambda, unsigned solver,
+                                                int with_biases, int is_x_bias_last_row, double global_bias,
+                                                double* d_loss_rows_out, void* stream) {
+  int rc = check_variant(solver, with_biases, global_bias, true);
+  if (rc) return rc;
+  if (with_biases)
+    return run_half_iteration_implicit_biased(conf, d_X, d_Y, d_XtX, rank, lambda, solver, is_x_bias_last_row,
+                                              d_loss_rows_out, (hipStream_t)stream, global_bias);
+  if (!has_global_bias(global_bias))
+    return run_half_iteration(conf, true, d_X, d_Y, d_XtX, rank, lambda, solver, 0, 0, d_loss_rows_out,
+                              (hipStream_t)stream);
+  return run_half_iteration_implicit_global(conf, d_X, d_Y, d_XtX, rank, lambda, solver, global_bias, nullptr, nullptr,
+                                            d_loss_rows_out, (hipStream_t)stream);
+}
+
 int rsparse_hip_initialize_biases_implicit_device(const rsparse_hip_csc* c_ui, const rsparse_hip_csc* c_iu,
                                                   float* d_user_bias, float* d_item_bias, double lambda,
-                                                  int non_negative, void* stream) {
+                                                  int non_negative, int calculate_global_bias,
+                                                  double* global_bias_out, void* stream) {
   if (!c_ui || !c_iu || !d_user_bias || !d_item_bias) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or bias vector");
   const DevCSC& a = c_ui->d;   // users x items, columns = items
   const DevCSC& b = c_iu->d;   // items x users, columns = users
@@ -827,6 +896,17 @@ int rsparse_hip_initialize_biases_implicit_device(const rsparse_hip_csc* c_ui, c
   if ((e = launch_bias_implicit_prep(a.col_ptrs, a.vals, n_items, n_users, lambda, item_means, item_adj, s)) != hipSuccess ||
       (e = launch_bias_implicit_prep(b.col_ptrs, b.vals, n_users, n_items, lambda, user_means, user_adj, s)) != hipSuccess)
     return hip_fail(e, "launch_bias_implicit_prep");
+  double global_bias = 0.0;
+  if (calculate_global_bias) {   // :90-93: sum(x) / (sum(x) + n_users n_items - nnz)
+    if ((e = launch_values_sum(a.vals, a.nnz, g_ws.partials, g_ws.scalars + 2, s)) != hipSuccess)
+      return hip_fail(e, "launch_values_sum");
+    double sum = 0.0;
+    HIP_TRY(hipMemcpyAsync(&sum, g_ws.scalars + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    global_bias = sum / (sum + (double)n_users * (double)n_items - (double)a.nnz);
+  }
+  if (non_negative) global_bias = std::fmax(0.0, global_bias);
+  if (global_bias_out) *global_bias_out = global_bias;
   for (int iter = 0; iter < 5; iter++) {   // :130-162
     const double* usum = nullptr;
     if (iter > 0) {                        // mean of the user biases of the previous sweep (:131-135)
@@ -835,12 +915,12 @@ int rsparse_hip_initialize_biases_implicit_device(const rsparse_hip_csc* c_ui, c
       usum = g_ws.scalars + 2;
     }
     if ((e = launch_bias_implicit_sweep(a.col_ptrs, a.row_idx, a.vals, d_user_bias, n_items, n_users, usum, item_means,
-                                        item_adj, non_negative, d_item_bias, s)) != hipSuccess)
+                                        item_adj, non_negative, global_bias, d_item_bias, s)) != hipSuccess)
       return hip_fail(e, "launch_bias_implicit_sweep");
     if ((e = launch_values_sum(d_item_bias, n_items, g_ws.partials, g_ws.scalars + 3, s)) != hipSuccess)
       return hip_fail(e, "launch_values_sum");
     if ((e = launch_bias_implicit_sweep(b.col_ptrs, b.row_idx, b.vals, d_item_bias, n_users, n_items, g_ws.scalars + 3,
-                                        user_means, user_adj, non_negative, d_user_bias, s)) != hipSuccess)
+                                        user_means, user_adj, non_negative, global_bias, d_user_bias, s)) != hipSuccess)
       return hip_fail(e, "launch_bias_implicit_sweep");
   }
   HIP_TRY(hipStreamSynchronize(s));   // `stats` is released on return
@@ -1017,12 +1097,13 @@ int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_pt
                                    double lambda, int n_threads, unsigned solver, unsigned cg_steps,
                                    int with_biases, int is_x_bias_last_row, double global_bias,
                                    float* global_bias_base, int initialize_bias_base, double* loss_out) {
-  (void)n_threads; (void)global_bias_base; (void)initialize_bias_base;
+  (void)n_threads;
   int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
   if (rc) return rc;
   if ((rc = check_variant(solver, with_biases, global_bias))) return rc;
   return stateless<float>(true, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, nullptr, rank, lambda,
-                          solver, cg_steps, 0, loss_out, with_biases, is_x_bias_last_row);
+                          solver, cg_steps, 0, loss_out, with_biases, is_x_bias_last_row, global_bias, global_bias_base,
+                          initialize_bias_base);
 }
 
 int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
@@ -1030,13 +1111,93 @@ int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_p
                                     double lambda, int n_threads, unsigned solver, unsigned cg_steps,
                                     int with_biases, int is_x_bias_last_row, double global_bias,
                                     double* global_bias_base, int initialize_bias_base, double* loss_out) {
-  (void)n_threads; (void)global_bias_base; (void)initialize_bias_base;
+  (void)n_threads;
   int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
   if (rc) return rc;
   if ((rc = check_variant(solver, with_biases, global_bias))) return rc;
   return stateless<double>(true, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, nullptr, rank, lambda,
-                           solver, cg_steps, 0, loss_out, with_biases, is_x_bias_last_row);
+                           solver, cg_steps, 0, loss_out, with_biases, is_x_bias_last_row, global_bias, global_bias_base,
+                           initialize_bias_base);
 }
+
+}  // extern "C"
+
+namespace {
+
+// Stateless counterpart of the .Call targets _rsparse_initialize_biases_{double,float} (src/wrmf_init.cpp:5-34,
+// src/RcppExports.cpp:417-454): the two S4 matrices flattened to their slots, bias vectors in TX.
+template <class TX>
+int initialize_biases_host(int n_users, int n_items, const int32_t* csc_p, const int32_t* csc_i, double* csc_x,
+                           const int32_t* csr_p, const int32_t* csr_i, double* csr_x, TX* user_bias, TX* item_bias,
+                           double lambda, int dynamic_lambda, int non_negative, int calculate_global_bias,
+                           int is_explicit_feedback, double* global_bias_out) {
+  if (!user_bias || !item_bias) return fail(RSPARSE_HIP_ERR_INVALID, "user_bias or item_bias is NULL");
+  rsparse_hip_csc *c_ui = nullptr, *c_iu = nullptr;
+  int rc = rsparse_hip_csc_create_host(n_users, n_items, csc_p, csc_i, csc_x, &c_ui);   // columns = items
+  if (rc) return rc;
+  struct Guard { rsparse_hip_csc* c; ~Guard() { rsparse_hip_csc_destroy(c); } } g1{c_ui};
+  if ((rc = rsparse_hip_csc_create_host(n_items, n_users, csr_p, csr_i, csr_x, &c_iu))) return rc;   // columns = users
+  Guard g2{c_iu};
+  DevBuf dU, dI;
+  HIP_TRY(dU.alloc((size_t)n_users * 4));
+  HIP_TRY(dI.alloc((size_t)n_items * 4));
+  std::vector<float> tmp = to_f32(user_bias, (size_t)n_users);
+  if (n_users) HIP_TRY(hipMemcpy(dU.p, tmp.data(), (size_t)n_users * 4, hipMemcpyHostToDevice));
+  tmp = to_f32(item_bias, (size_t)n_items);
+  if (n_items) HIP_TRY(hipMemcpy(dI.p, tmp.data(), (size_t)n_items * 4, hipMemcpyHostToDevice));
+  double gb = 0.0;
+  if (is_explicit_feedback)
+    rc = rsparse_hip_initialize_biases_explicit_device(c_ui, c_iu, dU.as<float>(), dI.as<float>(), lambda, dynamic_lambda,
+                                                       non_negative, calculate_global_bias, &gb, nullptr);
+  else
+    rc = rsparse_hip_initialize_biases_implicit_device(c_ui, c_iu, dU.as<float>(), dI.as<float>(), lambda, non_negative,
+                                                       calculate_global_bias, &gb, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  tmp.resize((size_t)std::max(n_users, n_items));
+  if (n_users) HIP_TRY(hipMemcpy(tmp.data(), dU.p, (size_t)n_users * 4, hipMemcpyDeviceToHost));
+  for (int e = 0; e < n_users; e++) user_bias[e] = (TX)tmp[(size_t)e];
+  if (n_items) HIP_TRY(hipMemcpy(tmp.data(), dI.p, (size_t)n_items * 4, hipMemcpyDeviceToHost));
+  for (int e = 0; e < n_items; e++) item_bias[e] = (TX)tmp[(size_t)e];
+  if (is_explicit_feedback && calculate_global_bias) {
+    // the reference removes the global mean from the @x slots of BOTH matrices in place (wrmf_utils.hpp:41-52)
+    const int64_t nnz = csc_p[n_items];
+    for (int64_t e = 0; e < nnz; e++) csc_x[e] -= gb;
+    for (int64_t e = 0; e < nnz; e++) csr_x[e] -= gb;
+  }
+  if (global_bias_out) *global_bias_out = gb;
+  return RSPARSE_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsparse_hip_initialize_biases_float(int n_users, int n_items, const int32_t* csc_p, const int32_t* csc_i,
+                                        double* csc_x, const int32_t* csr_p, const int32_t* csr_i, double* csr_x,
+                                        float* user_bias, float* item_bias, double lambda, int dynamic_lambda,
+                                        int non_negative, int calculate_global_bias, int is_explicit_feedback,
+                                        double* global_bias_out) {
+  return initialize_biases_host<float>(n_users, n_items, csc_p, csc_i, csc_x, csr_p, csr_i, csr_x, user_bias, item_bias,
+                                       lambda, dynamic_lambda, non_negative, calculate_global_bias, is_explicit_feedback,
+                                       global_bias_out);
+}
+int rsparse_hip_initialize_biases_double(int n_users, int n_items, const int32_t* csc_p, const int32_t* csc_i,
+                                         double* csc_x, const int32_t* csr_p, const int32_t* csr_i, double* csr_x,
+                                         double* user_bias, double* item_bias, double lambda, int dynamic_lambda,
+                                         int non_negative, int calculate_global_bias, int is_explicit_feedback,
+                                         double* global_bias_out) {
+  return initialize_biases_host<double>(n_users, n_items, csc_p, csc_i, csc_x, csr_p, csr_i, csr_x, user_bias, item_bias,
+                                        lambda, dynamic_lambda, non_negative, calculate_global_bias, is_explicit_feedback,
+                                        global_bias_out);
+}
+
+}  // extern "C"
+
+namespace {
+}  // namespace
+
+extern "C" {
 
 int rsparse_hip_als_explicit_float(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
                                    const double* values, const float* X, float* Y, const float* cnt_X, int rank,

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a
         __syncthreads();  // tile free (and y published in sV on the first pass)
         if (tid < ccnt) {
           sC[tid] = a.vals[base + tid];
-          sC1[tid] = a.loss_tgt ? a.loss_tgt[base + tid] : 1.f;
+          sC1[tid] = a.loss_tgt ? a.loss_tgt[base + tid] : a.loss_tgt_const;
         }
         chol_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
         __syncthreads();

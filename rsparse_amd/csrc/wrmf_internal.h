@@ -58,7 +58,8 @@ struct AlsArgs {
   const float* zero_row;  // >= 128 zero floats: what the padding slots of a gather read
   // user/item biases with implicit feedback (Cholesky / NNLS kernels only; all nullptr otherwise):
   const float* rhs_vals;   // per non-zero: coefficient of x_j in the right-hand side, c - x_b (c - 1)  (default: vals)
-  const float* loss_tgt;   // per non-zero: target of the loss term, 1 - x_b                             (default: 1)
+  const float* loss_tgt;   // per non-zero: target of the loss term, 1 - global_bias - x_b               (default: loss_tgt_const)
+  float loss_tgt_const;    // target of the loss term when loss_tgt is nullptr: 1, or 1 - global_bias (wrmf_implicit.hpp:262-264)
   const float* rhs_init;   // k floats added to every right-hand side; non-null also means "solve empty rows too"
   float* tscr;
   const int64_t* stream_off;
@@ -116,15 +117,16 @@ hipError_t launch_bias_sweep(const int32_t* p, const int32_t* i, const float* x,
                              float lambda, int dynamic_lambda, int non_negative, float* out, hipStream_t s);
 hipError_t launch_values_sum(const float* x, int64_t n, double* partials, double* out, hipStream_t s);
 hipError_t launch_bias_implicit_terms(const float* vals, const int32_t* row_idx, const float* X, int k, int bias_row,
-                                      int64_t nnz, float* rhs_vals, float* loss_tgt, hipStream_t s);
-hipError_t launch_bias_rhs_init(const float* X, int k, int off, int k1, int bias_row, int n, float* scratch, float* out,
-                                hipStream_t s);
+                                      int64_t nnz, float global_bias, float* rhs_vals, float* loss_tgt, hipStream_t s);
+// out[t] = - sum_e X[off + t, e] * ((bias_row >= 0 ? X[bias_row, e] : 0) + global_bias),  t < k1
+hipError_t launch_bias_rhs_init(const float* X, int k, int off, int k1, int bias_row, float global_bias, int n,
+                                float* scratch, float* out, hipStream_t s);
 size_t bias_rhs_init_scratch_floats();
 hipError_t launch_bias_implicit_prep(const int32_t* p, const float* x, int n_cols, int n_other, double lambda,
                                      double* means, double* adj, hipStream_t s);
 hipError_t launch_bias_implicit_sweep(const int32_t* p, const int32_t* i, const float* x, const float* other, int n_cols,
                                       int n_other, const double* other_sum, const double* means, const double* adj,
-                                      int non_negative, float* out, hipStream_t s);
+                                      int non_negative, double global_bias, float* out, hipStream_t s);
 hipError_t launch_values_subtract_mean(float* x, int64_t n, const double* sum, double inv_count, hipStream_t s);
 
 // Gramian: scratch must hold gramian_scratch_floats(k, n) floats.

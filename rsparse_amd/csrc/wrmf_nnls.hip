@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
         __syncthreads();
         if (tid < ccnt) {
           sC[tid] = a.vals[base + tid];
-          sC1[tid] = a.loss_tgt ? a.loss_tgt[base + tid] : 1.f;
+          sC1[tid] = a.loss_tgt ? a.loss_tgt[base + tid] : a.loss_tgt_const;
         }
         nnls_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
         __syncthreads();

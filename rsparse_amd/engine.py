@@ -181,11 +181,17 @@ class HipBackend:
                                                        self._stream()))
 
     def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out,
-                       bias_last_row=None):
+                       bias_last_row=None, global_bias=0.0):
         """bias_last_row: None = no user/item biases; True/False = als_explicit's is_x_bias_last_row with
         with_biases = TRUE (explicit feedback only)."""
         k = F.shape[1]
-        if bias_last_row is not None and implicit:
+        if implicit and global_bias:
+            # implicit feedback with a global bias, with or without user/item biases (Cholesky / NNLS)
+            _lib.check(self.lib.rsparse_hip_als_implicit_global_bias_device(
+                csc.h, F.data_ptr(), S_block.data_ptr(), G.data_ptr(), k, float(lambda_), int(solver),
+                int(bias_last_row is not None), int(bool(bias_last_row)), float(global_bias), loss_out.data_ptr(),
+                self._stream()))
+        elif bias_last_row is not None and implicit:
             # G: (k-1) x (k-1) Gramian of F without its bias row, ridge included (R/model_WRMF.R:463-486)
             _lib.check(self.lib.rsparse_hip_als_implicit_bias_device(csc.h, F.data_ptr(), S_block.data_ptr(), G.data_ptr(),
                                                                      k, float(lambda_), int(solver),
@@ -216,11 +222,14 @@ class HipBackend:
             int(bool(non_negative)), int(bool(calculate_global_bias)), ctypes.byref(gb), self._stream()))
         return gb.value
 
-    def initialize_biases_implicit(self, csc_ui, csc_iu, user_bias, item_bias, lambda_, non_negative):
-        """wrmf_utils.hpp:86-165 (no global bias) on the device."""
+    def initialize_biases_implicit(self, csc_ui, csc_iu, user_bias, item_bias, lambda_, non_negative,
+                                   calculate_global_bias=False):
+        """wrmf_utils.hpp:86-165 on the device.  Returns the global bias (0 unless calculate_global_bias)."""
+        gb = ctypes.c_double(0.0)
         _lib.check(self.lib.rsparse_hip_initialize_biases_implicit_device(
             csc_ui.h, csc_iu.h, user_bias.data_ptr(), item_bias.data_ptr(), float(lambda_), int(bool(non_negative)),
-            self._stream()))
+            int(bool(calculate_global_bias)), ctypes.byref(gb), self._stream()))
+        return gb.value
 
     def subtract_mean(self, x, x_other=None):
         """global_bias = mean(x), removed in place from x (and from the other orientation's values) -- R/model_WRMF.R:278-282"""
@@ -304,6 +313,7 @@ class ShardedALS:
         self.G = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
         self.Gpart = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float64, device=dev)   # [0] sumsq, [1] loss rows, [2] spare
+        self.global_bias = 0.0 # implicit feedback: the model's global bias (R/model_WRMF.R:285-287); explicit: data are shifted
         self.cnt_user = None   # nnz per user / item in GLOBAL order (weights of the explicit regulariser)
         self.cnt_item = None
 
@@ -422,7 +432,8 @@ class ShardedALS:
             if c1 > c0:
                 a = layS.sub_start(self.me, j)
                 self.be.half_iteration(sub, self.implicit, F, S[a:a + (c1 - c0)], G, self.lambda_, solver,
-                                       self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1], blr)
+                                       self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1], blr,
+                                       **({"global_bias": self.global_bias} if self.global_bias else {}))
             works.append(self._gather_slab(S, layS, j))
         for w in works:
             if w is not None:

@@ -9,8 +9,9 @@ Differences forced by the host language, nothing else:
   * `lambda` is a Python keyword -> `lambda_`;
   * `x` is a scipy.sparse matrix (users x items) instead of a Matrix::sparseMatrix;
   * R's global RNG (large_rand_matrix / flrnorm, src/utils.cpp:131-143) -> `rng` (seed or Generator);
-  * not on the device path: the implicit-feedback global bias, and user/item biases with implicit feedback and the
-    conjugate-gradient solver (a combination the reference itself cannot run, wrmf_implicit.hpp:189,197) -- the
+  * not on the device path: the implicit-feedback global bias with the conjugate-gradient solver
+    (cg_solver_implicit_global_bias; the Cholesky / NNLS branches are), and user/item biases with implicit feedback and
+    the conjugate-gradient solver (a combination the reference itself cannot run, wrmf_implicit.hpp:189,197) -- the
     C ABI answers RSPARSE_HIP_ERR_UNSUPPORTED and this class raises `UnsupportedOnDevice` (an R shim would keep
     the package's CPU code for them).
 """
@@ -49,14 +50,20 @@ class WRMF:
         if not callable(preprocess):
             raise TypeError("preprocess must be a function")                      # :165
         self._non_negative = solver == "nnls"
-        if with_global_bias and feedback != "explicit":
+        if self._non_negative and with_global_bias:
+            with_global_bias = False                                              # :90-93 (the reference warns)
+        if with_global_bias and feedback != "explicit" and solver == "conjugate_gradient":
             raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED,
-                                           "the global bias with implicit feedback is not on the device path")
+                                           "global bias + conjugate_gradient with implicit feedback "
+                                           "(cg_solver_implicit_global_bias) is not on the device path; use solver='cholesky'")
         if with_user_item_bias and feedback != "explicit" and solver == "conjugate_gradient":
             raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "user/item biases + conjugate_gradient with implicit "
                                            "feedback: the reference cannot run this combination either")
-        if self._non_negative and with_global_bias:
-            with_global_bias = False                                              # :90-93 (the reference warns)
+        if precision == "double":
+            import warnings
+            warnings.warn("rsparse_amd.WRMF(precision='double'): the device path computes in fp32 (the reference's "
+                          "precision='float' arithmetic); inputs and results are converted at the boundary.  Pass "
+                          "precision='float' to silence this.", RuntimeWarning, stacklevel=2)
         self._with_bias, self._with_global_bias = bool(with_user_item_bias), bool(with_global_bias)
         self._solver_code = SOLVER_CODES[solver]                                   # :99-100
         self._precision, self._feedback = precision, feedback
@@ -143,22 +150,26 @@ class WRMF:
                 gb = be.initialize_biases_explicit(als.csc_items, als.csc_users, user_bias, item_bias, self._lambda,
                                                    self._dynamic_lambda, self._non_negative, self._with_global_bias)
             else:
-                be.initialize_biases_implicit(als.csc_items, als.csc_users, user_bias, item_bias, self._lambda,
-                                              self._non_negative)
-                gb = 0.0
+                gb = be.initialize_biases_implicit(als.csc_items, als.csc_users, user_bias, item_bias, self._lambda,
+                                                   self._non_negative, self._with_global_bias)
             V[:, 0] = item_bias
             U[:, k - 1] = user_bias
             if self._with_global_bias:
                 self.global_bias = gb
-        elif self._with_global_bias:                                               # explicit only (:278-282)
+        elif self._with_global_bias and self._feedback == "explicit":              # :278-284
             self.global_bias = be.subtract_mean(d_ui[2], d_iu[2])
+        elif self._with_global_bias:                                               # :285-287
+            sm = float(c_ui.data.sum())
+            self.global_bias = sm / (sm + float(n_user) * float(n_item) - float(c_ui.nnz))
+        if self._feedback == "implicit":
+            als.global_bias = self.global_bias
         loss_prev = float("inf")
         self.losses = []
         for it in range(int(n_iter)):
             li = als.half_iteration("items", U, V, self._solver_code)              # :321
             lu = als.half_iteration("users", U, V, self._solver_code)              # :327
             self.losses.append((li, lu))
-            if loss_prev / lu - 1 < convergence_tol:                               # :332-335
+            if (loss_prev / lu if lu != 0 else float("inf")) - 1 < convergence_tol:   # :332-335 (R: x / 0 = Inf)
                 break
             loss_prev = lu
         be.check_numeric()
@@ -195,9 +206,10 @@ class WRMF:
             res[:, 0] = 1.0                                                                   # :427-429
         solver = 0 if self._solver_code == 1 else self._solver_code                          # :112
         loss = torch.zeros(1, dtype=torch.float64, device=self._V.device)
+        gb = {"global_bias": self.global_bias} if (self._feedback == "implicit" and self.global_bias) else {}
         be.half_iteration(csc_users, self._feedback == "implicit", self._V, res, self._XtX, self._lambda,
                           solver, self._cg_steps, self._dynamic_lambda, loss,
-                          False if self._with_bias else None)                                 # is_bias_last_row = FALSE
+                          False if self._with_bias else None, **gb)                           # is_bias_last_row = FALSE
         be.check_numeric()
         return res
 

@@ -262,3 +262,185 @@ def test_hip_initialize_biases_match_oracle(ml_train, explicit):
     # items nobody rated: 0 / (lambda * 0 + 0) = NaN with dynamic_lambda, in the reference as here (wrmf_utils.hpp:64-65)
     assert np.allclose(dub.cpu().numpy(), ub, rtol=2e-4, atol=2e-6, equal_nan=True)
     assert np.allclose(dib.cpu().numpy(), ib, rtol=2e-4, atol=2e-6, equal_nan=True)
+
+
+# ------------------------------------------------------------------------- implicit global bias
+@pytest.mark.parametrize("with_biases", [False, True])
+def test_oracle_implicit_global_bias_matches_dense_solve(with_biases):
+    """wrmf_implicit.hpp:108-112 (global_bias_base = -g rowSums(X)), :152 (with biases rhs_init = -X' (x_b + g)),
+    :228-229 (rhs = X_nnz c + rhs_init), :262-270 (loss against 1 - g)."""
+    m, X, Y0 = _problem(35)
+    m.data[:] = np.abs(m.data) + 1.0
+    k, lam, gb = X.shape[0], 0.2, 0.013
+    p, i, x = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    if with_biases:
+        X[0, :] = 1.0; Y0[k - 1, :] = 1.0
+        Xp, xb = X[:k - 1], X[k - 1]
+        keep = slice(0, k - 1)
+    else:
+        Xp, xb, keep = X, np.zeros(X.shape[1]), slice(0, k)
+    G = O.gramian(np.asfortranarray(Xp), lam)
+    Y = Y0.copy(order="F")
+    base = np.zeros(k)
+    loss = O.als_implicit(p, i, x, X, Y, G, lam, 0, 3, with_biases=with_biases, is_x_bias_last_row=True,
+                          global_bias=gb, base_out=None if with_biases else base)
+    rhs_init = -Xp @ (xb + gb)
+    if not with_biases:
+        assert np.allclose(base, rhs_init, rtol=1e-12)
+    tot = 0.0
+    for c in range(m.shape[1]):
+        idx, val = i[p[c]:p[c + 1]], x[p[c]:p[c + 1]]
+        Xn, b = Xp[:, idx], xb[idx]
+        # as the reference has it: the global bias enters through rhs_init only, X_nnz's share keeps c - x_b (c - 1)
+        ref = np.linalg.solve(G + (Xn * (val - 1.0)) @ Xn.T, rhs_init + Xn @ (val - b * (val - 1.0)))
+        assert np.allclose(Y[keep, c], ref, rtol=1e-8, atol=1e-10), c
+        tot += np.sum(val * ((1.0 - gb) - ref @ Xn - b) ** 2) + lam * ref @ ref
+    if with_biases:
+        tot += lam * np.sum(np.delete(X, 0, axis=0) ** 2)
+    else:
+        tot += lam * np.sum(X ** 2)
+    assert np.isclose(loss, tot / m.nnz, rtol=1e-10)
+    with pytest.raises(NotImplementedError):                 # the CG variant is not restated
+        O.als_implicit(p, i, x, X, Y, G, lam, 1, 3, with_biases=with_biases, is_x_bias_last_row=True, global_bias=gb)
+
+
+def test_oracle_init_biases_implicit_global():
+    """wrmf_utils.hpp:90-93: global_bias = sum(x) / (sum(x) + n_users n_items - nnz); :143,:159 the biases absorb it."""
+    m, _, _ = _problem(36)
+    m.data[:] = np.abs(m.data) + 1.0
+    t = m.T.tocsc()
+    csc = (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data)
+    csr = (t.indptr.astype(np.int32), t.indices.astype(np.int32), t.data)
+    ub, ib = np.zeros(m.shape[0]), np.zeros(m.shape[1])
+    gb = O.init_biases_implicit(csc, csr, ub, ib, 0.1, calculate_global_bias=True)
+    s = m.data.sum()
+    assert np.isclose(gb, s / (s + m.shape[0] * m.shape[1] - m.nnz), rtol=1e-14)
+    ub0, ib0 = np.zeros(m.shape[0]), np.zeros(m.shape[1])
+    assert O.init_biases_implicit(csc, csr, ub0, ib0, 0.1, calculate_global_bias=False) == 0.0
+    assert not np.allclose(ub, ub0) and np.all(np.isfinite(ub)) and np.all(np.isfinite(ib))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [0, 2])
+@pytest.mark.parametrize("with_biases", [False, True])
+@pytest.mark.parametrize("k", [6, 34, 128])
+@pytest.mark.parametrize("precision", ["float", "double"])
+def test_hip_implicit_global_bias_half_iteration(solver, with_biases, k, precision):
+    """Stateless als_implicit_{float,double} with global_bias (R/model_WRMF.R:456-496): the base vector comes back when
+    initialize_bias_base, is read when not, and both give the oracle's factors and loss."""
+    from rsparse_amd import als
+    if k == 128 and precision == "double":
+        pytest.skip("same kernels as float; the 128 case is covered there")
+    dt = np.float32 if precision == "float" else np.float64
+    m, X, Y0 = _problem(300 + k, n_rows=300, n_cols=200, k=k, density=0.08)
+    m.data[:] = np.abs(m.data) + 1.0
+    gb = 0.021
+    if solver == 2:
+        X, Y0 = np.abs(X), np.abs(Y0)
+    if with_biases:
+        X[0, :] = 1.0; Y0[k - 1, :] = 1.0
+    X32, Y32 = np.asfortranarray(X, dtype=np.float32), np.asfortranarray(Y0, dtype=np.float32)
+    p, i, x = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    X64, Y64 = np.asfortranarray(X32, dtype=np.float64), np.asfortranarray(Y32, dtype=np.float64).copy(order="F")
+    XX = np.asfortranarray(X64[:-1]) if with_biases else X64
+    base_ref = np.zeros(k)
+    lref = O.als_implicit(p, i, x, X64, Y64, O.gramian(XX, 0.1), 0.1, solver, 3, with_biases=with_biases,
+                          is_x_bias_last_row=True, global_bias=gb, base_out=None if with_biases else base_ref)
+    Y32o = Y32.copy(order="F")
+    O.als_implicit(p, i, x, X32, Y32o, O.gramian(np.asfortranarray(XX, dtype=np.float32), 0.1), 0.1, solver, 3,
+                   with_biases=with_biases, is_x_bias_last_row=True, global_bias=gb)
+    err32 = rel_fro(Y32o, Y64)
+    tol = max(2e-3, 3 * err32) if solver == 2 else 1e-4
+    Xd, Y = np.asfortranarray(X32, dtype=dt), np.asfortranarray(Y32, dtype=dt).copy(order="F")
+    base = np.zeros(k, dtype=dt)
+    csc = (m.shape[0], m.shape[1], p, i, x)
+    loss = als.als_implicit(csc, Xd, Y, 0.1, 1, solver, 3, precision, with_biases, True, initialize_bias_base=True,
+                            global_bias=gb, global_bias_base=base)
+    assert rel_fro(Y, Y64) < tol, (rel_fro(Y, Y64), err32)
+    assert abs(loss - lref) <= max(tol, 1e-4) * abs(lref)
+    if with_biases:
+        assert np.array_equal(Y[k - 1], Y32[k - 1].astype(dt))
+        assert not base.any()                                # wrmf_implicit.hpp:111: untouched with biases
+    else:
+        assert rel_fro(base, base_ref) < 1e-5
+        # second call reads the base it is handed (initialize_bias_base = FALSE, R/model_WRMF.R:317-318)
+        Y2 = np.asfortranarray(Y32, dtype=dt).copy(order="F")
+        loss2 = als.als_implicit(csc, Xd, Y2, 0.1, 1, solver, 3, precision, False, True, initialize_bias_base=False,
+                                 global_bias=gb, global_bias_base=base.copy())
+        assert np.array_equal(Y2, Y) and loss2 == loss
+    # below sqrt(eps) the global bias counts as zero (wrmf_implicit.hpp:108-109)
+    Ya, Yb = (np.asfortranarray(Y32, dtype=dt).copy(order="F") for _ in range(2))
+    la = als.als_implicit(csc, Xd, Ya, 0.1, 1, solver, 3, precision, with_biases, True, global_bias=1e-5)
+    lb = als.als_implicit(csc, Xd, Yb, 0.1, 1, solver, 3, precision, with_biases, True, global_bias=0.0)
+    assert np.array_equal(Ya, Yb) and la == lb
+    with pytest.raises(NotImplementedError):                 # CG + global bias: UNSUPPORTED
+        als.als_implicit(csc, Xd, Y, 0.1, 1, 1, 3, precision, with_biases, True, global_bias=gb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("explicit", [True, False])
+@pytest.mark.parametrize("global_bias", [True, False])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hip_stateless_initialize_biases(ml_train, explicit, global_bias, dtype):
+    """rsparse_hip_initialize_biases_{float,double} = the .Call target of src/wrmf_init.cpp:5-34 (9 arguments, the two
+    matrices flattened to their slots)."""
+    from rsparse_amd import als
+    n_user, n_item, p, i, x = ml_train
+    t = O.csc_transpose(n_user, n_item, p, i, x)
+    ub, ib = np.zeros(n_user), np.zeros(n_item)
+    x_ref, t_ref = x.astype(np.float64).copy(), t[2].astype(np.float64).copy()
+    if explicit:
+        gb = O.init_biases_explicit((p, i, x_ref), (t[0], t[1], t_ref), ub, ib, 0.1, True, False, global_bias)
+    else:
+        gb = O.init_biases_implicit((p, i, x_ref), (t[0], t[1], t_ref), ub, ib, 0.1, False,
+                                    calculate_global_bias=global_bias)
+    dub, dib = np.zeros(n_user, dtype=dtype), np.zeros(n_item, dtype=dtype)
+    xv, tv = x.astype(np.float64).copy(), t[2].astype(np.float64).copy()
+    got = als.initialize_biases((n_user, n_item, p, i, xv), (n_item, n_user, t[0], t[1], tv), dub, dib, 0.1, True, False,
+                                global_bias, explicit)
+    assert abs(got - gb) <= 1e-6 * max(1.0, abs(gb))
+    assert (gb != 0.0) == global_bias
+    # explicit + global: the mean leaves both @x slots (wrmf_utils.hpp:41-52); otherwise they are untouched
+    assert np.allclose(xv, x_ref, atol=1e-6) and np.allclose(tv, t_ref, atol=1e-6)
+    if not (explicit and global_bias):
+        assert np.array_equal(xv, x) and np.array_equal(tv, t[2])
+    assert np.allclose(dub, ub, rtol=2e-4, atol=2e-6, equal_nan=True)
+    assert np.allclose(dib, ib, rtol=2e-4, atol=2e-6, equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["cholesky", "nnls"])
+@pytest.mark.parametrize("bias", [False, True])
+def test_hip_wrmf_implicit_global_bias(ml_train, solver, bias):
+    """WRMF$new(feedback = "implicit", with_global_bias = TRUE) (R/model_WRMF.R:128-131, :262-272, :317-318) against the
+    oracle driver, same initial factors."""
+    from rsparse_amd import WRMF
+    n_user, n_item, p, i, x = ml_train
+    train = sp.csc_matrix((x, i, p), shape=(n_user, n_item))
+    rng = np.random.default_rng(77 + bias)
+    rank0 = 8
+    rank = rank0 + 2 * bias
+    U0 = np.abs(rng.standard_normal((n_user, rank)) * 0.01).astype(np.float32)
+    V0 = np.abs(rng.standard_normal((rank, n_item)) * 0.01).astype(np.float32)
+    model = WRMF(rank=rank0, lambda_=0.1, feedback="implicit", solver=solver, with_user_item_bias=bias,
+                 with_global_bias=True, precision="float", init=V0.copy())
+    model._init_user_factors = U0
+    emb = model.fit_transform(train, n_iter=3, convergence_tol=-1)
+    ref = O.OracleWRMF(rank0, lam=0.1, feedback="implicit", solver=solver, dtype=np.float64, n_threads=8,
+                       with_user_item_bias=bias, with_global_bias=True)
+    ref_emb = ref.fit_transform(n_user, n_item, p, i, x, U0.T.astype(np.float64), n_iter=3, convergence_tol=-1,
+                                init_components=V0.astype(np.float64))
+    if solver == "nnls":                                     # R/model_WRMF.R:90-93: nnls switches the global bias off
+        assert model.global_bias == 0.0 and ref.global_bias == 0.0
+    else:
+        assert model.global_bias > 0 and abs(model.global_bias - ref.global_bias) < 1e-6 * ref.global_bias
+    tol = 1e-4
+    if solver == "nnls":
+        ref32 = O.OracleWRMF(rank0, lam=0.1, feedback="implicit", solver=solver, dtype=np.float32, n_threads=8,
+                             with_user_item_bias=bias, with_global_bias=True)
+        e32 = ref32.fit_transform(n_user, n_item, p, i, x, U0.T.copy(), n_iter=3, convergence_tol=-1,
+                                  init_components=V0.copy())
+        tol = max(tol, 3 * rel_fro(e32, ref_emb), 3 * rel_fro(ref32.components, ref.components))
+    assert rel_fro(emb, ref_emb) < tol and rel_fro(model.components, ref.components) < tol
+    assert np.allclose([l[1] for l in model.losses], [l[1] for l in ref.losses], rtol=max(tol, 1e-4))
+    assert np.array_equal(emb, model.transform(train))

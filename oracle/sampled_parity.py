@@ -61,10 +61,12 @@ def gramian64(F, lam):
 
 
 def check(csc, F, S_before, S_after, rows, lam, solver, cg_steps, implicit, dynamic_lambda=True, G64=None,
-          n_threads=32):
+          n_threads=32, yardstick=False):
     """csc = (p int32, i int32, x f32) tensors of the solved side (columns = solved rows); F: (n_fixed, k) fixed-side
     factors; S_before / S_after: (len(rows), k) warm starts / device results of the sampled rows (any device).
-    Returns dict(rows_checked, max_row_err, fro_err, worst_row, worst_len, per_class)."""
+    Returns dict(rows_checked, max_row_err, fro_err, worst_row, worst_len, per_class).  yardstick: also solve the sample
+    with the oracle in float (the reference's precision = "float" arithmetic) and report ITS distance from the fp64
+    solution as max_row_err_f32_oracle -- what fp32 arithmetic costs on these very systems."""
     p, i, x = csc
     rows = rows.to(p.device)
     p64 = p.to(torch.int64)
@@ -91,6 +93,17 @@ def check(csc, F, S_before, S_after, rows, lam, solver, cg_steps, implicit, dyna
     else:
         cnt = np.zeros(Xs.shape[1])
         O.als_explicit(ps, isub, val, Xs, Y, cnt, lam, solver, cg_steps, dynamic_lambda, n_threads=n_threads)
+    err32 = None
+    if yardstick:
+        Y32 = np.asfortranarray(S_before.float().cpu().numpy().T).copy(order="F")
+        Xs32 = np.asfortranarray(Xs, dtype=np.float32)
+        if implicit:
+            O.als_implicit(ps, isub, val, Xs32, Y32, np.asfortranarray(G, dtype=np.float32), lam, solver, cg_steps,
+                           n_threads=n_threads)
+        else:
+            O.als_explicit(ps, isub, val, Xs32, Y32, np.zeros(Xs.shape[1], dtype=np.float32), lam, solver, cg_steps,
+                           dynamic_lambda, n_threads=n_threads)
+        err32 = np.linalg.norm(Y32.astype(np.float64) - Y, axis=0) / np.maximum(np.linalg.norm(Y, axis=0), 1e-300)
     got = S_after.double().cpu().numpy().T
     den = np.maximum(np.linalg.norm(Y, axis=0), 1e-300)
     err = np.linalg.norm(got - Y, axis=0) / den
@@ -104,14 +117,15 @@ def check(csc, F, S_before, S_after, rows, lam, solver, cg_steps, implicit, dyna
                 "rows": int(m.sum()), "max_row_err": float(err[m].max()),
                 "fro_err": float(np.linalg.norm(got[:, m] - Y[:, m]) / max(np.linalg.norm(Y[:, m]), 1e-300)),
                 "longest": int(lens_h[m].max())}
-    return {"rows_checked": int(rows.numel()), "nnz_checked": tot,
+    extra = {} if err32 is None else {"max_row_err_f32_oracle": float(err32.max()) if err32.size else 0.0}
+    return {**extra, "rows_checked": int(rows.numel()), "nnz_checked": tot,
             "max_row_err": float(err.max()) if err.size else 0.0,
             "fro_err": float(np.linalg.norm(got - Y) / max(np.linalg.norm(Y), 1e-300)),
             "worst_row": int(rows[w]) if err.size else -1, "worst_len": int(lens_h[w]) if err.size else 0,
             "per_class": per_class}
 
 
-def half_iteration_with_check(als, side, U, V, solver, per_bucket=64, seed=0, n_threads=32):
+def half_iteration_with_check(als, side, U, V, solver, per_bucket=64, seed=0, n_threads=32, yardstick=False):
     """Run one half-iteration of a single-rank rsparse_amd.engine.ShardedALS and check a sample of its rows.
     Returns (loss, report)."""
     if side == "items":
@@ -125,6 +139,6 @@ def half_iteration_with_check(als, side, U, V, solver, per_bucket=64, seed=0, n_
     G64 = gramian64(F[:nF], als.lambda_) if als.implicit else None
     loss = als.half_iteration(side, U, V, solver)
     rep = check((p, i, x), F[:nF], before, S[rows], rows, als.lambda_, solver, als.cg_steps, als.implicit,
-                als.dynamic_lambda, G64=G64, n_threads=n_threads)
+                als.dynamic_lambda, G64=G64, n_threads=n_threads, yardstick=yardstick)
     rep["side"] = side
     return loss, rep

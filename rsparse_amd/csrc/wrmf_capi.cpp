@@ -213,6 +213,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   d.q_order = nullptr;
   d.q_stream_off = nullptr;
   d.q_ne_rows = nullptr; d.q_ne_ptr = nullptr; d.q_ne_wg = 0;
+  d.q_n_chol_long = 0;
   d.q_cfg = cgq_default_cfg();
   if (n <= 0) return RSPARSE_HIP_OK;
   const int max_len = d.max_len;
@@ -222,6 +223,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     const int len = host_col_ptrs[i + 1] - host_col_ptrs[i];
     start[(size_t)(max_len - len) + 1]++;
     const int b = cgq_bucket_of(len, d.q_cfg);
+    if (len > kCholLongLen) d.q_n_chol_long++;
     cnt_b[b]++;
     d.q_nnz[b] += len;
   }
@@ -336,7 +338,8 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   qs.cfg = d.q_cfg;
   for (int b = 0; b < 7; b++) qs.off[b] = d.q_off[b];
   qs.ne_rows = d.q_ne_rows; qs.ne_ptr = d.q_ne_ptr; qs.ne_wg = d.q_ne_wg;
-  const size_t slots = cgq ? cgq_loss_slots(qs, rank) : (cg ? cg_loss_slots(d.n_cols, d.n_long) : chol_loss_slots(d.n_cols));
+  const size_t slots = cgq ? cgq_loss_slots(qs, rank) : (cg ? cg_loss_slots(d.n_cols, d.n_long)
+                                   : (solver == RSPARSE_SOLVER_NNLS ? chol_loss_slots(d.n_cols) : chol2_loss_slots(d.n_cols)));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
   double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
   if (d.n_cols == 0) {
@@ -347,6 +350,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.col_ptrs = d.col_ptrs; a.row_idx = d.row_idx; a.vals = d.vals;
   a.X = d_X; a.Y = d_Y; a.XtX = implicit ? d_XtX : nullptr;
   a.long_rows = d.long_rows; a.n_long = d.n_long; a.n_cols = d.n_cols;
+  a.chol_long_rows = d.q_order; a.n_chol_long = d.q_order ? d.q_n_chol_long : 0;
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails; a.zero_row = g_ws.zero_row;
@@ -371,13 +375,11 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     }
   }
   hipEvent_t* ev = g_prof.begin();
-  static const char* chol_env = std::getenv("RSPARSE_HIP_CHOL");
-  const bool chol_lds = chol_env && std::strcmp(chol_env, "lds") == 0;
   hipError_t e = cgq ? launch_als_cgq(a, qs, implicit, s, ev)
                      : (cg ? launch_als_cg(a, implicit, s, ev)
                            : (solver == RSPARSE_SOLVER_NNLS
                                   ? launch_als_nnls(a, implicit, s, ev)
-                                  : (chol_lds ? launch_als_chol(a, implicit, s, ev) : launch_als_chol2(a, implicit, s, ev))));
+                                  : launch_als_chol2(a, implicit, s, ev)));
   if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
   e = launch_sum_partials(g_ws.partials, slots, out, s);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");

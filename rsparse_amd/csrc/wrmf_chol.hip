@@ -73,13 +73,17 @@ __device__ __forceinline__ void chol_gather_chunk(const AlsArgs& a, int base, in
   }
 }
 
-template <int KP, bool IMPLICIT, bool VEC>
 // 3 waves per SIMD (168 VGPRs): three rows per CU overlap each other's serial phases; measured 0.160 s ->
 // 0.133 s per 1M users at k = 128 against 2 (a fourth changes nothing and spills)
 #ifndef RSP_CHOL_MINW
 #define RSP_CHOL_MINW 3
 #endif
-__global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a) {
+// LONG: the launch for rows of more than kCholLongLen non-zeros (a.chol_long_rows, longest first).  A row of n
+// non-zeros summed one rank-one update after the other in fp32 drifts by ~n eps (8e-4 on the 5e5-non-zero item of
+// the 10M x 1M configuration); here the running block is folded into a second register block every kFold chunks, so
+// no partial sum sees more than 128 terms before it joins a sum of n/128 terms.  Twice the registers: 2 waves per SIMD.
+template <int KP, bool IMPLICIT, bool VEC, bool LONG>
+__global__ __launch_bounds__(256, LONG ? 2 : RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a, int loss_slot0) {
   using SM = Chol2Smem<KP>;
   constexpr int BS = SM::BS, TC = SM::TC, LDT = SM::LDT, NB = 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,9 +106,12 @@ __global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a
   __syncthreads();
   double wloss = 0.0;
 
-  for (int row = blockIdx.x; row < a.n_cols; row += gridDim.x) {
+  const int n_iter = LONG ? a.n_chol_long : a.n_cols;
+  for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    const int row = LONG ? rfl(a.chol_long_rows[it]) : it;
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     const int cnt = p2 - p1;
+    if (!LONG && a.n_chol_long > 0 && cnt > kCholLongLen) continue;   // the LONG launch owns it
     float* yrow = a.Y + (size_t)row * k;
     if (cnt <= 0 && !a.rhs_init) {
       for (int e = tid; e < k; e += 256) yrow[e] = 0.f;
@@ -128,6 +135,15 @@ __global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a
         else gv = (rr == cc) ? lam_use : 0.f;
         acc[x][y] = gv;
       }
+    float acc2[LONG ? BS : 1][LONG ? BS : 1];
+    if constexpr (LONG) {
+#pragma unroll
+      for (int x = 0; x < BS; x++)
+#pragma unroll
+        for (int y = 0; y < BS; y++) { acc2[x][y] = acc[x][y]; acc[x][y] = 0.f; }
+    }
+    constexpr int kFold = 4;
+    int fold = 0;
     float rhs = 0.f;  // thread tid < KP owns rhs[tid]
     for (int base = p1; base < p2; base += TC) {
       const int ccnt = min(TC, p2 - base);
@@ -159,6 +175,21 @@ __global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a
         for (int j = 0; j < ccnt; j++) s = fmaf(sC[j], sT[j * LDT + tid], s);
         rhs += s;
       }
+      if constexpr (LONG) {
+        if (++fold == kFold) {
+          fold = 0;
+#pragma unroll
+          for (int x = 0; x < BS; x++)
+#pragma unroll
+            for (int y = 0; y < BS; y++) { acc2[x][y] += acc[x][y]; acc[x][y] = 0.f; }
+        }
+      }
+    }
+    if constexpr (LONG) {
+#pragma unroll
+      for (int x = 0; x < BS; x++)
+#pragma unroll
+        for (int y = 0; y < BS; y++) acc[x][y] += acc2[x][y];
     }
     __syncthreads();
     if (tid < KP) sV[tid] = rhs + ((a.rhs_init && tid < k) ? a.rhs_init[tid] : 0.f);
@@ -341,22 +372,60 @@ __global__ __launch_bounds__(256, RSP_CHOL_MINW) void als_chol2_kernel(AlsArgs a
   if (lane == 0) sLoss[wv] = wloss;
   __syncthreads();
   if (tid == 0) {
-    a.loss_partials[blockIdx.x] = (sLoss[0] + sLoss[1]) + (sLoss[2] + sLoss[3]);
+    a.loss_partials[loss_slot0 + blockIdx.x] = (sLoss[0] + sLoss[1]) + (sLoss[2] + sLoss[3]);
     if (*sFlag) atomicAdd(a.fail_counter, 1);
   }
 }
+
+struct LongStream {
+  hipStream_t st = nullptr;
+  hipEvent_t fork = nullptr, done = nullptr;
+  int device = -1;
+  hipError_t ensure() {
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess || dev == device) return err;
+    device = dev;  // a process drives one GPU, so this happens once
+    if ((err = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return err;
+    if ((err = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return err;
+    return hipEventCreateWithFlags(&done, hipEventDisableTiming);
+  }
+};
+LongStream g_long_stream;
 
 template <int KP, bool IMPLICIT, bool VEC>
 hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   using SM = Chol2Smem<KP>;
   hipError_t err;
   const int grid = (int)chol_loss_slots(a.n_cols);
-  auto kc = als_chol2_kernel<KP, IMPLICIT, VEC>;
-  if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)SM::bytes)) != hipSuccess)
+  const int grid_long = a.n_chol_long < kCholLongGrid ? a.n_chol_long : kCholLongGrid;
+  auto kc = als_chol2_kernel<KP, IMPLICIT, VEC, false>;
+  auto kl = als_chol2_kernel<KP, IMPLICIT, VEC, true>;
+  for (const void* f : {reinterpret_cast<const void*>(kc), reinterpret_cast<const void*>(kl)})
+    if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::bytes)) != hipSuccess)
+      return err;
+  if ((err = hipMemsetAsync(a.loss_partials + grid, 0, (size_t)kCholLongGrid * sizeof(double), s)) != hipSuccess)
     return err;
   if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
-  hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a);
+  // The long rows are few and the longest of them decides when the half-iteration ends: their launch runs on a side
+  // stream next to the main one (disjoint rows), forked from / joined to the caller's stream with events.  With
+  // per-kernel timing (ev) both go back to back on the caller's stream.
+  if (grid_long > 0) {
+    hipStream_t ls = s;
+    if (!ev) {
+      if ((err = g_long_stream.ensure()) != hipSuccess) return err;
+      ls = g_long_stream.st;
+      if ((err = hipEventRecord(g_long_stream.fork, s)) != hipSuccess) return err;
+      if ((err = hipStreamWaitEvent(ls, g_long_stream.fork, 0)) != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(kl, dim3(grid_long), dim3(256), SM::bytes, ls, a, grid);
+    if ((err = hipGetLastError()) != hipSuccess) return err;
+    if (!ev) {
+      if ((err = hipEventRecord(g_long_stream.done, ls)) != hipSuccess) return err;
+      if ((err = hipStreamWaitEvent(s, g_long_stream.done, 0)) != hipSuccess) return err;
+    }
+  }
+  hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a, 0);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   if (ev) {
     if ((err = hipEventRecord(ev[1], s)) != hipSuccess) return err;
@@ -366,6 +435,8 @@ hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
 }
 
 }  // namespace
+
+size_t chol2_loss_slots(int n_cols) { return chol_loss_slots(n_cols) + (size_t)kCholLongGrid; }
 
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(a.k);

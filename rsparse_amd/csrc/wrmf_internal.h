@@ -28,6 +28,7 @@ struct DevCSC {
   int64_t* q_stream_off = nullptr;  // prefix sums of the streamed bucket's row lengths (device)
   // normal-equation kernel (wrmf_ne.hip): the long rows (bucket 0) dealt to q_ne_wg workgroups, longest processing
   // time first; workgroup b owns q_ne_rows[q_ne_ptr[b], q_ne_ptr[b+1])
+  int q_n_chol_long = 0;   // rows of more than kCholLongLen non-zeros (a prefix of q_order)
   int32_t* q_ne_rows = nullptr;
   int32_t* q_ne_ptr = nullptr;
   int q_ne_wg = 0;
@@ -64,6 +65,9 @@ struct AlsArgs {
   float* tscr;
   const int64_t* stream_off;
   int64_t stream_nnz;
+  // Cholesky: rows of more than kCholLongLen non-zeros = the first n_chol_long entries of the length-sorted row order
+  const int32_t* chol_long_rows;
+  int n_chol_long;
   unsigned long long* ne_prof;   // RSP_NE_PROF builds: [workgroup][wave][8] cycle counters of wrmf_ne.hip (else nullptr)
 };
 
@@ -106,8 +110,11 @@ size_t chol_loss_slots(int n_cols);
 // Optional per-kernel timing: when `ev` is non-null the launchers record ev[0] before the first
 // kernel, ev[1] between kernels and ev[2] after the last one (all on stream s).
 hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
-hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
-// register-blocked Cholesky (wrmf_chol.hip); launch_als_chol is the older LDS-matrix version kept for A/B
+// register-blocked Cholesky (wrmf_chol.hip); rows beyond kCholLongLen non-zeros go to a second launch that sums the
+// rank-one updates in two levels (see there); its workgroups' loss slots follow the main launch's
+constexpr int kCholLongLen = 1024;
+constexpr int kCholLongGrid = 512;
+size_t chol2_loss_slots(int n_cols);
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s);

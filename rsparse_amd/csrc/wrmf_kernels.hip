@@ -5,9 +5,6 @@
 //        the OpenMP column loop of als_implicit<T> / als_explicit<T> with solver == CG
 //        (inst/include/wrmf_implicit.hpp:162-197,254-283 + cg_solver_implicit :8-32;
 //         inst/include/wrmf_explicit.hpp:68-100,128-144 + cg_solver_explicit :8-31)
-//   als_chol_kernel
-//        the same loops with solver == CHOLESKY (wrmf_implicit.hpp:206-208,231,236;
-//        wrmf_explicit.hpp:103-108)
 //   gramian_partial_kernel / gramian_reduce_kernel
 //        XtX = tcrossprod(X) + fl(lambda) I done on the R side with threaded BLAS
 //        (R/model_WRMF.R:474-486, :347-353) -- the one MFMA kernel
@@ -352,192 +349,6 @@ __global__ __launch_bounds__(W * 64) void als_cg_long_kernel(AlsArgs a, size_t l
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cholesky: one workgroup (256 threads) per row; k x k system assembled in registers (each thread a
-// BS x BS block, BS = KP/16), factorised in LDS.
-// ------------------------------------------------------------------------------------------------
-template <int KP, bool IMPLICIT>
-struct CholSmem {
-  static constexpr int LDA = KP + 16;  // 16*(ty&1)+tx bank pattern: conflict free for the 16x16 thread grid
-  static constexpr int TC = 32;        // non-zeros gathered per assembly chunk
-  static constexpr int LDT = KP + 4;
-  static constexpr size_t gram_floats = IMPLICIT ? (size_t)KP * KP : 0;
-  static constexpr size_t a_floats = (size_t)KP * LDA;
-  static constexpr size_t tile_floats = (size_t)TC * LDT;
-  static constexpr size_t misc_floats = KP /*rhs*/ + 2 * TC /*c, c1*/ + 8;
-  static constexpr size_t bytes = (gram_floats + a_floats + tile_floats + misc_floats) * 4 + 16;
-};
-
-template <int KP, bool IMPLICIT>
-__global__ __launch_bounds__(256) void als_chol_kernel(AlsArgs a) {
-  using SM = CholSmem<KP, IMPLICIT>;
-  constexpr int BS = KP / 16, LDA = SM::LDA, TC = SM::TC, LDT = SM::LDT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sG = reinterpret_cast<float*>(smem);
-  float* sA = sG + SM::gram_floats;
-  float* sT = sA + SM::a_floats;
-  float* sB = sT + SM::tile_floats;
-  float* sC = sB + KP;     // confidence / rating of the chunk
-  float* sC1 = sC + TC;    // weight on the rank-one update
-  int* sFlag = reinterpret_cast<int*>(sC1 + TC);
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
-  const int tx = tid & 15, ty = tid >> 4;
-  const int k = a.k;
-  if constexpr (IMPLICIT) load_gram_lds<KP, 4>(sG, a.XtX, k, tid);
-  for (int e = tid; e < (int)SM::tile_floats; e += 256) sT[e] = 0.f;
-  if (tid == 0) *sFlag = 0;
-  __syncthreads();
-  double wloss = 0.0;
-
-  for (int row = blockIdx.x; row < a.n_cols; row += gridDim.x) {
-    const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
-    const int cnt = p2 - p1;
-    float* yrow = a.Y + (size_t)row * k;
-    if (cnt <= 0) {
-      for (int e = tid; e < k; e += 256) yrow[e] = 0.f;
-      continue;
-    }
-    const float lam_use =
-        IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)cnt : 1.0));
-
-    // ---- assembly: lhs = G + X_nnz diag(c1) X_nnz^T, rhs = X_nnz c  (registers) ----
-    float acc[BS][BS];
-#pragma unroll
-    for (int i = 0; i < BS; i++)
-#pragma unroll
-      for (int j = 0; j < BS; j++) acc[i][j] = 0.f;
-    float rhs = 0.f;  // thread tid < KP owns rhs[tid]
-    for (int base = p1; base < p2; base += TC) {
-      const int ccnt = min(TC, p2 - base);
-      __syncthreads();  // previous chunk fully consumed
-      if (tid < ccnt) {
-        const float cv = a.vals[base + tid];
-        sC[tid] = cv;
-        sC1[tid] = IMPLICIT ? cv - 1.f : 1.f;
-      }
-      // gather: wave w loads vectors w, w+4, ...
-      for (int j = wv; j < ccnt; j += 4) {
-        const int id = rfl(a.row_idx[base + j]);
-        const float* src = a.X + (size_t)id * k;
-        for (int e = lane; e < k; e += 64) sT[j * LDT + e] = src[e];
-      }
-      __syncthreads();
-      for (int j = 0; j < ccnt; j++) {
-        const float c1 = sC1[j];
-        float av[BS], bv[BS];
-#pragma unroll
-        for (int i = 0; i < BS; i++) {
-          av[i] = sT[j * LDT + ty * BS + i];
-          bv[i] = sT[j * LDT + tx * BS + i] * c1;
-        }
-#pragma unroll
-        for (int i = 0; i < BS; i++)
-#pragma unroll
-          for (int jj = 0; jj < BS; jj++) acc[i][jj] = fmaf(av[i], bv[jj], acc[i][jj]);
-      }
-      if (tid < KP) {
-        float s = 0.f;
-        for (int j = 0; j < ccnt; j++) s = fmaf(sC[j], sT[j * LDT + tid], s);
-        rhs += s;
-      }
-    }
-    // ---- spill the system to LDS ----
-#pragma unroll
-    for (int i = 0; i < BS; i++)
-#pragma unroll
-      for (int j = 0; j < BS; j++) {
-        const int rr = ty * BS + i, cc = tx * BS + j;
-        float g;
-        if constexpr (IMPLICIT) g = sG[rr * KP + cc];
-        else g = (rr == cc) ? lam_use : 0.f;
-        // padded rows/cols get an identity diagonal so the factorisation stays well defined
-        if (rr >= k || cc >= k) g = (rr == cc) ? 1.f : 0.f;
-        sA[rr * LDA + cc] = acc[i][j] + g;
-      }
-    if (tid < KP) sB[tid] = rhs;
-    __syncthreads();
-
-    // ---- right-looking Cholesky, lower triangle, row-major sA[i][j] (i >= j) ----
-    for (int j = 0; j < k; j++) {
-      if (tid == 0) {
-        float dj = sA[j * LDA + j];
-        if (!(dj > 0.f)) { *sFlag = 1; dj = 1.f; }
-        sA[j * LDA + j] = sqrtf(dj);
-      }
-      __syncthreads();
-      const float inv = 1.f / sA[j * LDA + j];
-      for (int i = j + 1 + tid; i < k; i += 256) sA[i * LDA + j] *= inv;
-      __syncthreads();
-      // trailing update A[i][m] -= L[i][j] L[m][j] for j < m <= i < k
-      for (int i = j + 1 + ty; i < k; i += 16) {
-        const float lij = sA[i * LDA + j];
-        for (int m = j + 1 + tx; m <= i; m += 16) sA[i * LDA + m] = fmaf(-lij, sA[m * LDA + j], sA[i * LDA + m]);
-      }
-      __syncthreads();
-    }
-    // ---- substitutions by wave 0 (no workgroup barriers) ----
-    if (wv == 0) {
-      // forward: z[i] = (b[i] - sum_{m<i} L[i][m] z[m]) / L[i][i]; lane holds z[lane], z[lane+64]
-      float z0 = sB[lane], z1 = (KP > 64) ? sB[lane + 64 < KP ? lane + 64 : lane] : 0.f;
-      for (int i = 0; i < k; i++) {
-        float part = 0.f;
-        if (lane < i) part = sA[i * LDA + lane] * z0;
-        if (KP > 64 && lane + 64 < i) part = fmaf(sA[i * LDA + lane + 64], z1, part);
-        const float s = wave_sum(part);
-        const float bi = (i < 64) ? readlane_f(z0, i & 63) : readlane_f(z1, i & 63);
-        const float zi = (bi - s) / sA[i * LDA + i];
-        if (i < 64) { if (lane == i) z0 = zi; }
-        else { if (lane == i - 64) z1 = zi; }
-      }
-      // backward: y[i] = z[i] / L[i][i]; z[m] -= L[i][m] y[i] for m < i
-      for (int i = k - 1; i >= 0; i--) {
-        const float zi = (i < 64) ? readlane_f(z0, i & 63) : readlane_f(z1, i & 63);
-        const float yi = zi / sA[i * LDA + i];
-        if (i < 64) { if (lane == i) z0 = yi; }
-        else { if (lane == i - 64) z1 = yi; }
-        if (lane < i) z0 = fmaf(-sA[i * LDA + lane], yi, z0);
-        if (KP > 64 && lane + 64 < i) z1 = fmaf(-sA[i * LDA + lane + 64], yi, z1);
-      }
-      if (lane < k) { yrow[lane] = z0; sB[lane] = z0; }
-      if (KP > 64 && lane + 64 < k) { yrow[lane + 64] = z1; sB[lane + 64] = z1; }
-    }
-    __syncthreads();
-    // ---- loss row term: needs t_j = y . x_j over all chunks (re-gathered through L2) ----
-    {
-      float lpart = 0.f;
-      for (int j = wv; j < cnt; j += 4) {
-        const int id = rfl(a.row_idx[p1 + j]);
-        const float cv = a.vals[p1 + j];
-        const float* src = a.X + (size_t)id * k;
-        float part = 0.f;
-        for (int e = lane; e < k; e += 64) part = fmaf(src[e], sB[e], part);
-        const float t = wave_sum(part);
-        const float d = IMPLICIT ? 1.f - t : cv - t;
-        lpart += IMPLICIT ? cv * d * d : d * d;
-      }
-      float xxp = 0.f;
-      if (wv == 0) {
-        for (int e = lane; e < k; e += 64) xxp = fmaf(sB[e], sB[e], xxp);
-        xxp = wave_sum(xxp);
-      }
-      if (lane == 0) {
-        wloss += (double)lpart;
-        if (wv == 0) wloss += IMPLICIT ? a.lambda_loss * (double)xxp : (double)(lam_use * xxp);
-      }
-    }
-  }
-  // workgroup loss = sum over its 4 waves (fixed order)
-  __syncthreads();
-  double* sL = reinterpret_cast<double*>(sA);
-  if (lane == 0) sL[wv] = wloss;
-  __syncthreads();
-  if (tid == 0) {
-    a.loss_partials[blockIdx.x] = (sL[0] + sL[1]) + (sL[2] + sL[3]);
-    if (*sFlag) atomicAdd(a.fail_counter, 1);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Gramian  G = X X^T (+ ridge I),  X is k x n column-major: fp32 MFMA 32x32x2, lower-triangular
 // 32x32 tiles only, one partial per wave, deterministic two-stage reduction.
 // ------------------------------------------------------------------------------------------------
@@ -680,23 +491,6 @@ hipError_t launch_cg_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   return hipSuccess;
 }
 
-template <int KP, bool IMPLICIT>
-hipError_t launch_chol_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
-  using SM = CholSmem<KP, IMPLICIT>;
-  hipError_t err;
-  const int grid = (int)chol_loss_slots(a.n_cols);
-  auto kc = als_chol_kernel<KP, IMPLICIT>;
-  if ((err = set_lds(kc, SM::bytes)) != hipSuccess) return err;
-  if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
-  hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a);
-  if ((err = hipGetLastError()) != hipSuccess) return err;
-  if (ev) {
-    if ((err = hipEventRecord(ev[1], s)) != hipSuccess) return err;
-    if ((err = hipEventRecord(ev[2], s)) != hipSuccess) return err;
-  }
-  return hipSuccess;
-}
-
 }  // namespace
 
 int padded_rank(int k) {
@@ -726,17 +520,6 @@ hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s, hipEven
     if (implicit) return vec ? launch_cg_t<KPV, true, true>(a, s, ev) : launch_cg_t<KPV, true, false>(a, s, ev); \
     return vec ? launch_cg_t<KPV, false, true>(a, s, ev) : launch_cg_t<KPV, false, false>(a, s, ev);             \
   }
-  RSP_DISPATCH(32)
-  RSP_DISPATCH(64)
-  RSP_DISPATCH(128)
-#undef RSP_DISPATCH
-  return hipErrorInvalidValue;
-}
-
-hipError_t launch_als_chol(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev) {
-  const int KP = padded_rank(a.k);
-#define RSP_DISPATCH(KPV)                                                  \
-  if (KP == KPV) return implicit ? launch_chol_t<KPV, true>(a, s, ev) : launch_chol_t<KPV, false>(a, s, ev);
   RSP_DISPATCH(32)
   RSP_DISPATCH(64)
   RSP_DISPATCH(128)

@@ -52,7 +52,7 @@ struct Workspace {
   size_t partial_slots = 0;
   double* scalars = nullptr;  // [0] loss rows, [1] sumsq, [2..] spare
   int* fails = nullptr;
-  int* counter = nullptr;     // row queue of the normal-equation kernel
+  unsigned* ne_stats = nullptr;   // normal-equation kernel: max |x|, max c, any c < 1 (launch_ne_stats)
   float* zero_row = nullptr;  // 256 zero floats (padding slots of the CG gathers)
   float* tscr = nullptr;   // streamed CG rows: per-non-zero dot products of every sweep
   size_t tscr_floats = 0;
@@ -75,9 +75,9 @@ struct Workspace {
       HIP_TRY(hipMalloc(&fails, sizeof(int)));
       HIP_TRY(hipMemset(fails, 0, sizeof(int)));
     }
-    if (!counter) {
-      HIP_TRY(hipMalloc(&counter, 4 * sizeof(int)));
-      HIP_TRY(hipMemset(counter, 0, 4 * sizeof(int)));
+    if (!ne_stats) {
+      HIP_TRY(hipMalloc(&ne_stats, 4 * sizeof(unsigned)));
+      HIP_TRY(hipMemset(ne_stats, 0, 4 * sizeof(unsigned)));
     }
     if (!zero_row) {
       HIP_TRY(hipMalloc(&zero_row, 256 * sizeof(float)));
@@ -137,8 +137,8 @@ struct Workspace {
     if (partials) (void)hipFree(partials);
     if (scalars) (void)hipFree(scalars);
     if (fails) (void)hipFree(fails);
-    if (counter) (void)hipFree(counter);
-    counter = nullptr;
+    if (ne_stats) (void)hipFree(ne_stats);
+    ne_stats = nullptr;
     if (zero_row) (void)hipFree(zero_row);
     gram = nullptr; partials = nullptr; scalars = nullptr; fails = nullptr; zero_row = nullptr;
     gram_floats = 0; partial_slots = 0;
@@ -360,6 +360,13 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.loss_tgt_const = bias ? bias->tgt_const : 1.f;
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
   a.ne_prof = nullptr;
+  a.ne_stats = nullptr;
+  if (cgq && implicit && d.q_ne_wg > 0 && ne_supported(rank) && !bias) {
+    // operand scales of the fp16 normal-equation kernel (and whether it may run at all), decided on the device
+    hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s);
+    if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
+    a.ne_stats = g_ws.ne_stats;
+  }
 #ifdef RSP_NE_PROF
   static unsigned long long* prof_buf = nullptr;
   if (!prof_buf) { HIP_TRY(hipMalloc(&prof_buf, 1024 * 4 * 20 * 8)); }

@@ -68,6 +68,7 @@ struct AlsArgs {
   // Cholesky: rows of more than kCholLongLen non-zeros = the first n_chol_long entries of the length-sorted row order
   const int32_t* chol_long_rows;
   int n_chol_long;
+  const unsigned* ne_stats;      // implicit NE launches: {bits of max |x|, bits of max c, any c < 1} (launch_ne_stats), or nullptr
   unsigned long long* ne_prof;   // RSP_NE_PROF builds: [workgroup][wave][8] cycle counters of wrmf_ne.hip (else nullptr)
 };
 
@@ -90,6 +91,7 @@ int cgq_bucket_of(int len, int cfg);
 size_t cgq_loss_slots(const QSchedule& q, int k);
 // long rows (bucket 0) by one-pass normal equations on the matrix cores (wrmf_ne.hip) instead of the streamed CG kernel
 bool ne_supported(int k);
+hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s);
 hipError_t launch_als_ne(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
                          double* row_loss, hipStream_t s);
 // ev (optional): 7 events, ev[b] before bucket b's kernel, ev[6] after the last one

@@ -59,8 +59,13 @@ constexpr int kStepNnz = 16;        // K of v_mfma_f32_32x32x16_bf16
 struct NeMfmaOp { int slot, m, R, C, pa, pb; };   // acc[slot] += (m == 0 ? A-operand term pa : x term pa) of block R x (x term pb of block C)
 struct NeUnit { int kind, t, pair; };             // a pair of floats to split: kind 0 = x, 1 = (c - 1) x; block t, floats 2 pair, 2 pair + 1
 
-template <int KP, int NS, bool IMPLICIT>
+// SYM (implicit feedback, every confidence >= 1): both matrices are symmetric products of ONE operand set each,
+//   M1 = a' a'^T with a' = sqrt(c - 1) s1 x,   M2 = (s2 x)(s2 x)^T     (s1, s2: powers of two, see ne_scales),
+// split exactly into 2 fp16 terms (22 bits) with 3 products kept (2^-21 per product): half the matrix-core work of the
+// bf16 path and, in a PAIR, half the split arithmetic per wave -- role 0 = M1 (needs only a'), role 1 = M2 + b (only x).
+template <int KP, int NS, bool IMPLICIT, bool SYM = false>
 struct NeRoles {
+  static_assert(!SYM || (IMPLICIT && NS == 2), "SYM: implicit feedback, two fp16 terms");
   static constexpr int NB = KP / 32;
   static constexpr int NT = NB * (NB + 1) / 2;
   static constexpr bool PAIR = IMPLICIT && KP == 128;
@@ -71,7 +76,7 @@ struct NeRoles {
   __host__ __device__ static constexpr int slot(int role, int m, int R, int C) {
     if (!IMPLICIT) return m == 0 ? tile(R, C) : -1;
     if (!PAIR) return m * NT + tile(R, C);
-    if (NS >= 3) {
+    if (NS >= 3 && !SYM) {
       // role 0: M1 tile rows 2, 3 (slots 0..6, 42 products) + M2 tiles (0,0), (1,1) (slots 7, 8; 6 products)
       // role 1: M1 tile rows 0, 1 (slots 0..2, 18 products) + the other 8 M2 tiles (slots 3..10; 24 products)
       const bool m2_r0 = R == C && R < 2;
@@ -82,7 +87,7 @@ struct NeRoles {
     }
     return m == role ? tile(R, C) : -1;
   }
-  static constexpr int NSLOT = !IMPLICIT ? NT : (!PAIR ? 2 * NT : (NS >= 3 ? 11 : 10));
+  static constexpr int NSLOT = !IMPLICIT ? NT : (!PAIR ? 2 * NT : (NS >= 3 && !SYM ? 11 : 10));
   __host__ __device__ static constexpr bool owns_row(int role, int R) { return IMPLICIT && slot(role, 0, R, 0) >= 0; }
   __host__ __device__ static constexpr int rhs_role() { return PAIR ? 1 : 0; }  // who accumulates b and sum c
 
@@ -120,12 +125,15 @@ struct NeRoles {
     return NeMfmaOp{-1, 0, 0, 0, 0, 0};
   }
   // The split work of one step: the 4 float pairs of every block of x, then those of (c - 1) x for the owned tile rows
+  // (SYM pair: role 0 only a', role 1 only x)
   __host__ __device__ static constexpr int unit_count(int role) {
+    if (SYM && PAIR) return 4 * NB;
     int n = 4 * NB;
     for (int t = 0; t < NB; t++) n += owns_row(role, t) ? 4 : 0;
     return n;
   }
   __host__ __device__ static constexpr NeUnit unit(int role, int u) {
+    if (SYM && PAIR) return NeUnit{role == 0 ? 1 : 0, u / 4, u % 4};
     if (u < 4 * NB) return NeUnit{0, u / 4, u % 4};
     int n = 4 * NB;
     for (int t = 0; t < NB; t++)
@@ -219,6 +227,34 @@ __device__ __forceinline__ unsigned split_stage(f32x2& r, bool last) {
   return pk;
 }
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// the same with fp16 terms (v_cvt_pk_f16_f32, round to nearest even; x - fl16(x) is exact in fp32 whatever fl16 did)
+__device__ __forceinline__ unsigned split_stage_h(f32x2& r, bool last) {
+  const f16x2 hb = __builtin_convertvector(r, f16x2);
+  if (!last) r -= __builtin_convertvector(hb, f32x2);
+  return __builtin_bit_cast(unsigned, hb);
+}
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// Powers of two that bring the operands of the SYM path into fp16 range: the largest |s2 x| and |s1 sqrt(c-1) x| land
+// in [2^13, 2^15) (fp16 holds 65504; the terms of small entries may be subnormal, which costs absolute, not relative,
+// accuracy: <= 2^-39 of the largest entry).  stats = {bits of max |x|, bits of max c, any c < 1} (ne_stats_kernel).
+struct NeScales { float s1, s2, inv1, inv2; };
+__device__ __forceinline__ NeScales ne_scales(const unsigned* stats) {
+  const float mx = __uint_as_float(stats[0]), mc = __uint_as_float(stats[1]);
+  const float ma = mx * __builtin_sqrtf(fmaxf(mc - 1.f, 0.f));
+  auto pow2_for = [](float m) {
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e);   // m = f 2^e, f in [0.5, 1)
+    e = max(-40, min(40, 14 - e));                     // m 2^(14 - e) < 2^14 ... rounding of sqrt and products: one bit spare
+    return e;
+  };
+  const int e1 = pow2_for(ma), e2 = pow2_for(mx);
+  return NeScales{ldexpf(1.f, e1), ldexpf(1.f, e2), ldexpf(1.f, -2 * e1), ldexpf(1.f, -2 * e2)};
+}
+
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
                                                  0);
@@ -277,11 +313,11 @@ struct NeParts {   // MFMA operands of one step: block t, term q
   u32x4 a[NB][NS];   // (c - 1) x   (tile rows this wave owns; implicit only)
 };
 
-template <int KP, int NS, bool IMPLICIT>
+template <int KP, int NS, bool IMPLICIT, bool SYM>
 __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t* __restrict__ wg_rows,
                                                          const int32_t* __restrict__ wg_ptr, int slot0,
-                                                         double* __restrict__ row_loss) {
-  using RL = NeRoles<KP, NS, IMPLICIT>;
+                                                         double* __restrict__ row_loss, int only_if_lt1) {
+  using RL = NeRoles<KP, NS, IMPLICIT, SYM>;
   using G_ = NeGeo<KP, RL::PAIR, IMPLICIT>;
   constexpr int NB = G_::NB, NT = G_::NT, NI = G_::NI, LPV = G_::LPV, D = G_::D, IDXR = G_::IDXR, TLD = G_::TLD;
   constexpr int NM = IMPLICIT ? 2 : 1;  // accumulated matrices: implicit {M1, M2}, explicit {M2}
@@ -291,6 +327,21 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int h = lane >> 5, d = lane & 31;
   const int k = a.k;
+  // Which of the two launches of an implicit half-iteration does the work is decided on the device (no host round trip):
+  // the SYM kernel needs every confidence >= 1 (it takes sqrt(c - 1)), the bf16 kernel behind it runs only otherwise.
+  NeScales scl = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (IMPLICIT) {
+    if (a.ne_stats) {
+      const int lt1 = sload(reinterpret_cast<const int*>(a.ne_stats) + 2);
+      if (SYM ? lt1 != 0 : (only_if_lt1 != 0 && lt1 == 0)) return;
+      if constexpr (SYM) {
+        unsigned st[2];
+        st[0] = (unsigned)sload(reinterpret_cast<const int*>(a.ne_stats));
+        st[1] = (unsigned)sload(reinterpret_cast<const int*>(a.ne_stats) + 1);
+        scl = ne_scales(st);
+      }
+    }
+  }
   const int wset = PAIR ? wv >> 1 : wv;   // ring group: its steps of a row are wset, wset + NSETS, ...
   const int wrole = PAIR ? wv & 1 : 0;
 
@@ -500,8 +551,14 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
         for (int q = 0; q < NS; q++) pA.x[t][q] = pA.a[t][q] = pB.x[t][q] = pB.a[t][q] = u32x4{0u, 0u, 0u, 0u};
       auto mfma_j = [&](auto jc, Parts& cur) {
         constexpr auto op = RL::mfma_op(ROLE, decltype(jc)::value);
-        if constexpr (IMPLICIT && op.m == 0) acc[op.slot] = mfma_bf16(cur.a[op.R][op.pa], cur.x[op.C][op.pb], acc[op.slot]);
-        else acc[op.slot] = mfma_bf16(cur.x[op.R][op.pa], cur.x[op.C][op.pb], acc[op.slot]);
+        if constexpr (SYM) {
+          if constexpr (op.m == 0) acc[op.slot] = mfma_f16(cur.a[op.R][op.pa], cur.a[op.C][op.pb], acc[op.slot]);
+          else acc[op.slot] = mfma_f16(cur.x[op.R][op.pa], cur.x[op.C][op.pb], acc[op.slot]);
+        } else if constexpr (IMPLICIT && op.m == 0) {
+          acc[op.slot] = mfma_bf16(cur.a[op.R][op.pa], cur.x[op.C][op.pb], acc[op.slot]);
+        } else {
+          acc[op.slot] = mfma_bf16(cur.x[op.R][op.pa], cur.x[op.C][op.pb], acc[op.slot]);
+        }
       };
       // pipeline synchronisation of step i: returns false if this group has no step i (PAIR: barrier count)
       auto sync_step = [&](const int i) {
@@ -547,8 +604,13 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
           }
         };
         f32x2 ur[NU];   // residuals of the pairs between the two slices of a unit
-        f32x2 cm1[4];   // (c - 1) of the lane's 4 pairs
-        if constexpr (IMPLICIT) {
+        f32x2 cm1[4];   // (c - 1) of the lane's 4 pairs; SYM: s1 sqrt(c - 1) (padding slots: c = 0 -> 0)
+        if constexpr (SYM) {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            cm1[q] = f32x2{scl.s1 * __builtin_amdgcn_sqrtf(fmaxf(c[2 * q] - 1.f, 0.f)),
+                           scl.s1 * __builtin_amdgcn_sqrtf(fmaxf(c[2 * q + 1] - 1.f, 0.f))};
+        } else if constexpr (IMPLICIT) {
 #pragma unroll
           for (int q = 0; q < 4; q++) cm1[q] = f32x2{c[2 * q] - 1.f, c[2 * q + 1] - 1.f};
         }
@@ -560,17 +622,22 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
             f32x2 r = {raw[U / 4][2 * un.pair], raw[U / 4][2 * un.pair + 1]};
             if constexpr (un.kind == 0) {
               if constexpr (RHS) bp[un.t] = fmaf(c[2 * un.pair + 1], r.y, fmaf(c[2 * un.pair], r.x, bp[un.t]));
-              nxt.x[un.t][0][un.pair] = split_stage(r, NS == 1);
+              if constexpr (SYM) {
+                r *= f32x2{scl.s2, scl.s2};
+                nxt.x[un.t][0][un.pair] = split_stage_h(r, false);
+              } else {
+                nxt.x[un.t][0][un.pair] = split_stage(r, NS == 1);
+              }
             } else {
               r *= cm1[un.pair];
-              nxt.a[un.t][0][un.pair] = split_stage(r, NS == 1);
+              nxt.a[un.t][0][un.pair] = SYM ? split_stage_h(r, false) : split_stage(r, NS == 1);
             }
             ur[U] = r;
           } else {
             f32x2 r = ur[U];
 #pragma unroll
             for (int q = 1; q < NS; q++) {
-              const unsigned pk = split_stage(r, q == NS - 1);
+              const unsigned pk = SYM ? split_stage_h(r, q == NS - 1) : split_stage(r, q == NS - 1);
               if constexpr (un.kind == 0) nxt.x[un.t][q][un.pair] = pk;
               else nxt.a[un.t][q][un.pair] = pk;
             }
@@ -673,7 +740,8 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
             int toff = G_::tile(R, C) * 32 * TLD + 4 * h * TLD + d;
             asm volatile("" : "+v"(toff));
             float* ta = sA + toff;
-            const f32x16 v = acc[RL::slot(ROLE, 0, R, C)];
+            f32x16 v = acc[RL::slot(ROLE, 0, R, C)];
+            if constexpr (SYM) v *= scl.inv1;
             if (first) {
               float g[16];
 #pragma unroll
@@ -711,8 +779,10 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
 #pragma unroll
           for (int m = 0; m < NM; m++)
             if (RL::slot(ROLE, m, R, C) >= 0) {
+              float sm = 0.f;
 #pragma unroll
-              for (int e = 0; e < 16; e++) s = fmaf(acc[RL::slot(ROLE, m, R, C)][e], yi[e], s);
+              for (int e = 0; e < 16; e++) sm = fmaf(acc[RL::slot(ROLE, m, R, C)][e], yi[e], sm);
+              s += SYM ? sm * (m == 0 ? scl.inv1 : scl.inv2) : sm;
             }
           qf = fmaf(R == C ? 1.f : 2.f, s * x[C], qf);
         }
@@ -899,16 +969,53 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
 #endif
 }
 
-template <int KP, int NS, bool IMPLICIT>
+template <int KP, int NS, bool IMPLICIT, bool SYM>
 hipError_t launch_ne_t(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int grid, double* row_loss,
-                       hipStream_t s) {
-  auto kern = als_ne_kernel<KP, NS, IMPLICIT>;
-  constexpr int lds = NeGeo<KP, NeRoles<KP, NS, IMPLICIT>::PAIR, IMPLICIT>::BYTES;
+                       hipStream_t s, int only_if_lt1) {
+  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM>;
+  constexpr int lds = NeGeo<KP, NeRoles<KP, NS, IMPLICIT, SYM>::PAIR, IMPLICIT>::BYTES;
   hipError_t err =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, wg_rows, wg_ptr, 0, row_loss);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, wg_rows, wg_ptr, 0, row_loss, only_if_lt1);
   return hipGetLastError();
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp<0xB1>(v));
+  v = fmaxf(v, dpp<0x4E>(v));
+  v = fmaxf(v, dpp<0x141>(v));
+  v = fmaxf(v, dpp<0x140>(v));
+  return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+
+// max |x| over the fixed side, max c and "some c < 1" over the confidences -> stats[0..2] (zeroed by the caller).
+// Non-negative floats order like their bit patterns, so one atomicMax per workgroup does it; a negative c only sets the flag.
+__global__ __launch_bounds__(256) void ne_stats_kernel(const float* __restrict__ X, int64_t nx, const float* __restrict__ vals,
+                                                        int64_t nnz, unsigned* __restrict__ stats) {
+  float mx = 0.f, mc = 0.f;
+  int lt1 = 0;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4, t0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  for (int64_t e = t0; e + 3 < nx; e += stride) {
+    const float4 v = *reinterpret_cast<const float4*>(X + e);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int64_t e = (nx & ~(int64_t)3) + (int64_t)blockIdx.x * 256 + threadIdx.x; e < nx; e += (int64_t)gridDim.x * 256)
+    mx = fmaxf(mx, fabsf(X[e]));
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
+    const float c = vals[e];
+    mc = fmaxf(mc, c);
+    lt1 |= !(c >= 1.f);
+  }
+  mx = wave_max(mx);
+  mc = wave_max(mc);
+  lt1 = __any(lt1);
+  if ((threadIdx.x & 63) == 0) {
+    if (!(mx < 3.0e38f)) mx = 3.0e38f;   // inf / nan in the factors: the solve will report it, the scales stay finite
+    atomicMax(stats, __float_as_uint(mx));
+    atomicMax(stats + 1, __float_as_uint(fmaxf(mc, 0.f)));
+    if (lt1) atomicOr(stats + 2, 1u);
+  }
 }
 
 }  // namespace
@@ -917,19 +1024,31 @@ bool ne_supported(int k) { return k > 32 && k <= 128 && k % 4 == 0; }
 
 // wg_rows / wg_ptr: per-workgroup row lists (host-balanced, wrmf_capi.cpp build_ne_lists); row_loss: one double per
 // entry of wg_rows
+hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s) {
+  hipError_t err = hipMemsetAsync(stats, 0, 4 * sizeof(unsigned), s);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(ne_stats_kernel, dim3(2048), dim3(256), 0, s, X, nx, vals, nnz, stats);
+  return hipGetLastError();
+}
+
+// Implicit feedback with a.ne_stats: the fp16 SYM kernel and, behind it, the bf16 kernel that takes over when some
+// confidence is below 1 (exactly one of the two does the work; the other returns at once).  Explicit feedback, or no
+// stats: the bf16 kernel alone.
 hipError_t launch_als_ne(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
                          double* row_loss, hipStream_t s) {
   if (n_wg <= 0) return hipSuccess;
   const int KP = padded_rank(a.k);
-#ifndef RSP_NE_SPLIT
-#define RSP_NE_SPLIT 3
-#endif
-  if (KP == 128)
-    return implicit ? launch_ne_t<128, RSP_NE_SPLIT, true>(a, wg_rows, wg_ptr, n_wg, row_loss, s)
-                    : launch_ne_t<128, RSP_NE_SPLIT, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s);
-  if (KP == 64)
-    return implicit ? launch_ne_t<64, RSP_NE_SPLIT, true>(a, wg_rows, wg_ptr, n_wg, row_loss, s)
-                    : launch_ne_t<64, RSP_NE_SPLIT, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s);
+  hipError_t err;
+#define RSP_NE_DISPATCH(KPV)                                                                                          \
+  if (KP == KPV) {                                                                                                    \
+    if (!implicit) return launch_ne_t<KPV, 3, false, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0);                \
+    if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0);               \
+    if ((err = launch_ne_t<KPV, 2, true, true>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) != hipSuccess) return err;  \
+    return launch_ne_t<KPV, 3, true, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 1);                                \
+  }
+  RSP_NE_DISPATCH(128)
+  RSP_NE_DISPATCH(64)
+#undef RSP_NE_DISPATCH
   return hipErrorInvalidValue;
 }
 

@@ -47,6 +47,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef RSP_ABL
+#define RSP_ABL 0   // dev builds only: ablations of the accumulate step (1 = no MFMA, 2 = no split, 4 = no look-ahead copies)
+#endif
 constexpr float kCgTolNe = 1e-10f;  // CG_TOL, inst/include/wrmf.hpp:22
 constexpr int kStepNnz = 16;        // K of v_mfma_f32_32x32x16_bf16
 
@@ -184,21 +187,11 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // ---- LDS-DMA, issued from asm so that the loop's s_waitcnt can be counted (see the header) ----
 // One 16-byte piece per lane: LDS destination = M0 + lane * 16 (wave-uniform base), source = each lane's own pointer.
 __device__ __forceinline__ void dma16(const void* g, unsigned lds_base) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(g), "s"(lds_base)
-      : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory", "m0");
 }
 // One dword per lane: LDS destination = M0 + lane * 4.
 __device__ __forceinline__ void dma4(const void* g, unsigned lds_base) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(g), "s"(lds_base)
-      : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -232,8 +225,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // the same with fp16 terms (v_cvt_pk_f16_f32, round to nearest even; x - fl16(x) is exact in fp32 whatever fl16 did)
 __device__ __forceinline__ unsigned split_stage_h(f32x2& r, bool last) {
   const f16x2 hb = __builtin_convertvector(r, f16x2);
-  if (!last) r -= __builtin_convertvector(hb, f32x2);
-  return __builtin_bit_cast(unsigned, hb);
+  const unsigned pk = __builtin_bit_cast(unsigned, hb);
+  if (!last) {   // r - fl16(r) in one mixed-precision FMA per element (no widening conversions)
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(pk), "v"(r.x));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(pk), "v"(r.y));
+    r = f32x2{r0, r1};
+  }
+  return pk;
+}
+// one packed multiply (hipcc scalarises the pair when its consumer is the mixed-precision FMA above)
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 __device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -241,7 +246,7 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f
 // Powers of two that bring the operands of the SYM path into fp16 range: the largest |s2 x| and |s1 sqrt(c-1) x| land
 // in [2^13, 2^15) (fp16 holds 65504; the terms of small entries may be subnormal, which costs absolute, not relative,
 // accuracy: <= 2^-39 of the largest entry).  stats = {bits of max |x|, bits of max c, any c < 1} (ne_stats_kernel).
-struct NeScales { float s1, s2, inv1, inv2; };
+struct NeScales { float s1sq, s2, inv1, inv2; };
 __device__ __forceinline__ NeScales ne_scales(const unsigned* stats) {
   const float mx = __uint_as_float(stats[0]), mc = __uint_as_float(stats[1]);
   const float ma = mx * __builtin_sqrtf(fmaxf(mc - 1.f, 0.f));
@@ -252,7 +257,7 @@ __device__ __forceinline__ NeScales ne_scales(const unsigned* stats) {
     return e;
   };
   const int e1 = pow2_for(ma), e2 = pow2_for(mx);
-  return NeScales{ldexpf(1.f, e1), ldexpf(1.f, e2), ldexpf(1.f, -2 * e1), ldexpf(1.f, -2 * e2)};
+  return NeScales{ldexpf(1.f, 2 * e1), ldexpf(1.f, e2), ldexpf(1.f, -2 * e1), ldexpf(1.f, -2 * e2)};
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
@@ -529,9 +534,9 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
     for (int t = 0; t < NSLOT; t++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
-    float bp[NB], bp_hi[NB];
+    f32x2 bp[NB], bp_hi[NB];   // (even, odd non-zero of a pair) summed separately, joined after the row
 #pragma unroll
-    for (int t = 0; t < NB; t++) bp[t] = bp_hi[t] = 0.f;
+    for (int t = 0; t < NB; t++) bp[t] = bp_hi[t] = f32x2{0.f, 0.f};
     double sc = 0.0;
 
     // ---- accumulate.  Software-pipelined by one step: the MFMAs of step i-1 (operands `cur`, split in the previous
@@ -604,12 +609,15 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
           }
         };
         f32x2 ur[NU];   // residuals of the pairs between the two slices of a unit
+        const f32x2 s2v = {scl.s2, scl.s2};
         f32x2 cm1[4];   // (c - 1) of the lane's 4 pairs; SYM: s1 sqrt(c - 1) (padding slots: c = 0 -> 0)
         if constexpr (SYM) {
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            cm1[q] = f32x2{scl.s1 * __builtin_amdgcn_sqrtf(fmaxf(c[2 * q] - 1.f, 0.f)),
-                           scl.s1 * __builtin_amdgcn_sqrtf(fmaxf(c[2 * q + 1] - 1.f, 0.f))};
+            // s1 sqrt(c - 1) = sqrt(|s1^2 c - s1^2|): every real confidence is >= 1; the padding slots (c = 0, masked
+            // steps only) multiply vectors that were zeroed
+            cm1[q] = f32x2{__builtin_amdgcn_sqrtf(__builtin_fabsf(fmaf(c[2 * q], scl.s1sq, -scl.s1sq))),
+                           __builtin_amdgcn_sqrtf(__builtin_fabsf(fmaf(c[2 * q + 1], scl.s1sq, -scl.s1sq)))};
         } else if constexpr (IMPLICIT) {
 #pragma unroll
           for (int q = 0; q < 4; q++) cm1[q] = f32x2{c[2 * q] - 1.f, c[2 * q + 1] - 1.f};
@@ -621,15 +629,16 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
             if constexpr (U % 4 == 0 && U + 4 < NU) load_group(std::integral_constant<int, U / 4 + 1>{});
             f32x2 r = {raw[U / 4][2 * un.pair], raw[U / 4][2 * un.pair + 1]};
             if constexpr (un.kind == 0) {
-              if constexpr (RHS) bp[un.t] = fmaf(c[2 * un.pair + 1], r.y, fmaf(c[2 * un.pair], r.x, bp[un.t]));
+              if constexpr (RHS) bp[un.t] += f32x2{c[2 * un.pair], c[2 * un.pair + 1]} * r;
               if constexpr (SYM) {
-                r *= f32x2{scl.s2, scl.s2};
+                r = pk_mul(r, s2v);
                 nxt.x[un.t][0][un.pair] = split_stage_h(r, false);
               } else {
                 nxt.x[un.t][0][un.pair] = split_stage(r, NS == 1);
               }
             } else {
-              r *= cm1[un.pair];
+              if constexpr (SYM) r = pk_mul(r, cm1[un.pair]);
+              else r *= cm1[un.pair];
               nxt.a[un.t][0][un.pair] = SYM ? split_stage_h(r, false) : split_stage(r, NS == 1);
             }
             ur[U] = r;
@@ -669,18 +678,26 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
         static_for<NMFMA>([&](auto jc) {
           constexpr int J = decltype(jc)::value;
           pin(jc);
+#if !(RSP_ABL & 1)
           mfma_j(jc, cur);
+#endif
+#if !(RSP_ABL & 2)
           if constexpr (J >= BARE && J - BARE < NHU) half_unit(std::integral_constant<int, J - BARE>{});
+#endif
           // piece n of the look-ahead copy behind MFMA (n + 1) NMFMA / (GROUP + 1)
           static_for<G_::GROUP>([&](auto nc) {
+#if !(RSP_ABL & 4)
             if constexpr (J == (decltype(nc)::value + 1) * NMFMA / (G_::GROUP + 1))
               piece(std::integral_constant<int, PAIR ? ROLE : 0>{}, nc);
+#endif
           });
           __builtin_amdgcn_sched_barrier(0);
         });
+#if !(RSP_ABL & 2)
         static_for<(NHU > NMFMA - BARE ? NHU - (NMFMA - BARE) : 0)>([&](auto hc) {
           half_unit(std::integral_constant<int, decltype(hc)::value + NMFMA - BARE>{});
         });
+#endif
         if constexpr (RHS) {
           float s = 0.f;
 #pragma unroll
@@ -690,8 +707,8 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
           const float fm = (i & 63) == 63 ? 1.f : 0.f;
 #pragma unroll
           for (int t = 0; t < NB; t++) {
-            bp_hi[t] = fmaf(fm, bp[t], bp_hi[t]);
-            bp[t] = fmaf(-fm, bp[t], bp[t]);
+            bp_hi[t] += f32x2{fm, fm} * bp[t];
+            bp[t] -= f32x2{fm, fm} * bp[t];
           }
         }
         NE_T(3)
@@ -712,14 +729,20 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
         }
       }
       static_for<NMFMA>([&](auto jc) { mfma_j(jc, pA); });   // the last step
+      float bsum[NB];
+#pragma unroll
+      for (int t = 0; t < NB; t++) bsum[t] = 0.f;
       if constexpr (RHS) {
 #pragma unroll
-        for (int t = 0; t < NB; t++) bp[t] = half_swap_sum(bp_hi[t] + bp[t]);
+        for (int t = 0; t < NB; t++) {
+          const f32x2 v = bp_hi[t] + bp[t];
+          bsum[t] = half_swap_sum(v.x + v.y);
+        }
         sc += __shfl_xor(sc, 32);  // sc is uniform inside each half of the wave
       }
       if (lane < 32) {
 #pragma unroll
-        for (int t = 0; t < NB; t++) sB[wv * KP + 32 * t + lane] = RHS ? bp[t] : 0.f;
+        for (int t = 0; t < NB; t++) sB[wv * KP + 32 * t + lane] = bsum[t];
       }
       if (lane == 0) reinterpret_cast<double*>(sScal)[wv] = RHS ? sc : 0.0;
       NE_T(4)

@@ -446,6 +446,18 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
   // computing; spread out, every one finds room and the copy runs behind the arithmetic.
   const void* pre_src[G_::GROUP];   // per piece: this lane's source address
   unsigned pre_dst[G_::GROUP];      // ... wave-uniform LDS destination
+  int pre_id[NI];                   // indices of the step being prepared (read from the ring ahead of their use)
+  auto prepare_read = [&]() {
+    const int* ix = reinterpret_cast<const int*>(ring + D * G_::SLOT_BYTES + vislot * 256) + dq * NI;
+    if constexpr (NI == 8) {
+      const int4 i0 = *reinterpret_cast<const int4*>(ix), i1 = *reinterpret_cast<const int4*>(ix + 4);
+      pre_id[0] = i0.x; pre_id[1] = i0.y; pre_id[2] = i0.z; pre_id[3] = i0.w;
+      pre_id[4] = i1.x; pre_id[5] = i1.y; pre_id[6] = i1.z; pre_id[7] = i1.w;
+    } else {
+      const int4 i0 = *reinterpret_cast<const int4*>(ix);
+      pre_id[0] = i0.x; pre_id[1] = i0.y; pre_id[2] = i0.z; pre_id[3] = i0.w;
+    }
+  };
   auto prepare = [&](auto role_tag) {
     constexpr int LR = decltype(role_tag)::value;
     int n = 0;
@@ -456,21 +468,11 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
     }
     islot = islot + 1 == IDXR ? 0 : islot + 1;
     advance(ci);
-    const int* ix = reinterpret_cast<const int*>(ring + D * G_::SLOT_BYTES + vislot * 256) + dq * NI;
-    int id[NI];
-    if constexpr (NI == 8) {
-      const int4 i0 = *reinterpret_cast<const int4*>(ix), i1 = *reinterpret_cast<const int4*>(ix + 4);
-      id[0] = i0.x; id[1] = i0.y; id[2] = i0.z; id[3] = i0.w;
-      id[4] = i1.x; id[5] = i1.y; id[6] = i1.z; id[7] = i1.w;
-    } else {
-      const int4 i0 = *reinterpret_cast<const int4*>(ix);
-      id[0] = i0.x; id[1] = i0.y; id[2] = i0.z; id[3] = i0.w;
-    }
     const unsigned base = ring_a + (unsigned)(vslot * G_::SLOT_BYTES);
 #pragma unroll
     for (int e = 0; e < NI; e++)
       if (e / (NI / G_::LOADERS) == LR) {
-        pre_src[n] = a.X + (size_t)id[e] * k + dl4;
+        pre_src[n] = a.X + (size_t)pre_id[e] * k + dl4;
         pre_dst[n++] = base + e * 1024;
       }
     if (LR == G_::LOADERS - 1) {
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
         NE_T(0)
         if constexpr (PAIR) __builtin_amdgcn_s_barrier();  // ... and the partner's share; the previous slot is released
         NE_T(1)
-        if (has) prepare(std::integral_constant<int, PAIR ? ROLE : 0>{});
+        if (has) prepare_read();   // the addresses are formed inside the step, behind its first MFMAs
         NE_T(2)
         return has;
       };
@@ -681,6 +683,9 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
 #if !(RSP_ABL & 1)
           mfma_j(jc, cur);
 #endif
+          // (before the first look-ahead piece, which goes behind MFMA NMFMA / (GROUP + 1))
+          if constexpr (J == (BARE - 1 < NMFMA / (G_::GROUP + 1) ? BARE - 1 : NMFMA / (G_::GROUP + 1)))
+            prepare(std::integral_constant<int, PAIR ? ROLE : 0>{});
 #if !(RSP_ABL & 2)
           if constexpr (J >= BARE && J - BARE < NHU) half_unit(std::integral_constant<int, J - BARE>{});
 #endif
@@ -747,16 +752,20 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
       if (lane == 0) reinterpret_cast<double*>(sScal)[wv] = RHS ? sc : 0.0;
       NE_T(4)
     };
-    // ---- A = XtX + M1 (explicit: lambda_use I + M2): the first ring group writes G + its partial sums, the others add
-    // theirs (read-add-write), one group after the other (fixed order, hence deterministic); element (tile, e) of
-    // lane (h, d) is row 8 (e / 4) + 4 h + e % 4, column d of the tile
-    auto chain_add = [&](auto role_tag, const bool first) {
+    // ---- A = XtX + M1 (explicit: lambda_use I + M2).  The tiles are dealt round robin to the ring groups: in phase ph
+    // group g works on the tiles t with t % NSETS == (g + ph) % NSETS -- in phase 0 it writes G + its partial sums there,
+    // in the later phases it adds its partial sums to what the groups before it left (read-add-write).  Every group is
+    // busy in every phase, every tile sees the groups in a fixed order (deterministic); element (tile, e) of lane
+    // (h, d) is row 8 (e / 4) + 4 h + e % 4, column d of the tile
+    auto chain_add = [&](auto role_tag, const int ph) {
       constexpr int ROLE = decltype(role_tag)::value;
+      const bool first = ph == 0;
+      const int mine = (wset + ph) % NSETS;
 #pragma unroll
       for (int R = 0; R < NB; R++)
 #pragma unroll
         for (int C = 0; C <= R; C++)
-          if (RL::slot(ROLE, 0, R, C) >= 0) {
+          if (RL::slot(ROLE, 0, R, C) >= 0 && G_::tile(R, C) % NSETS == mine) {
             // one address register per tile, opaque to hipcc: the element offsets then fit the 16-bit immediate of
             // the DS instructions (the tiles sit beyond 64 KB; without this it keeps one hoisted, spilled address
             // register per element)
@@ -819,10 +828,8 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
     __syncthreads();   // warm start and every wave's right-hand-side partial are in LDS
     NE_T(12)
     for (int ph = 0; ph < NSETS; ph++) {
-      if (wset == ph) {
-        if (!PAIR || wrole == 0) chain_add(std::integral_constant<int, 0>{}, ph == 0);
-        else chain_add(std::integral_constant<int, 1>{}, ph == 0);
-      }
+      if (!PAIR || wrole == 0) chain_add(std::integral_constant<int, 0>{}, ph);
+      else chain_add(std::integral_constant<int, 1>{}, ph);
       NE_T(13)
       __syncthreads();
       NE_T(14)
@@ -857,33 +864,40 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
       wave_sync();
       float* part = sPart + buf * NB * NB * 32;
       NE_T(15)
-      for (int u = wv; u < NB * NB; u += 4) {
+      // the wave's NB^2 / 4 units together: all their LDS reads first (hipcc otherwise waits for each read before it
+      // issues the next -- 16 round trips per unit), then the arithmetic
+      constexpr int UW = NB * NB / 4;
+      float tv[UW][16], vv[UW][16];
+#pragma unroll
+      for (int i = 0; i < UW; i++) {
+        const int u = wv + 4 * i;
         const int tg = u / NB, sl = u % NB;
         const bool by_rows = sl >= tg;
         const int R = by_rows ? sl : tg, C = by_rows ? tg : sl;
         const float* T = sA + (R * (R + 1) / 2 + C) * 32 * TLD + (by_rows ? d + 16 * h * TLD : d * TLD + 16 * h);
         const int sv = by_rows ? TLD : 1;
         const float* vb = pub + 32 * sl + 16 * h;
-        // all 20 LDS reads first (hipcc otherwise waits for each one before it issues the next: 16 round trips)
-        float tv[16], vv[16];
 #pragma unroll
         for (int q4 = 0; q4 < 4; q4++) {
           const float4 v4 = *reinterpret_cast<const float4*>(vb + 4 * q4);
-          vv[4 * q4] = v4.x; vv[4 * q4 + 1] = v4.y; vv[4 * q4 + 2] = v4.z; vv[4 * q4 + 3] = v4.w;
+          vv[i][4 * q4] = v4.x; vv[i][4 * q4 + 1] = v4.y; vv[i][4 * q4 + 2] = v4.z; vv[i][4 * q4 + 3] = v4.w;
         }
 #pragma unroll
-        for (int q = 0; q < 16; q++) tv[q] = T[q * sv];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < 16; q++) tv[i][q] = T[q * sv];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < UW; i++) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int q4 = 0; q4 < 4; q4++) {
-          s0 = fmaf(tv[4 * q4 + 0], vv[4 * q4 + 0], s0);
-          s1 = fmaf(tv[4 * q4 + 1], vv[4 * q4 + 1], s1);
-          s2 = fmaf(tv[4 * q4 + 2], vv[4 * q4 + 2], s2);
-          s3 = fmaf(tv[4 * q4 + 3], vv[4 * q4 + 3], s3);
+          s0 = fmaf(tv[i][4 * q4 + 0], vv[i][4 * q4 + 0], s0);
+          s1 = fmaf(tv[i][4 * q4 + 1], vv[i][4 * q4 + 1], s1);
+          s2 = fmaf(tv[i][4 * q4 + 2], vv[i][4 * q4 + 2], s2);
+          s3 = fmaf(tv[i][4 * q4 + 3], vv[i][4 * q4 + 3], s3);
         }
-        float s = half_swap_sum((s0 + s1) + (s2 + s3));
-        if (h == 0) part[u * 32 + d] = s;
+        const float s = half_swap_sum((s0 + s1) + (s2 + s3));
+        if (h == 0) part[(wv + 4 * i) * 32 + d] = s;
       }
       NE_T(16)
       __syncthreads();

@@ -252,7 +252,9 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int n_wg = std::min(n_stream, std::max(cus, 1));
+    // two lists per CU: the rank-128 fp16 kernel runs two workgroups per CU; the one-per-CU kernels work through two
+    // lists each, one after the other
+    const int n_wg = std::min(n_stream, 2 * std::max(cus, 1));
     std::vector<int64_t> load((size_t)n_wg, 0);
     std::vector<int> owner((size_t)n_stream);
     std::vector<int32_t> cnt_wg((size_t)n_wg + 1, 0);

@@ -66,18 +66,26 @@ struct NeUnit { int kind, t, pair; };             // a pair of floats to split: 
 //   M1 = a' a'^T with a' = sqrt(c - 1) s1 x,   M2 = (s2 x)(s2 x)^T     (s1, s2: powers of two, see ne_scales),
 // split exactly into 2 fp16 terms (22 bits) with 3 products kept (2^-21 per product): half the matrix-core work of the
 // bf16 path and, in a PAIR, half the split arithmetic per wave -- role 0 = M1 (needs only a'), role 1 = M2 + b (only x).
-template <int KP, int NS, bool IMPLICIT, bool SYM = false>
+// QUAD (SYM at rank 128): all four waves of the workgroup consume the same steps, five tiles each -- roles 0, 1 the two
+// halves of M1, roles 2, 3 those of M2 (role 3 also b).  80 accumulator registers per wave and one ring instead of
+// two: the workgroup fits the CU twice, and the two resident workgroups overlap each other's matrix, vector, copy and
+// per-row solve phases -- inside ONE wave they add up (measured: MFMA + split + copy issue = the step time).
+template <int KP, int NS, bool IMPLICIT, bool SYM = false, bool QUAD = false>
 struct NeRoles {
   static_assert(!SYM || (IMPLICIT && NS == 2), "SYM: implicit feedback, two fp16 terms");
+  static_assert(!QUAD || (SYM && KP == 128), "QUAD: the fp16 path at rank 128");
   static constexpr int NB = KP / 32;
   static constexpr int NT = NB * (NB + 1) / 2;
-  static constexpr bool PAIR = IMPLICIT && KP == 128;
-  static constexpr int NSETS = PAIR ? 2 : 4;  // ring groups
+  static constexpr bool PAIR = IMPLICIT && KP == 128 && !QUAD;
+  static constexpr int NROLES = QUAD ? 4 : (PAIR ? 2 : 1);   // waves that consume the same steps
+  static constexpr int NSETS = 4 / NROLES;                   // ring groups
+  static constexpr int QH = 5;                               // QUAD: tiles 0..4 = half 0 (blocks 0..2), 5..9 = half 1
   // Accumulator slot of tile (R, C) of matrix m (0 = the matrix of the system: implicit M1, explicit M2; 1 = implicit M2,
   // loss only) for a wave of the given role, or -1 if that wave does not accumulate the tile
   __host__ __device__ static constexpr int tile(int R, int C) { return R * (R + 1) / 2 + C; }
   __host__ __device__ static constexpr int slot(int role, int m, int R, int C) {
     if (!IMPLICIT) return m == 0 ? tile(R, C) : -1;
+    if (QUAD) return (m == role / 2 && tile(R, C) / QH == role % 2) ? tile(R, C) % QH : -1;
     if (!PAIR) return m * NT + tile(R, C);
     if (NS >= 3 && !SYM) {
       // role 0: M1 tile rows 2, 3 (slots 0..6, 42 products) + M2 tiles (0,0), (1,1) (slots 7, 8; 6 products)
@@ -90,9 +98,9 @@ struct NeRoles {
     }
     return m == role ? tile(R, C) : -1;
   }
-  static constexpr int NSLOT = !IMPLICIT ? NT : (!PAIR ? 2 * NT : (NS >= 3 && !SYM ? 11 : 10));
+  static constexpr int NSLOT = !IMPLICIT ? NT : (QUAD ? QH : (!PAIR ? 2 * NT : (NS >= 3 && !SYM ? 11 : 10)));
   __host__ __device__ static constexpr bool owns_row(int role, int R) { return IMPLICIT && slot(role, 0, R, 0) >= 0; }
-  __host__ __device__ static constexpr int rhs_role() { return PAIR ? 1 : 0; }  // who accumulates b and sum c
+  __host__ __device__ static constexpr int rhs_role() { return QUAD ? 3 : (PAIR ? 1 : 0); }  // who accumulates b and sum c
 
   // The MFMAs of one step in issue order: product-major, so that two MFMAs on the same accumulator are a whole sweep over
   // the tiles apart.  M2 (implicit) takes the products of its first two terms, the system matrix those of total order < NS.
@@ -130,12 +138,14 @@ struct NeRoles {
   // The split work of one step: the 4 float pairs of every block of x, then those of (c - 1) x for the owned tile rows
   // (SYM pair: role 0 only a', role 1 only x)
   __host__ __device__ static constexpr int unit_count(int role) {
+    if (QUAD) return 4 * (role % 2 == 0 ? 3 : 4);
     if (SYM && PAIR) return 4 * NB;
     int n = 4 * NB;
     for (int t = 0; t < NB; t++) n += owns_row(role, t) ? 4 : 0;
     return n;
   }
   __host__ __device__ static constexpr NeUnit unit(int role, int u) {
+    if (QUAD) return NeUnit{role < 2 ? 1 : 0, u / 4, u % 4};
     if (SYM && PAIR) return NeUnit{role == 0 ? 1 : 0, u / 4, u % 4};
     if (u < 4 * NB) return NeUnit{0, u / 4, u % 4};
     int n = 4 * NB;
@@ -150,8 +160,9 @@ struct NeRoles {
   __host__ __device__ static constexpr bool first_of_block(int role, int u) { return unit(role, u).pair == 0; }
 };
 
-template <int KP, bool PAIR, bool IMPLICIT>
+template <int KP, int NROLES, bool IMPLICIT>
 struct NeGeo {
+  static constexpr bool PAIR = NROLES == 2, QUAD = NROLES == 4;
   static constexpr int NB = KP / 32;               // 32-wide blocks of the factor dimension
   static constexpr int NT = NB * (NB + 1) / 2;     // lower-triangular tiles
   static constexpr int VPI = 256 / KP;             // vectors per DMA instruction (64 lanes x 16 B)
@@ -159,23 +170,28 @@ struct NeGeo {
   static constexpr int LPV = 64 / VPI;             // lanes per vector
   static constexpr int VEC_BYTES = NI * 1024;      // one step of gathered vectors
   static constexpr int SLOT_BYTES = VEC_BYTES + 256 /* values */;
-  static constexpr int NRING = PAIR ? 2 : 4;
+  static constexpr int NRING = 4 / NROLES;
   static constexpr int D = KP == 128 ? 3 : 6;      // slots per ring; D - 1 steps requested ahead (a wave keeps only ~10 KB
                                                    // of LDS-DMA in flight -- measured, tools/probes -- so more does not help)
   static constexpr int IDXR = 2 * D - 1;           // index-chunk slots per ring (256 B each)
-  static constexpr int LOADERS = PAIR ? 2 : 1;     // waves of a ring group that issue its DMA: all of them
-  static constexpr int GROUP = NI / LOADERS + (PAIR ? 1 : 2);  // DMA instructions per step and wave: its share of the
-                                                               // vector pieces + the index chunk and / or the values
+  static constexpr int LOADERS = NROLES;           // waves of a ring group that issue its DMA: all of them
+  // DMA instructions per step and wave: its share of the vector pieces + the index chunk (first loader) and / or the
+  // values (last loader)
+  __host__ __device__ static constexpr int group_of(int role) {
+    return NI / LOADERS + (role == 0 ? 1 : 0) + (role == LOADERS - 1 ? 1 : 0);
+  }
+  static constexpr int GROUP = NI / LOADERS + (LOADERS == 1 ? 2 : 1);   // the largest of them
   static constexpr int RING_BYTES = D * SLOT_BYTES + IDXR * 256;
   static constexpr int TLD = 33;                   // row stride inside a 32 x 32 tile (conflict-free by rows and by columns)
   static constexpr int A_FLOATS = NT * 32 * TLD;
-  static constexpr int G_FLOATS = IMPLICIT ? A_FLOATS : 0;   // XtX as tiles, resident for the whole launch
-  static constexpr int YB = 8;                     // solved rows buffered in LDS before one wave stores them
+  static constexpr int G_FLOATS = IMPLICIT && !QUAD ? A_FLOATS : 0;   // XtX as tiles, resident for the whole launch
+                                                                     // (QUAD reads it from L2: half the LDS per workgroup)
+  static constexpr int YB = QUAD ? 4 : 8;          // solved rows buffered in LDS before one wave stores them
   static constexpr int V_FLOATS = 4 * KP /* b partials */ + 2 * NB * NB * 32 /* matvec partials, double buffered */ +
                                   4 * KP /* per-wave published vector */ + 256 /* warm start (DMA target, 1 KB) */ +
                                   YB * KP + 4 * YB /* row ids, loss slots, losses (double) */ + 64 /* scalars */;
   static constexpr int BYTES = NRING * RING_BYTES + (A_FLOATS + G_FLOATS + V_FLOATS) * 4;
-  static_assert(BYTES <= 160 * 1024, "LDS budget");
+  static_assert(BYTES <= (QUAD ? 80 : 160) * 1024, "LDS budget");
   static_assert((D - 2) * GROUP <= 63, "vmcnt is a 6-bit field");
   __host__ __device__ static constexpr int tile(int R, int C) { return R * (R + 1) / 2 + C; }
 };
@@ -257,7 +273,8 @@ __device__ __forceinline__ NeScales ne_scales(const unsigned* stats) {
     return e;
   };
   const int e1 = pow2_for(ma), e2 = pow2_for(mx);
-  return NeScales{ldexpf(1.f, 2 * e1), ldexpf(1.f, e2), ldexpf(1.f, -2 * e1), ldexpf(1.f, -2 * e2)};
+  auto uni = [](float v) { return __int_as_float(rfl(__float_as_int(v))); };   // wave-uniform: keep them in SGPRs
+  return NeScales{uni(ldexpf(1.f, 2 * e1)), uni(ldexpf(1.f, e2)), uni(ldexpf(1.f, -2 * e1)), uni(ldexpf(1.f, -2 * e2))};
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
@@ -318,12 +335,13 @@ struct NeParts {   // MFMA operands of one step: block t, term q
   u32x4 a[NB][NS];   // (c - 1) x   (tile rows this wave owns; implicit only)
 };
 
-template <int KP, int NS, bool IMPLICIT, bool SYM>
-__global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t* __restrict__ wg_rows,
-                                                         const int32_t* __restrict__ wg_ptr, int slot0,
-                                                         double* __restrict__ row_loss, int only_if_lt1) {
-  using RL = NeRoles<KP, NS, IMPLICIT, SYM>;
-  using G_ = NeGeo<KP, RL::PAIR, IMPLICIT>;
+template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD>
+__global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, const int32_t* __restrict__ wg_rows,
+                                                                    const int32_t* __restrict__ wg_ptr, int slot0,
+                                                                    double* __restrict__ row_loss, int only_if_lt1) {
+  using RL = NeRoles<KP, NS, IMPLICIT, SYM, QUAD>;
+  using G_ = NeGeo<KP, RL::NROLES, IMPLICIT>;
+  constexpr int NROLES = RL::NROLES;
   constexpr int NB = G_::NB, NT = G_::NT, NI = G_::NI, LPV = G_::LPV, D = G_::D, IDXR = G_::IDXR, TLD = G_::TLD;
   constexpr int NM = IMPLICIT ? 2 : 1;  // accumulated matrices: implicit {M1, M2}, explicit {M2}
   constexpr int NSETS = RL::NSETS, NSLOT = RL::NSLOT, YB = G_::YB;
@@ -347,8 +365,22 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
       }
     }
   }
-  const int wset = PAIR ? wv >> 1 : wv;   // ring group: its steps of a row are wset, wset + NSETS, ...
-  const int wrole = PAIR ? wv & 1 : 0;
+  const int wset = wv / NROLES;   // ring group: its steps of a row are wset, wset + NSETS, ...
+  const int wrole = wv % NROLES;
+  // f(integral_constant<int, role of this wave>)
+  auto with_role = [&](auto&& f) {
+    if constexpr (NROLES == 1) {
+      f(std::integral_constant<int, 0>{});
+    } else if constexpr (NROLES == 2) {
+      if (wrole == 0) f(std::integral_constant<int, 0>{});
+      else f(std::integral_constant<int, 1>{});
+    } else {
+      if (wrole == 0) f(std::integral_constant<int, 0>{});
+      else if (wrole == 1) f(std::integral_constant<int, 1>{});
+      else if (wrole == 2) f(std::integral_constant<int, 2>{});
+      else f(std::integral_constant<int, 3>{});
+    }
+  };
 
   char* ring = smem + wset * G_::RING_BYTES;
   const unsigned ring_a = rfl((int)lds_addr(ring));
@@ -369,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
                                                  // (never past the vector) and are zeroed when they are consumed
   const int list_begin = sload(wg_ptr + blockIdx.x), list_end = sload(wg_ptr + blockIdx.x + 1);
 
-  if constexpr (IMPLICIT) {   // XtX -> LDS tiles, once (ordinary loads: the DMA queue is still empty)
+  if constexpr (G_::G_FLOATS > 0) {   // XtX -> LDS tiles, once (ordinary loads: the DMA queue is still empty)
     for (int e = tid; e < NT * 1024; e += 256) {
       const int t = e >> 10, i = (e >> 5) & 31, j = e & 31;
       const int R = t >= 6 ? 3 : (t >= 3 ? 2 : (t >= 1 ? 1 : 0)), C = t - R * (R + 1) / 2;
@@ -486,9 +518,11 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
   };
   auto piece = [&](auto role_tag, auto nc) {   // piece n of the prepared step: 4-byte copies are the index / value chunks
     constexpr int LR = decltype(role_tag)::value, N = decltype(nc)::value;
-    constexpr bool small = (LR == 0 && N == 0) || (LR == G_::LOADERS - 1 && N == G_::GROUP - 1);
-    if constexpr (small) dma4(pre_src[N], pre_dst[N]);
-    else dma16(pre_src[N], pre_dst[N]);
+    if constexpr (N < G_::group_of(LR)) {
+      constexpr bool small = (LR == 0 && N == 0) || (LR == G_::LOADERS - 1 && N == G_::group_of(LR) - 1);
+      if constexpr (small) dma4(pre_src[N], pre_dst[N]);
+      else dma16(pre_src[N], pre_dst[N]);
+    }
   };
   {
     start(ci);
@@ -500,8 +534,7 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
     __syncthreads();   // the partner reads the index chunks too; XtX tiles are in place
     for (int j = 0; j < D - 1; j++) {
       issue_idx();
-      if (wrole == 0) issue_vec(std::integral_constant<int, 0>{});
-      else issue_vec(std::integral_constant<int, 1>{});
+      with_role([&](auto rc) { issue_vec(rc); });
     }
   }
   int cslot = 0;  // ring slot of the next step this wave consumes
@@ -548,6 +581,8 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
     auto accumulate = [&](auto role_tag) {
       constexpr int ROLE = decltype(role_tag)::value;
       constexpr bool RHS = ROLE == RL::rhs_role();
+      // QUAD: the two M2 roles share b (role 2: its blocks 0..2 and sum c; role 3: block 3) -- role 3 splits one block more
+      constexpr bool ANYRHS = QUAD ? ROLE >= 2 : RHS, SCR = QUAD ? ROLE == 2 : RHS;
       constexpr int NMFMA = RL::mfma_count(ROLE), NU = RL::unit_count(ROLE), NHU = 2 * NU;
       constexpr int BARE = 4;   // MFMAs issued before the first split slice: they cover the latency of the ring reads
       using Parts = NeParts<NB, NS>;
@@ -570,9 +605,9 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
       // pipeline synchronisation of step i: returns false if this group has no step i (PAIR: barrier count)
       auto sync_step = [&](const int i) {
         const bool has = i < nst;   // PAIR mode: a group with one step fewer than group 0 still meets the barrier
-        if (has) wait_vm<(D - 2) * G_::GROUP>();  // this wave's share of the step has landed; D-2 later ones in flight
+        if (has) wait_vm<(D - 2) * G_::group_of(ROLE)>();  // this wave's share of the step has landed; D-2 later ones in flight
         NE_T(0)
-        if constexpr (PAIR) __builtin_amdgcn_s_barrier();  // ... and the partner's share; the previous slot is released
+        if constexpr (NROLES > 1) __builtin_amdgcn_s_barrier();  // ... and the partners' shares; the previous slot is released
         NE_T(1)
         if (has) prepare_read();   // the addresses are formed inside the step, behind its first MFMAs
         NE_T(2)
@@ -685,7 +720,7 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
 #endif
           // (before the first look-ahead piece, which goes behind MFMA NMFMA / (GROUP + 1))
           if constexpr (J == (BARE - 1 < NMFMA / (G_::GROUP + 1) ? BARE - 1 : NMFMA / (G_::GROUP + 1)))
-            prepare(std::integral_constant<int, PAIR ? ROLE : 0>{});
+            prepare(std::integral_constant<int, ROLE>{});
 #if !(RSP_ABL & 2)
           if constexpr (J >= BARE && J - BARE < NHU) half_unit(std::integral_constant<int, J - BARE>{});
 #endif
@@ -693,7 +728,7 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
           static_for<G_::GROUP>([&](auto nc) {
 #if !(RSP_ABL & 4)
             if constexpr (J == (decltype(nc)::value + 1) * NMFMA / (G_::GROUP + 1))
-              piece(std::integral_constant<int, PAIR ? ROLE : 0>{}, nc);
+              piece(std::integral_constant<int, ROLE>{}, nc);
 #endif
           });
           __builtin_amdgcn_sched_barrier(0);
@@ -718,26 +753,109 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
         }
         NE_T(3)
       };
-      const int niter = PAIR ? nst_max : nst;
+      // QUAD: no software pipeline and no pinned interleave -- the second workgroup on the CU fills this wave's gaps.
+      // Split the step's operands, start the look-ahead copies, then the 15 MFMAs back to back.
+      auto step_quad = [&](auto masked_tag, const int i) {
+        constexpr bool masked = decltype(masked_tag)::value;
+        constexpr int NBLK = NU / 4, KIND = RL::unit(ROLE, 0).kind;
+        const int rem = cnt - i * kStepNnz;
+        const char* slot = ring + cslot * G_::SLOT_BYTES;
+        cslot = cslot + 1 == D ? 0 : cslot + 1;
+        float c[8];
+        {
+          const float4 c0 = *reinterpret_cast<const float4*>(slot + G_::VEC_BYTES + h * 32);
+          const float4 c1 = *reinterpret_cast<const float4*>(slot + G_::VEC_BYTES + h * 32 + 16);
+          c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
+          c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+        }
+        if constexpr (masked) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) c[e] = (8 * h + e < rem) ? c[e] : 0.f;
+        }
+        const char* lbase = slot + h * (8 / NI) * (KP * 4) + d * 4;
+        float raw[NBLK][8];
+#pragma unroll
+        for (int t = 0; t < NBLK; t++) {
+#pragma unroll
+          for (int e = 0; e < 8; e++)
+            raw[t][e] = *reinterpret_cast<const float*>(lbase + (e % NI) * 1024 + (e / NI) * (KP * 4) + t * 128);
+          if constexpr (masked) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) raw[t][e] = (32 * t + d < k && 8 * h + e < rem) ? raw[t][e] : 0.f;
+          }
+        }
+        prepare(std::integral_constant<int, ROLE>{});
+        static_for<G_::GROUP>([&](auto nc) { piece(std::integral_constant<int, ROLE>{}, nc); });
+        f32x2 mul[4];   // per pair: s1 sqrt(c - 1) (M1 roles) or s2 (M2 roles)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if constexpr (KIND == 1)
+            mul[q] = f32x2{__builtin_amdgcn_sqrtf(__builtin_fabsf(fmaf(c[2 * q], scl.s1sq, -scl.s1sq))),
+                           __builtin_amdgcn_sqrtf(__builtin_fabsf(fmaf(c[2 * q + 1], scl.s1sq, -scl.s1sq)))};
+          else
+            mul[q] = f32x2{scl.s2, scl.s2};
+        }
+        u32x4 op[NBLK][2];
+#pragma unroll
+        for (int t = 0; t < NBLK; t++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            f32x2 r = {raw[t][2 * q], raw[t][2 * q + 1]};
+            if ((ROLE == 2 && t < 3) || (ROLE == 3 && t == 3)) bp[t] += f32x2{c[2 * q], c[2 * q + 1]} * r;
+            r = pk_mul(r, mul[q]);
+            op[t][0][q] = split_stage_h(r, false);
+            op[t][1][q] = split_stage_h(r, true);
+          }
+        static_for<NMFMA>([&](auto jc) {
+          constexpr auto o = RL::mfma_op(ROLE, decltype(jc)::value);
+          acc[o.slot] = mfma_f16(op[o.R][o.pa], op[o.C][o.pb], acc[o.slot]);
+        });
+        if constexpr (SCR) {
+          float s = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; e++) s += c[e];
+          sc += (double)s;
+        }
+        if constexpr (ANYRHS) {
+          const float fm = (i & 63) == 63 ? 1.f : 0.f;
+#pragma unroll
+          for (int t = 0; t < NB; t++)
+            if ((ROLE == 2 && t < 3) || (ROLE == 3 && t == 3)) {
+              bp_hi[t] += f32x2{fm, fm} * bp[t];
+              bp[t] -= f32x2{fm, fm} * bp[t];
+            }
+        }
+        NE_T(3)
+      };
+      const int niter = NROLES > 1 ? nst_max : nst;
       // only the row's last step can be partial, and it belongs to exactly one ring group; rank < KP: all masked
       const bool part = nst > 0 && cnt - (wset + NSETS * (nst - 1)) * kStepNnz < kStepNnz;
       const int nfull = k != KP ? 0 : (part ? nst - 1 : nst);
-      for (int i = 0; i < nfull; i++) {
-        sync_step(i);
-        step(std::false_type{}, i, pA, pB);
-        pA = pB;   // (two steps per trip with swapped operand sets would save these copies, but hipcc then moves the
-      }            //  split arithmetic of the first step across the barrier and un-interleaves both)
-      for (int i = nfull; i < niter; i++) {   // partial step, rank < KP, missing step of a shorter group
-        if (sync_step(i)) {
-          step(std::true_type{}, i, pA, pB);
-          pA = pB;
+      if constexpr (QUAD) {
+        for (int i = 0; i < nfull; i++) {
+          sync_step(i);
+          step_quad(std::false_type{}, i);
         }
+        for (int i = nfull; i < niter; i++)
+          if (sync_step(i)) step_quad(std::true_type{}, i);
+      } else {
+        for (int i = 0; i < nfull; i++) {
+          sync_step(i);
+          step(std::false_type{}, i, pA, pB);
+          pA = pB;   // (two steps per trip with swapped operand sets would save these copies, but hipcc then moves the
+        }            //  split arithmetic of the first step across the barrier and un-interleaves both)
+        for (int i = nfull; i < niter; i++) {   // partial step, rank < KP, missing step of a shorter group
+          if (sync_step(i)) {
+            step(std::true_type{}, i, pA, pB);
+            pA = pB;
+          }
+        }
+        static_for<NMFMA>([&](auto jc) { mfma_j(jc, pA); });   // the last step
       }
-      static_for<NMFMA>([&](auto jc) { mfma_j(jc, pA); });   // the last step
       float bsum[NB];
 #pragma unroll
       for (int t = 0; t < NB; t++) bsum[t] = 0.f;
-      if constexpr (RHS) {
+      if constexpr (ANYRHS) {
 #pragma unroll
         for (int t = 0; t < NB; t++) {
           const f32x2 v = bp_hi[t] + bp[t];
@@ -749,7 +867,7 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
 #pragma unroll
         for (int t = 0; t < NB; t++) sB[wv * KP + 32 * t + lane] = bsum[t];
       }
-      if (lane == 0) reinterpret_cast<double*>(sScal)[wv] = RHS ? sc : 0.0;
+      if (lane == 0) reinterpret_cast<double*>(sScal)[wv] = SCR ? sc : 0.0;
       NE_T(4)
     };
     // ---- A = XtX + M1 (explicit: lambda_use I + M2).  The tiles are dealt round robin to the ring groups: in phase ph
@@ -757,6 +875,45 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
     // in the later phases it adds its partial sums to what the groups before it left (read-add-write).  Every group is
     // busy in every phase, every tile sees the groups in a fixed order (deterministic); element (tile, e) of lane
     // (h, d) is row 8 (e / 4) + 4 h + e % 4, column d of the tile
+    // QUAD (one ring group, every M1 tile has exactly one owner): XtX comes from L2 -- all of a wave's 80 loads in flight
+    // together (plain loads: hipcc drains the queue for them, look-ahead copies included), then G + M1 straight into the tile
+    auto chain_add_quad = [&](auto role_tag) {
+      constexpr int ROLE = decltype(role_tag)::value;
+      if constexpr (ROLE < 2) {
+        int h4 = 4 * h;
+        asm volatile("" : "+v"(h4));   // keeps the 80 offsets out of the row loop's preheader (they would be spilled)
+        // in two batches (3 + 2 tiles): 48 loads in flight next to the 80 accumulator registers
+        static_for<2>([&](auto bc) {
+          constexpr int T0 = decltype(bc)::value * 3, TN = decltype(bc)::value == 0 ? 3 : RL::QH - 3;
+          float g[TN][16];
+          static_for<TN>([&](auto tc) {
+            constexpr int T = RL::QH * ROLE + T0 + decltype(tc)::value;
+            constexpr int R = T >= 6 ? 3 : (T >= 3 ? 2 : (T >= 1 ? 1 : 0)), C = T - R * (R + 1) / 2;
+            const int gj = min(32 * C + d, k - 1);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+              const int gi = min(32 * R + 8 * (e >> 2) + (e & 3) + h4, k - 1);
+              g[decltype(tc)::value][e] = a.XtX[(unsigned)(gi * k + gj)];
+            }
+          });
+          static_for<TN>([&](auto tc) {
+            constexpr int TL = T0 + decltype(tc)::value, T = RL::QH * ROLE + TL;
+            constexpr int R = T >= 6 ? 3 : (T >= 3 ? 2 : (T >= 1 ? 1 : 0)), C = T - R * (R + 1) / 2;
+            int toff = T * 32 * TLD + 4 * h * TLD + d;
+            asm volatile("" : "+v"(toff));
+            float* ta = sA + toff;
+            const float cm = (32 * C + d < k) ? 1.f : 0.f;   // rank < 128: the padding of the tile is zero, not a clamped copy
+            const f32x16 v = acc[TL] * scl.inv1;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+              const float rm = (32 * R + 8 * (e >> 2) + (e & 3) + h4 < k) ? cm : 0.f;
+              ta[(8 * (e >> 2) + (e & 3)) * TLD] = fmaf(g[decltype(tc)::value][e], rm, v[e]);
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    };
     auto chain_add = [&](auto role_tag, const int ph) {
       constexpr int ROLE = decltype(role_tag)::value;
       const bool first = ph == 0;
@@ -778,8 +935,11 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
               float g[16];
 #pragma unroll
               for (int e = 0; e < 16; e++) {
-                if constexpr (IMPLICIT) g[e] = (sG + toff)[(8 * (e >> 2) + (e & 3)) * TLD];
-                else g[e] = (R == C && 8 * (e >> 2) + (e & 3) + 4 * h == d) ? lam_use : 0.f;
+                if constexpr (IMPLICIT) {
+                  g[e] = (sG + toff)[(8 * (e >> 2) + (e & 3)) * TLD];
+                } else {
+                  g[e] = (R == C && 8 * (e >> 2) + (e & 3) + 4 * h == d) ? lam_use : 0.f;
+                }
               }
 #pragma unroll
               for (int e = 0; e < 16; e++) ta[(8 * (e >> 2) + (e & 3)) * TLD] = v[e] + g[e];
@@ -822,14 +982,13 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
       return wave_sum_all(qf);
     };
 
-    if (!PAIR || wrole == 0) accumulate(std::integral_constant<int, 0>{});
-    else accumulate(std::integral_constant<int, 1>{});
+    with_role([&](auto rc) { accumulate(rc); });
     if (wv == 0 && nst < D) wait_vm<0>();   // short row: make sure the warm start has landed (see above)
     __syncthreads();   // warm start and every wave's right-hand-side partial are in LDS
     NE_T(12)
     for (int ph = 0; ph < NSETS; ph++) {
-      if (!PAIR || wrole == 0) chain_add(std::integral_constant<int, 0>{}, ph);
-      else chain_add(std::integral_constant<int, 1>{}, ph);
+      if constexpr (QUAD) with_role([&](auto rc) { chain_add_quad(rc); });
+      else with_role([&](auto rc) { chain_add(rc, ph); });
       NE_T(13)
       __syncthreads();
       NE_T(14)
@@ -866,11 +1025,13 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
       NE_T(15)
       // the wave's NB^2 / 4 units together: all their LDS reads first (hipcc otherwise waits for each read before it
       // issues the next -- 16 round trips per unit), then the arithmetic
-      constexpr int UW = NB * NB / 4;
-      float tv[UW][16], vv[UW][16];
+      constexpr int UW = NB * NB / 4, UB = QUAD ? 1 : UW;   // units in flight together (QUAD: 256 registers per wave, 80 of them accumulators)
 #pragma unroll
-      for (int i = 0; i < UW; i++) {
-        const int u = wv + 4 * i;
+      for (int i0 = 0; i0 < UW; i0 += UB) {
+      float tv[UB][16], vv[UB][16];
+#pragma unroll
+      for (int i = 0; i < UB; i++) {
+        const int u = wv + 4 * (i0 + i);
         const int tg = u / NB, sl = u % NB;
         const bool by_rows = sl >= tg;
         const int R = by_rows ? sl : tg, C = by_rows ? tg : sl;
@@ -887,7 +1048,7 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < UW; i++) {
+      for (int i = 0; i < UB; i++) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int q4 = 0; q4 < 4; q4++) {
@@ -897,7 +1058,9 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
           s3 = fmaf(tv[i][4 * q4 + 3], vv[i][4 * q4 + 3], s3);
         }
         const float s = half_swap_sum((s0 + s1) + (s2 + s3));
-        if (h == 0) part[(wv + 4 * i) * 32 + d] = s;
+        if (h == 0) part[(wv + 4 * (i0 + i)) * 32 + d] = s;
+      }
+      __builtin_amdgcn_sched_barrier(0);
       }
       NE_T(16)
       __syncthreads();
@@ -959,8 +1122,8 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
       for (int t = 0; t < NB; t++) pub[32 * t + d] = x[t];
     }
     wave_sync();
-    const float qf = (!PAIR || wrole == 0) ? quad_form(std::integral_constant<int, 0>{}, pub, x)
-                                           : quad_form(std::integral_constant<int, 1>{}, pub, x);
+    float qf = 0.f;
+    with_role([&](auto rc) { qf = quad_form(rc, pub, x); });
     NE_T(10)
     if (lane == 0) sScal[16 + wv] = qf;
     const float yb = dot(x, b), yy = dot(x, x);
@@ -1006,11 +1169,11 @@ __global__ __launch_bounds__(256, 1) void als_ne_kernel(AlsArgs a, const int32_t
 #endif
 }
 
-template <int KP, int NS, bool IMPLICIT, bool SYM>
+template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD = false>
 hipError_t launch_ne_t(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int grid, double* row_loss,
                        hipStream_t s, int only_if_lt1) {
-  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM>;
-  constexpr int lds = NeGeo<KP, NeRoles<KP, NS, IMPLICIT, SYM>::PAIR, IMPLICIT>::BYTES;
+  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM, QUAD>;
+  constexpr int lds = NeGeo<KP, NeRoles<KP, NS, IMPLICIT, SYM, QUAD>::NROLES, IMPLICIT>::BYTES;
   hipError_t err =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (err != hipSuccess) return err;
@@ -1080,7 +1243,8 @@ hipError_t launch_als_ne(const AlsArgs& a, const int32_t* wg_rows, const int32_t
   if (KP == KPV) {                                                                                                    \
     if (!implicit) return launch_ne_t<KPV, 3, false, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0);                \
     if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0);               \
-    if ((err = launch_ne_t<KPV, 2, true, true>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) != hipSuccess) return err;  \
+    if ((err = launch_ne_t<KPV, 2, true, true, KPV == 128>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) != hipSuccess)  \
+      return err;                                                                                                     \
     return launch_ne_t<KPV, 3, true, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 1);                                \
   }
   RSP_NE_DISPATCH(128)

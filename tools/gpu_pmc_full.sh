@@ -11,5 +11,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 (cd /tmp && timeout 900 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $REPO/$OUT/sq -o p -- $CMD > $REPO/$OUT/sq.log 2>&1); echo "pass sq rc=$?"
 python tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
-grep -A12 "als_cgq" $OUT/summary.txt | cut -c1-200 | head -120
+grep -A14 "als_cgq\|als_ne" $OUT/summary.txt | cut -c1-200 | head -120
 find $OUT -name "*kernel_trace.csv" -size +5M -delete

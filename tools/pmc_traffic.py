@@ -17,7 +17,7 @@ for c in vals:
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] != c:
                     continue
-                m = re.search(r"(als_cgq_kernel<[^>]*>)", r.get("Kernel_Name", ""))
+                m = re.search(r"(als_(?:cgq|ne)_kernel<[^>]*>)", r.get("Kernel_Name", ""))
                 if m:
                     vals[c][m.group(1)].append(float(r["Counter_Value"]))
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB per dispatch, mean over the dispatches of "

@@ -714,6 +714,14 @@ int rsparse_hip_csc_create_device(int n_rows, int n_cols, const int32_t* d_col_p
   if (hp[0] != 0) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs must start at 0");
   const int64_t nnz = hp[n_cols];
   if (nnz > 0 && (!d_row_indices || !d_values)) return fail(RSPARSE_HIP_ERR_INVALID, "row_indices or values is NULL");
+  if (nnz < 0) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs must be non-decreasing");
+  for (int c = 0; c < n_cols; c++)
+    if (hp[(size_t)c + 1] < hp[(size_t)c]) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs must be non-decreasing");
+  {   // the same validation the host constructor does: the kernels gather X[row_index] unchecked
+    int bad = 0;
+    HIP_TRY(check_row_indices_device(d_row_indices, nnz, n_rows, nullptr, &bad));
+    if (bad) return fail(RSPARSE_HIP_ERR_INVALID, "row index out of range");
+  }
   rsparse_hip_csc* m = new rsparse_hip_csc();
   struct Guard { rsparse_hip_csc* c; ~Guard() { if (c) rsparse_hip_csc_destroy(c); } } guard{m};
   if (hipGetDevice(&m->device) != hipSuccess) return fail(RSPARSE_HIP_ERR_RUNTIME, "no HIP device");

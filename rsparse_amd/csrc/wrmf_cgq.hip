@@ -577,7 +577,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       sweep(p, 1, ap, dummy, live && !conv, itc + 1);
       if (!conv) {
         const float pap = dot16(p, ap);
-        const float alpha = rsold / pap;
+        // rsold / alpha / beta as the reference holds them: double scalars fed by T-valued dot products
+        // (wrmf_implicit.hpp:18-27), rounded to float where they meet the vectors
+        const float alpha = (float)((double)rsold / (double)pap);
 #pragma unroll
         for (int s2 = 0; s2 < kMaxSavedSweeps; s2++)
           if (s2 == itc) alph[s2] = alpha;
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         if (rsnew < kCgTolQ) {
           conv = true;
         } else {
-          const float beta = rsnew / rsold;
+          const float beta = (float)((double)rsnew / (double)rsold);
 #pragma unroll
           for (int rr = 0; rr < RPN; rr++) p[rr] = fmaf(p[rr], beta, r[rr]);
           rsold = rsnew;

@@ -64,6 +64,25 @@ __global__ __launch_bounds__(256) void ingest_range_check_kernel(const int32_t* 
 
 }  // namespace
 
+// *bad_index = 1 when some i[e] is outside [0, n_rows) (synchronises the stream)
+hipError_t check_row_indices_device(const int32_t* i, int64_t nnz, int n_rows, hipStream_t s, int* bad_index) {
+  *bad_index = 0;
+  if (nnz <= 0) return hipSuccess;
+  int* d_bad = nullptr;
+  hipError_t err = hipMalloc(&d_bad, sizeof(int));
+  if (err != hipSuccess) return err;
+  int host_bad = 0;
+  if ((err = hipMemsetAsync(d_bad, 0, sizeof(int), s)) == hipSuccess) {
+    hipLaunchKernelGGL(ingest_range_check_kernel, dim3(256 * 8), dim3(256), 0, s, i, nnz, n_rows, d_bad);
+    if ((err = hipGetLastError()) == hipSuccess &&
+        (err = hipMemcpyAsync(&host_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s)) == hipSuccess)
+      err = hipStreamSynchronize(s);
+  }
+  (void)hipFree(d_bad);
+  *bad_index = host_bad;
+  return err;
+}
+
 // Returns hipSuccess, or hipErrorInvalidValue with *bad_index = 1 when a row index is outside [0, n_rows).
 hipError_t transpose_csc_device(int n_rows, int n_cols, int64_t nnz, const int32_t* p, const int32_t* i, const float* x,
                                 int32_t* pt, int32_t* it, float* xt, hipStream_t s, int* bad_index) {

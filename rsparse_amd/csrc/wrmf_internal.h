@@ -145,6 +145,7 @@ hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* 
 hipError_t launch_weighted_sumsq(const float* X, int k, int64_t n, const float* w, double* out,
                                  double* scratch /* >= 1024 doubles */, hipStream_t s);
 hipError_t launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s);
+hipError_t check_row_indices_device(const int32_t* i, int64_t nnz, int n_rows, hipStream_t s, int* bad_index);
 hipError_t transpose_csc_device(int n_rows, int n_cols, int64_t nnz, const int32_t* p, const int32_t* i, const float* x,
                                 int32_t* pt, int32_t* it, float* xt, hipStream_t s, int* bad_index);
 hipError_t launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t s);

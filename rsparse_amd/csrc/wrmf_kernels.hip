@@ -142,7 +142,7 @@ __global__ __launch_bounds__(W * 64) void als_cg_short_kernel(AlsArgs a) {
 #pragma unroll
       for (int u = 0; u < EPL; u++) pap = fmaf(p[u], ap[u], pap);
       pap = wave_sum(pap);
-      const float alpha = rsold / pap;
+      const float alpha = (float)((double)rsold / (double)pap);   // double scalars like the reference (wrmf_implicit.hpp:18)
       rs = 0.f;
 #pragma unroll
       for (int u = 0; u < EPL; u++) {
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(W * 64) void als_cg_short_kernel(AlsArgs a) {
       }
       const float rsnew = wave_sum(rs);
       if (rsnew < kCgTol) break;
-      const float beta = rsnew / rsold;
+      const float beta = (float)((double)rsnew / (double)rsold);
 #pragma unroll
       for (int u = 0; u < EPL; u++) p[u] = fmaf(p[u], beta, r[u]);
       rsold = rsnew;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(W * 64) void als_cg_long_kernel(AlsArgs a, size_t l
 #pragma unroll
       for (int u = 0; u < EPL; u++) pap = fmaf(p[u], ap[u], pap);
       pap = wave_sum(pap);
-      const float alpha = rsold / pap;
+      const float alpha = (float)((double)rsold / (double)pap);   // double scalars like the reference (wrmf_implicit.hpp:18)
       rs = 0.f;
 #pragma unroll
       for (int u = 0; u < EPL; u++) {
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(W * 64) void als_cg_long_kernel(AlsArgs a, size_t l
       }
       const float rsnew = wave_sum(rs);
       if (rsnew < kCgTol) break;  // identical in every wave of the workgroup
-      const float beta = rsnew / rsold;
+      const float beta = (float)((double)rsnew / (double)rsold);
 #pragma unroll
       for (int u = 0; u < EPL; u++) p[u] = fmaf(p[u], beta, r[u]);
       rsold = rsnew;

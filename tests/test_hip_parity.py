@@ -237,3 +237,99 @@ def test_config2_scale_properties():
         b = Xn.T @ c
         worst = max(worst, float(torch.linalg.norm(A @ Ucc[u] - b) / torch.linalg.norm(b)))
     assert worst < 1e-4
+
+
+@pytest.mark.parametrize("k", [128, 64, 40])
+@pytest.mark.parametrize("implicit", [True, False])
+def test_cholesky_long_rows(k, implicit):
+    """Rows up to ~2500 non-zeros through the exact solver: rows beyond 1024 non-zeros take the second launch of
+    wrmf_chol.hip (two-level accumulation of the rank-one updates), the rest the main one; per-row bound."""
+    fb = "implicit" if implicit else "explicit"
+    d = synth.make_dataset(260, 3000, seed=31 + k, mean_deg=400, d_max=2500, feedback=fb, device="cpu")
+    p, i, x = (t.numpy() for t in d["c_iu"])
+    x = x.astype(np.float64)
+    assert np.diff(p).max() > 1024
+    rng = np.random.default_rng(k)
+    X = np.asfortranarray((rng.standard_normal((k, 3000)) * 0.05).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, 260)) * 0.05).astype(np.float32))
+    csc = (3000, 260, p, i, x)
+    cnt = np.bincount(i, minlength=3000).astype(np.float64)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 0, 3, implicit, True, cnt)
+    Y = Y0.copy(order="F")
+    if implicit:
+        loss = als.als_implicit(csc, X, Y, 0.1, 1, 0, 3, "float", False, False)
+    else:
+        loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), 0.1, 1, 0, 3, True, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, (int(err.argmax()), float(err.max()), int(np.diff(p)[err.argmax()]))
+    assert abs(loss - lref) <= TOL * abs(lref)
+
+
+@pytest.mark.parametrize("k", [128, 64])
+def test_implicit_cg_long_rows_with_confidence_below_one(k):
+    """The fp16 normal-equation kernel takes sqrt(c - 1); a matrix with some confidence below 1 is detected on the device
+    and its long rows go through the bf16 kernel instead (wrmf_ne.hip) -- same answer, no host round trip."""
+    d = synth.make_dataset(200, 2500, seed=5 + k, mean_deg=420, d_max=2200, feedback="implicit", device="cpu")
+    p, i, x = (t.numpy() for t in d["c_iu"])
+    x = x.astype(np.float64)
+    x[::7] = 0.25                      # confidences below 1 in many rows, long ones included
+    assert np.diff(p).max() > 1024
+    rng = np.random.default_rng(k)
+    X = np.asfortranarray((rng.standard_normal((k, 2500)) * 0.05).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, 200)) * 0.05).astype(np.float32))
+    csc = (2500, 200, p, i, x)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 1, 3, True)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, 0.1, 1, 1, 3, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, (int(err.argmax()), float(err.max()))
+    assert abs(loss - lref) <= TOL * abs(lref)
+
+
+def test_factor_scale_does_not_matter_to_the_fp16_path():
+    """The fp16 normal-equation kernel rescales its operands by powers of two taken from max |x| and max c: factors of
+    the order 1e-4 or 30 (far outside fp16's comfortable range unscaled) give the same relative accuracy."""
+    d = synth.make_dataset(120, 2000, seed=77, mean_deg=600, d_max=1800, feedback="implicit", device="cpu")
+    p, i, x = (t.numpy() for t in d["c_iu"])
+    x = x.astype(np.float64)
+    x[::5] *= 400.0                    # confidences up to several thousand
+    csc = (2000, 120, p, i, x)
+    lens = np.diff(p)
+    for scale in (1e-4, 30.0):
+        rng = np.random.default_rng(3)
+        X = np.asfortranarray((rng.standard_normal((128, 2000)) * scale).astype(np.float32))
+        X[:, 17] *= 50.0               # one outlier vector sets the scale for everybody
+        Y0 = np.asfortranarray((rng.standard_normal((128, 120)) * scale).astype(np.float32))
+        Yref, lref = _oracle64(csc, X, Y0, 0.1, 1, 3, True)
+        # yardstick: the same half-iteration by the oracle in float (three CG steps on systems this badly scaled lose
+        # digits in ANY fp32 arithmetic; the claim is that the fp16 operands add nothing to that)
+        Y32 = Y0.copy(order="F")
+        O.als_implicit(p, i, x, X, Y32, O.gramian(X, 0.1), 0.1, 1, 3)
+        Y = Y0.copy(order="F")
+        loss = als.als_implicit(csc, X, Y, 0.1, 1, 1, 3, "float", False, False)
+        den = np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+        err = np.linalg.norm(Y - Yref, axis=0) / den
+        err32 = np.linalg.norm(Y32 - Yref, axis=0) / den
+        bound = np.maximum(TOL, 3.0 * err32)
+        worst = int(np.argmax(err / bound))
+        assert np.all(err <= bound), (scale, worst, int(lens[worst]), float(err[worst]), float(err32[worst]))
+        assert (lens > 512).sum() >= 20
+        assert abs(loss - lref) <= max(TOL, 3.0 * float(np.max(err32))) * abs(lref)
+
+
+def test_cholesky_reports_systems_that_are_not_positive_definite():
+    """The reference's solve(lhs, rhs, fast + likely_sympd) falls back to a general solver with a warning when the
+    Cholesky factorisation fails (wrmf_implicit.hpp:236); the device path has no such fallback: it finishes the
+    half-iteration and answers RSPARSE_HIP_ERR_NUMERIC with the count of failed systems (include/rsparse_wrmf_hip.h)."""
+    from rsparse_amd import _lib
+    csc, X, Y0 = _problem(300, 40, 16, seed=4, feedback="implicit", scale=0.3)
+    csc = csc[:4] + (np.full_like(csc[4], 0.25),)            # c - 1 = -0.75: lhs = XtX - 0.75 X_nnz X_nnz^T
+    Y = Y0.copy(order="F")
+    with pytest.raises(_lib.RsparseHipError) as e:
+        als.als_implicit(csc, X, Y, 0.0, 1, 0, 3, "float", False, False, XtX=np.zeros((16, 16), np.float32, order="F"))
+    assert e.value.code == _lib.ERR_NUMERIC and "positive definite" in str(e.value)
+    # the library stays usable and the counter was reset by the failing call
+    Y2 = Y0.copy(order="F")
+    csc_ok = csc[:4] + (np.full_like(csc[4], 2.0),)
+    als.als_implicit(csc_ok, X, Y2, 0.1, 1, 0, 3, "float", False, False)
+    assert np.all(np.isfinite(Y2))

@@ -105,3 +105,24 @@ def test_transpose_config2_scale_properties():
     cols = torch.repeat_interleave(torch.arange(100_000, device=be.device), torch.diff(pt).to(torch.int64))
     same_col = cols[1:] == cols[:-1]
     assert bool(torch.all(it[1:][same_col] > it[:-1][same_col]))
+
+
+@gpu
+def test_csc_create_device_validates_like_the_host_constructor():
+    """rsparse_hip_csc_create_device runs the same row-index range check as rsparse_hip_csc_create_host (the kernels
+    gather X[row_index] unchecked) and rejects decreasing column pointers."""
+    import torch
+    from rsparse_amd import _lib
+    from rsparse_amd.engine import HipBackend
+    be = HipBackend(0)
+    ok = (be.to_device(np.array([0, 2, 3], np.int32), torch.int32), be.to_device(np.array([0, 3, 1], np.int32), torch.int32),
+          be.to_device(np.ones(3, np.float32), torch.float32))
+    be.make_csc(4, 2, *ok)
+    for bad_i in ([0, 4, 1], [0, -1, 1]):
+        bad = (ok[0], be.to_device(np.array(bad_i, np.int32), torch.int32), ok[2])
+        with pytest.raises(_lib.RsparseHipError) as e:
+            be.make_csc(4, 2, *bad)
+        assert e.value.code == _lib.ERR_INVALID
+    with pytest.raises(_lib.RsparseHipError) as e:
+        be.make_csc(4, 2, be.to_device(np.array([0, 3, 2], np.int32), torch.int32), ok[1], ok[2])
+    assert e.value.code == _lib.ERR_INVALID

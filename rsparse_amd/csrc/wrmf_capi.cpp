@@ -280,10 +280,9 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   return RSPARSE_HIP_OK;
 }
 
-// which CG implementation: "q" (register-resident quad layout, default when rank % 4 == 0) or "lds"
+// the register-resident quad-layout CG kernels need rank % 4 == 0 and 16-byte aligned factor matrices; other ranks take
+// the LDS-tile kernels of wrmf_kernels.hip
 bool use_cgq(int rank, const void* X, const void* Y) {
-  static const char* env = std::getenv("RSPARSE_HIP_CG");
-  if (env && std::strcmp(env, "lds") == 0) return false;
   return rank % 4 == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0;
 }
 
@@ -375,13 +374,11 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   HIP_TRY(hipMemsetAsync(prof_buf, 0, 1024 * 4 * 20 * 8, s));
   a.ne_prof = prof_buf;
 #endif
-  {
-    static const char* ts_env = std::getenv("RSPARSE_HIP_TSCRATCH");
-    const bool ts_on = !(ts_env && ts_env[0] == '0');
-    if (cgq && ts_on && !ne_supported(rank) && d.q_stream_off && d.q_nnz[0] > 0 && cg_steps >= 1 && cg_steps <= 4) {
-      if ((rc = g_ws.ensure_tscr((size_t)(cg_steps + 1) * (size_t)d.q_nnz[0]))) return rc;
-      a.tscr = g_ws.tscr;
-    }
+  // ranks the normal-equation kernel does not take (<= 32): the streamed CG bucket keeps its per-sweep dot products in
+  // an HBM scratch instead of re-gathering for the loss
+  if (cgq && !ne_supported(rank) && d.q_stream_off && d.q_nnz[0] > 0 && cg_steps >= 1 && cg_steps <= 4) {
+    if ((rc = g_ws.ensure_tscr((size_t)(cg_steps + 1) * (size_t)d.q_nnz[0]))) return rc;
+    a.tscr = g_ws.tscr;
   }
   hipEvent_t* ev = g_prof.begin();
   hipError_t e = cgq ? launch_als_cgq(a, qs, implicit, s, ev)

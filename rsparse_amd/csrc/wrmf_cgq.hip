@@ -636,14 +636,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 //             workgroups (two per CU: they run out of phase, one gathers while the other sweeps)
 //   bucket 5  <= 32 non-zeros: one wave per row with a 32-slot tile (half the redundant gather slots)
 // Every instantiation is capped at 256 VGPRs (2 waves per SIMD, 8 waves per CU).
-// cfg 1 / cfg 2 are the uniform W = 8 / W = 4 tables kept for A/B runs (RSPARSE_HIP_CGQ_CFG).
 struct BucketDef { int waves, wpr, capq, stream, max_len; };
 constexpr int kNB = 6;
-constexpr int kNCfg = 3;
+constexpr int kNCfg = 1;
 constexpr BucketDef kBuckets[kNCfg][kNB] = {
     {{8, 8, 16, 1, 0x7fffffff}, {8, 8, 16, 0, 512}, {4, 4, 16, 0, 256}, {4, 2, 16, 0, 128}, {4, 1, 16, 0, 64}, {4, 1, 8, 0, 32}},
-    {{8, 8, 16, 1, 0x7fffffff}, {8, 8, 16, 0, 512}, {8, 4, 16, 0, 256}, {8, 2, 16, 0, 128}, {8, 1, 16, 0, 64}, {8, 1, 8, 0, 32}},
-    {{4, 4, 16, 1, 0x7fffffff}, {4, 4, 16, 0, 256}, {4, 2, 16, 0, 128}, {4, 1, 16, 0, 64}, {4, 1, 8, 0, 32}, {0, 0, 0, 0, -1}},
 };
 
 template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT>
@@ -715,6 +712,8 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
         if (D.stream && ne_supported(a.k)) {                                                                \
           if ((err = launch_als_ne(a, q.ne_rows, q.ne_ptr, q.ne_wg, IMPLICIT, a.loss_partials + slot, bs)) != hipSuccess) \
             return err;                                                                                     \
+        } else if constexpr (D.stream && KP > 32) {   /* ranks above 32 always take the branch above */     \
+          return hipErrorInvalidValue;                                                                      \
         } else if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, grid, slot, \
                                                                                 bs)) != hipSuccess)         \
           return err;                                                                                       \
@@ -751,12 +750,10 @@ int cgq_bucket_grid(int n_rows, int b, int cfg) {
   const int teams = d.waves / d.wpr;
   // rows per team: amortises the per-workgroup start-up (64 KB Gramian load, LDS clear); the streamed
   // bucket holds few, very long rows and keeps a small quota for balance
-  static const char* env = std::getenv("RSPARSE_HIP_RPT");
-  const int scale = env ? std::atoi(env) : 1;
   // (measured on config 3: doubling the quota of the team kernels from 4 / 16 is worth 3 % of the iteration, a
   // further doubling is flat; the one-wave kernels prefer 64)
   const int base = d.stream ? 16 : (d.wpr == 1 ? 64 : (d.wpr == 2 ? 64 : 32));
-  int rows_per_team = base * (scale > 0 ? scale : 1);
+  int rows_per_team = base;
   // small buckets (shards of a multi-GPU run, tiny matrices): spread the rows over the CUs first -- the quota
   // only grows once there are two workgroups per CU
   const long spread = (long)teams * 512;
@@ -785,19 +782,13 @@ size_t cgq_loss_slots(const QSchedule& q, int k) {
   return n;
 }
 
-int cgq_default_cfg() {
-  static const char* env = std::getenv("RSPARSE_HIP_CGQ_CFG");
-  const int c = env ? std::atoi(env) : 0;
-  return (c >= 0 && c < kNCfg) ? c : 0;
-}
+int cgq_default_cfg() { return 0; }
 
 hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(a.k);
 #define RSP_DISPATCH(KPV)                                                                                   \
   if (KP == KPV) {                                                                                          \
-    if (q.cfg == 0) return implicit ? launch_all<KPV, 0, true>(a, q, s, ev) : launch_all<KPV, 0, false>(a, q, s, ev); \
-    if (q.cfg == 1) return implicit ? launch_all<KPV, 1, true>(a, q, s, ev) : launch_all<KPV, 1, false>(a, q, s, ev); \
-    return implicit ? launch_all<KPV, 2, true>(a, q, s, ev) : launch_all<KPV, 2, false>(a, q, s, ev);       \
+    return implicit ? launch_all<KPV, 0, true>(a, q, s, ev) : launch_all<KPV, 0, false>(a, q, s, ev);       \
   }
   RSP_DISPATCH(32)
   RSP_DISPATCH(64)

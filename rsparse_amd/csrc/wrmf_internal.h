@@ -114,7 +114,7 @@ size_t chol_loss_slots(int n_cols);
 hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 // register-blocked Cholesky (wrmf_chol.hip); rows beyond kCholLongLen non-zeros go to a second launch that sums the
 // rank-one updates in two levels (see there); its workgroups' loss slots follow the main launch's
-constexpr int kCholLongLen = 1024;
+constexpr int kCholLongLen = 4096;
 constexpr int kCholLongGrid = 512;
 size_t chol2_loss_slots(int n_cols);
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);

@@ -242,18 +242,20 @@ def test_config2_scale_properties():
 @pytest.mark.parametrize("k", [128, 64, 40])
 @pytest.mark.parametrize("implicit", [True, False])
 def test_cholesky_long_rows(k, implicit):
-    """Rows up to ~2500 non-zeros through the exact solver: rows beyond 1024 non-zeros take the second launch of
+    """Rows up to ~6000 non-zeros through the exact solver: rows beyond 4096 non-zeros take the second launch of
     wrmf_chol.hip (two-level accumulation of the rank-one updates), the rest the main one; per-row bound."""
     fb = "implicit" if implicit else "explicit"
-    d = synth.make_dataset(260, 3000, seed=31 + k, mean_deg=400, d_max=2500, feedback=fb, device="cpu")
+    n_fix, n_solve = 9000, 120
+    d = synth.make_dataset(n_solve, n_fix, seed=31 + k, mean_deg=900, d_max=6000, feedback=fb, device="cpu")
     p, i, x = (t.numpy() for t in d["c_iu"])
     x = x.astype(np.float64)
-    assert np.diff(p).max() > 1024
+    lens = np.diff(p)
+    assert lens.max() > 4096 and (lens <= 4096).sum() > 10
     rng = np.random.default_rng(k)
-    X = np.asfortranarray((rng.standard_normal((k, 3000)) * 0.05).astype(np.float32))
-    Y0 = np.asfortranarray((rng.standard_normal((k, 260)) * 0.05).astype(np.float32))
-    csc = (3000, 260, p, i, x)
-    cnt = np.bincount(i, minlength=3000).astype(np.float64)
+    X = np.asfortranarray((rng.standard_normal((k, n_fix)) * 0.05).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, n_solve)) * 0.05).astype(np.float32))
+    csc = (n_fix, n_solve, p, i, x)
+    cnt = np.bincount(i, minlength=n_fix).astype(np.float64)
     Yref, lref = _oracle64(csc, X, Y0, 0.1, 0, 3, implicit, True, cnt)
     Y = Y0.copy(order="F")
     if implicit:
@@ -261,7 +263,7 @@ def test_cholesky_long_rows(k, implicit):
     else:
         loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), 0.1, 1, 0, 3, True, "float", False, False)
     err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
-    assert err.max() < TOL, (int(err.argmax()), float(err.max()), int(np.diff(p)[err.argmax()]))
+    assert err.max() < TOL, (int(err.argmax()), float(err.max()), int(lens[err.argmax()]))
     assert abs(loss - lref) <= TOL * abs(lref)
 
 

@@ -53,6 +53,9 @@ struct Workspace {
   double* scalars = nullptr;  // [0] loss rows, [1] sumsq, [2..] spare
   int* fails = nullptr;
   unsigned* ne_stats = nullptr;   // normal-equation kernel: max |x|, max c, any c < 1 (launch_ne_stats)
+  float* ne_seg_scratch = nullptr;
+  int* ne_seg_flags = nullptr;
+  size_t ne_seg_slots = 0;
   float* zero_row = nullptr;  // 256 zero floats (padding slots of the CG gathers)
   float* tscr = nullptr;   // streamed CG rows: per-non-zero dot products of every sweep
   size_t tscr_floats = 0;
@@ -82,6 +85,17 @@ struct Workspace {
     if (!zero_row) {
       HIP_TRY(hipMalloc(&zero_row, 256 * sizeof(float)));
       HIP_TRY(hipMemset(zero_row, 0, 256 * sizeof(float)));
+    }
+    return RSPARSE_HIP_OK;
+  }
+  int ensure_ne_seg(size_t slots) {   // split rows of the normal-equation kernel: partial accumulators + ready flags
+    if (slots > ne_seg_slots) {
+      if (ne_seg_scratch) (void)hipFree(ne_seg_scratch);
+      if (ne_seg_flags) (void)hipFree(ne_seg_flags);
+      ne_seg_scratch = nullptr; ne_seg_flags = nullptr; ne_seg_slots = 0;
+      HIP_TRY(hipMalloc(&ne_seg_scratch, slots * (size_t)kNeSegFloats * sizeof(float)));
+      HIP_TRY(hipMalloc(&ne_seg_flags, slots * sizeof(int)));
+      ne_seg_slots = slots;
     }
     return RSPARSE_HIP_OK;
   }
@@ -139,6 +153,9 @@ struct Workspace {
     if (fails) (void)hipFree(fails);
     if (ne_stats) (void)hipFree(ne_stats);
     ne_stats = nullptr;
+    if (ne_seg_scratch) (void)hipFree(ne_seg_scratch);
+    if (ne_seg_flags) (void)hipFree(ne_seg_flags);
+    ne_seg_scratch = nullptr; ne_seg_flags = nullptr; ne_seg_slots = 0;
     if (zero_row) (void)hipFree(zero_row);
     gram = nullptr; partials = nullptr; scalars = nullptr; fails = nullptr; zero_row = nullptr;
     gram_floats = 0; partial_slots = 0;
@@ -213,6 +230,8 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   d.q_order = nullptr;
   d.q_stream_off = nullptr;
   d.q_ne_rows = nullptr; d.q_ne_ptr = nullptr; d.q_ne_wg = 0;
+  d.q_ne_segs = nullptr; d.q_ne_nseg = 0; d.q_ne_entries = 0;
+  d.q_ne_split_rows = nullptr; d.q_ne_split_ptr = nullptr; d.q_ne_nsplit = 0;
   d.q_n_chol_long = 0;
   d.q_cfg = cgq_default_cfg();
   if (n <= 0) return RSPARSE_HIP_OK;
@@ -255,26 +274,79 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     // two lists per CU: the rank-128 fp16 kernel runs two workgroups per CU; the one-per-CU kernels work through two
     // lists each, one after the other
     const int n_wg = std::min(n_stream, 2 * std::max(cus, 1));
-    std::vector<int64_t> load((size_t)n_wg, 0);
-    std::vector<int> owner((size_t)n_stream);
+    // Items of the deal: whole rows, and SEGMENTS of the rows that are too long to balance (the 5e5-non-zero item of the
+    // bench matrix is by itself an average workgroup's share; on a rank of an 8-GPU run it is eight shares).  A row
+    // whose cost exceeds half a share is cut into up to kNeMaxSeg runs of whole steps of about a quarter share; the
+    // workgroups that get the leading segments write their partial accumulators to an HBM scratch, the one with the
+    // last segment adds them in segment order and solves (wrmf_ne.hip).  List entry >= 0: a row; -(s + 1): segment s
+    // of the table {row, first non-zero, non-zeros, index within the row, segments of the row, scratch slot}.
+    auto steps_of = [](int64_t len) { return (len + 15) / 16; };
+    int64_t total = 0;
+    for (int r = 0; r < n_stream; r++) total += steps_of(soff[(size_t)r + 1] - soff[(size_t)r]) + 12;
+    const int64_t share = std::max<int64_t>(1, total / n_wg);
+    struct Item { int64_t cost; int32_t entry; };
+    std::vector<Item> items;
+    items.reserve((size_t)n_stream + 64);
+    std::vector<int32_t> segs;
+    int n_seg = 0;
+    for (int r = 0; r < n_stream; r++) {
+      const int64_t len = soff[(size_t)r + 1] - soff[(size_t)r];
+      const int64_t st = steps_of(len);
+      int parts = 1;
+      if (n_wg >= 8 && 2 * (st + 12) > share) parts = (int)std::min<int64_t>(kNeMaxSeg, (4 * st + share - 1) / share);
+      if (parts < 2 || n_seg + parts > kNeMaxSegTotal) {
+        items.push_back({st + 12, order[(size_t)r]});
+        continue;
+      }
+      const int64_t per = (st + parts - 1) / parts;   // steps per segment
+      const int slot = n_seg;
+      int made = 0;
+      for (int64_t s0 = 0; s0 < st; s0 += per, made++) {}
+      int idx = 0;
+      for (int64_t s0 = 0; s0 < st; s0 += per, idx++) {
+        const int64_t n0 = s0 * 16, n1 = std::min(len, (s0 + per) * 16);
+        segs.insert(segs.end(), {order[(size_t)r], (int32_t)n0, (int32_t)(n1 - n0), idx, made, slot});
+        items.push_back({steps_of(n1 - n0) + 12, -(int32_t)(n_seg + 1)});
+        n_seg++;
+      }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
+    const size_t n_items = items.size();
+    std::vector<int> owner(n_items);
     std::vector<int32_t> cnt_wg((size_t)n_wg + 1, 0);
     std::priority_queue<std::pair<int64_t, int>, std::vector<std::pair<int64_t, int>>, std::greater<>> heap;
     for (int w = 0; w < n_wg; w++) heap.push({0, w});
-    for (int r = 0; r < n_stream; r++) {
+    for (size_t e = 0; e < n_items; e++) {
       auto top = heap.top();
       heap.pop();
-      const int64_t len = soff[(size_t)r + 1] - soff[(size_t)r];
-      owner[(size_t)r] = top.second;
+      owner[e] = top.second;
       cnt_wg[(size_t)top.second + 1]++;
-      heap.push({top.first + (len + 15) / 16 + 12, top.second});
+      heap.push({top.first + items[e].cost, top.second});
     }
     for (int w = 0; w < n_wg; w++) cnt_wg[(size_t)w + 1] += cnt_wg[(size_t)w];
-    std::vector<int32_t> lists((size_t)n_stream), fill(cnt_wg.begin(), cnt_wg.end() - 1);
-    for (int r = 0; r < n_stream; r++) lists[(size_t)fill[(size_t)owner[(size_t)r]]++] = order[(size_t)r];
+    std::vector<int32_t> lists(n_items), fill(cnt_wg.begin(), cnt_wg.end() - 1);
+    for (size_t e = 0; e < n_items; e++) lists[(size_t)fill[(size_t)owner[e]]++] = items[e].entry;
     HIP_TRY(hipMalloc(&d.q_ne_rows, lists.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(d.q_ne_rows, lists.data(), lists.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&d.q_ne_ptr, cnt_wg.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(d.q_ne_ptr, cnt_wg.data(), cnt_wg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (n_seg > 0) {
+      HIP_TRY(hipMalloc(&d.q_ne_segs, segs.size() * sizeof(int32_t)));
+      HIP_TRY(hipMemcpy(d.q_ne_segs, segs.data(), segs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      std::vector<int32_t> srows, sptr{0};
+      for (int sg = 0; sg < n_seg; sg++)
+        if (segs[(size_t)sg * 6 + 3] == 0) {   // first segment of its row
+          srows.push_back(-(int32_t)(sg + 1));
+          sptr.push_back((int32_t)srows.size());
+        }
+      HIP_TRY(hipMalloc(&d.q_ne_split_rows, srows.size() * sizeof(int32_t)));
+      HIP_TRY(hipMemcpy(d.q_ne_split_rows, srows.data(), srows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&d.q_ne_split_ptr, sptr.size() * sizeof(int32_t)));
+      HIP_TRY(hipMemcpy(d.q_ne_split_ptr, sptr.data(), sptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      d.q_ne_nsplit = (int)srows.size();
+    }
+    d.q_ne_nseg = n_seg;
+    d.q_ne_entries = (int)n_items;
     d.q_ne_wg = n_wg;
   }
   return RSPARSE_HIP_OK;
@@ -338,7 +410,8 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   qs.order = d.q_order;
   qs.cfg = d.q_cfg;
   for (int b = 0; b < 7; b++) qs.off[b] = d.q_off[b];
-  qs.ne_rows = d.q_ne_rows; qs.ne_ptr = d.q_ne_ptr; qs.ne_wg = d.q_ne_wg;
+  qs.ne_rows = d.q_ne_rows; qs.ne_ptr = d.q_ne_ptr; qs.ne_wg = d.q_ne_wg; qs.ne_entries = d.q_ne_entries;
+  qs.ne_split_rows = d.q_ne_split_rows; qs.ne_split_ptr = d.q_ne_split_ptr; qs.ne_nsplit = d.q_ne_nsplit;
   const size_t slots = cgq ? cgq_loss_slots(qs, rank) : (cg ? cg_loss_slots(d.n_cols, d.n_long)
                                    : (solver == RSPARSE_SOLVER_NNLS ? chol_loss_slots(d.n_cols) : chol2_loss_slots(d.n_cols)));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
@@ -362,6 +435,11 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
   a.ne_prof = nullptr;
   a.ne_stats = nullptr;
+  a.ne_segs = nullptr; a.ne_seg_scratch = nullptr; a.ne_seg_flags = nullptr;
+  if (cgq && d.q_ne_nseg > 0 && ne_supported(rank)) {
+    if ((rc = g_ws.ensure_ne_seg((size_t)d.q_ne_nseg))) return rc;
+    a.ne_segs = d.q_ne_segs; a.ne_seg_scratch = g_ws.ne_seg_scratch; a.ne_seg_flags = g_ws.ne_seg_flags;
+  }
   if (cgq && implicit && d.q_ne_wg > 0 && ne_supported(rank) && !bias) {
     // operand scales of the fp16 normal-equation kernel (and whether it may run at all), decided on the device
     hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s);
@@ -769,6 +847,9 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   if (d.q_stream_off) (void)hipFree(d.q_stream_off);
   if (d.q_ne_rows) (void)hipFree(d.q_ne_rows);
   if (d.q_ne_ptr) (void)hipFree(d.q_ne_ptr);
+  if (d.q_ne_segs) (void)hipFree(d.q_ne_segs);
+  if (d.q_ne_split_rows) (void)hipFree(d.q_ne_split_rows);
+  if (d.q_ne_split_ptr) (void)hipFree(d.q_ne_split_ptr);
   if (d.owns_matrix) {
     if (d.col_ptrs) (void)hipFree(const_cast<int32_t*>(d.col_ptrs));
     if (d.row_idx) (void)hipFree(const_cast<int32_t*>(d.row_idx));

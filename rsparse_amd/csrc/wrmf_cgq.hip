@@ -710,7 +710,7 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
           if ((err = hipStreamWaitEvent(bs, g_bs.fork, 0)) != hipSuccess) return err;                       \
         }                                                                                                   \
         if (D.stream && ne_supported(a.k)) {                                                                \
-          if ((err = launch_als_ne(a, q.ne_rows, q.ne_ptr, q.ne_wg, IMPLICIT, a.loss_partials + slot, bs)) != hipSuccess) \
+          if ((err = launch_als_ne(a, q, IMPLICIT, a.loss_partials + slot, bs)) != hipSuccess)                  \
             return err;                                                                                     \
         } else if constexpr (D.stream && KP > 32) {   /* ranks above 32 always take the branch above */     \
           return hipErrorInvalidValue;                                                                      \
@@ -722,7 +722,7 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
           if ((err = hipStreamWaitEvent(s, g_bs.done[B], 0)) != hipSuccess) return err;                     \
         }                                                                                                   \
       }                                                                                                     \
-      slot += (D.stream && ne_supported(a.k)) ? (size_t)n : (size_t)grid * D.waves;                         \
+      slot += (D.stream && ne_supported(a.k)) ? (size_t)(q.ne_entries + q.ne_nsplit) : (size_t)grid * D.waves; \
     }                                                                                                       \
   }
   RSP_BUCKET(0)
@@ -776,7 +776,7 @@ size_t cgq_loss_slots(const QSchedule& q, int k) {
   size_t n = 0;
   for (int b = 0; b < kNB; b++) {
     const int rows = q.off[b + 1] - q.off[b];
-    if (kBuckets[q.cfg][b].stream && ne_supported(k)) n += (size_t)rows;  // one slot per row (wrmf_ne.hip)
+    if (kBuckets[q.cfg][b].stream && ne_supported(k)) n += (size_t)(q.ne_entries + q.ne_nsplit);  // one slot per list entry and split row (wrmf_ne.hip)
     else n += (size_t)cgq_bucket_grid(rows, b, q.cfg) * kBuckets[q.cfg][b].waves;
   }
   return n;

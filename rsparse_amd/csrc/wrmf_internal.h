@@ -32,6 +32,12 @@ struct DevCSC {
   int32_t* q_ne_rows = nullptr;
   int32_t* q_ne_ptr = nullptr;
   int q_ne_wg = 0;
+  int32_t* q_ne_segs = nullptr;   // [q_ne_nseg][6]: segments of the rows split across workgroups (wrmf_capi.cpp)
+  int q_ne_nseg = 0;
+  int q_ne_entries = 0;           // list entries = rows that are not split + segments
+  int32_t* q_ne_split_rows = nullptr;   // lists of the COLLECT launch (one workgroup per split row)
+  int32_t* q_ne_split_ptr = nullptr;
+  int q_ne_nsplit = 0;
   int64_t nnz_long = 0;
   int n_empty = 0;
   bool owns_matrix = false;
@@ -68,6 +74,10 @@ struct AlsArgs {
   // Cholesky: rows of more than kCholLongLen non-zeros = the first n_chol_long entries of the length-sorted row order
   const int32_t* chol_long_rows;
   int n_chol_long;
+  // rows split across workgroups: segment table, per-segment partial accumulators (kNeSegFloats floats each) and flags
+  const int32_t* ne_segs;
+  float* ne_seg_scratch;
+  int* ne_seg_flags;
   const unsigned* ne_stats;      // implicit NE launches: {bits of max |x|, bits of max c, any c < 1} (launch_ne_stats), or nullptr
   unsigned long long* ne_prof;   // RSP_NE_PROF builds: [workgroup][wave][8] cycle counters of wrmf_ne.hip (else nullptr)
 };
@@ -79,6 +89,10 @@ struct QSchedule {
   const int32_t* ne_rows;  // see DevCSC::q_ne_*
   const int32_t* ne_ptr;
   int ne_wg;
+  int ne_entries;                 // list entries = rows that are not split + segments
+  const int32_t* ne_split_rows;   // per split row: -(index of its first segment + 1); ne_split_ptr = 0, 1, 2, ...
+  const int32_t* ne_split_ptr;
+  int ne_nsplit;
 };
 int cgq_default_cfg();
 int cgq_num_buckets();               // 6
@@ -91,9 +105,12 @@ int cgq_bucket_of(int len, int cfg);
 size_t cgq_loss_slots(const QSchedule& q, int k);
 // long rows (bucket 0) by one-pass normal equations on the matrix cores (wrmf_ne.hip) instead of the streamed CG kernel
 bool ne_supported(int k);
+constexpr int kNeMaxSeg = 16;        // segments per split row
+constexpr int kNeMaxSegTotal = 64;   // ... per matrix
+constexpr int kNeSegFloats = 4 * (11 * 16 * 64 + 128 + 2);   // per segment: 4 waves x (<= 11 accumulator tiles + b + sum c)
 hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s);
-hipError_t launch_als_ne(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
-                         double* row_loss, hipStream_t s);
+struct QSchedule;
+hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s);
 // ev (optional): 7 events, ev[b] before bucket b's kernel, ev[6] after the last one
 hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 

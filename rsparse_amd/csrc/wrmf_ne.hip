@@ -335,7 +335,10 @@ struct NeParts {   // MFMA operands of one step: block t, term q
   u32x4 a[NB][NS];   // (c - 1) x   (tile rows this wave owns; implicit only)
 };
 
-template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD>
+// COLLECT: the second launch for the rows that were split across workgroups (see the publish step below): one workgroup
+// per split row, no streaming -- it sums the published partial sums of the row's segments in segment order (the same
+// per-wave register images, so every geometry above works unchanged) and runs the same per-row solve.
+template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD, bool COLLECT>
 __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, const int32_t* __restrict__ wg_rows,
                                                                     const int32_t* __restrict__ wg_ptr, int slot0,
                                                                     double* __restrict__ row_loss, int only_if_lt1) {
@@ -410,13 +413,36 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
     }
   }
 
+  // List entry -> the run of non-zeros to stream.  entry >= 0: a whole row; -(s + 1): segment s of a row that the host
+  // split across workgroups (wrmf_capi.cpp): {row, first non-zero, non-zeros, index, segments of the row, scratch slot}
+  struct NeEntry { int row, p1, cnt, cnt_row, seg, nseg, slot; };
+  auto decode = [&](const int li) {
+    NeEntry en;
+    const int e = sload(wg_rows + li);
+    if (e >= 0) {
+      en.row = e;
+      en.p1 = sload(a.col_ptrs + e);
+      en.cnt = en.cnt_row = sload(a.col_ptrs + e + 1) - en.p1;
+      en.seg = 0; en.nseg = 1; en.slot = 0;
+    } else {
+      const int32_t* sg = a.ne_segs + (size_t)(-e - 1) * 6;
+      en.row = sload(sg);
+      const int rp = sload(a.col_ptrs + en.row);
+      en.cnt_row = sload(a.col_ptrs + en.row + 1) - rp;
+      en.p1 = rp + sload(sg + 1);
+      en.cnt = sload(sg + 2);
+      en.seg = sload(sg + 3); en.nseg = sload(sg + 4); en.slot = sload(sg + 5);
+    }
+    return en;
+  };
+
   // ---- gather stream of this ring group ----
   auto load_row = [&](NeCursor& c) {
     c.s = 0;
     if (c.li < list_end) {
-      const int row = sload(wg_rows + c.li);
-      c.p1 = sload(a.col_ptrs + row);
-      c.cnt = sload(a.col_ptrs + row + 1) - c.p1;
+      const NeEntry en = decode(c.li);
+      c.p1 = en.p1;
+      c.cnt = en.cnt;
       const int nsteps = (c.cnt + kStepNnz - 1) / kStepNnz;
       c.nst = (nsteps - wset + NSETS - 1) / NSETS;
     } else {
@@ -524,7 +550,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
       else dma16(pre_src[N], pre_dst[N]);
     }
   };
-  {
+  if constexpr (!COLLECT) {
     start(ci);
     start(cv);
     // steady state, consuming stream position q: issue {index chunk q + 2(D-1), vectors q + D-1}.  Prologue = the
@@ -550,13 +576,12 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
 #endif
 
   for (int li = list_begin; li < list_end; li++) {
-    const int row = sload(wg_rows + li);
-    const int p1 = sload(a.col_ptrs + row);
-    const int cnt = sload(a.col_ptrs + row + 1) - p1;
+    const NeEntry en = decode(li);
+    const int row = en.row, p1 = en.p1, cnt = en.cnt;
     const int nsteps = (cnt + kStepNnz - 1) / kStepNnz;
     const int nst = (nsteps - wset + NSETS - 1) / NSETS;   // this group's steps
     const int nst_max = (nsteps + NSETS - 1) / NSETS;      // group 0's steps (barrier count in PAIR mode)
-    const float lam_use = IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)cnt : 1.0));
+    const float lam_use = IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)en.cnt_row : 1.0));
     // warm start -> LDS by DMA (an ordinary load would make hipcc drain the look-ahead queue where the value is used).
     // It is older than every vector group this row issues, so it has landed once a step issued in this row has been
     // waited for, i.e. after D - 1 steps of wave 0's group; shorter rows drain explicitly below
@@ -982,8 +1007,52 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
       return wave_sum_all(qf);
     };
 
-    with_role([&](auto rc) { accumulate(rc); });
-    if (wv == 0 && nst < D) wait_vm<0>();   // short row: make sure the warm start has landed (see above)
+    constexpr int PER_WAVE = kNeSegFloats / 4;
+    static_assert(PER_WAVE >= NSLOT * 1024 + KP + 2, "scratch per wave");
+    bool solved = true;
+    if constexpr (!COLLECT) {
+      with_role([&](auto rc) { accumulate(rc); });
+      // ---- a segment of a row that the host split across workgroups: publish this wave's partial sums as they are
+      // (accumulator registers, its b partial and sum c) and go on; the COLLECT launch adds them up and solves the row
+      if (en.nseg > 1) {
+        float* scr = a.ne_seg_scratch + (size_t)(en.slot + en.seg) * kNeSegFloats + wv * PER_WAVE;
+        // (one opaque base pointer per tile and a compiler barrier between tiles: the element offsets fit the store's
+        //  immediate field and nothing of this rare path is hoisted into the row loop's preheader)
+#pragma unroll
+        for (int t = 0; t < NSLOT; t++) {
+          float* st = scr + t * 1024 + lane;
+          asm volatile("" : "+v"(st) : : "memory");
+#pragma unroll
+          for (int e = 0; e < 16; e++) st[e * 64] = acc[t][e];
+        }
+        wave_sync();
+        for (int e = lane; e < KP; e += 64) scr[NSLOT * 1024 + e] = sB[wv * KP + e];
+        if (lane == 0) {
+          *reinterpret_cast<double*>(scr + NSLOT * 1024 + KP) = reinterpret_cast<const double*>(sScal)[wv];
+          if (wv == 0) row_loss[li - slot0] = 0.0;
+        }
+        solved = false;
+      }
+    } else {
+      for (int s2 = 0; s2 < en.nseg; s2++) {
+        const float* o = a.ne_seg_scratch + (size_t)(en.slot + s2) * kNeSegFloats + wv * PER_WAVE;
+#pragma unroll
+        for (int t = 0; t < NSLOT; t++) {
+          const float* ot = o + t * 1024 + lane;
+          asm volatile("" : "+v"(ot) : : "memory");
+#pragma unroll
+          for (int e = 0; e < 16; e++) acc[t][e] += ot[e * 64];
+        }
+        for (int e = lane; e < KP; e += 64) sB[wv * KP + e] = (s2 ? sB[wv * KP + e] : 0.f) + o[NSLOT * 1024 + e];
+        wave_sync();
+        if (lane == 0)
+          reinterpret_cast<double*>(sScal)[wv] = (s2 ? reinterpret_cast<const double*>(sScal)[wv] : 0.0) +
+                                                 *reinterpret_cast<const double*>(o + NSLOT * 1024 + KP);
+      }
+      wave_sync();
+    }
+    auto solve_row = [&]() __attribute__((always_inline)) {
+    if (wv == 0 && (COLLECT || nst < D)) wait_vm<0>();   // short row: make sure the warm start has landed (see above)
     __syncthreads();   // warm start and every wave's right-hand-side partial are in LDS
     NE_T(12)
     for (int ph = 0; ph < NSETS; ph++) {
@@ -1142,7 +1211,11 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
         for (int t = 0; t < NB; t++) sY[nbuf * KP + 32 * t + d] = x[t];
       }
     }
-    nbuf++;
+    };
+    if (solved) {
+      solve_row();
+      nbuf++;
+    }
     __syncthreads();  // A, b and the scalars are rewritten by the next row; the parked row is visible
     if (nbuf == YB || li + 1 == list_end) {
       // One wave stores the parked rows.  Stores count in vmcnt too and are not ordered with loads, so it drains its
@@ -1169,10 +1242,10 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
 #endif
 }
 
-template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD = false>
+template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD = false, bool COLLECT = false>
 hipError_t launch_ne_t(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int grid, double* row_loss,
                        hipStream_t s, int only_if_lt1) {
-  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM, QUAD>;
+  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM, QUAD, COLLECT>;
   constexpr int lds = NeGeo<KP, NeRoles<KP, NS, IMPLICIT, SYM, QUAD>::NROLES, IMPLICIT>::BYTES;
   hipError_t err =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1234,23 +1307,34 @@ hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_
 // Implicit feedback with a.ne_stats: the fp16 SYM kernel and, behind it, the bf16 kernel that takes over when some
 // confidence is below 1 (exactly one of the two does the work; the other returns at once).  Explicit feedback, or no
 // stats: the bf16 kernel alone.
-hipError_t launch_als_ne(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
-                         double* row_loss, hipStream_t s) {
-  if (n_wg <= 0) return hipSuccess;
+template <bool COLLECT>
+hipError_t launch_ne_mode(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
+                          double* row_loss, hipStream_t s) {
   const int KP = padded_rank(a.k);
   hipError_t err;
-#define RSP_NE_DISPATCH(KPV)                                                                                          \
-  if (KP == KPV) {                                                                                                    \
-    if (!implicit) return launch_ne_t<KPV, 3, false, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0);                \
-    if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0);               \
-    if ((err = launch_ne_t<KPV, 2, true, true, KPV == 128>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) != hipSuccess)  \
-      return err;                                                                                                     \
-    return launch_ne_t<KPV, 3, true, false>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 1);                                \
+#define RSP_NE_DISPATCH(KPV)                                                                                           \
+  if (KP == KPV) {                                                                                                     \
+    if (!implicit) return launch_ne_t<KPV, 3, false, false, false, COLLECT>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
+    if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false, false, COLLECT>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
+    if ((err = launch_ne_t<KPV, 2, true, true, KPV == 128, COLLECT>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) !=      \
+        hipSuccess)                                                                                                    \
+      return err;                                                                                                      \
+    return launch_ne_t<KPV, 3, true, false, false, COLLECT>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 1);                 \
   }
   RSP_NE_DISPATCH(128)
   RSP_NE_DISPATCH(64)
 #undef RSP_NE_DISPATCH
   return hipErrorInvalidValue;
+}
+
+// The long rows of one half-iteration: the streaming launch over the per-workgroup lists (q.ne_rows / ne_ptr; an entry is
+// a row or a segment of a split row), then, if rows were split, the COLLECT launch (one workgroup per split row).
+// row_loss: one double per list entry, then one per split row.
+hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s) {
+  if (q.ne_wg <= 0) return hipSuccess;
+  hipError_t err = launch_ne_mode<false>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s);
+  if (err != hipSuccess || q.ne_nsplit <= 0) return err;
+  return launch_ne_mode<true>(a, q.ne_split_rows, q.ne_split_ptr, q.ne_nsplit, implicit, row_loss + q.ne_entries, s);
 }
 
 }  // namespace rsparse_hip

@@ -168,7 +168,8 @@ int rsparse_hip_csc_transpose_device(int n_rows, int n_cols, const int32_t* d_p,
 int rsparse_hip_values_to_float_device(int64_t n, const double* d_src, float* d_dst, void* stream);
 /* info_out: [0] n_rows, [1] n_cols, [2] nnz, [3] rows with more than [7] non-zeros ("long" rows),
  * [4] longest row, [5] non-zeros in long rows, [6] empty rows, [7] per-wave tile capacity (32),
- * [8..13] rows and [14..19] non-zeros per CG launch bucket, [20] launch-table id, [22..27] waves per row
+ * [8..13] rows and [14..19] non-zeros per CG launch bucket, [20] launch-table id, [21] segments of the long rows that
+ * are split across workgroups (0 = none is), [22..27] waves per row
  * (team size) of each bucket (0 = bucket unused), [28..33] resident quads (4 non-zeros) per wave,
  * [34..39] waves per workgroup (negative = the bucket streams rows longer than the resident capacity). */
 int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[40]);

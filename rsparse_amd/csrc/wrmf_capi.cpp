@@ -867,6 +867,7 @@ int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[40]) {
     info_out[14 + b] = m->d.q_nnz[b];
   }
   info_out[20] = m->d.q_cfg;
+  info_out[21] = m->d.q_ne_nseg;
   for (int b = 0; b < 6; b++) {
     info_out[22 + b] = cgq_bucket_wpr(m->d.q_cfg, b);
     info_out[28 + b] = cgq_bucket_capq(m->d.q_cfg, b);

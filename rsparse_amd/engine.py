@@ -271,7 +271,7 @@ class _CscHandle:
         _lib.check(self.lib.rsparse_hip_csc_info(self.h, buf))
         return dict(n_rows=buf[0], n_cols=buf[1], nnz=buf[2], n_long=buf[3], max_len=buf[4], nnz_long=buf[5],
                     n_empty=buf[6], tile_nnz=buf[7], bucket_rows=list(buf[8:14]), bucket_nnz=list(buf[14:20]),
-                    cgq_cfg=buf[20], bucket_wpr=list(buf[22:28]), bucket_capq=list(buf[28:34]),
+                    cgq_cfg=buf[20], ne_segments=buf[21], bucket_wpr=list(buf[22:28]), bucket_capq=list(buf[28:34]),
                     bucket_waves=[abs(v) for v in buf[34:40]], bucket_stream=[int(v < 0) for v in buf[34:40]])
 
     def __del__(self):

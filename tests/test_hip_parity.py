@@ -335,3 +335,34 @@ def test_cholesky_reports_systems_that_are_not_positive_definite():
     csc_ok = csc[:4] + (np.full_like(csc[4], 2.0),)
     als.als_implicit(csc_ok, X, Y2, 0.1, 1, 0, 3, "float", False, False)
     assert np.all(np.isfinite(Y2))
+
+
+@pytest.mark.parametrize("k,implicit", [(128, True), (64, True), (64, False)])
+def test_one_giant_row_is_split_across_workgroups(k, implicit):
+    """A row far longer than a workgroup's share of the long rows is cut into segments that different workgroups stream;
+    their partial sums meet in the COLLECT launch (wrmf_ne.hip).  600 ordinary long rows + one of 60000 non-zeros, as
+    on a rank of a multi-GPU run that owns the most popular item."""
+    from rsparse_amd.engine import HipBackend
+    rng = np.random.default_rng(7 + k)
+    n_fix, n_long, giant = 70000, 600, 60000
+    lens = np.concatenate([[giant], rng.integers(520, 900, n_long)])
+    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    i = np.concatenate([np.sort(rng.choice(n_fix, int(n), replace=False)) for n in lens]).astype(np.int32)
+    x = (1.0 + rng.random(i.size) * 4.0) if implicit else rng.integers(1, 6, i.size).astype(np.float64)
+    X = np.asfortranarray((rng.standard_normal((k, n_fix)) * 0.05).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, lens.size)) * 0.05).astype(np.float32))
+    csc = (n_fix, lens.size, p, i, x)
+    be = HipBackend(0)
+    h = be.make_csc(n_fix, lens.size, be.to_device(p, torch.int32), be.to_device(i, torch.int32),
+                    be.to_device(x.astype(np.float32), torch.float32))
+    assert h.info()["ne_segments"] >= 4            # the giant row (at least) was cut
+    cnt = np.bincount(i, minlength=n_fix).astype(np.float64)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 1, 3, implicit, True, cnt)
+    Y = Y0.copy(order="F")
+    if implicit:
+        loss = als.als_implicit(csc, X, Y, 0.1, 1, 1, 3, "float", False, False)
+    else:
+        loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), 0.1, 1, 1, 3, True, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, (int(err.argmax()), float(err.max()), float(err[0]))
+    assert abs(loss - lref) <= TOL * abs(lref)

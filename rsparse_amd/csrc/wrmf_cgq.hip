@@ -152,6 +152,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   for (int e = tid; e < (int)(SM::vec_floats + SM::red_floats + SM::tsv_floats); e += WAVES * 64) sVec[e] = 0.f;
   __syncthreads();
 
+  // One-wave rows of <= 32 non-zeros are bound by the LDS traffic of the dense G v product (64 KB per row and sweep) and
+  // use only 64 registers for their vectors: the first NRES of the 8 four-row slabs of G that a 16-lane group walks stay
+  // in registers for the whole launch (32 registers per slab), the rest is read from LDS as before.
+  constexpr int NRES = (IMPLICIT && CAPQ == 8 && WPR == 1 && !STREAM && KP == 128) ? 2 : 0;
+  piece_t gres[NRES > 0 ? NRES : 1][4][NV];
+  if constexpr (NRES > 0) {
+#pragma unroll
+    for (int rs = 0; rs < NRES; rs++)
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int b = 0; b < NV; b++)
+          gres[rs][u][b] = *reinterpret_cast<const piece_t*>(sG + (4 * (g + 4 * rs) + u) * KP + b * 16 * VW + i * VW);
+  }
   float* vec = sVec + wv * KP;
   float* tacc = sTsv + wv * 2 * CAP;  // resident rows only
   float* tcur = tacc + CAP;
@@ -414,7 +428,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         auto dense_part = [&]() {
           if (IMPLICIT && mode != 2) {
             const float sign = mode == 0 ? -1.f : 1.f;
-            for (int s4 = tw * 4 + g; s4 < KP / 4; s4 += WPR * 4) {
+            if constexpr (NRES > 0) {
+#pragma unroll
+              for (int rs = 0; rs < NRES; rs++) {
+                const int kk = 4 * (g + 4 * rs);
+                const float4 vb = *reinterpret_cast<const float4*>(vec + kk);
+                const float vv[4] = {sign * vb.x, sign * vb.y, sign * vb.z, sign * vb.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                  for (int b = 0; b < NV; b++) {
+                    const float* pf = reinterpret_cast<const float*>(&gres[rs][u][b]);
+#pragma unroll
+                    for (int c = 0; c < VW; c++) acc[b * VW + c] = fmaf(vv[u], pf[c], acc[b * VW + c]);
+                  }
+              }
+            }
+            for (int s4 = tw * 4 + g + 4 * NRES; s4 < KP / 4; s4 += WPR * 4) {
               const int kk = 4 * s4;
               const float4 vb = *reinterpret_cast<const float4*>(vec + kk);
               const float vv[4] = {sign * vb.x, sign * vb.y, sign * vb.z, sign * vb.w};

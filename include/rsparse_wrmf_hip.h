@@ -180,6 +180,19 @@ int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[40]);
 int rsparse_hip_gramian_device(const float* d_X, int rank, int64_t n, double lambda,
                                float* d_XtX_out, double* d_sumsq_out, void* stream);
 
+/* The same, and *d_absmax_inout = max(*d_absmax_inout, max |X|) (device float, nullable; the caller zeroes it before the
+ * first block): the matrix is read here anyway.  What it is for: the long-row kernel of the implicit CG half-iteration
+ * (wrmf_ne.hip) scales its fp16 operands by a power of two taken from max |X|, which it otherwise finds by scanning X
+ * once per half-iteration call. */
+int rsparse_hip_gramian_absmax_device(const float* d_X, int rank, int64_t n, double lambda, float* d_XtX_out,
+                                      double* d_sumsq_out, float* d_absmax_inout, void* stream);
+
+/* Optional hint for rsparse_hip_als_implicit_device: while it is set, half-iterations whose fixed side is d_X take
+ * max |X| from *d_absmax (device float; any value >= the true maximum is correct, a tight one is accurate) instead of
+ * scanning X -- a sharded driver sets it once per half-iteration (all-reduced maximum of its ranks' blocks) and solves
+ * its sub-blocks under it.  The caller keeps *d_absmax valid and current while the hint is set; (NULL, NULL) clears it. */
+int rsparse_hip_hint_factor_absmax(const float* d_X, const float* d_absmax);
+
 /* One implicit half-iteration over the columns of `conf` (als_implicit<float>, no-bias branch).
  * d_Y points at column 0 of this matrix's block (rank x n_cols).  Writes to d_loss_rows_out
  * (nullable, device double[1]) the un-normalised row part of the loss:

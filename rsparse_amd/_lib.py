@@ -33,6 +33,8 @@ SIGNATURES = {
     "rsparse_hip_gramian_float": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp]),
     "rsparse_hip_csc_create_host": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "rsparse_hip_csc_create_device": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
+    "rsparse_hip_gramian_absmax_device": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp, _vp, _vp, _vp]),
+    "rsparse_hip_hint_factor_absmax": (_c_int, [_vp, _vp]),
     "rsparse_hip_csc_destroy": (_c_int, [_vp]),
     "rsparse_hip_csc_info": (_c_int, [_vp, ctypes.POINTER(_c_i64)]),
     "rsparse_hip_als_implicit_bias_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_int, _vp, _vp]),

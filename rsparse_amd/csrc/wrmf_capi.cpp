@@ -352,6 +352,9 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   return RSPARSE_HIP_OK;
 }
 
+// max |X| supplied by the caller for the half-iterations on X (rsparse_hip_hint_factor_absmax)
+struct AbsmaxHint { const float* X = nullptr; const float* absmax = nullptr; } g_absmax_hint;
+
 // the register-resident quad-layout CG kernels need rank % 4 == 0 and 16-byte aligned factor matrices; other ranks take
 // the LDS-tile kernels of wrmf_kernels.hip
 bool use_cgq(int rank, const void* X, const void* Y) {
@@ -442,7 +445,8 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   }
   if (cgq && implicit && d.q_ne_wg > 0 && ne_supported(rank) && !bias) {
     // operand scales of the fp16 normal-equation kernel (and whether it may run at all), decided on the device
-    hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s);
+    const float* hint = (g_absmax_hint.X == d_X && g_absmax_hint.absmax) ? g_absmax_hint.absmax : nullptr;
+    hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, hint);
     if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
     a.ne_stats = g_ws.ne_stats;
   }
@@ -900,6 +904,17 @@ int rsparse_hip_profile_last(double ms_out[8]) {
 
 int rsparse_hip_gramian_device(const float* d_X, int rank, int64_t n, double lambda, float* d_XtX_out,
                                double* d_sumsq_out, void* stream) {
+  return rsparse_hip_gramian_absmax_device(d_X, rank, n, lambda, d_XtX_out, d_sumsq_out, nullptr, stream);
+}
+
+int rsparse_hip_hint_factor_absmax(const float* d_X, const float* d_absmax) {
+  g_absmax_hint.X = d_X;
+  g_absmax_hint.absmax = d_X ? d_absmax : nullptr;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_gramian_absmax_device(const float* d_X, int rank, int64_t n, double lambda, float* d_XtX_out,
+                                      double* d_sumsq_out, float* d_absmax_inout, void* stream) {
   if (!d_X || !d_XtX_out) return fail(RSPARSE_HIP_ERR_INVALID, "X or XtX_out is NULL");
   if (rank <= 0 || n < 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive and n non-negative");
   if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
@@ -908,7 +923,8 @@ int rsparse_hip_gramian_device(const float* d_X, int rank, int64_t n, double lam
   if ((rc = g_ws.ensure_gram(gramian_scratch_floats(rank, n)))) return rc;
   const float ridge = (float)lambda;  // float::fl(diag(lambda)), R/model_WRMF.R:476
   hipEvent_t* ev = g_prof.begin();
-  hipError_t e = launch_gramian(d_X, rank, n, ridge, d_XtX_out, d_sumsq_out, g_ws.gram, (hipStream_t)stream, ev);
+  hipError_t e = launch_gramian(d_X, rank, n, ridge, d_XtX_out, d_sumsq_out, g_ws.gram, (hipStream_t)stream, ev,
+                                reinterpret_cast<unsigned*>(d_absmax_inout));
   if (e != hipSuccess) return hip_fail(e, "launch_gramian");
   if (ev) {
     g_prof.have = true;

@@ -108,7 +108,9 @@ bool ne_supported(int k);
 constexpr int kNeMaxSeg = 16;        // segments per split row
 constexpr int kNeMaxSegTotal = 64;   // ... per matrix
 constexpr int kNeSegFloats = 4 * (11 * 16 * 64 + 128 + 2);   // per segment: 4 waves x (<= 11 accumulator tiles + b + sum c)
-hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s);
+// absmax_hint (nullable, device float): max |X| supplied by the caller -- X is then not scanned
+hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s,
+                           const float* absmax_hint = nullptr);
 struct QSchedule;
 hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s);
 // ev (optional): 7 events, ev[b] before bucket b's kernel, ev[6] after the last one
@@ -157,8 +159,8 @@ hipError_t launch_values_subtract_mean(float* x, int64_t n, const double* sum, d
 
 // Gramian: scratch must hold gramian_scratch_floats(k, n) floats.
 size_t gramian_scratch_floats(int k, int64_t n);
-hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* XtX, double* sumsq,
-                          float* scratch, hipStream_t s, hipEvent_t* ev = nullptr);
+hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* XtX, double* sumsq, float* scratch,
+                          hipStream_t s, hipEvent_t* ev = nullptr, unsigned* absmax_bits = nullptr);
 hipError_t launch_weighted_sumsq(const float* X, int k, int64_t n, const float* w, double* out,
                                  double* scratch /* >= 1024 doubles */, hipStream_t s);
 hipError_t launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s);

@@ -356,7 +356,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int KP>
 __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __restrict__ X, int k, int64_t n,
-                                                              float* __restrict__ partials) {
+                                                              float* __restrict__ partials,
+                                                              unsigned* __restrict__ absmax_bits) {
   constexpr int NT = KP / 32, U = 4;
   const int lane = threadIdx.x & 63;
   const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
+  float amax = 0.f;   // max |x| of what this lane reads: the matrix is read here anyway (wrmf_ne.hip wants its scale)
   for (int64_t n0 = gw * 2 * U; n0 < n; n0 += nw * 2 * U) {
     float av[U][NT];
 #pragma unroll
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
       for (int mt = 0; mt < NT; mt++) {
         const int aidx = mt * 32 + col;
         av[u][mt] = (ent < n && aidx < k) ? X[ent * k + aidx] : 0.f;
+        amax = fmaxf(amax, fabsf(av[u][mt]));
       }
     }
 #pragma unroll
@@ -387,6 +390,11 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
 #pragma unroll
         for (int nt = 0; nt <= mt; nt++)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], av[u][nt], acc[mt][nt], 0, 0, 0);
+  }
+  if (absmax_bits) {   // non-negative floats order like their bit patterns
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) atomicMax(absmax_bits, __float_as_uint(amax < 3.0e38f ? amax : 3.0e38f));
   }
   float* out = partials + (size_t)gw * KP * KP;
 #pragma unroll
@@ -544,8 +552,9 @@ size_t gramian_scratch_floats(int k, int64_t n) {
   return (size_t)gramian_waves(n) * KP * KP + 2 * 128 /* diag doubles */ + 16;
 }
 
+// absmax_bits (nullable): device word that receives max(its content, bits of max |X|) -- the caller zeroes it
 hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* XtX, double* sumsq,
-                          float* scratch, hipStream_t s, hipEvent_t* ev) {
+                          float* scratch, hipStream_t s, hipEvent_t* ev, unsigned* absmax_bits) {
   const int KP = padded_rank(k);
   if (!KP) return hipErrorInvalidValue;
   const int waves = gramian_waves(n);
@@ -553,9 +562,9 @@ hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* 
   double* diag = reinterpret_cast<double*>(scratch + (((size_t)waves * KP * KP + 1) & ~(size_t)1));
   const int grid = waves / 4;
   if (ev) (void)hipEventRecord(ev[0], s);
-  if (KP == 32) hipLaunchKernelGGL(gramian_partial_kernel<32>, dim3(grid), dim3(256), 0, s, X, k, n, partials);
-  else if (KP == 64) hipLaunchKernelGGL(gramian_partial_kernel<64>, dim3(grid), dim3(256), 0, s, X, k, n, partials);
-  else hipLaunchKernelGGL(gramian_partial_kernel<128>, dim3(grid), dim3(256), 0, s, X, k, n, partials);
+  if (KP == 32) hipLaunchKernelGGL(gramian_partial_kernel<32>, dim3(grid), dim3(256), 0, s, X, k, n, partials, absmax_bits);
+  else if (KP == 64) hipLaunchKernelGGL(gramian_partial_kernel<64>, dim3(grid), dim3(256), 0, s, X, k, n, partials, absmax_bits);
+  else hipLaunchKernelGGL(gramian_partial_kernel<128>, dim3(grid), dim3(256), 0, s, X, k, n, partials, absmax_bits);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
   if (ev) (void)hipEventRecord(ev[1], s);

@@ -1265,8 +1265,13 @@ __device__ __forceinline__ float wave_max(float v) {
 // max |x| over the fixed side, max c and "some c < 1" over the confidences -> stats[0..2] (zeroed by the caller).
 // Non-negative floats order like their bit patterns, so one atomicMax per workgroup does it; a negative c only sets the flag.
 __global__ __launch_bounds__(256) void ne_stats_kernel(const float* __restrict__ X, int64_t nx, const float* __restrict__ vals,
-                                                        int64_t nnz, unsigned* __restrict__ stats) {
+                                                        int64_t nnz, unsigned* __restrict__ stats,
+                                                        const float* __restrict__ absmax_hint) {
   float mx = 0.f, mc = 0.f;
+  if (absmax_hint) {   // the caller knows max |X| (rsparse_hip_hint_factor_absmax): nothing of X is read
+    nx = 0;
+    mx = fabsf(*absmax_hint);
+  }
   int lt1 = 0;
   const int64_t stride = (int64_t)gridDim.x * 256 * 4, t0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   for (int64_t e = t0; e + 3 < nx; e += stride) {
@@ -1275,10 +1280,25 @@ __global__ __launch_bounds__(256) void ne_stats_kernel(const float* __restrict__
   }
   for (int64_t e = (nx & ~(int64_t)3) + (int64_t)blockIdx.x * 256 + threadIdx.x; e < nx; e += (int64_t)gridDim.x * 256)
     mx = fmaxf(mx, fabsf(X[e]));
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
-    const float c = vals[e];
-    mc = fmaxf(mc, c);
-    lt1 |= !(c >= 1.f);
+  {   // 16-byte loads over the aligned middle of vals, single floats at its two ends
+    const int64_t head = min(nnz, (int64_t)((16 - (reinterpret_cast<uintptr_t>(vals) & 15)) & 15) / 4);
+    const int64_t nvec = (nnz - head) / 4;
+    const float4* v4 = reinterpret_cast<const float4*>(vals + head);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (int64_t)gridDim.x * 256) {
+      const float4 c = v4[e];
+      mc = fmaxf(fmaxf(mc, fmaxf(c.x, c.y)), fmaxf(c.z, c.w));
+      lt1 |= !(c.x >= 1.f) | !(c.y >= 1.f) | !(c.z >= 1.f) | !(c.w >= 1.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) {   // at most 3 leading and 3 trailing values
+      const int64_t tail0 = head + 4 * nvec;
+      const int64_t e = threadIdx.x < 4 ? (int64_t)threadIdx.x : tail0 + (threadIdx.x - 4);
+      const bool mine = threadIdx.x < 4 ? e < head : e < nnz;
+      if (mine) {
+        const float c = vals[e];
+        mc = fmaxf(mc, c);
+        lt1 |= !(c >= 1.f);
+      }
+    }
   }
   mx = wave_max(mx);
   mc = wave_max(mc);
@@ -1297,10 +1317,11 @@ bool ne_supported(int k) { return k > 32 && k <= 128 && k % 4 == 0; }
 
 // wg_rows / wg_ptr: per-workgroup row lists (host-balanced, wrmf_capi.cpp build_ne_lists); row_loss: one double per
 // entry of wg_rows
-hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s) {
+hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s,
+                           const float* absmax_hint) {
   hipError_t err = hipMemsetAsync(stats, 0, 4 * sizeof(unsigned), s);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(ne_stats_kernel, dim3(2048), dim3(256), 0, s, X, nx, vals, nnz, stats);
+  hipLaunchKernelGGL(ne_stats_kernel, dim3(2048), dim3(256), 0, s, X, nx, vals, nnz, stats, absmax_hint);
   return hipGetLastError();
 }
 

@@ -174,11 +174,18 @@ class HipBackend:
                                                                self._stream()))
         return out
 
-    def gramian(self, F, lambda_, out, sumsq_out):
+    def gramian(self, F, lambda_, out, sumsq_out, absmax_inout=None):
+        """absmax_inout (float32[1], optional): receives max(its content, max |F|) -- the Gramian reads F anyway."""
         n, k = F.shape
-        _lib.check(self.lib.rsparse_hip_gramian_device(F.data_ptr(), k, n, float(lambda_), out.data_ptr(),
-                                                       None if sumsq_out is None else sumsq_out.data_ptr(),
-                                                       self._stream()))
+        _lib.check(self.lib.rsparse_hip_gramian_absmax_device(
+            F.data_ptr(), k, n, float(lambda_), out.data_ptr(), None if sumsq_out is None else sumsq_out.data_ptr(),
+            None if absmax_inout is None else absmax_inout.data_ptr(), self._stream()))
+
+    def hint_absmax(self, F, absmax):
+        """While set, implicit half-iterations on F take max |F| from `absmax` (float32[1]) instead of scanning F;
+        hint_absmax(None, None) clears it."""
+        _lib.check(self.lib.rsparse_hip_hint_factor_absmax(None if F is None else F.data_ptr(),
+                                                           None if absmax is None else absmax.data_ptr()))
 
     def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out,
                        bias_last_row=None, global_bias=0.0):
@@ -313,6 +320,8 @@ class ShardedALS:
         self.G = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
         self.Gpart = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float64, device=dev)   # [0] sumsq, [1] loss rows, [2] spare
+        self.absmax = torch.zeros(1, dtype=torch.float32, device=dev)   # max |F| of the fixed side (gramian())
+        self.absmax_of = None
         self.global_bias = 0.0 # implicit feedback: the model's global bias (R/model_WRMF.R:285-287); explicit: data are shifted
         self.cnt_user = None   # nnz per user / item in GLOBAL order (weights of the explicit regulariser)
         self.cnt_item = None
@@ -382,18 +391,26 @@ class ShardedALS:
         """G = F F^T + fl(lambda) I over the real rows of F (storage order, layout `lay`), reduced over the ranks;
         scal[0] = sum(F^2)."""
         pieces = self._my_pieces(lay)
+        # max |F| rides along (the long-row kernel scales its fp16 operands by it): own blocks here, maximum over the
+        # ranks below; half_iteration() hands it to the library so that no half-iteration call scans F again
+        self.absmax.zero_()
+        self.absmax_of = None
         if self.ws == 1 and len(pieces) == 1:
             a, b = pieces[0]
-            self.be.gramian(F[a:b], self.lambda_, self.G, self.scal[0:1])
+            self.be.gramian(F[a:b], self.lambda_, self.G, self.scal[0:1], self.absmax)
+            self.absmax_of = F
             return self.G
         self.G.zero_()
         self.scal[0:1].zero_()
         for a, b in pieces:
-            self.be.gramian(F[a:b], 0.0, self.Gpart, self.scal[2:3])
+            self.be.gramian(F[a:b], 0.0, self.Gpart, self.scal[2:3], self.absmax)
             self.G += self.Gpart
             self.scal[0:1] += self.scal[2:3]
         self._all_reduce(self.G)
         self._all_reduce(self.scal[0:1])
+        if self.ws > 1:
+            torch.distributed.all_reduce(self.absmax, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        self.absmax_of = F
         self.G.diagonal().add_(float(np.float32(self.lambda_)))   # fl(diag(lambda)), R/model_WRMF.R:476
         return self.G
 
@@ -428,6 +445,9 @@ class ShardedALS:
         # solve sub-block j, start its exchange, solve sub-block j+1 meanwhile (both halves alike)
         works = []
         self.scal_sub.zero_()
+        hinted = self.implicit and getattr(self, "absmax_of", None) is F and hasattr(self.be, "hint_absmax")
+        if hinted:
+            self.be.hint_absmax(F, self.absmax)
         for j, (c0, c1, sub) in enumerate(subs):
             if c1 > c0:
                 a = layS.sub_start(self.me, j)
@@ -435,6 +455,9 @@ class ShardedALS:
                                        self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1], blr,
                                        **({"global_bias": self.global_bias} if self.global_bias else {}))
             works.append(self._gather_slab(S, layS, j))
+        if hinted:
+            self.be.hint_absmax(None, None)
+            self.absmax_of = None   # F's owner may change it before the next Gramian
         for w in works:
             if w is not None:
                 w.wait()

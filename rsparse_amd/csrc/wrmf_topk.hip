@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void top_product_kernel(const float* __restric
   if (tid < kTopUsers) {
     sCnt[tid] = 0;
     sThr[tid] = -INFINITY;
+    sNeed[tid] = 0;   // entries [0, sNeed) of the user's buffer are the heap as the last reduction left it
   }
   // A operand: lane holds U[u0 + (lane & 31)][2t + half], t = 0..KP/2-1 (zero beyond the matrix)
   float afrag[NK2];
@@ -160,14 +161,83 @@ __global__ __launch_bounds__(256) void top_product_kernel(const float* __restric
           }
         }
         wave_sync();
-        for (int c = lane; c < topk; c += 64) {
-          bv[c] = tv[c];
-          bi[c] = ti[c];
-        }
-        wave_sync();
-        if (lane == 0) {
-          sCnt[ul] = topk;
-          sThr[ul] = tv[topk - 1];
+        // More candidates at the k-th score than places for them?  Then WHICH of them survive depends on the order in
+        // which the reference's heap met them (it evicts the smallest index among tied minima, but a tied newcomer
+        // never enters a full heap: scores [1,1,5], k = 2 -> {2,1}; [1,5,1] -> {1,0}), and the arrivals since the last
+        // reduction are replayed through that heap in index order.  Everything that arrived before was reduced the
+        // same way, so the buffer's first sNeed entries ARE the reference's heap at that point.
+        const float kth = tv[topk - 1];
+        int ge = 0;
+        for (int c = lane; c < n; c += 64) ge += bv[c] >= kth ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ge += __shfl_xor(ge, off);
+        if (ge > topk) {   // wave-uniform
+          const int old = sNeed[ul];
+          wave_sync();
+          for (int c = lane; c < n; c += 64) {   // heap as it is, then the new arrivals sorted by item index
+            int dst = c;
+            if (c >= old) {
+              const int ix = bi[c];
+              int r = 0;
+              for (int c2 = old; c2 < n; c2++) r += bi[c2] < ix ? 1 : 0;
+              dst = old + r;
+            }
+            tv[dst] = bv[c];
+            ti[dst] = bi[c];
+          }
+          wave_sync();
+          int h = old;
+          for (int c = old; c < n; c++) {
+            const float v = tv[c];
+            const int ix = ti[c];
+            if (h < topk) {
+              if (lane == 0) {
+                bv[h] = v;
+                bi[h] = ix;
+              }
+              h++;
+            } else {
+              // smallest (score, index) of the heap: what std::priority_queue<pair, greater> has on top
+              float mv = INFINITY;
+              int mi = 0x7fffffff, mp = -1;
+              for (int e = lane; e < topk; e += 64) {
+                const float hv = bv[e];
+                const int hi = bi[e];
+                if (hv < mv || (hv == mv && hi < mi)) { mv = hv; mi = hi; mp = e; }
+              }
+#pragma unroll
+              for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(mv, off);
+                const int oi = __shfl_xor(mi, off), op = __shfl_xor(mp, off);
+                if (ov < mv || (ov == mv && oi < mi)) { mv = ov; mi = oi; mp = op; }
+              }
+              if (mv < v && lane == 0) {
+                bv[mp] = v;
+                bi[mp] = ix;
+              }
+            }
+            wave_sync();
+          }
+          float mn = INFINITY;
+          for (int e = lane; e < topk; e += 64) mn = fminf(mn, bv[e]);
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+          if (lane == 0) {
+            sCnt[ul] = topk;
+            sThr[ul] = mn;
+            sNeed[ul] = topk;
+          }
+        } else {
+          for (int c = lane; c < topk; c += 64) {
+            bv[c] = tv[c];
+            bi[c] = ti[c];
+          }
+          wave_sync();
+          if (lane == 0) {
+            sCnt[ul] = topk;
+            sThr[ul] = kth;
+            sNeed[ul] = topk;
+          }
         }
       }
     }

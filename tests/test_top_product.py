@@ -39,6 +39,16 @@ def test_oracle_exclusions_ties_and_na():
     assert list(res[0][:3]) == [6, 5, 4] and np.all(res[0][3:] == O.NA_INTEGER) and np.isnan(sc[0][3:]).all()
 
 
+def test_oracle_tie_eviction_order():
+    """src/matrix_top_product.cpp:61-86: a min-heap on (score, index) pairs; a newcomer replaces the top only if its score
+    is strictly larger, and the top among tied minima is the smallest index."""
+    one = np.ones((1, 1))
+    res, _ = O.top_product(one, np.array([[1.0, 1.0, 5.0]]), 2)
+    assert list(res[0]) == [3, 2]          # (1, item 0) is evicted by the 5, (1, item 1) stays
+    res, _ = O.top_product(one, np.array([[1.0, 5.0, 1.0]]), 2)
+    assert list(res[0]) == [2, 1]          # the heap is full with minimum 1 when the second 1 arrives: not admitted
+
+
 def _hip_top_product(x, y, k, nr=None, exclude=(), glob_mean=0.0):
     lib = _lib.load()
     nrow, rank = x.shape
@@ -94,6 +104,29 @@ def test_hip_ties_and_na_fill():
     got_i, got_s = _hip_top_product(x, y, 6, exclude=[1, 2, 3, 4, 5, 6, 7])
     assert np.array_equal(got_i, ref_i) and np.array_equal(np.isnan(got_s), np.isnan(ref_s))
     assert (got_i[:, 3:] == O.NA_INTEGER).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [2, 7, 40])
+def test_hip_tied_scores_follow_the_heap(k):
+    """Integer-valued factors: every user has many items tied at its k-th score, interleaved with larger scores; which of
+    them survive depends on the arrival order exactly as in the reference's heap (the device replays the arrivals of a
+    round through the heap when, and only when, there are more candidates at the k-th score than places)."""
+    one = np.ones((1, 1))
+    for sc, kk in (([1.0, 1.0, 5.0], 2), ([1.0, 5.0, 1.0], 2)):
+        ref_i, ref_s = O.top_product(one, np.array([sc]), kk)
+        got_i, got_s = _hip_top_product(one, np.array([sc]), kk)
+        assert np.array_equal(got_i, ref_i) and np.array_equal(got_s, ref_s)
+    rng = np.random.default_rng(100 + k)
+    x = rng.integers(0, 3, (70, 4)).astype(np.float64)
+    y = rng.integers(0, 3, (4, 1500)).astype(np.float64)          # scores are small integers: ties everywhere
+    nr = sp.random(70, 1500, density=0.02, format="csr", random_state=np.random.RandomState(k))
+    nr.sort_indices()
+    for kw in ({}, {"nr": nr, "exclude": [3, 77, 1400]}):
+        ref_i, ref_s = O.top_product(x, y, k, *((kw["nr"].indptr, kw["nr"].indices) if kw else (None, None)),
+                                     exclude=kw.get("exclude", ()))
+        got_i, got_s = _hip_top_product(x, y, k, **kw)
+        assert np.array_equal(got_i, ref_i) and np.array_equal(got_s, ref_s)
 
 
 @pytest.mark.gpu

@@ -115,7 +115,7 @@ struct Workspace {
       if (partials) (void)hipFree(partials);
       partials = nullptr;
       partial_slots = 0;
-      HIP_TRY(hipMalloc(&partials, slots * sizeof(double)));
+      HIP_TRY(hipMalloc(&partials, (slots + kSumStageBlocks) * sizeof(double)));   // + the tail of the two-stage sum
       partial_slots = slots;
     }
     return RSPARSE_HIP_OK;
@@ -469,7 +469,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
                                   ? launch_als_nnls(a, implicit, s, ev)
                                   : launch_als_chol2(a, implicit, s, ev)));
   if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
-  e = launch_sum_partials(g_ws.partials, slots, out, s);
+  e = launch_sum_partials(g_ws.partials, slots, out, s, g_ws.partials + g_ws.partial_slots);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
 #ifdef RSP_NE_PROF
   if (cgq && d.q_ne_wg > 0 && std::getenv("RSPARSE_NE_PROF")) {

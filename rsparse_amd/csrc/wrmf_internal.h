@@ -138,7 +138,8 @@ constexpr int kCholLongGrid = 512;
 size_t chol2_loss_slots(int n_cols);
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
-hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s);
+constexpr int kSumStageBlocks = 256;
+hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s, double* tail = nullptr);
 hipError_t launch_bias_shift_values(const float* vals, const int32_t* row_idx, const float* X, int k, int bias_row,
                                     int64_t nnz, float* out, hipStream_t s);
 hipError_t launch_bias_sweep(const int32_t* p, const int32_t* i, const float* x, const float* other, int n_cols,

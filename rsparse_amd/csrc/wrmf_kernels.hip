@@ -459,6 +459,20 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
   if (threadIdx.x == 0) *out = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// first stage for long arrays: block b sums the b-th of gridDim.x equal contiguous chunks (fixed partition and order:
+// deterministic) into tail[b]
+__global__ __launch_bounds__(256) void sum_partials_stage_kernel(const double* __restrict__ partials, size_t n,
+                                                                 double* __restrict__ tail) {
+  __shared__ double sh[4];
+  const size_t per = (n + gridDim.x - 1) / gridDim.x, lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double s = 0.0;
+  for (size_t e = lo + threadIdx.x; e < hi; e += 256) s += partials[e];
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) tail[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 __global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, size_t n) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
     out[e] = (float)in[e];
@@ -535,7 +549,15 @@ hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s, hipEven
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s) {
+// tail (nullable): kSumStageBlocks doubles of scratch; with it, long arrays are reduced in two stages
+hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s, double* tail) {
+  if (tail && n > 16384) {
+    hipLaunchKernelGGL(sum_partials_stage_kernel, dim3(kSumStageBlocks), dim3(256), 0, s, partials, n, tail);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, tail, (size_t)kSumStageBlocks, out);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partials, n, out);
   return hipGetLastError();
 }

@@ -456,8 +456,10 @@ def main():
                                      if (first_ref and losses) else None),
             "n_ranks_seen": n_ranks_seen, "shard_nnz_rank0": shard_nnz, "comm_ms": comm_ms,
             "partition": "contiguous blocks balanced by non-zeros, %d sub-blocks per rank and side (in-place slab all-gathers)" % lay_u.n_sub if ws > 1 else "single rank",
-            "launch_mode": "serial" if os.environ.get("RSPARSE_HIP_CONCURRENT", "1") == "0" else
-                           "overlapped (the per-kernel times under roofline are measured in a serialised pass)",
+            "launch_mode": {"0": "serial", "1": "every bucket on its own stream"}.get(
+                os.environ.get("RSPARSE_HIP_CONCURRENT", "2"),
+                "long-row launch alone, then the resident buckets on side streams (library default; the per-kernel "
+                "times under roofline are measured in a serialised pass)"),
             "datagen_s": t_gen,
             "roofline": roofline,
             "cpu_baseline": cpu,

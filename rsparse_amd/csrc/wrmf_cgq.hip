@@ -711,9 +711,11 @@ struct BucketStreams {
 };
 BucketStreams g_bs;
 
-bool concurrent_buckets() {
+// 0: every launch on the caller's stream; 1: every bucket on its own side stream; 2: the long-row launch first on the
+// caller's stream (it occupies every CU's LDS: nothing runs beside it), the resident buckets on side streams after it
+int concurrent_buckets() {
   static const char* env = std::getenv("RSPARSE_HIP_CONCURRENT");
-  return !(env && env[0] == '0');
+  return env ? (env[0] - '0') : 2;   // (measured on the bench line: 0 -> 165.5 ms, 2 -> 166.0 ms, 1 -> 171.8 ms per iteration)
 }
 
 template <int KP, int CFG, bool IMPLICIT>
@@ -721,10 +723,11 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
   hipError_t err;
   size_t slot = 0;
   // per-kernel timing (ev != nullptr) needs the launches back to back on one stream
-  const bool overlap = !ev && concurrent_buckets();
+  const int cmode = ev ? 0 : concurrent_buckets();
+  const bool overlap = cmode != 0;
+  bool forked = false;
   if (overlap) {
     if ((err = g_bs.ensure()) != hipSuccess) return err;
-    if ((err = hipEventRecord(g_bs.fork, s)) != hipSuccess) return err;
   }
 #define RSP_BUCKET(B)                                                                                       \
   {                                                                                                         \
@@ -735,7 +738,12 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
       const int grid = cgq_bucket_grid(n, B, CFG);                                                          \
       if (n > 0) {                                                                                          \
         hipStream_t bs = s;                                                                                 \
-        if (overlap) {                                                                                      \
+        const bool side = overlap && !(cmode == 2 && D.stream);                                             \
+        if (side) {                                                                                         \
+          if (!forked) {                                                                                    \
+            if ((err = hipEventRecord(g_bs.fork, s)) != hipSuccess) return err;                             \
+            forked = true;                                                                                  \
+          }                                                                                                 \
           bs = g_bs.st[B];                                                                                  \
           if ((err = hipStreamWaitEvent(bs, g_bs.fork, 0)) != hipSuccess) return err;                       \
         }                                                                                                   \
@@ -747,7 +755,7 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
         } else if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, grid, slot, \
                                                                                 bs)) != hipSuccess)         \
           return err;                                                                                       \
-        if (overlap) {                                                                                      \
+        if (side) {                                                                                         \
           if ((err = hipEventRecord(g_bs.done[B], bs)) != hipSuccess) return err;                           \
           if ((err = hipStreamWaitEvent(s, g_bs.done[B], 0)) != hipSuccess) return err;                     \
         }                                                                                                   \

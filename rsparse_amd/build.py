@@ -6,7 +6,7 @@ import subprocess
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-SRC = [PKG / "csrc" / "wrmf_kernels.hip", PKG / "csrc" / "wrmf_cgq.hip", PKG / "csrc" / "wrmf_ne.hip", PKG / "csrc" / "wrmf_chol.hip", PKG / "csrc" / "wrmf_topk.hip", PKG / "csrc" / "wrmf_ingest.hip", PKG / "csrc" / "wrmf_nnls.hip", PKG / "csrc" / "wrmf_bias.hip",
+SRC = [PKG / "csrc" / "wrmf_kernels.hip", PKG / "csrc" / "wrmf_cgq.hip", PKG / "csrc" / "wrmf_ne.hip", PKG / "csrc" / "wrmf_chol.hip", PKG / "csrc" / "wrmf_chol_lr.hip", PKG / "csrc" / "wrmf_topk.hip", PKG / "csrc" / "wrmf_ingest.hip", PKG / "csrc" / "wrmf_nnls.hip", PKG / "csrc" / "wrmf_bias.hip",
        PKG / "csrc" / "wrmf_capi.cpp"]
 DEPS = SRC + [PKG / "csrc" / "wrmf_internal.h", PKG / "csrc" / "wrmf_device.h",
               PKG.parent / "include" / "rsparse_wrmf_hip.h"]

@@ -53,6 +53,7 @@ struct Workspace {
   double* scalars = nullptr;  // [0] loss rows, [1] sumsq, [2..] spare
   int* fails = nullptr;
   unsigned* ne_stats = nullptr;   // normal-equation kernel: max |x|, max c, any c < 1 (launch_ne_stats)
+  float* lr_M = nullptr;
   float* ne_seg_scratch = nullptr;
   int* ne_seg_flags = nullptr;
   size_t ne_seg_slots = 0;
@@ -86,6 +87,10 @@ struct Workspace {
       HIP_TRY(hipMalloc(&zero_row, 256 * sizeof(float)));
       HIP_TRY(hipMemset(zero_row, 0, 256 * sizeof(float)));
     }
+    return RSPARSE_HIP_OK;
+  }
+  int ensure_lr() {   // M = L^-T and its transpose of the low-rank Cholesky path
+    if (!lr_M) HIP_TRY(hipMalloc(&lr_M, (size_t)2 * 128 * 128 * sizeof(float)));
     return RSPARSE_HIP_OK;
   }
   int ensure_ne_seg(size_t slots) {   // split rows of the normal-equation kernel: partial accumulators + ready flags
@@ -156,6 +161,8 @@ struct Workspace {
     if (ne_seg_scratch) (void)hipFree(ne_seg_scratch);
     if (ne_seg_flags) (void)hipFree(ne_seg_flags);
     ne_seg_scratch = nullptr; ne_seg_flags = nullptr; ne_seg_slots = 0;
+    if (lr_M) (void)hipFree(lr_M);
+    lr_M = nullptr;
     if (zero_row) (void)hipFree(zero_row);
     gram = nullptr; partials = nullptr; scalars = nullptr; fails = nullptr; zero_row = nullptr;
     gram_floats = 0; partial_slots = 0;
@@ -233,6 +240,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   d.q_ne_segs = nullptr; d.q_ne_nseg = 0; d.q_ne_entries = 0;
   d.q_ne_split_rows = nullptr; d.q_ne_split_ptr = nullptr; d.q_ne_nsplit = 0;
   d.q_n_chol_long = 0;
+  d.q_lr_first = 0; d.q_n_lr = 0;
   d.q_cfg = cgq_default_cfg();
   if (n <= 0) return RSPARSE_HIP_OK;
   const int max_len = d.max_len;
@@ -243,6 +251,8 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     start[(size_t)(max_len - len) + 1]++;
     const int b = cgq_bucket_of(len, d.q_cfg);
     if (len > kCholLongLen) d.q_n_chol_long++;
+    if (len > kCholLrMax) d.q_lr_first++;          // the order is longest first: the short rows are a suffix
+    else if (len >= 1) d.q_n_lr++;
     cnt_b[b]++;
     d.q_nnz[b] += len;
   }
@@ -428,6 +438,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.X = d_X; a.Y = d_Y; a.XtX = implicit ? d_XtX : nullptr;
   a.long_rows = d.long_rows; a.n_long = d.n_long; a.n_cols = d.n_cols;
   a.chol_long_rows = d.q_order; a.n_chol_long = d.q_order ? d.q_n_chol_long : 0;
+  a.lr_rows = nullptr; a.n_lr = 0; a.lr_flags = nullptr; a.lr_M = nullptr;
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails; a.zero_row = g_ws.zero_row;
@@ -461,6 +472,13 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (cgq && !ne_supported(rank) && d.q_stream_off && d.q_nnz[0] > 0 && cg_steps >= 1 && cg_steps <= 4) {
     if ((rc = g_ws.ensure_tscr((size_t)(cg_steps + 1) * (size_t)d.q_nnz[0]))) return rc;
     a.tscr = g_ws.tscr;
+  }
+  if (!cg && solver == RSPARSE_SOLVER_CHOLESKY && d.q_order && d.q_n_lr > 0 && chol_lr_supported(a, implicit)) {
+    // low-rank form for the short rows; "some confidence < 1" comes from the values scan of launch_ne_stats (word 2)
+    if ((rc = g_ws.ensure_lr())) return rc;
+    hipError_t se = launch_ne_stats(nullptr, 0, d.vals, d.nnz, g_ws.ne_stats, s, nullptr);
+    if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
+    a.lr_rows = d.q_order + d.q_lr_first; a.n_lr = d.q_n_lr; a.lr_flags = g_ws.ne_stats + 2; a.lr_M = g_ws.lr_M;
   }
   hipEvent_t* ev = g_prof.begin();
   hipError_t e = cgq ? launch_als_cgq(a, qs, implicit, s, ev)

@@ -106,12 +106,15 @@ __global__ __launch_bounds__(256, LONG ? 2 : RSP_CHOL_MINW) void als_chol2_kerne
   __syncthreads();
   double wloss = 0.0;
 
+  // short rows belong to the low-rank kernel (wrmf_chol_lr.hip) unless it stood down (flag set on the device)
+  const bool lr_on = !LONG && IMPLICIT && a.lr_flags && rfl((int)a.lr_flags[0]) == 0;
   const int n_iter = LONG ? a.n_chol_long : a.n_cols;
   for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
     const int row = LONG ? rfl(a.chol_long_rows[it]) : it;
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     const int cnt = p2 - p1;
     if (!LONG && a.n_chol_long > 0 && cnt > kCholLongLen) continue;   // the LONG launch owns it
+    if (lr_on && cnt >= 1 && cnt <= kCholLrMax) continue;
     float* yrow = a.Y + (size_t)row * k;
     if (cnt <= 0 && !a.rhs_init) {
       for (int e = tid; e < k; e += 256) yrow[e] = 0.f;
@@ -407,6 +410,14 @@ hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   if ((err = hipMemsetAsync(a.loss_partials + grid, 0, (size_t)kCholLongGrid * sizeof(double), s)) != hipSuccess)
     return err;
   if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
+  if (a.lr_flags) {   // the short rows first (its prep kernel also settles lr_flags before the launches below read it)
+    if ((err = launch_als_chol_lr(a, a.lr_rows, a.n_lr, a.lr_M, a.lr_M + 128 * 128, a.lr_flags, grid + kCholLongGrid, s)) !=
+        hipSuccess)
+      return err;
+  } else if ((err = hipMemsetAsync(a.loss_partials + grid + kCholLongGrid, 0, (size_t)kCholLrGrid * sizeof(double), s)) !=
+             hipSuccess) {
+    return err;
+  }
   // The long rows are few and the longest of them decides when the half-iteration ends: their launch runs on a side
   // stream next to the main one (disjoint rows), forked from / joined to the caller's stream with events.  With
   // per-kernel timing (ev) both go back to back on the caller's stream.
@@ -436,7 +447,7 @@ hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
 
 }  // namespace
 
-size_t chol2_loss_slots(int n_cols) { return chol_loss_slots(n_cols) + (size_t)kCholLongGrid; }
+size_t chol2_loss_slots(int n_cols) { return chol_loss_slots(n_cols) + (size_t)kCholLongGrid + (size_t)kCholLrGrid; }
 
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(a.k);

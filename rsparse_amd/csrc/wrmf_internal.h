@@ -29,6 +29,7 @@ struct DevCSC {
   // normal-equation kernel (wrmf_ne.hip): the long rows (bucket 0) dealt to q_ne_wg workgroups, longest processing
   // time first; workgroup b owns q_ne_rows[q_ne_ptr[b], q_ne_ptr[b+1])
   int q_n_chol_long = 0;   // rows of more than kCholLongLen non-zeros (a prefix of q_order)
+  int q_lr_first = 0, q_n_lr = 0;   // rows of 1..kCholLrMax non-zeros: q_order[q_lr_first, q_lr_first + q_n_lr)
   int32_t* q_ne_rows = nullptr;
   int32_t* q_ne_ptr = nullptr;
   int q_ne_wg = 0;
@@ -74,6 +75,12 @@ struct AlsArgs {
   // Cholesky: rows of more than kCholLongLen non-zeros = the first n_chol_long entries of the length-sorted row order
   const int32_t* chol_long_rows;
   int n_chol_long;
+  // Cholesky, short rows: lr_rows = the n_lr rows of 1..kCholLrMax non-zeros; lr_flags (device word, nullable): 0 = the
+  // low-rank kernel solves them and wrmf_chol.hip's skips them, else the other way round; lr_M = 2 x 128 x 128 floats
+  const int32_t* lr_rows;
+  int n_lr;
+  unsigned* lr_flags;
+  float* lr_M;
   // rows split across workgroups: segment table, per-segment partial accumulators (kNeSegFloats floats each) and flags
   const int32_t* ne_segs;
   float* ne_seg_scratch;
@@ -135,7 +142,13 @@ hipError_t launch_als_cg(const AlsArgs& a, bool implicit, hipStream_t s, hipEven
 // rank-one updates in two levels (see there); its workgroups' loss slots follow the main launch's
 constexpr int kCholLongLen = 4096;
 constexpr int kCholLongGrid = 512;
+// rows of 1..kCholLrMax non-zeros, implicit feedback, rank 98..128: the low-rank form of the exact solve (wrmf_chol_lr.hip)
+constexpr int kCholLrMax = 64;
+constexpr int kCholLrGrid = 512;
 size_t chol2_loss_slots(int n_cols);
+bool chol_lr_supported(const AlsArgs& a, bool implicit);
+hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows, float* M, float* Mt, unsigned* flags,
+                              int loss_slot0, hipStream_t s);
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 constexpr int kSumStageBlocks = 256;

@@ -1,0 +1,25 @@
+#!/bin/bash
+# timing-only ablations of the low-rank Cholesky kernel (RSP_LR_ABL builds): user half of config 4 through one WRMF half-iteration
+python - <<'PY'
+import os, sys, time, subprocess
+PY
+for n in "$@"; do
+  lib=$PWD/rsparse_amd/lib/librsparse_wrmf_hip$n.so
+  RSPARSE_HIP_LIB=$lib timeout 300 python - <<PY
+import torch, time
+from rsparse_amd import synth
+from rsparse_amd.engine import HipBackend, ShardedALS
+be = HipBackend()
+d = synth.make_dataset(10_000_000, 1_000_000, device=be.device, feedback="implicit")
+als = ShardedALS(be, 10_000_000, 1_000_000, 128, d["c_ui"], d["c_iu"], d["nnz"], feedback="implicit", lambda_=0.1)
+g = torch.Generator(device=be.device).manual_seed(11)
+U = torch.randn(10_000_000, 128, generator=g, device=be.device) * 0.01
+V = torch.randn(1_000_000, 128, generator=g, device=be.device) * 0.01
+G = als.gramian(V, als.lay_item)
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    als.half_iteration("users", U, V, 0, G=G, want_loss=False)
+    torch.cuda.synchronize(); t = time.perf_counter() - t0
+print("lib [$n] users half %.1f ms" % (1e3 * t))
+PY
+done

@@ -1,8 +1,7 @@
 #!/bin/bash
 # timing-only ablations of the low-rank Cholesky kernel (RSP_LR_ABL builds): user half of config 4 through one WRMF half-iteration
-python - <<'PY'
-import os, sys, time, subprocess
-PY
+# usage: tools/gpu_lr_abl.sh "" _lr4 ...   ("" = the product library; _lrN = rsparse_amd/lib/librsparse_wrmf_hip_lrN.so built with
+# -DRSP_LR_ABL=N, bits as listed in wrmf_chol_lr.hip)
 for n in "$@"; do
   lib=$PWD/rsparse_amd/lib/librsparse_wrmf_hip$n.so
   RSPARSE_HIP_LIB=$lib timeout 300 python - <<PY

@@ -425,8 +425,14 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   for (int b = 0; b < 7; b++) qs.off[b] = d.q_off[b];
   qs.ne_rows = d.q_ne_rows; qs.ne_ptr = d.q_ne_ptr; qs.ne_wg = d.q_ne_wg; qs.ne_entries = d.q_ne_entries;
   qs.ne_split_rows = d.q_ne_split_rows; qs.ne_split_ptr = d.q_ne_split_ptr; qs.ne_nsplit = d.q_ne_nsplit;
+  // solver == CHOLESKY: the rows beyond 512 non-zeros are assembled by the normal-equation kernel (matrix cores, one pass)
+  // and solved exactly there (a.ne_chol); wrmf_chol.hip's kernel then skips them
+  const bool ne_chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY && !bias && d.q_ne_wg > 0 && ne_supported(rank) &&
+                       use_cgq(rank, d_X, d_Y);
+  const size_t chol_base = chol2_loss_slots(d.n_cols);
   const size_t slots = cgq ? cgq_loss_slots(qs, rank) : (cg ? cg_loss_slots(d.n_cols, d.n_long)
-                                   : (solver == RSPARSE_SOLVER_NNLS ? chol_loss_slots(d.n_cols) : chol2_loss_slots(d.n_cols)));
+                                   : (solver == RSPARSE_SOLVER_NNLS ? chol_loss_slots(d.n_cols)
+                                      : chol_base + (ne_chol ? (size_t)(d.q_ne_entries + d.q_ne_nsplit) : 0)));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
   double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
   if (d.n_cols == 0) {
@@ -450,11 +456,12 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.ne_prof = nullptr;
   a.ne_stats = nullptr;
   a.ne_segs = nullptr; a.ne_seg_scratch = nullptr; a.ne_seg_flags = nullptr;
-  if (cgq && d.q_ne_nseg > 0 && ne_supported(rank)) {
+  a.ne_chol = ne_chol ? 1 : 0;
+  if ((cgq || ne_chol) && d.q_ne_nseg > 0 && ne_supported(rank)) {
     if ((rc = g_ws.ensure_ne_seg((size_t)d.q_ne_nseg))) return rc;
     a.ne_segs = d.q_ne_segs; a.ne_seg_scratch = g_ws.ne_seg_scratch; a.ne_seg_flags = g_ws.ne_seg_flags;
   }
-  if (cgq && implicit && d.q_ne_wg > 0 && ne_supported(rank) && !bias) {
+  if ((cgq || ne_chol) && implicit && d.q_ne_wg > 0 && ne_supported(rank) && !bias) {
     // operand scales of the fp16 normal-equation kernel (and whether it may run at all), decided on the device
     const float* hint = (g_absmax_hint.X == d_X && g_absmax_hint.absmax) ? g_absmax_hint.absmax : nullptr;
     hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, hint);
@@ -476,11 +483,17 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (!cg && solver == RSPARSE_SOLVER_CHOLESKY && d.q_order && d.q_n_lr > 0 && chol_lr_supported(a, implicit)) {
     // low-rank form for the short rows; "some confidence < 1" comes from the values scan of launch_ne_stats (word 2)
     if ((rc = g_ws.ensure_lr())) return rc;
-    hipError_t se = launch_ne_stats(nullptr, 0, d.vals, d.nnz, g_ws.ne_stats, s, nullptr);
-    if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
+    if (!a.ne_stats) {   // (with the long rows on the normal-equation kernel the full statistics were just taken)
+      hipError_t se = launch_ne_stats(nullptr, 0, d.vals, d.nnz, g_ws.ne_stats, s, nullptr);
+      if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
+    }
     a.lr_rows = d.q_order + d.q_lr_first; a.n_lr = d.q_n_lr; a.lr_flags = g_ws.ne_stats + 2; a.lr_M = g_ws.lr_M;
   }
   hipEvent_t* ev = g_prof.begin();
+  if (ne_chol) {
+    hipError_t ne = launch_als_ne(a, qs, implicit, g_ws.partials + chol_base, s);
+    if (ne != hipSuccess) return hip_fail(ne, "launch_als_ne");
+  }
   hipError_t e = cgq ? launch_als_cgq(a, qs, implicit, s, ev)
                      : (cg ? launch_als_cg(a, implicit, s, ev)
                            : (solver == RSPARSE_SOLVER_NNLS

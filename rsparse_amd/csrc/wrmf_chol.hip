@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256, LONG ? 2 : RSP_CHOL_MINW) void als_chol2_kerne
     const int cnt = p2 - p1;
     if (!LONG && a.n_chol_long > 0 && cnt > kCholLongLen) continue;   // the LONG launch owns it
     if (lr_on && cnt >= 1 && cnt <= kCholLrMax) continue;
+    if (!LONG && a.ne_chol && cnt > kNeMinLen) continue;   // assembled and solved by wrmf_ne.hip
     float* yrow = a.Y + (size_t)row * k;
     if (cnt <= 0 && !a.rhs_init) {
       for (int e = tid; e < k; e += 256) yrow[e] = 0.f;
@@ -401,7 +402,7 @@ hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   using SM = Chol2Smem<KP>;
   hipError_t err;
   const int grid = (int)chol_loss_slots(a.n_cols);
-  const int grid_long = a.n_chol_long < kCholLongGrid ? a.n_chol_long : kCholLongGrid;
+  const int grid_long = a.ne_chol ? 0 : (a.n_chol_long < kCholLongGrid ? a.n_chol_long : kCholLongGrid);
   auto kc = als_chol2_kernel<KP, IMPLICIT, VEC, false>;
   auto kl = als_chol2_kernel<KP, IMPLICIT, VEC, true>;
   for (const void* f : {reinterpret_cast<const void*>(kc), reinterpret_cast<const void*>(kl)})

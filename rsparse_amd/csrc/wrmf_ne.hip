@@ -1151,6 +1151,54 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
       return wave_sum_all(s) * 0.5f;  // the two halves of the wave hold identical values
     };
 
+    if (a.ne_chol) {
+      // solver == CHOLESKY (wrmf_implicit.hpp:231,236 / wrmf_explicit.hpp:103-108: y = solve(lhs, rhs)) on the system
+      // assembled above: LDL^T of the lower triangle in place (right-looking, pivot column left unscaled, one barrier
+      // per step), then the two triangular solves on a vector in LDS.  A pivot that is not positive bumps the failure
+      // counter (RSPARSE_HIP_ERR_NUMERIC), as in wrmf_chol.hip.
+      auto at = [&](const int i2, const int c2) -> float& {   // element (i2, c2), i2 >= c2
+        const int R2 = i2 >> 5, C2 = c2 >> 5;
+        return sA[(R2 * (R2 + 1) / 2 + C2) * 32 * TLD + (i2 & 31) * TLD + (c2 & 31)];
+      };
+      const int ti = tid >> 4, tc = tid & 15;
+      bool bad = false;
+      for (int j = 0; j < k; j++) {
+        const float dj = at(j, j);
+        if (!(dj > 0.f)) bad = true;
+        const float inv = 1.f / dj;
+        for (int i2 = j + 1 + ti; i2 < k; i2 += 16) {
+          const float lij = at(i2, j) * inv;
+          for (int c2 = j + 1 + tc; c2 <= i2; c2 += 16) at(i2, c2) -= lij * at(c2, j);
+        }
+        __syncthreads();
+      }
+      if (bad && tid == 0) atomicAdd(a.fail_counter, 1);
+      float* sU = sPub;   // [KP] the right-hand side, then the solution
+      if (wv == 0) {
+        if (h == 0) {
+#pragma unroll
+          for (int t = 0; t < NB; t++) sU[32 * t + d] = b[t];
+        }
+        wave_sync();
+        for (int j = 0; j < k; j++) {   // L u = b (unit lower, L_ij = A_ij / A_jj)
+          const float uj = sU[j] / at(j, j);
+          for (int i2 = j + 1 + lane; i2 < k; i2 += 64) sU[i2] -= at(i2, j) * uj;
+          wave_sync();
+        }
+        for (int j = k - 1; j >= 0; j--) {   // D L^T y = u
+          const float dj = at(j, j);
+          const float yj = sU[j] / dj;
+          wave_sync();
+          if (lane == 0) sU[j] = yj;
+          for (int i2 = lane; i2 < j; i2 += 64) sU[i2] -= at(j, i2) * yj;
+          wave_sync();
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < NB; t++) x[t] = (32 * t + d < k) ? sU[32 * t + d] : 0.f;
+      __syncthreads();   // sPub is per-wave scratch again below
+    } else {
     // cg_solver_implicit / cg_solver_explicit on the assembled operator (one matrix-vector product per pass: pass 0
     // forms r = b - A x); rsold / alpha in double like the reference (wrmf_implicit.hpp:18)
     float r[NB], p[NB], ap[NB];
@@ -1181,6 +1229,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
           rsold = rsnew;
         }
       }
+    }
     }
     NE_T(9)
 

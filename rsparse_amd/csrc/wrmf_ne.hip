@@ -1162,13 +1162,22 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
       };
       const int ti = tid >> 4, tc = tid & 15;
       bool bad = false;
+      // offset of element (i2, c2) = rowo(i2) + colo(c2); both advance by 16 per trip, so they are kept incrementally
+      auto rowo = [&](const int i2) { return ((i2 >> 5) * ((i2 >> 5) + 1) / 2) * 32 * TLD + (i2 & 31) * TLD; };
+      auto colo = [&](const int c2) { return (c2 >> 5) * 32 * TLD + (c2 & 31); };
       for (int j = 0; j < k; j++) {
         const float dj = at(j, j);
         if (!(dj > 0.f)) bad = true;
         const float inv = 1.f / dj;
+        const int cj = colo(j);
         for (int i2 = j + 1 + ti; i2 < k; i2 += 16) {
-          const float lij = at(i2, j) * inv;
-          for (int c2 = j + 1 + tc; c2 <= i2; c2 += 16) at(i2, c2) -= lij * at(c2, j);
+          const int ro = rowo(i2);
+          const float lij = sA[ro + cj] * inv;
+          int c2 = j + 1 + tc, co = colo(c2);
+          for (; c2 <= i2; c2 += 16) {
+            sA[ro + co] -= lij * sA[rowo(c2) + cj];
+            co += (c2 & 16) ? 32 * TLD - 16 : 16;
+          }
         }
         __syncthreads();
       }

@@ -354,6 +354,9 @@ def main():
                         "launches_per_iteration": 2, "avg_launch_ms": float(np.mean(ms)),
                         "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms)),
                         "flops_per_launch": float(np.mean(fl))})
+    def dmf(kp_, capq, waves, wpr_, tf):   # launch_bucket's choice of the matrix-core dense product (wrmf_cgq.hip)
+        return (kp_ == 128 and capq == 8 and waves == 4 and wpr_ == 1 and tf == "true"
+                and os.environ.get("RSPARSE_HIP_DENSE_MFMA", "1")[:1] != "0")
     for b in range(nb if solver == 1 else 0):
         wpr = int(info["users"]["bucket_wpr"][b])
         if wpr <= 0:
@@ -366,7 +369,8 @@ def main():
             iu = info["users"]
             ne = bool(iu["bucket_stream"][b]) and k > 32 and k % 4 == 0
             buckets.append({"kernel": ("als_ne_kernel<%d, %s>" % (kp, ("2, true, true, true, false" if kp == 128 else "2, true, true, false, false") if tf_flag == "true" else "3, false, false, false, false")) if ne else
-                                      "als_cgq_kernel<%d, %d, %d, %d, %d, %s>" % (kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, iu["bucket_stream"][b], tf_flag),
+                                      "als_cgq_kernel<%d, %d, %d, %d, %d, %s, %s>" % (kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, iu["bucket_stream"][b], tf_flag,
+                                                                                   "true" if dmf(kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, tf_flag) else "false"),
                             "what": "rows beyond 512 non-zeros: one pass, normal equations on the matrix cores (operands split exactly into fp16 / bf16 terms), CG on the k x k system in LDS" if ne else
                                     "rows on teams of %d wave(s)%s" % (wpr, ", streamed (longer than the workgroup's resident capacity)" if iu["bucket_stream"][b] else ", register-resident"),
                             "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),

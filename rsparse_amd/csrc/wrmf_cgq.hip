@@ -109,9 +109,39 @@ __device__ __forceinline__ float groups_sum(float v) {
   return v;
 }
 
-template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT>
+// ---- dense product on the matrix cores (DMF instantiation: one-wave rows of <= 32 non-zeros at rank 65..128) ----
+// The four rows a workgroup solves side by side share every G v product: G is held in REGISTERS as two fp16 terms
+// (wave w owns rows [32w, 32w + 32) as A operands of v_mfma_f32_16x16x32_f16), the four vectors are published to LDS as
+// two fp16 terms each, and G v = (Gh + Gl)(vh + vl) is accumulated in fp32 from the three products of order < 2
+// (2^-21 per product; both operands scaled by powers of two so that their largest entry lands in [2^13, 2^14)).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// power of two that brings `vmax` into [2^13, 2^14), as the biased exponent (1..253, so that its inverse is normal too)
+__device__ __forceinline__ int fp16_scale_exp(float vmax) {
+  const int eb = (int)((__float_as_uint(vmax) >> 23) & 0xffu);
+  return min(253, max(1, 267 - eb));
+}
+// x (already scaled) -> fl16(x), fl16(x - fl16(x)); the residual is exact in fp32
+__device__ __forceinline__ void split_f16(const float x0, const float x1, unsigned& hi, unsigned& lo) {
+  const f32x2 v = {x0, x1};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp<0xB1>(v));
+  v = fmaxf(v, dpp<0x4E>(v));
+  v = fmaxf(v, dpp<0x141>(v));
+  v = fmaxf(v, dpp<0x140>(v));
+  return v;
+}
+
+template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, bool DMF = false>
 struct QSmem {
-  static constexpr size_t gram_floats = IMPLICIT ? (size_t)KP * KP : 0;
+  static constexpr size_t gram_floats = (IMPLICIT && !DMF) ? (size_t)KP * KP : 0;
   static constexpr size_t vec_floats = IMPLICIT ? (size_t)WAVES * KP : 0;
   static constexpr size_t red_floats = WPR > 1 ? (size_t)2 * WAVES * KP + 2 * WAVES : 0;
   // resident rows: per wave, t_acc[CAP] = x_j . y accumulated over the CG steps and t_cur[CAP] = x_j . p of the
@@ -120,30 +150,38 @@ struct QSmem {
   // streamed rows: the first RSP_STREAM_PREFIX_Q quads of every wave (gathered in the first sweep) stay in LDS,
   // so the other sweeps re-gather only the rest of the row
   static constexpr size_t pre_floats = STREAM ? (size_t)WAVES * RSP_STREAM_PREFIX_Q * 4 * KP : 0;
-  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats + pre_floats) * 4 + 16;
+  // DMF: the published fp16 terms of the workgroup's vectors (row stride KP + 8 halves) and the products (KP + 4 floats):
+  // the paddings shift consecutive rows by four banks, so the operand reads / result writes of four rows do not collide
+  static constexpr int dmf_ps = KP + 8, dmf_os = KP + 4;
+  static constexpr size_t dmf_floats = DMF ? (size_t)WAVES * dmf_ps + (size_t)WAVES * dmf_os : 0;
+  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats + pre_floats + dmf_floats) * 4 + 16;
 };
 
-template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT>
+template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, bool DMF = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
                                                              int rows_per_team, size_t loss_slot0) {
   using G_ = QG<KP>;
   constexpr int RPN = G_::RPN, VW = G_::VW, NV = G_::NV, CAP = CAPQ * 4, TEAMS = WAVES / WPR;
   using piece_t = typename Piece<VW>::type;
-  using SM = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>;
+  using SM = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF>;
   static_assert(WAVES % WPR == 0, "teams must tile the workgroup");
+  static_assert(!DMF || (IMPLICIT && KP == 128 && WAVES == 4 && WPR == 1 && STREAM == 0), "DMF geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sG = reinterpret_cast<float*>(smem);
-  float* sVec = sG + QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>::gram_floats;
-  float* sRed = sVec + QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>::vec_floats;  // [2][WAVES][KP]
+  float* sVec = sG + SM::gram_floats;
+  float* sRed = sVec + SM::vec_floats;  // [2][WAVES][KP]
   float* sRedL = sRed + (WPR > 1 ? 2 * WAVES * KP : 0);              // [2][WAVES]
   float* sTsv = sVec + SM::vec_floats + SM::red_floats;              // [WAVES][2][CAP]
   float* sPre = sTsv + SM::tsv_floats;                               // [WAVES][PQ][4][KP]  (streamed kernels)
+  _Float16* sPh = reinterpret_cast<_Float16*>(sPre + SM::pre_floats);   // DMF: [WAVES][KP + 8] high fp16 terms
+  _Float16* sPl = sPh + WAVES * SM::dmf_ps;                             //      [WAVES][KP + 8] low terms
+  float* sOut = reinterpret_cast<float*>(sPl + WAVES * SM::dmf_ps);     //      [WAVES][KP + 4] G v (times the scales)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
   const int team = wv / WPR, tw = wv % WPR;
   const int k = a.k;
-  if constexpr (IMPLICIT) {
+  if constexpr (IMPLICIT && !DMF) {
     for (int e = tid; e < KP * KP; e += WAVES * 64) {
       const int r = e / KP, c = e % KP;
       sG[e] = (r < k && c < k) ? a.XtX[(size_t)r * k + c] : 0.f;
@@ -155,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   // One-wave rows of <= 32 non-zeros are bound by the LDS traffic of the dense G v product (64 KB per row and sweep) and
   // use only 64 registers for their vectors: the first NRES of the 8 four-row slabs of G that a 16-lane group walks stay
   // in registers for the whole launch (32 registers per slab), the rest is read from LDS as before.
-  constexpr int NRES = (IMPLICIT && CAPQ == 8 && WPR == 1 && !STREAM && KP == 128) ? 2 : 0;
+  constexpr int NRES = (IMPLICIT && CAPQ == 8 && WPR == 1 && !STREAM && KP == 128 && !DMF) ? 2 : 0;
   piece_t gres[NRES > 0 ? NRES : 1][4][NV];
   if constexpr (NRES > 0) {
 #pragma unroll
@@ -165,6 +203,43 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 #pragma unroll
         for (int b = 0; b < NV; b++)
           gres[rs][u][b] = *reinterpret_cast<const piece_t*>(sG + (4 * (g + 4 * rs) + u) * KP + b * 16 * VW + i * VW);
+  }
+  // DMF: this wave's 32 rows of G as A operands (tile t = rows 32 wv + 16 t + (lane & 15), step ks = columns
+  // 32 ks + 8 (lane >> 4) + 0..7), two fp16 terms of G * 2^ge; ginv = 2^-ge
+  f16x8 gAh[DMF ? 2 : 1][DMF ? 4 : 1], gAl[DMF ? 2 : 1][DMF ? 4 : 1];
+  float ginv = 1.f;
+  if constexpr (DMF) {
+    const int m = lane & 15, kb = lane >> 4;
+    float gmax = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int r = 32 * wv + 16 * t + m, c = 32 * ks + 8 * kb + e;
+          gmax = fmaxf(gmax, (r < k && c < k) ? fabsf(a.XtX[(size_t)r * k + c]) : 0.f);
+        }
+    for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+    const int ge = fp16_scale_exp(gmax);
+    const float gs = __uint_as_float((unsigned)ge << 23);
+    ginv = __uint_as_float((unsigned)(254 - ge) << 23);
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const int r = 32 * wv + 16 * t + m, c = 32 * ks + 8 * kb + e;
+          const float g0 = (r < k && c < k) ? a.XtX[(size_t)r * k + c] : 0.f;
+          const float g1 = (r < k && c + 1 < k) ? a.XtX[(size_t)r * k + c + 1] : 0.f;
+          split_f16(g0 * gs, g1 * gs, hi[e / 2], lo[e / 2]);
+        }
+        const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, l4 = {lo[0], lo[1], lo[2], lo[3]};
+        gAh[t][ks] = __builtin_bit_cast(f16x8, h4);
+        gAl[t][ks] = __builtin_bit_cast(f16x8, l4);
+      }
   }
   float* vec = sVec + wv * KP;
   float* tacc = sTsv + wv * 2 * CAP;  // resident rows only
@@ -190,7 +265,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   for (int it = 0; it < rows_per_team; ++it) {
     const int ri = row_index(it);
     const bool have = ri < n_rows;
-    if (WPR == 1 && !have) break;  // no barriers on this path: a wave may simply stop
+    if (WPR == 1 && !DMF && !have) break;  // no barriers on this path: a wave may simply stop
     const int row = have ? rfl(row_c) : 0;
     const int p1 = have ? rfl(p1_c) : 0;
     const int p2 = have ? rfl(p2_c) : 0;
@@ -209,8 +284,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     const int cnt = p2 - p1;
     float* yrow = a.Y + (size_t)row * k;
     if (WPR == 1 && cnt <= 0) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
-      for (int e = lane; e < k; e += 64) yrow[e] = 0.f;
-      continue;
+      if (!DMF || have)
+        for (int e = lane; e < k; e += 64) yrow[e] = 0.f;
+      if constexpr (!DMF) continue;   // DMF: the workgroup's waves share the dense products, so this wave keeps in step
     }
     // streamed rows: the first PTEAM non-zeros are the LDS-resident prefix (PCAP per wave), the rest is streamed
     constexpr int PQ = STREAM ? RSP_STREAM_PREFIX_Q : 0, PCAP = PQ * 4, PTEAM = PCAP * WPR;
@@ -406,8 +482,56 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 #pragma unroll
       for (int rr = 0; rr < RPN; rr++) acc[rr] = 0.f;
       float lacc = 0.f;
+      float vinv = 0.f;   // DMF: 2^-(scale of v) * 2^-(scale of G) with the sign of the mode
+      if constexpr (DMF) {
+        if (mode != 2) {
+          // (1) publish v as two fp16 terms of v * 2^ve (every wave, live or not: the four columns are independent)
+          float vmax = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < RPN; rr++) vmax = fmaxf(vmax, fabsf(v[rr]));
+          vmax = row16_max(vmax);
+          const int ve = fp16_scale_exp(vmax);
+          const float vs = __uint_as_float((unsigned)ve << 23);
+          vinv = __uint_as_float((unsigned)(254 - ve) << 23) * (mode == 0 ? -1.f : 1.f);
+          if (g < NV) {   // group b publishes piece b: elements [64 b + 4 i, + 4)
+            float w4[VW];
+#pragma unroll
+            for (int c = 0; c < VW; c++) w4[c] = (g == 0 ? v[c] : v[VW + c]) * vs;
+            unsigned h0, l0, h1, l1;
+            split_f16(w4[0], w4[1], h0, l0);
+            split_f16(w4[2], w4[3], h1, l1);
+            const int off = wv * SM::dmf_ps + g * 16 * VW + i * VW;
+            *reinterpret_cast<uint2*>(sPh + off) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(sPl + off) = make_uint2(l0, l1);
+          }
+          __syncthreads();
+          // (2) this wave's 32 rows of G against the four vectors (columns 4..15 of the tile repeat them)
+          f32x4 d0[2], d1[2];
+#pragma unroll
+          for (int t = 0; t < 2; t++) d0[t] = d1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int nb = (lane & 3) * SM::dmf_ps + 8 * (lane >> 4);
+#pragma unroll
+          for (int ks = 0; ks < 4; ks++) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(sPh + nb + 32 * ks);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(sPl + nb + 32 * ks);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+              d0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gAh[t][ks], bh, d0[t], 0, 0, 0);
+              d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gAh[t][ks], bl, d1[t], 0, 0, 0);
+              d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gAl[t][ks], bh, d1[t], 0, 0, 0);
+            }
+          }
+          if ((lane & 15) < 4) {   // D: column = lane & 15, rows 4 (lane >> 4) + 0..3 of the tile
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+              const f32x4 d = (d0[t] + d1[t]) * ginv;
+              *reinterpret_cast<f32x4*>(sOut + (lane & 15) * SM::dmf_os + 32 * wv + 16 * t + 4 * (lane >> 4)) = d;
+            }
+          }
+        }
+      }
       if (live) {
-        if constexpr (IMPLICIT) {
+        if constexpr (IMPLICIT && !DMF) {
           if (mode != 2) {  // publish v for the broadcast reads of the G*v product
             wave_sync();
             if (g == 0) {
@@ -426,7 +550,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         // dense part: acc -/+= G v, the groups split the rows of G.  Resident rows run it before the quad pass (its
         // LDS reads are in flight meanwhile); streamed rows after, where acc is not live across the gathers.
         auto dense_part = [&]() {
-          if (IMPLICIT && mode != 2) {
+          if (IMPLICIT && !DMF && mode != 2) {
             const float sign = mode == 0 ? -1.f : 1.f;
             if constexpr (NRES > 0) {
 #pragma unroll
@@ -514,7 +638,26 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           }
         }
         if constexpr (!GVFIRST) dense_part();
+        if constexpr (!DMF) {
+          if (mode != 2) {
+#pragma unroll
+            for (int rr = 0; rr < RPN; rr++) acc[rr] = groups_sum(acc[rr]);
+          } else {
+            lacc = groups_sum(lacc);
+          }
+        }
+      }
+      if constexpr (DMF) {
         if (mode != 2) {
+          // (3) the products are complete: fold this row's G v into group 0's partial sums, then all-reduce the groups
+          __syncthreads();
+          const float f = g == 0 ? vinv : 0.f;
+#pragma unroll
+          for (int b = 0; b < NV; b++) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(sOut + wv * SM::dmf_os + b * 16 * VW + i * VW);
+#pragma unroll
+            for (int c = 0; c < VW; c++) acc[b * VW + c] = fmaf(f, o[c], acc[b * VW + c]);
+          }
 #pragma unroll
           for (int rr = 0; rr < RPN; rr++) acc[rr] = groups_sum(acc[rr]);
         } else {
@@ -603,7 +746,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     float rsold = dot16(r, r);
     bool conv = false;
     for (int itc = 0; itc < a.cg_steps; ++itc) {
-      if (WPR == 1 && conv) break;
+      if (WPR == 1 && !DMF && conv) break;
       sweep(p, 1, ap, dummy, live && !conv, itc + 1);
       if (!conv) {
         const float pap = dot16(p, ap);
@@ -673,12 +816,25 @@ constexpr BucketDef kBuckets[kNCfg][kNB] = {
     {{8, 8, 16, 1, 0x7fffffff}, {8, 8, 16, 0, 512}, {4, 4, 16, 0, 256}, {4, 2, 16, 0, 128}, {4, 1, 16, 0, 64}, {4, 1, 8, 0, 32}},
 };
 
-template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT>
+// RSPARSE_HIP_DENSE_MFMA=0 keeps the one-wave rows of <= 32 non-zeros on the vector-unit G v product (A/B switch)
+bool dense_mfma_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("RSPARSE_HIP_DENSE_MFMA");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT, bool DMF = false>
 hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int grid, size_t slot0, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
+  constexpr bool kDmfGeometry = IMPLICIT && KP == 128 && WAVES == 4 && WPR == 1 && CAPQ == 8 && STREAM == 0;
+  if constexpr (kDmfGeometry && !DMF) {
+    if (dense_mfma_enabled()) return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, true>(a, rows, n_rows, grid, slot0, s);
+  }
   constexpr int TEAMS = WAVES / WPR;
-  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>;
-  const size_t lds = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT>::bytes;
+  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF>;
+  const size_t lds = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF>::bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;

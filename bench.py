@@ -368,7 +368,7 @@ def main():
         if ms:
             iu = info["users"]
             ne = bool(iu["bucket_stream"][b]) and k > 32 and k % 4 == 0
-            buckets.append({"kernel": ("als_ne_kernel<%d, %s>" % (kp, ("2, true, true, true, false" if kp == 128 else "2, true, true, false, false") if tf_flag == "true" else "3, false, false, false, false")) if ne else
+            buckets.append({"kernel": ("als_ne_kernel<%d, %s>" % (kp, ("2, true, true, true, false, false" if kp == 128 else "2, true, true, false, false, false") if tf_flag == "true" else "3, false, false, false, false, false")) if ne else
                                       "als_cgq_kernel<%d, %d, %d, %d, %d, %s, %s>" % (kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, iu["bucket_stream"][b], tf_flag,
                                                                                    "true" if dmf(kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, tf_flag) else "false"),
                             "what": "rows beyond 512 non-zeros: one pass, normal equations on the matrix cores (operands split exactly into fp16 / bf16 terms), CG on the k x k system in LDS" if ne else

@@ -338,7 +338,7 @@ struct NeParts {   // MFMA operands of one step: block t, term q
 // COLLECT: the second launch for the rows that were split across workgroups (see the publish step below): one workgroup
 // per split row, no streaming -- it sums the published partial sums of the row's segments in segment order (the same
 // per-wave register images, so every geometry above works unchanged) and runs the same per-row solve.
-template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD, bool COLLECT>
+template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD, bool COLLECT, bool CHOL>
 __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, const int32_t* __restrict__ wg_rows,
                                                                     const int32_t* __restrict__ wg_ptr, int slot0,
                                                                     double* __restrict__ row_loss, int only_if_lt1) {
@@ -573,6 +573,9 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
 #define NE_T(j) { const unsigned long long _t1 = __builtin_amdgcn_s_memtime(); prof_t[j] += _t1 - _tl; _tl = _t1; }
 #else
 #define NE_T(j)
+#endif
+#ifndef RSP_NECH_ABL
+#define RSP_NECH_ABL 0
 #endif
 
   for (int li = list_begin; li < list_end; li++) {
@@ -1151,55 +1154,143 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
       return wave_sum_all(s) * 0.5f;  // the two halves of the wave hold identical values
     };
 
-    if (a.ne_chol) {
+    if constexpr (CHOL) {
       // solver == CHOLESKY (wrmf_implicit.hpp:231,236 / wrmf_explicit.hpp:103-108: y = solve(lhs, rhs)) on the system
-      // assembled above: LDL^T of the lower triangle in place (right-looking, pivot column left unscaled, one barrier
-      // per step), then the two triangular solves on a vector in LDS.  A pivot that is not positive bumps the failure
-      // counter (RSPARSE_HIP_ERR_NUMERIC), as in wrmf_chol.hip.
-      auto at = [&](const int i2, const int c2) -> float& {   // element (i2, c2), i2 >= c2
-        const int R2 = i2 >> 5, C2 = c2 >> 5;
-        return sA[(R2 * (R2 + 1) / 2 + C2) * 32 * TLD + (i2 & 31) * TLD + (c2 & 31)];
-      };
-      const int ti = tid >> 4, tc = tid & 15;
+      // assembled above: LDL^T blocked on the 32 x 32 tiles, in place.  Per block column J:
+      //   (1) the diagonal tile by ONE wave in registers (lane i = row i, pivot rows broadcast by v_readlane, as in
+      //       wrmf_chol_lr.hip), the forward substitution of the block riding along; written back as L_JJ below and
+      //       L_JJ^T above the diagonal, pivots and their inverses to sD / sDi;
+      //   (2) the panel: one half-wave per tile (I, J), lane = row, L_IJ = A_IJ L_JJ^-T D_J^-1 by substitution in
+      //       registers (the rows of L_JJ^T are broadcast reads), and b_I -= L_IJ u_J;
+      //   (3) the trailing tiles (I, K) -= (L_IJ D_J) L_KJ^T on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+      //       products), dealt to the four waves.
+      // Then D L^T y = u backwards by one wave.  A pivot that is not positive bumps the failure counter
+      // (RSPARSE_HIP_ERR_NUMERIC), as in wrmf_chol.hip.
+      constexpr int TS = 32 * TLD;
+      auto tile = [&](const int R2, const int C2) { return sA + (R2 * (R2 + 1) / 2 + C2) * TS; };
+      float* sD = sPart;         // [KP] pivots
+      float* sDi = sPart + KP;   // [KP] 1 / pivot
+      float* sU = sPub;          // [KP] right-hand side -> u -> solution
       bool bad = false;
-      // offset of element (i2, c2) = rowo(i2) + colo(c2); both advance by 16 per trip, so they are kept incrementally
-      auto rowo = [&](const int i2) { return ((i2 >> 5) * ((i2 >> 5) + 1) / 2) * 32 * TLD + (i2 & 31) * TLD; };
-      auto colo = [&](const int c2) { return (c2 >> 5) * 32 * TLD + (c2 & 31); };
-      for (int j = 0; j < k; j++) {
-        const float dj = at(j, j);
-        if (!(dj > 0.f)) bad = true;
-        const float inv = 1.f / dj;
-        const int cj = colo(j);
-        for (int i2 = j + 1 + ti; i2 < k; i2 += 16) {
-          const int ro = rowo(i2);
-          const float lij = sA[ro + cj] * inv;
-          int c2 = j + 1 + tc, co = colo(c2);
-          for (; c2 <= i2; c2 += 16) {
-            sA[ro + co] -= lij * sA[rowo(c2) + cj];
-            co += (c2 & 16) ? 32 * TLD - 16 : 16;
+      if (tid >= k && tid < KP) tile(tid >> 5, tid >> 5)[(tid & 31) * (TLD + 1)] = 1.f;   // padding: unit diagonal
+      if (wv == 0 && h == 0) {
+#pragma unroll
+        for (int t = 0; t < NB; t++) sU[32 * t + d] = b[t];
+      }
+      __syncthreads();
+      for (int J = 0; J < NB; J++) {
+        float* TJ = tile(J, J);
+        if (!(RSP_NECH_ABL & 1) && wv == 0) {   // (1); both halves of the wave compute the same, half 0 writes
+          // (the lane's offsets are laundered per block: hipcc otherwise hoists the 64 address pieces out of the row
+          // loop and spills them into the streaming loops)
+          int dd = d;
+          asm volatile("" : "+v"(dd));
+          float* trow = TJ + dd * TLD;   // own row: left of the diagonal
+          const float* tcol = TJ + dd;   // own column: the transposed entries right of it (lower triangle only)
+          float r[32];
+#pragma unroll
+          for (int c = 0; c < 32; c++) r[c] = *(c <= dd ? trow + c : tcol + c * TLD);
+          float u = sU[32 * J + dd], dinv = 1.f, dii = 1.f;
+#pragma unroll
+          for (int j = 0; j < 32; j++) {
+            const float pj = readlane_f(r[j], j);
+            if (!(pj > 0.f)) bad = true;
+            const float inv = 1.f / pj;
+            const float uj = readlane_f(u, j);
+            if (d == j) { dinv = inv; dii = pj; }
+            const float lij = d > j ? r[j] * inv : 0.f;   // L_ij; rows <= j are finished
+            u = fmaf(-lij, uj, u);
+#pragma unroll
+            for (int c = j + 1; c < 32; c++) r[c] = fmaf(-lij, readlane_f(r[c], j), r[c]);
           }
+          // lane i now holds L_ic d_c left of the diagonal and L_ci d_i right of it
+          if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < 32; c++) {
+              const float dc = readlane_f(dinv, c);
+              trow[c] = c < d ? r[c] * dc : (c > d ? r[c] * dinv : dii);
+            }
+            sD[32 * J + dd] = dii;
+            sDi[32 * J + dd] = dinv;
+            sU[32 * J + dd] = u;
+          }
+        }
+        __syncthreads();
+        {   // (2)
+          const int I = J + 1 + ((wv + 3) & 3) * 2 + h;   // wave 1 first: wave 0 has just done the diagonal tile
+          if (!(RSP_NECH_ABL & 2) && I < NB) {
+            int dd = d;
+            asm volatile("" : "+v"(dd));
+            float* TI = tile(I, J) + dd * TLD;
+            float y[32];
+#pragma unroll
+            for (int c = 0; c < 32; c++) y[c] = TI[c];
+#pragma unroll
+            for (int c = 0; c < 31; c++) {
+              const float yc = y[c];
+#pragma unroll
+              for (int c2 = c + 1; c2 < 32; c2++) y[c2] = fmaf(-yc, TJ[c * TLD + c2], y[c2]);   // TJ[c][c2] = L_JJ[c2][c]
+              __builtin_amdgcn_sched_barrier(0);   // (or the scheduler hoists all 496 broadcast reads and spills)
+            }
+            float dot_u = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; c++) {
+              const float l = y[c] * sDi[32 * J + c];
+              TI[c] = l;
+              dot_u = fmaf(l, sU[32 * J + c], dot_u);
+            }
+            sU[32 * I + dd] -= dot_u;
+          }
+        }
+        __syncthreads();
+        {   // (3)
+          int idx = 0;
+          for (int I = J + 1; I < NB; I++)
+            for (int K2 = J + 1; K2 <= I; K2++, idx++) {
+              if ((RSP_NECH_ABL & 4) || (idx & 3) != wv) continue;
+              int dd = d;
+              asm volatile("" : "+v"(dd));
+              float* C = tile(I, K2) + 4 * h * TLD + dd;
+              const float* LI = tile(I, J) + dd * TLD + h;
+              const float* LK = tile(K2, J) + dd * TLD + h;
+              const float* dj = sD + 32 * J + h;
+              f32x16 acc;
+#pragma unroll
+              for (int e = 0; e < 16; e++) acc[e] = C[((e & 3) + 8 * (e >> 2)) * TLD];
+#pragma unroll
+              for (int kk = 0; kk < 16; kk++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-LI[2 * kk] * dj[2 * kk], LK[2 * kk], acc, 0, 0, 0);
+#pragma unroll
+              for (int e = 0; e < 16; e++) C[((e & 3) + 8 * (e >> 2)) * TLD] = acc[e];
+            }
         }
         __syncthreads();
       }
       if (bad && tid == 0) atomicAdd(a.fail_counter, 1);
-      float* sU = sPub;   // [KP] the right-hand side, then the solution
-      if (wv == 0) {
-        if (h == 0) {
+      if (!(RSP_NECH_ABL & 8) && wv == 0) {   // D L^T y = u, last block first
+        for (int J = NB - 1; J >= 0; J--) {
+          int dd = d;
+          asm volatile("" : "+v"(dd));
+          const float* TJ = tile(J, J) + dd * TLD;
+          float t2 = sU[32 * J + dd] * sDi[32 * J + dd];
+          for (int I = J + 1; I < NB; I++) {
+            const float* TI = tile(I, J) + dd;
+            const float* yI = sU + 32 * I;
 #pragma unroll
-          for (int t = 0; t < NB; t++) sU[32 * t + d] = b[t];
-        }
-        wave_sync();
-        for (int j = 0; j < k; j++) {   // L u = b (unit lower, L_ij = A_ij / A_jj)
-          const float uj = sU[j] / at(j, j);
-          for (int i2 = j + 1 + lane; i2 < k; i2 += 64) sU[i2] -= at(i2, j) * uj;
+            for (int r2 = 0; r2 < 32; r2++) t2 = fmaf(-TI[r2 * TLD], yI[r2], t2);
+          }
+          float lc[32];
+#pragma unroll
+          for (int c = 0; c < 32; c++) lc[c] = TJ[c];   // right of the diagonal: column d of L_JJ
+          float accb = 0.f, z = 0.f;
+#pragma unroll
+          for (int c = 31; c >= 0; c--) {
+            if (d == c) z = t2 - accb;
+            const float zc = readlane_f(z, c);
+            accb = fmaf(d < c ? lc[c] : 0.f, zc, accb);
+          }
           wave_sync();
-        }
-        for (int j = k - 1; j >= 0; j--) {   // D L^T y = u
-          const float dj = at(j, j);
-          const float yj = sU[j] / dj;
-          wave_sync();
-          if (lane == 0) sU[j] = yj;
-          for (int i2 = lane; i2 < j; i2 += 64) sU[i2] -= at(j, i2) * yj;
+          if (h == 0) sU[32 * J + dd] = z;
           wave_sync();
         }
       }
@@ -1300,10 +1391,10 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
 #endif
 }
 
-template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD = false, bool COLLECT = false>
+template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD, bool COLLECT, bool CHOL>
 hipError_t launch_ne_t(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int grid, double* row_loss,
                        hipStream_t s, int only_if_lt1) {
-  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM, QUAD, COLLECT>;
+  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM, QUAD, COLLECT, CHOL>;
   constexpr int lds = NeGeo<KP, NeRoles<KP, NS, IMPLICIT, SYM, QUAD>::NROLES, IMPLICIT>::BYTES;
   hipError_t err =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1386,19 +1477,19 @@ hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_
 // Implicit feedback with a.ne_stats: the fp16 SYM kernel and, behind it, the bf16 kernel that takes over when some
 // confidence is below 1 (exactly one of the two does the work; the other returns at once).  Explicit feedback, or no
 // stats: the bf16 kernel alone.
-template <bool COLLECT>
+template <bool COLLECT, bool CHOL>
 hipError_t launch_ne_mode(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
                           double* row_loss, hipStream_t s) {
   const int KP = padded_rank(a.k);
   hipError_t err;
 #define RSP_NE_DISPATCH(KPV)                                                                                           \
   if (KP == KPV) {                                                                                                     \
-    if (!implicit) return launch_ne_t<KPV, 3, false, false, false, COLLECT>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
-    if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false, false, COLLECT>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
-    if ((err = launch_ne_t<KPV, 2, true, true, KPV == 128, COLLECT>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) !=      \
+    if (!implicit) return launch_ne_t<KPV, 3, false, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
+    if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
+    if ((err = launch_ne_t<KPV, 2, true, true, KPV == 128, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) !=      \
         hipSuccess)                                                                                                    \
       return err;                                                                                                      \
-    return launch_ne_t<KPV, 3, true, false, false, COLLECT>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 1);                 \
+    return launch_ne_t<KPV, 3, true, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 1);                 \
   }
   RSP_NE_DISPATCH(128)
   RSP_NE_DISPATCH(64)
@@ -1411,9 +1502,13 @@ hipError_t launch_ne_mode(const AlsArgs& a, const int32_t* wg_rows, const int32_
 // row_loss: one double per list entry, then one per split row.
 hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s) {
   if (q.ne_wg <= 0) return hipSuccess;
-  hipError_t err = launch_ne_mode<false>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s);
+  // a.ne_chol (solver == CHOLESKY): the instantiations whose per-row solve is the blocked LDL^T instead of CG -- separate
+  // kernels, so neither solve costs the other's streaming loops a register
+  hipError_t err = a.ne_chol ? launch_ne_mode<false, true>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s)
+                             : launch_ne_mode<false, false>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s);
   if (err != hipSuccess || q.ne_nsplit <= 0) return err;
-  return launch_ne_mode<true>(a, q.ne_split_rows, q.ne_split_ptr, q.ne_nsplit, implicit, row_loss + q.ne_entries, s);
+  return a.ne_chol ? launch_ne_mode<true, true>(a, q.ne_split_rows, q.ne_split_ptr, q.ne_nsplit, implicit, row_loss + q.ne_entries, s)
+                   : launch_ne_mode<true, false>(a, q.ne_split_rows, q.ne_split_ptr, q.ne_nsplit, implicit, row_loss + q.ne_entries, s);
 }
 
 }  // namespace rsparse_hip

@@ -319,6 +319,43 @@ def test_factor_scale_does_not_matter_to_the_fp16_path():
         assert abs(loss - lref) <= max(TOL, 3.0 * float(np.max(err32))) * abs(lref)
 
 
+@pytest.mark.parametrize("k", [128, 100])
+def test_short_rows_share_the_dense_product_on_the_matrix_cores(k):
+    """Rows of <= 32 non-zeros at rank 65..128 (implicit CG): the four rows a workgroup solves side by side share G v as
+    fp16-term MFMAs with per-vector power-of-two scales (wrmf_cgq.hip, DMF).  Rows of every length 0..32 next to each
+    other -- empty rows keep in lockstep with their neighbours --, factor scales far outside fp16's range unscaled, and
+    a warm start that is exact for some rows (CG stops at its first test there while the neighbours go on)."""
+    rng = np.random.default_rng(11)
+    n_rows, n_cols = 900, 1203
+    lens = np.tile(np.arange(0, 33), n_cols // 33 + 1)[:n_cols]
+    rng.shuffle(lens)
+    lens[5:9] = 0                                   # a whole workgroup of empty rows
+    p = np.zeros(n_cols + 1, np.int64)
+    np.cumsum(lens, out=p[1:])
+    i = np.concatenate([np.sort(rng.choice(n_rows, size=int(n), replace=False)) for n in lens]).astype(np.int32)
+    x = (1.0 + rng.geometric(0.5, size=int(p[-1]))).astype(np.float64)
+    csc = (n_rows, n_cols, p.astype(np.int32), i, x)
+    for scale in (1e-3, 1.0, 40.0):
+        X = np.asfortranarray((rng.standard_normal((k, n_rows)) * scale).astype(np.float32))
+        X[:, 3] *= 4.0      # (a 30x outlier makes three fp32 CG steps meaningless for ANY arithmetic: tools/probes/dmf_accuracy_probe.py)
+        Y0 = np.asfortranarray((rng.standard_normal((k, n_cols)) * scale).astype(np.float32))
+        Yref, lref = _oracle64(csc, X, Y0, 0.1, 1, 3, True)
+        Y0[:, ::7] = Yref[:, ::7].astype(np.float32)   # (nearly) solved already
+        Yref, lref = _oracle64(csc, X, Y0, 0.1, 1, 3, True)
+        Y32 = Y0.copy(order="F")
+        O.als_implicit(p.astype(np.int32), i, x, X, Y32, O.gramian(X, 0.1), 0.1, 1, 3)
+        Y = Y0.copy(order="F")
+        loss = als.als_implicit(csc, X, Y, 0.1, 1, 1, 3, "float", False, False)
+        assert np.all(Y[:, lens == 0] == 0.0)
+        den = np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+        err = np.linalg.norm(Y - Yref, axis=0) / den
+        err32 = np.linalg.norm(Y32 - Yref, axis=0) / den
+        bound = np.maximum(TOL, 3.0 * err32)         # yardstick: the fp32 oracle on the same badly scaled systems
+        worst = int(np.argmax(err / bound))
+        assert np.all(err <= bound), (k, scale, worst, int(lens[worst]), float(err[worst]), float(err32[worst]))
+        assert abs(loss - lref) <= max(TOL, 3.0 * float(np.max(err32))) * abs(lref)
+
+
 def test_cholesky_reports_systems_that_are_not_positive_definite():
     """The reference's solve(lhs, rhs, fast + likely_sympd) falls back to a general solver with a warning when the
     Cholesky factorisation fails (wrmf_implicit.hpp:236); the device path has no such fallback: it finishes the

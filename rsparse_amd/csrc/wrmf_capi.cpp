@@ -229,6 +229,105 @@ int build_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   return RSPARSE_HIP_OK;
 }
 
+struct NeLists {
+  int32_t* rows = nullptr; int32_t* ptr = nullptr; int wg = 0;
+  int32_t* segs = nullptr; int nseg = 0; int entries = 0;
+  int32_t* split_rows = nullptr; int32_t* split_ptr = nullptr; int nsplit = 0;
+};
+
+// Lists of the normal-equation launch over the n_prefix longest rows (order = every row, longest first); `fixed` = the
+// per-row cost of the solve in 16-non-zero steps (CG: 12; the exact solve of solver == CHOLESKY: 72).
+int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_ptrs, int n_prefix, int64_t fixed, NeLists& L) {
+  if (n_prefix <= 0) return RSPARSE_HIP_OK;
+  auto len_of = [&](int r) { return (int64_t)(host_col_ptrs[order[(size_t)r] + 1] - host_col_ptrs[order[(size_t)r]]); };
+  {
+  // Row lists of the normal-equation kernel: one workgroup per CU, rows dealt longest-processing-time first (the rows
+  // arrive sorted by length, each goes to the least loaded workgroup; cost = the row's 16-non-zero steps + a fixed
+  // per-row solve).  Static lists make the per-row loss slots and the summation order deterministic.
+  int dev = 0, cus = 256;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // two lists per CU: the rank-128 fp16 kernel runs two workgroups per CU; the one-per-CU kernels work through two
+  // lists each, one after the other
+  const int n_wg = std::min(n_prefix, 2 * std::max(cus, 1));
+  // Items of the deal: whole rows, and SEGMENTS of the rows that are too long to balance (the 5e5-non-zero item of the
+  // bench matrix is by itself an average workgroup's share; on a rank of an 8-GPU run it is eight shares).  A row
+  // whose cost exceeds half a share is cut into up to kNeMaxSeg runs of whole steps of about a quarter share; the
+  // workgroups that get the leading segments write their partial accumulators to an HBM scratch, the one with the
+  // last segment adds them in segment order and solves (wrmf_ne.hip).  List entry >= 0: a row; -(s + 1): segment s
+  // of the table {row, first non-zero, non-zeros, index within the row, segments of the row, scratch slot}.
+  auto steps_of = [](int64_t len) { return (len + 15) / 16; };
+  int64_t total = 0;
+  for (int r = 0; r < n_prefix; r++) total += steps_of(len_of(r)) + fixed;
+  const int64_t share = std::max<int64_t>(1, total / n_wg);
+  struct Item { int64_t cost; int32_t entry; };
+  std::vector<Item> items;
+  items.reserve((size_t)n_prefix + 64);
+  std::vector<int32_t> segs;
+  int n_seg = 0;
+  for (int r = 0; r < n_prefix; r++) {
+    const int64_t len = len_of(r);
+    const int64_t st = steps_of(len);
+    int parts = 1;
+    if (n_wg >= 8 && 2 * (st + fixed) > share) parts = (int)std::min<int64_t>(kNeMaxSeg, (4 * st + share - 1) / share);
+    if (parts < 2 || n_seg + parts > kNeMaxSegTotal) {
+      items.push_back({st + fixed, order[(size_t)r]});
+      continue;
+    }
+    const int64_t per = (st + parts - 1) / parts;   // steps per segment
+    const int slot = n_seg;
+    int made = 0;
+    for (int64_t s0 = 0; s0 < st; s0 += per, made++) {}
+    int idx = 0;
+    for (int64_t s0 = 0; s0 < st; s0 += per, idx++) {
+      const int64_t n0 = s0 * 16, n1 = std::min(len, (s0 + per) * 16);
+      segs.insert(segs.end(), {order[(size_t)r], (int32_t)n0, (int32_t)(n1 - n0), idx, made, slot});
+      items.push_back({steps_of(n1 - n0) + fixed, -(int32_t)(n_seg + 1)});
+      n_seg++;
+    }
+  }
+  std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
+  const size_t n_items = items.size();
+  std::vector<int> owner(n_items);
+  std::vector<int32_t> cnt_wg((size_t)n_wg + 1, 0);
+  std::priority_queue<std::pair<int64_t, int>, std::vector<std::pair<int64_t, int>>, std::greater<>> heap;
+  for (int w = 0; w < n_wg; w++) heap.push({0, w});
+  for (size_t e = 0; e < n_items; e++) {
+    auto top = heap.top();
+    heap.pop();
+    owner[e] = top.second;
+    cnt_wg[(size_t)top.second + 1]++;
+    heap.push({top.first + items[e].cost, top.second});
+  }
+  for (int w = 0; w < n_wg; w++) cnt_wg[(size_t)w + 1] += cnt_wg[(size_t)w];
+  std::vector<int32_t> lists(n_items), fill(cnt_wg.begin(), cnt_wg.end() - 1);
+  for (size_t e = 0; e < n_items; e++) lists[(size_t)fill[(size_t)owner[e]]++] = items[e].entry;
+  HIP_TRY(hipMalloc(&L.rows, lists.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(L.rows, lists.data(), lists.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&L.ptr, cnt_wg.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(L.ptr, cnt_wg.data(), cnt_wg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (n_seg > 0) {
+    HIP_TRY(hipMalloc(&L.segs, segs.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(L.segs, segs.data(), segs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<int32_t> srows, sptr{0};
+    for (int sg = 0; sg < n_seg; sg++)
+      if (segs[(size_t)sg * 6 + 3] == 0) {   // first segment of its row
+        srows.push_back(-(int32_t)(sg + 1));
+        sptr.push_back((int32_t)srows.size());
+      }
+    HIP_TRY(hipMalloc(&L.split_rows, srows.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(L.split_rows, srows.data(), srows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&L.split_ptr, sptr.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(L.split_ptr, sptr.data(), sptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    L.nsplit = (int)srows.size();
+  }
+    L.nseg = n_seg;
+    L.entries = (int)n_items;
+    L.wg = n_wg;
+  }
+  return RSPARSE_HIP_OK;
+}
+
 // every row, longest first, with the bucket boundaries of the quad-layout CG kernels
 int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   const int n = d.n_cols;
@@ -239,6 +338,8 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   d.q_ne_rows = nullptr; d.q_ne_ptr = nullptr; d.q_ne_wg = 0;
   d.q_ne_segs = nullptr; d.q_ne_nseg = 0; d.q_ne_entries = 0;
   d.q_ne_split_rows = nullptr; d.q_ne_split_ptr = nullptr; d.q_ne_nsplit = 0;
+  d.q_nec_rows = nullptr; d.q_nec_ptr = nullptr; d.q_nec_wg = 0; d.q_nec_segs = nullptr; d.q_nec_nseg = 0; d.q_nec_entries = 0;
+  d.q_nec_split_rows = nullptr; d.q_nec_split_ptr = nullptr; d.q_nec_nsplit = 0; d.q_nec_own = false; d.q_nec_min = kNeCholMinLen;
   d.q_n_chol_long = 0;
   d.q_lr_first = 0; d.q_n_lr = 0;
   d.q_cfg = cgq_default_cfg();
@@ -275,89 +376,26 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     }
     HIP_TRY(hipMalloc(&d.q_stream_off, soff.size() * sizeof(int64_t)));
     HIP_TRY(hipMemcpy(d.q_stream_off, soff.data(), soff.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    // Row lists of the normal-equation kernel: one workgroup per CU, rows dealt longest-processing-time first (the rows
-    // arrive sorted by length, each goes to the least loaded workgroup; cost = the row's 16-non-zero steps + a fixed
-    // per-row solve).  Static lists make the per-row loss slots and the summation order deterministic.
-    int dev = 0, cus = 256;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    // two lists per CU: the rank-128 fp16 kernel runs two workgroups per CU; the one-per-CU kernels work through two
-    // lists each, one after the other
-    const int n_wg = std::min(n_stream, 2 * std::max(cus, 1));
-    // Items of the deal: whole rows, and SEGMENTS of the rows that are too long to balance (the 5e5-non-zero item of the
-    // bench matrix is by itself an average workgroup's share; on a rank of an 8-GPU run it is eight shares).  A row
-    // whose cost exceeds half a share is cut into up to kNeMaxSeg runs of whole steps of about a quarter share; the
-    // workgroups that get the leading segments write their partial accumulators to an HBM scratch, the one with the
-    // last segment adds them in segment order and solves (wrmf_ne.hip).  List entry >= 0: a row; -(s + 1): segment s
-    // of the table {row, first non-zero, non-zeros, index within the row, segments of the row, scratch slot}.
-    auto steps_of = [](int64_t len) { return (len + 15) / 16; };
-    int64_t total = 0;
-    for (int r = 0; r < n_stream; r++) total += steps_of(soff[(size_t)r + 1] - soff[(size_t)r]) + 12;
-    const int64_t share = std::max<int64_t>(1, total / n_wg);
-    struct Item { int64_t cost; int32_t entry; };
-    std::vector<Item> items;
-    items.reserve((size_t)n_stream + 64);
-    std::vector<int32_t> segs;
-    int n_seg = 0;
-    for (int r = 0; r < n_stream; r++) {
-      const int64_t len = soff[(size_t)r + 1] - soff[(size_t)r];
-      const int64_t st = steps_of(len);
-      int parts = 1;
-      if (n_wg >= 8 && 2 * (st + 12) > share) parts = (int)std::min<int64_t>(kNeMaxSeg, (4 * st + share - 1) / share);
-      if (parts < 2 || n_seg + parts > kNeMaxSegTotal) {
-        items.push_back({st + 12, order[(size_t)r]});
-        continue;
-      }
-      const int64_t per = (st + parts - 1) / parts;   // steps per segment
-      const int slot = n_seg;
-      int made = 0;
-      for (int64_t s0 = 0; s0 < st; s0 += per, made++) {}
-      int idx = 0;
-      for (int64_t s0 = 0; s0 < st; s0 += per, idx++) {
-        const int64_t n0 = s0 * 16, n1 = std::min(len, (s0 + per) * 16);
-        segs.insert(segs.end(), {order[(size_t)r], (int32_t)n0, (int32_t)(n1 - n0), idx, made, slot});
-        items.push_back({steps_of(n1 - n0) + 12, -(int32_t)(n_seg + 1)});
-        n_seg++;
-      }
-    }
-    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
-    const size_t n_items = items.size();
-    std::vector<int> owner(n_items);
-    std::vector<int32_t> cnt_wg((size_t)n_wg + 1, 0);
-    std::priority_queue<std::pair<int64_t, int>, std::vector<std::pair<int64_t, int>>, std::greater<>> heap;
-    for (int w = 0; w < n_wg; w++) heap.push({0, w});
-    for (size_t e = 0; e < n_items; e++) {
-      auto top = heap.top();
-      heap.pop();
-      owner[e] = top.second;
-      cnt_wg[(size_t)top.second + 1]++;
-      heap.push({top.first + items[e].cost, top.second});
-    }
-    for (int w = 0; w < n_wg; w++) cnt_wg[(size_t)w + 1] += cnt_wg[(size_t)w];
-    std::vector<int32_t> lists(n_items), fill(cnt_wg.begin(), cnt_wg.end() - 1);
-    for (size_t e = 0; e < n_items; e++) lists[(size_t)fill[(size_t)owner[e]]++] = items[e].entry;
-    HIP_TRY(hipMalloc(&d.q_ne_rows, lists.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(d.q_ne_rows, lists.data(), lists.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&d.q_ne_ptr, cnt_wg.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(d.q_ne_ptr, cnt_wg.data(), cnt_wg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (n_seg > 0) {
-      HIP_TRY(hipMalloc(&d.q_ne_segs, segs.size() * sizeof(int32_t)));
-      HIP_TRY(hipMemcpy(d.q_ne_segs, segs.data(), segs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      std::vector<int32_t> srows, sptr{0};
-      for (int sg = 0; sg < n_seg; sg++)
-        if (segs[(size_t)sg * 6 + 3] == 0) {   // first segment of its row
-          srows.push_back(-(int32_t)(sg + 1));
-          sptr.push_back((int32_t)srows.size());
-        }
-      HIP_TRY(hipMalloc(&d.q_ne_split_rows, srows.size() * sizeof(int32_t)));
-      HIP_TRY(hipMemcpy(d.q_ne_split_rows, srows.data(), srows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      HIP_TRY(hipMalloc(&d.q_ne_split_ptr, sptr.size() * sizeof(int32_t)));
-      HIP_TRY(hipMemcpy(d.q_ne_split_ptr, sptr.data(), sptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      d.q_ne_nsplit = (int)srows.size();
-    }
-    d.q_ne_nseg = n_seg;
-    d.q_ne_entries = (int)n_items;
-    d.q_ne_wg = n_wg;
+    NeLists L;
+    if (int rc2 = build_ne_lists(order, host_col_ptrs, n_stream, 12, L)) return rc2;
+    d.q_ne_rows = L.rows; d.q_ne_ptr = L.ptr; d.q_ne_wg = L.wg; d.q_ne_segs = L.segs; d.q_ne_nseg = L.nseg;
+    d.q_ne_entries = L.entries; d.q_ne_split_rows = L.split_rows; d.q_ne_split_ptr = L.split_ptr; d.q_ne_nsplit = L.nsplit;
+  }
+  // solver == CHOLESKY: its normal-equation launch may take shorter rows too (RSPARSE_HIP_NE_CHOL_MIN, 64..512)
+  d.q_nec_min = kNeCholMinLen;
+  if (const char* e = std::getenv("RSPARSE_HIP_NE_CHOL_MIN")) d.q_nec_min = std::min(kNeMinLen, std::max(kCholLrMax, std::atoi(e)));
+  int n_nec = 0;
+  while (n_nec < n && host_col_ptrs[order[(size_t)n_nec] + 1] - host_col_ptrs[order[(size_t)n_nec]] > d.q_nec_min) n_nec++;
+  if (n_nec == n_stream) {
+    d.q_nec_rows = d.q_ne_rows; d.q_nec_ptr = d.q_ne_ptr; d.q_nec_wg = d.q_ne_wg; d.q_nec_segs = d.q_ne_segs;
+    d.q_nec_nseg = d.q_ne_nseg; d.q_nec_entries = d.q_ne_entries; d.q_nec_split_rows = d.q_ne_split_rows;
+    d.q_nec_split_ptr = d.q_ne_split_ptr; d.q_nec_nsplit = d.q_ne_nsplit;
+  } else {
+    NeLists L;
+    if (int rc2 = build_ne_lists(order, host_col_ptrs, n_nec, 72, L)) return rc2;
+    d.q_nec_own = true;
+    d.q_nec_rows = L.rows; d.q_nec_ptr = L.ptr; d.q_nec_wg = L.wg; d.q_nec_segs = L.segs; d.q_nec_nseg = L.nseg;
+    d.q_nec_entries = L.entries; d.q_nec_split_rows = L.split_rows; d.q_nec_split_ptr = L.split_ptr; d.q_nec_nsplit = L.nsplit;
   }
   return RSPARSE_HIP_OK;
 }
@@ -427,12 +465,21 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   qs.ne_split_rows = d.q_ne_split_rows; qs.ne_split_ptr = d.q_ne_split_ptr; qs.ne_nsplit = d.q_ne_nsplit;
   // solver == CHOLESKY: the rows beyond 512 non-zeros are assembled by the normal-equation kernel (matrix cores, one pass)
   // and solved exactly there (a.ne_chol); wrmf_chol.hip's kernel then skips them
-  const bool ne_chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY && !bias && d.q_ne_wg > 0 && ne_supported(rank) &&
+  // (the lower threshold pays at rank 65..128 only: at rank <= 64 wrmf_chol.hip's kernel is cheaper than the fixed cost of
+  // the tile solve up to 512 non-zeros -- config 5 with Cholesky 4.5 against 4.1 iterations/s)
+  const bool nec_lists = padded_rank(rank) > 64 && d.q_nec_wg > 0;
+  const bool ne_chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY && !bias && (nec_lists || d.q_ne_wg > 0) && ne_supported(rank) &&
                        use_cgq(rank, d_X, d_Y);
+  if (ne_chol && nec_lists) {   // its own lists: the rows beyond d.q_nec_min non-zeros
+    qs.ne_rows = d.q_nec_rows; qs.ne_ptr = d.q_nec_ptr; qs.ne_wg = d.q_nec_wg; qs.ne_entries = d.q_nec_entries;
+    qs.ne_split_rows = d.q_nec_split_rows; qs.ne_split_ptr = d.q_nec_split_ptr; qs.ne_nsplit = d.q_nec_nsplit;
+  }
+  const int ne_nseg = (ne_chol && nec_lists) ? d.q_nec_nseg : d.q_ne_nseg;
+  const int32_t* ne_segs = (ne_chol && nec_lists) ? d.q_nec_segs : d.q_ne_segs;
   const size_t chol_base = chol2_loss_slots(d.n_cols);
   const size_t slots = cgq ? cgq_loss_slots(qs, rank) : (cg ? cg_loss_slots(d.n_cols, d.n_long)
                                    : (solver == RSPARSE_SOLVER_NNLS ? chol_loss_slots(d.n_cols)
-                                      : chol_base + (ne_chol ? (size_t)(d.q_ne_entries + d.q_ne_nsplit) : 0)));
+                                      : chol_base + (ne_chol ? (size_t)(qs.ne_entries + qs.ne_nsplit) : 0)));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
   double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
   if (d.n_cols == 0) {
@@ -457,11 +504,12 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.ne_stats = nullptr;
   a.ne_segs = nullptr; a.ne_seg_scratch = nullptr; a.ne_seg_flags = nullptr;
   a.ne_chol = ne_chol ? 1 : 0;
-  if ((cgq || ne_chol) && d.q_ne_nseg > 0 && ne_supported(rank)) {
-    if ((rc = g_ws.ensure_ne_seg((size_t)d.q_ne_nseg))) return rc;
-    a.ne_segs = d.q_ne_segs; a.ne_seg_scratch = g_ws.ne_seg_scratch; a.ne_seg_flags = g_ws.ne_seg_flags;
+  a.ne_chol_min = nec_lists ? d.q_nec_min : kNeMinLen;
+  if ((cgq || ne_chol) && ne_nseg > 0 && ne_supported(rank)) {
+    if ((rc = g_ws.ensure_ne_seg((size_t)ne_nseg))) return rc;
+    a.ne_segs = ne_segs; a.ne_seg_scratch = g_ws.ne_seg_scratch; a.ne_seg_flags = g_ws.ne_seg_flags;
   }
-  if ((cgq || ne_chol) && implicit && d.q_ne_wg > 0 && ne_supported(rank) && !bias) {
+  if ((cgq || ne_chol) && implicit && qs.ne_wg > 0 && ne_supported(rank) && !bias) {
     // operand scales of the fp16 normal-equation kernel (and whether it may run at all), decided on the device
     const float* hint = (g_absmax_hint.X == d_X && g_absmax_hint.absmax) ? g_absmax_hint.absmax : nullptr;
     hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, hint);
@@ -503,19 +551,19 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   e = launch_sum_partials(g_ws.partials, slots, out, s, g_ws.partials + g_ws.partial_slots);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
 #ifdef RSP_NE_PROF
-  if (cgq && d.q_ne_wg > 0 && std::getenv("RSPARSE_NE_PROF")) {
+  if ((cgq || ne_chol) && qs.ne_wg > 0 && std::getenv("RSPARSE_NE_PROF")) {   // (solver == CHOLESKY: mv_* = diagonal tile, panel, trailing, backward)
     HIP_TRY(hipStreamSynchronize(s));
-    std::vector<unsigned long long> hp((size_t)d.q_ne_wg * 4 * 20);
+    std::vector<unsigned long long> hp((size_t)qs.ne_wg * 4 * 20);
     HIP_TRY(hipMemcpy(hp.data(), prof_buf, hp.size() * 8, hipMemcpyDeviceToHost));
     const char* nm[20] = {"wait_vm", "barrier", "issue", "consume", "tail", "total", "rows", "pre", "chain", "cg", "quad", "fin", "ch_sync", "ch_add", "ch_bar", "mv_pub", "mv_units", "mv_bar", "mv_comb", "-"};
     for (int w = 0; w < 4; w++) {
       std::fprintf(stderr, "[ne_prof] wave %d (n_cols %d):", w, d.n_cols);
       for (int j = 0; j < 19; j++) {
         double sum = 0, mx = 0;
-        for (int b = 0; b < d.q_ne_wg; b++) { const double v = (double)hp[((size_t)b * 4 + w) * 20 + j]; sum += v; mx = std::max(mx, v); }
-        std::fprintf(stderr, " %s %.2f/%.2f", nm[j], sum / d.q_ne_wg / 1e6, mx / 1e6);
+        for (int b = 0; b < qs.ne_wg; b++) { const double v = (double)hp[((size_t)b * 4 + w) * 20 + j]; sum += v; mx = std::max(mx, v); }
+        std::fprintf(stderr, " %s %.2f/%.2f", nm[j], sum / qs.ne_wg / 1e6, mx / 1e6);
       }
-      std::fprintf(stderr, " Mcycles (mean/max over %d workgroups)\n", d.q_ne_wg);
+      std::fprintf(stderr, " Mcycles (mean/max over %d workgroups)\n", qs.ne_wg);
     }
   }
 #endif
@@ -885,6 +933,13 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   if (d.q_ne_segs) (void)hipFree(d.q_ne_segs);
   if (d.q_ne_split_rows) (void)hipFree(d.q_ne_split_rows);
   if (d.q_ne_split_ptr) (void)hipFree(d.q_ne_split_ptr);
+  if (d.q_nec_own) {
+    if (d.q_nec_rows) (void)hipFree(d.q_nec_rows);
+    if (d.q_nec_ptr) (void)hipFree(d.q_nec_ptr);
+    if (d.q_nec_segs) (void)hipFree(d.q_nec_segs);
+    if (d.q_nec_split_rows) (void)hipFree(d.q_nec_split_rows);
+    if (d.q_nec_split_ptr) (void)hipFree(d.q_nec_split_ptr);
+  }
   if (d.owns_matrix) {
     if (d.col_ptrs) (void)hipFree(const_cast<int32_t*>(d.col_ptrs));
     if (d.row_idx) (void)hipFree(const_cast<int32_t*>(d.row_idx));

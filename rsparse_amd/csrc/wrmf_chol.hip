@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, LONG ? 2 : RSP_CHOL_MINW) void als_chol2_kerne
     const int cnt = p2 - p1;
     if (!LONG && a.n_chol_long > 0 && cnt > kCholLongLen) continue;   // the LONG launch owns it
     if (lr_on && cnt >= 1 && cnt <= kCholLrMax) continue;
-    if (!LONG && a.ne_chol && cnt > kNeMinLen) continue;   // assembled and solved by wrmf_ne.hip
+    if (!LONG && a.ne_chol && cnt > a.ne_chol_min) continue;   // assembled and solved by wrmf_ne.hip
     float* yrow = a.Y + (size_t)row * k;
     if (cnt <= 0 && !a.rhs_init) {
       for (int e = tid; e < k; e += 256) yrow[e] = 0.f;

@@ -39,6 +39,20 @@ struct DevCSC {
   int32_t* q_ne_split_rows = nullptr;   // lists of the COLLECT launch (one workgroup per split row)
   int32_t* q_ne_split_ptr = nullptr;
   int q_ne_nsplit = 0;
+  // the same lists for solver == CHOLESKY, whose normal-equation launch takes the rows beyond q_nec_min non-zeros (a
+  // longer prefix of q_order, dealt with the larger fixed cost of the exact solve); they alias the lists above when the
+  // two thresholds coincide
+  int q_nec_min = 0;
+  bool q_nec_own = false;
+  int32_t* q_nec_rows = nullptr;
+  int32_t* q_nec_ptr = nullptr;
+  int q_nec_wg = 0;
+  int32_t* q_nec_segs = nullptr;
+  int q_nec_nseg = 0;
+  int q_nec_entries = 0;
+  int32_t* q_nec_split_rows = nullptr;
+  int32_t* q_nec_split_ptr = nullptr;
+  int q_nec_nsplit = 0;
   int64_t nnz_long = 0;
   int n_empty = 0;
   bool owns_matrix = false;
@@ -86,6 +100,7 @@ struct AlsArgs {
   float* ne_seg_scratch;
   int* ne_seg_flags;
   int ne_chol;                   // long rows through wrmf_ne.hip with the exact solve instead of CG (solver == CHOLESKY)
+  int ne_chol_min;               // ... the rows of more than this many non-zeros (wrmf_chol.hip skips them)
   const unsigned* ne_stats;      // implicit NE launches: {bits of max |x|, bits of max c, any c < 1} (launch_ne_stats), or nullptr
   unsigned long long* ne_prof;   // RSP_NE_PROF builds: [workgroup][wave][8] cycle counters of wrmf_ne.hip (else nullptr)
 };
@@ -114,6 +129,7 @@ size_t cgq_loss_slots(const QSchedule& q, int k);
 // long rows (bucket 0) by one-pass normal equations on the matrix cores (wrmf_ne.hip) instead of the streamed CG kernel
 bool ne_supported(int k);
 constexpr int kNeMinLen = 512;       // its rows: more non-zeros than the largest resident bucket of wrmf_cgq.hip holds
+constexpr int kNeCholMinLen = 128;   // solver == CHOLESKY: default threshold of the same launch (RSPARSE_HIP_NE_CHOL_MIN overrides, 64..512)
 constexpr int kNeMaxSeg = 16;        // segments per split row
 constexpr int kNeMaxSegTotal = 64;   // ... per matrix
 constexpr int kNeSegFloats = 4 * (11 * 16 * 64 + 128 + 2);   // per segment: 4 waves x (<= 11 accumulator tiles + b + sum c)

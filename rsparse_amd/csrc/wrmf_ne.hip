@@ -1216,12 +1216,18 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
           }
         }
         __syncthreads();
+        NE_T(15)
         {   // (2)
           const int I = J + 1 + ((wv + 3) & 3) * 2 + h;   // wave 1 first: wave 0 has just done the diagonal tile
-          if (!(RSP_NECH_ABL & 2) && I < NB) {
+          if (J + 1 + ((wv + 3) & 3) * 2 < NB) {   // wave-uniform: at least this wave's first half has a tile
             int dd = d;
             asm volatile("" : "+v"(dd));
-            float* TI = tile(I, J) + dd * TLD;
+            // row dd of L_JJ in registers (both halves alike): the multipliers of the substitution are then lane
+            // broadcasts (v_readlane) instead of 496 dependent LDS round trips
+            float lr[32];
+#pragma unroll
+            for (int c = 0; c < 32; c++) lr[c] = TJ[dd * TLD + c];
+            float* TI = tile(min(I, NB - 1), J) + dd * TLD;
             float y[32];
 #pragma unroll
             for (int c = 0; c < 32; c++) y[c] = TI[c];
@@ -1229,20 +1235,22 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
             for (int c = 0; c < 31; c++) {
               const float yc = y[c];
 #pragma unroll
-              for (int c2 = c + 1; c2 < 32; c2++) y[c2] = fmaf(-yc, TJ[c * TLD + c2], y[c2]);   // TJ[c][c2] = L_JJ[c2][c]
-              __builtin_amdgcn_sched_barrier(0);   // (or the scheduler hoists all 496 broadcast reads and spills)
+              for (int c2 = c + 1; c2 < 32; c2++) y[c2] = fmaf(-yc, readlane_f(lr[c], c2), y[c2]);   // L_JJ[c2][c]
             }
-            float dot_u = 0.f;
+            if (I < NB) {
+              float dot_u = 0.f;
 #pragma unroll
-            for (int c = 0; c < 32; c++) {
-              const float l = y[c] * sDi[32 * J + c];
-              TI[c] = l;
-              dot_u = fmaf(l, sU[32 * J + c], dot_u);
+              for (int c = 0; c < 32; c++) {
+                const float l = y[c] * sDi[32 * J + c];
+                TI[c] = l;
+                dot_u = fmaf(l, sU[32 * J + c], dot_u);
+              }
+              sU[32 * I + dd] -= dot_u;
             }
-            sU[32 * I + dd] -= dot_u;
           }
         }
         __syncthreads();
+        NE_T(16)
         {   // (3)
           int idx = 0;
           for (int I = J + 1; I < NB; I++)
@@ -1265,6 +1273,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
             }
         }
         __syncthreads();
+        NE_T(17)
       }
       if (bad && tid == 0) atomicAdd(a.fail_counter, 1);
       if (!(RSP_NECH_ABL & 8) && wv == 0) {   // D L^T y = u, last block first
@@ -1295,6 +1304,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
         }
       }
       __syncthreads();
+      NE_T(18)
 #pragma unroll
       for (int t = 0; t < NB; t++) x[t] = (32 * t + d < k) ? sU[32 * t + d] : 0.f;
       __syncthreads();   // sPub is per-wave scratch again below

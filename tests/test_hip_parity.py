@@ -267,6 +267,37 @@ def test_cholesky_long_rows(k, implicit):
     assert abs(loss - lref) <= TOL * abs(lref)
 
 
+@pytest.mark.parametrize("k", [128, 100, 64])
+@pytest.mark.parametrize("implicit", [True, False])
+def test_cholesky_rows_of_every_length_class(k, implicit):
+    """solver == CHOLESKY dispatches by row length (and rank): <= 64 non-zeros in low-rank form (implicit, rank 98..128),
+    up to 128 (rank > 64) or 512 (rank <= 64) on wrmf_chol.hip's kernel, beyond that assembled by the normal-equation
+    kernel and solved by the blocked LDL^T in its LDS tiles.  Lengths 1..700 with every class well populated, and most
+    of the long rows NOT split (enough rows per workgroup list); per-row bound."""
+    fb = "implicit" if implicit else "explicit"
+    n_fix, n_solve = 4000, 1500
+    d = synth.make_dataset(n_solve, n_fix, seed=77 + k, mean_deg=150, d_max=700, feedback=fb, device="cpu")
+    p, i, x = (t.numpy() for t in d["c_iu"])
+    x = x.astype(np.float64)
+    lens = np.diff(p)
+    for lo, hi in ((0, 64), (64, 128), (128, 256), (256, 512), (512, 700)):
+        assert ((lens > lo) & (lens <= hi)).sum() >= 20, (lo, hi)
+    rng = np.random.default_rng(k)
+    X = np.asfortranarray((rng.standard_normal((k, n_fix)) * 0.1).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, n_solve)) * 0.1).astype(np.float32))
+    csc = (n_fix, n_solve, p, i, x)
+    cnt = np.bincount(i, minlength=n_fix).astype(np.float64)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 0, 3, implicit, True, cnt)
+    Y = Y0.copy(order="F")
+    if implicit:
+        loss = als.als_implicit(csc, X, Y, 0.1, 1, 0, 3, "float", False, False)
+    else:
+        loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), 0.1, 1, 0, 3, True, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, (int(err.argmax()), float(err.max()), int(lens[err.argmax()]))
+    assert abs(loss - lref) <= TOL * abs(lref)
+
+
 @pytest.mark.parametrize("k", [128, 64])
 def test_implicit_cg_long_rows_with_confidence_below_one(k):
     """The fp16 normal-equation kernel takes sqrt(c - 1); a matrix with some confidence below 1 is detected on the device

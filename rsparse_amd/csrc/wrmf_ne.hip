@@ -1178,98 +1178,116 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
         for (int t = 0; t < NB; t++) sU[32 * t + d] = b[t];
       }
       __syncthreads();
-      for (int J = 0; J < NB; J++) {
-        float* TJ = tile(J, J);
-        if (!(RSP_NECH_ABL & 1) && wv == 0) {   // (1); both halves of the wave compute the same, half 0 writes
-          // (the lane's offsets are laundered per block: hipcc otherwise hoists the 64 address pieces out of the row
+      for (int J2 = 0; J2 < 2 * NB; J2++) {   // block columns of 16 inside the 32 x 32 tiles
+        const int JT = J2 >> 1, hc = J2 & 1, c0 = 16 * hc, jb = 16 * J2;
+        float* TJ = tile(JT, JT);
+        if (!(RSP_NECH_ABL & 1) && wv == 0) {   // (1); the four 16-lane groups compute the same, lanes 0..15 write
+          // (the lane's offsets are laundered per block: hipcc otherwise hoists the address pieces out of the row
           // loop and spills them into the streaming loops)
-          int dd = d;
+          int dd = lane & 15;
           asm volatile("" : "+v"(dd));
-          float* trow = TJ + dd * TLD;   // own row: left of the diagonal
-          const float* tcol = TJ + dd;   // own column: the transposed entries right of it (lower triangle only)
-          float r[32];
+          float* trow = TJ + (c0 + dd) * TLD + c0;   // own row of the block: left of the diagonal
+          const float* tcol = TJ + c0 * TLD + c0 + dd;   // own column: the transposed entries right of it (lower triangle only)
+          float r[16];
 #pragma unroll
-          for (int c = 0; c < 32; c++) r[c] = *(c <= dd ? trow + c : tcol + c * TLD);
-          float u = sU[32 * J + dd], dinv = 1.f, dii = 1.f;
+          for (int c = 0; c < 16; c++) r[c] = *(c <= dd ? trow + c : tcol + c * TLD);
+          float u = sU[jb + dd], dinv = 1.f, dii = 1.f;
 #pragma unroll
-          for (int j = 0; j < 32; j++) {
+          for (int j = 0; j < 16; j++) {
             const float pj = readlane_f(r[j], j);
             if (!(pj > 0.f)) bad = true;
             const float inv = 1.f / pj;
             const float uj = readlane_f(u, j);
-            if (d == j) { dinv = inv; dii = pj; }
-            const float lij = d > j ? r[j] * inv : 0.f;   // L_ij; rows <= j are finished
+            if (dd == j) { dinv = inv; dii = pj; }
+            const float lij = dd > j ? r[j] * inv : 0.f;   // L_ij; rows <= j are finished
             u = fmaf(-lij, uj, u);
 #pragma unroll
-            for (int c = j + 1; c < 32; c++) r[c] = fmaf(-lij, readlane_f(r[c], j), r[c]);
+            for (int c = j + 1; c < 16; c++) r[c] = fmaf(-lij, readlane_f(r[c], j), r[c]);
           }
-          // lane i now holds L_ic d_c left of the diagonal and L_ci d_i right of it
-          if (h == 0) {
+          // lane i now holds L_ic d_c left of the diagonal; the block is kept as its lower triangle (unit L, pivot on
+          // the diagonal)
+          if (lane < 16) {
 #pragma unroll
-            for (int c = 0; c < 32; c++) {
+            for (int c = 0; c < 16; c++) {
               const float dc = readlane_f(dinv, c);
-              trow[c] = c < d ? r[c] * dc : (c > d ? r[c] * dinv : dii);
+              if (c <= dd) trow[c] = c < dd ? r[c] * dc : dii;
             }
-            sD[32 * J + dd] = dii;
-            sDi[32 * J + dd] = dinv;
-            sU[32 * J + dd] = u;
+            sD[jb + dd] = dii;
+            sDi[jb + dd] = dinv;
+            sU[jb + dd] = u;
           }
         }
         __syncthreads();
         NE_T(15)
-        {   // (2)
-          const int I = J + 1 + ((wv + 3) & 3) * 2 + h;   // wave 1 first: wave 0 has just done the diagonal tile
-          if (J + 1 + ((wv + 3) & 3) * 2 < NB) {   // wave-uniform: at least this wave's first half has a tile
+        {   // (2) the rows below the block: rows 16..31 of the diagonal tile (first block column of a tile), then the tiles
+            // under it; one half-wave each, lane = row
+          const int unit = ((wv + 3) & 3) * 2 + h;   // wave 1 first: wave 0 has just done the diagonal block
+          const int unit0 = ((wv + 3) & 3) * 2;      // the wave's first half
+          const int n_units = (NB - 1 - JT) + (1 - hc);
+          if (!(RSP_NECH_ABL & 2) && unit0 < n_units) {   // wave-uniform
             int dd = d;
             asm volatile("" : "+v"(dd));
-            // row dd of L_JJ in registers (both halves alike): the multipliers of the substitution are then lane
-            // broadcasts (v_readlane) instead of 496 dependent LDS round trips
-            float lr[32];
+            // row (lane & 15) of the block's L in registers (every 16-lane group alike): the multipliers of the
+            // substitution are lane broadcasts (v_readlane)
+            float lr[16];
 #pragma unroll
-            for (int c = 0; c < 32; c++) lr[c] = TJ[dd * TLD + c];
-            float* TI = tile(min(I, NB - 1), J) + dd * TLD;
-            float y[32];
+            for (int c = 0; c < 16; c++) lr[c] = TJ[(c0 + (dd & 15)) * TLD + c0 + c];
+            const bool mine = unit < n_units;
+            const bool diag_half = hc == 0 && unit == 0;             // rows 16..31 of tile (JT, JT)
+            const int I = hc == 0 ? JT + unit : JT + 1 + unit;       // tile row of this half's unit
+            const int trow_i = diag_half ? 16 + (dd & 15) : dd;
+            float* TI = tile(mine ? I : JT, JT) + trow_i * TLD + c0;
+            const bool act = mine && (!diag_half || dd < 16);
+            float y[16];
 #pragma unroll
-            for (int c = 0; c < 32; c++) y[c] = TI[c];
+            for (int c = 0; c < 16; c++) y[c] = TI[c];
 #pragma unroll
-            for (int c = 0; c < 31; c++) {
+            for (int c = 0; c < 15; c++) {
               const float yc = y[c];
 #pragma unroll
-              for (int c2 = c + 1; c2 < 32; c2++) y[c2] = fmaf(-yc, readlane_f(lr[c], c2), y[c2]);   // L_JJ[c2][c]
+              for (int c2 = c + 1; c2 < 16; c2++) y[c2] = fmaf(-yc, readlane_f(lr[c], c2), y[c2]);   // L[c2][c]
             }
-            if (I < NB) {
+            if (act) {
               float dot_u = 0.f;
 #pragma unroll
-              for (int c = 0; c < 32; c++) {
-                const float l = y[c] * sDi[32 * J + c];
+              for (int c = 0; c < 16; c++) {
+                const float l = y[c] * sDi[jb + c];
                 TI[c] = l;
-                dot_u = fmaf(l, sU[32 * J + c], dot_u);
+                dot_u = fmaf(l, sU[jb + c], dot_u);
               }
-              sU[32 * I + dd] -= dot_u;
+              sU[32 * I + trow_i] -= dot_u;
             }
           }
         }
         __syncthreads();
         NE_T(16)
-        {   // (3)
+        {   // (3) trailing tiles (I, K), K >= JT (first block column of a tile: the tile column JT itself, right half only)
           int idx = 0;
-          for (int I = J + 1; I < NB; I++)
-            for (int K2 = J + 1; K2 <= I; K2++, idx++) {
-              if ((RSP_NECH_ABL & 4) || (idx & 3) != wv) continue;
+          for (int I = JT; I < NB; I++)
+            for (int K2 = JT + hc; K2 <= I; K2++) {
+              if (I == JT && hc == 1) continue;             // nothing left of the diagonal tile
+              const bool here = (idx & 3) == wv;
+              idx++;
+              if ((RSP_NECH_ABL & 4) || !here) continue;
               int dd = d;
               asm volatile("" : "+v"(dd));
               float* C = tile(I, K2) + 4 * h * TLD + dd;
-              const float* LI = tile(I, J) + dd * TLD + h;
-              const float* LK = tile(K2, J) + dd * TLD + h;
-              const float* dj = sD + 32 * J + h;
+              const float* LI = tile(I, JT) + dd * TLD + c0 + h;
+              const float* LK = tile(K2, JT) + dd * TLD + c0 + h;
+              const float* dj = sD + jb + h;
               f32x16 acc;
 #pragma unroll
               for (int e = 0; e < 16; e++) acc[e] = C[((e & 3) + 8 * (e >> 2)) * TLD];
 #pragma unroll
-              for (int kk = 0; kk < 16; kk++)
+              for (int kk = 0; kk < 8; kk++)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-LI[2 * kk] * dj[2 * kk], LK[2 * kk], acc, 0, 0, 0);
+              const bool col_ok = K2 > JT || dd >= 16;      // tile column JT: its left half is final L
+              const bool low_only = I == JT;                // diagonal tile: its upper-left block is final too
+              if (col_ok) {
 #pragma unroll
-              for (int e = 0; e < 16; e++) C[((e & 3) + 8 * (e >> 2)) * TLD] = acc[e];
+                for (int e = 0; e < 16; e++)
+                  if (e >= 8 || !low_only) C[((e & 3) + 8 * (e >> 2)) * TLD] = acc[e];
+              }
             }
         }
         __syncthreads();
@@ -1280,7 +1298,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
         for (int J = NB - 1; J >= 0; J--) {
           int dd = d;
           asm volatile("" : "+v"(dd));
-          const float* TJ = tile(J, J) + dd * TLD;
+          const float* TJ0 = tile(J, J);
           float t2 = sU[32 * J + dd] * sDi[32 * J + dd];
           for (int I = J + 1; I < NB; I++) {
             const float* TI = tile(I, J) + dd;
@@ -1290,7 +1308,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
           }
           float lc[32];
 #pragma unroll
-          for (int c = 0; c < 32; c++) lc[c] = TJ[c];   // right of the diagonal: column d of L_JJ
+          for (int c = 0; c < 32; c++) lc[c] = TJ0[c * TLD + dd];   // column d of L_JJ, read below the diagonal (c > d)
           float accb = 0.f, z = 0.f;
 #pragma unroll
           for (int c = 31; c >= 0; c--) {

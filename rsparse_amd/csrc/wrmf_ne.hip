@@ -1196,7 +1196,10 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
           for (int j = 0; j < 16; j++) {
             const float pj = readlane_f(r[j], j);
             if (!(pj > 0.f)) bad = true;
-            const float inv = 1.f / pj;
+            // 1 / pivot: v_rcp_f32 and one Newton step (<= 1 ulp) -- the IEEE division sequence is three times as long,
+            // and the sixteen of them are the serial spine of this block
+            const float r0 = __builtin_amdgcn_rcpf(pj);
+            const float inv = fmaf(fmaf(-pj, r0, 1.f), r0, r0);
             const float uj = readlane_f(u, j);
             if (dd == j) { dinv = inv; dii = pj; }
             const float lij = dd > j ? r[j] * inv : 0.f;   // L_ij; rows <= j are finished

@@ -241,7 +241,9 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
         float dinv = 1.f;   // 1 / d_i, set when row i is the pivot row
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-          const float inv = 1.f / readlane_f(r[j], j);
+          const float pj = readlane_f(r[j], j);   // >= 1 (S = I + W W^T)
+          const float r0 = __builtin_amdgcn_rcpf(pj);
+          const float inv = fmaf(fmaf(-pj, r0, 1.f), r0, r0);   // v_rcp_f32 + one Newton step: the pivots' serial spine
           const float uj = readlane_f(u, j);
           if (i == j) dinv = inv;
           const float lij = i > j ? r[j] * inv : 0.f;   // L_ij; rows <= j are finished

@@ -1178,50 +1178,15 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
         for (int t = 0; t < NB; t++) sU[32 * t + d] = b[t];
       }
       __syncthreads();
-      for (int J2 = 0; J2 < 2 * NB; J2++) {   // block columns of 16 inside the 32 x 32 tiles
-        const int JT = J2 >> 1, hc = J2 & 1, c0 = 16 * hc, jb = 16 * J2;
+      // Look-ahead: the first trailing tile of a block column is the one that holds the NEXT diagonal block; wave 0 takes
+      // it, then factors that block while waves 1..3 finish the other trailing tiles.  J2 = -1 is the start-up pass
+      // (diagonal block 0 only).
+      for (int J2 = -1; J2 < 2 * NB; J2++) {   // block columns of 16 inside the 32 x 32 tiles
+        const int JT = max(J2, 0) >> 1, hc = max(J2, 0) & 1, c0 = 16 * hc, jb = 16 * max(J2, 0);
         float* TJ = tile(JT, JT);
-        if (!(RSP_NECH_ABL & 1) && wv == 0) {   // (1); the four 16-lane groups compute the same, lanes 0..15 write
-          // (the lane's offsets are laundered per block: hipcc otherwise hoists the address pieces out of the row
-          // loop and spills them into the streaming loops)
-          int dd = lane & 15;
-          asm volatile("" : "+v"(dd));
-          float* trow = TJ + (c0 + dd) * TLD + c0;   // own row of the block: left of the diagonal
-          const float* tcol = TJ + c0 * TLD + c0 + dd;   // own column: the transposed entries right of it (lower triangle only)
-          float r[16];
-#pragma unroll
-          for (int c = 0; c < 16; c++) r[c] = *(c <= dd ? trow + c : tcol + c * TLD);
-          float u = sU[jb + dd], dinv = 1.f, dii = 1.f;
-#pragma unroll
-          for (int j = 0; j < 16; j++) {
-            const float pj = readlane_f(r[j], j);
-            if (!(pj > 0.f)) bad = true;
-            // 1 / pivot: v_rcp_f32 and one Newton step (<= 1 ulp) -- the IEEE division sequence is three times as long,
-            // and the sixteen of them are the serial spine of this block
-            const float r0 = __builtin_amdgcn_rcpf(pj);
-            const float inv = fmaf(fmaf(-pj, r0, 1.f), r0, r0);
-            const float uj = readlane_f(u, j);
-            if (dd == j) { dinv = inv; dii = pj; }
-            const float lij = dd > j ? r[j] * inv : 0.f;   // L_ij; rows <= j are finished
-            u = fmaf(-lij, uj, u);
-#pragma unroll
-            for (int c = j + 1; c < 16; c++) r[c] = fmaf(-lij, readlane_f(r[c], j), r[c]);
-          }
-          // lane i now holds L_ic d_c left of the diagonal; the block is kept as its lower triangle (unit L, pivot on
-          // the diagonal)
-          if (lane < 16) {
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-              const float dc = readlane_f(dinv, c);
-              if (c <= dd) trow[c] = c < dd ? r[c] * dc : dii;
-            }
-            sD[jb + dd] = dii;
-            sDi[jb + dd] = dinv;
-            sU[jb + dd] = u;
-          }
-        }
-        __syncthreads();
-        NE_T(15)
+        const int JN = J2 + 1, cn = 16 * (JN & 1), jn = 16 * JN;
+        float* TN = tile(min(JN >> 1, NB - 1), min(JN >> 1, NB - 1));
+        if (J2 >= 0) {
         {   // (2) the rows below the block: rows 16..31 of the diagonal tile (first block column of a tile), then the tiles
             // under it; one half-wave each, lane = row
           const int unit = ((wv + 3) & 3) * 2 + h;   // wave 1 first: wave 0 has just done the diagonal block
@@ -1269,7 +1234,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
           for (int I = JT; I < NB; I++)
             for (int K2 = JT + hc; K2 <= I; K2++) {
               if (I == JT && hc == 1) continue;             // nothing left of the diagonal tile
-              const bool here = (idx & 3) == wv;
+              const bool here = idx == 0 ? wv == 0 : (idx - 1) % 3 + 1 == wv;   // wave 0: the tile of the next diagonal block only
               idx++;
               if ((RSP_NECH_ABL & 4) || !here) continue;
               int dd = d;
@@ -1293,8 +1258,48 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
               }
             }
         }
+        }
+        if (!(RSP_NECH_ABL & 1) && wv == 0 && J2 + 1 < 2 * NB) {   // (1) of the NEXT block column; the four 16-lane groups compute the same, lanes 0..15 write
+          // (the lane's offsets are laundered per block: hipcc otherwise hoists the address pieces out of the row
+          // loop and spills them into the streaming loops)
+          int dd = lane & 15;
+          asm volatile("" : "+v"(dd));
+          float* trow = TN + (cn + dd) * TLD + cn;   // own row of the block: left of the diagonal
+          const float* tcol = TN + cn * TLD + cn + dd;   // own column: the transposed entries right of it (lower triangle only)
+          float r[16];
+#pragma unroll
+          for (int c = 0; c < 16; c++) r[c] = *(c <= dd ? trow + c : tcol + c * TLD);
+          float u = sU[jn + dd], dinv = 1.f, dii = 1.f;
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            const float pj = readlane_f(r[j], j);
+            if (!(pj > 0.f)) bad = true;
+            // 1 / pivot: v_rcp_f32 and one Newton step (<= 1 ulp) -- the IEEE division sequence is three times as long,
+            // and the sixteen of them are the serial spine of this block
+            const float r0 = __builtin_amdgcn_rcpf(pj);
+            const float inv = fmaf(fmaf(-pj, r0, 1.f), r0, r0);
+            const float uj = readlane_f(u, j);
+            if (dd == j) { dinv = inv; dii = pj; }
+            const float lij = dd > j ? r[j] * inv : 0.f;   // L_ij; rows <= j are finished
+            u = fmaf(-lij, uj, u);
+#pragma unroll
+            for (int c = j + 1; c < 16; c++) r[c] = fmaf(-lij, readlane_f(r[c], j), r[c]);
+          }
+          // lane i now holds L_ic d_c left of the diagonal; the block is kept as its lower triangle (unit L, pivot on
+          // the diagonal)
+          if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+              const float dc = readlane_f(dinv, c);
+              if (c <= dd) trow[c] = c < dd ? r[c] * dc : dii;
+            }
+            sD[jn + dd] = dii;
+            sDi[jn + dd] = dinv;
+            sU[jn + dd] = u;
+          }
+        }
         __syncthreads();
-        NE_T(17)
+        NE_T(15)
       }
       if (bad && tid == 0) atomicAdd(a.fail_counter, 1);
       if (!(RSP_NECH_ABL & 8) && wv == 0) {   // D L^T y = u, last block first

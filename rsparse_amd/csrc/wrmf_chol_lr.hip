@@ -132,24 +132,83 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
   // (or across the gather) spills.
 
   double wloss = 0.0;
-  for (int it = blockIdx.x; it < n_rows; it += gridDim.x) {
-    const int row = rfl(rows[it]);
-    const int p1 = rfl(a.col_ptrs[row]), n = rfl(a.col_ptrs[row + 1]) - p1;   // 1 <= n <= 64 (launcher)
+  // Row metadata runs ahead of the solves so that the gather of a row is ONE memory round trip (it was a chain of four:
+  // row id -> pointers -> index -> vector, and that per vector): the row id three rows ahead, its pointers two ahead,
+  // its indices and confidences (lane j holds non-zero j) one ahead.
+  const int G = gridDim.x;
+  int it = blockIdx.x;
+  int row_c = 0, p1_c = 0, n_c = 0, row_n = 0, p1_n = 0, n_n = 0, row_nn = 0;
+  if (it < n_rows) {
+    row_c = rows[it];
+    p1_c = a.col_ptrs[row_c];
+    n_c = a.col_ptrs[row_c + 1] - p1_c;
+  }
+  if (it + G < n_rows) {
+    row_n = rows[it + G];
+    p1_n = a.col_ptrs[row_n];
+    n_n = a.col_ptrs[row_n + 1] - p1_n;
+  }
+  if (it + 2 * G < n_rows) row_nn = rows[it + 2 * G];
+  int id_c = 0;
+  float c_c = 1.f;
+  if (it < n_rows && lane < n_c) {
+    id_c = a.row_idx[p1_c + lane];
+    c_c = a.vals[p1_c + lane];
+  }
+  for (; it < n_rows; it += G) {
+    const int row = rfl(row_c);
+    const int p1 = rfl(p1_c), n = rfl(n_c);   // 1 <= n <= 64 (launcher)
     const int nrt = n <= 32 ? 1 : 2;   // 32-row tiles
     __syncthreads();                   // the previous row's buffers are free
-    // 1. gather: wave w takes vectors w, w + 4, ...; a lane copies 2 floats of each
-    for (int j = wv; j < 32 * nrt; j += 4) {
-      float2 v = {0.f, 0.f};
-      float c = 1.f;
-      if (!(RSP_LR_ABL & 32) && j < n) {
-        const int id = a.row_idx[p1 + j];
-        c = a.vals[p1 + j];
-        if (2 * lane < k) v = *reinterpret_cast<const float2*>(a.X + (size_t)id * k + 2 * lane);
+    // requests for the rows to come (consumed at the bottom of this iteration)
+    int id_nx = 0, p1_nn = 0, n_nn = 0, row_n3 = 0;
+    float c_nx = 1.f;
+    {
+      const int p1n = rfl(p1_n), nn = rfl(n_n);
+      if (it + G < n_rows && lane < nn) {
+        id_nx = a.row_idx[p1n + lane];
+        c_nx = a.vals[p1n + lane];
       }
-      *reinterpret_cast<float2*>(sX + j * LD + 2 * lane) = v;
-      if (lane == 0) {
-        sC[j] = j < n ? c : 0.f;
-        sQ[j] = j < n ? sqrtf(fmaxf(c - 1.f, 0.f)) : 0.f;
+      if (it + 2 * G < n_rows) {
+        const int rnn = rfl(row_nn);
+        p1_nn = a.col_ptrs[rnn];
+        n_nn = a.col_ptrs[rnn + 1] - p1_nn;
+      }
+      if (it + 3 * G < n_rows) row_n3 = rows[it + 3 * G];
+    }
+    // 1. gather: wave w takes vectors w, w + 4, ...; a lane copies 2 floats of each.  All of a wave's loads are issued
+    // before the first LDS store (slots past the row repeat its last vector and are stored as zeros).
+    {
+      float2 v[16];
+      const bool on = !(RSP_LR_ABL & 32);
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int id = __builtin_amdgcn_readlane(id_c, min(wv + 4 * u, n - 1));
+        v[u] = (on && 2 * lane < k) ? *reinterpret_cast<const float2*>(a.X + (size_t)id * k + 2 * lane) : float2{0.f, 0.f};
+      }
+      if (nrt == 2) {
+#pragma unroll
+        for (int u = 8; u < 16; u++) {
+          const int id = __builtin_amdgcn_readlane(id_c, min(wv + 4 * u, n - 1));
+          v[u] = (on && 2 * lane < k) ? *reinterpret_cast<const float2*>(a.X + (size_t)id * k + 2 * lane) : float2{0.f, 0.f};
+        }
+      }
+      if (wv == 0 && lane < 32 * nrt) {
+        const float c = on ? c_c : 1.f;
+        sC[lane] = lane < n ? c : 0.f;
+        sQ[lane] = lane < n ? sqrtf(fmaxf(c - 1.f, 0.f)) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = wv + 4 * u;
+        *reinterpret_cast<float2*>(sX + j * LD + 2 * lane) = j < n ? v[u] : float2{0.f, 0.f};
+      }
+      if (nrt == 2) {
+#pragma unroll
+        for (int u = 8; u < 16; u++) {
+          const int j = wv + 4 * u;
+          *reinterpret_cast<float2*>(sX + j * LD + 2 * lane) = j < n ? v[u] : float2{0.f, 0.f};
+        }
       }
     }
     __syncthreads();
@@ -231,7 +290,8 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
     // (column i of L times d_i) -- both triangular solves read nothing but the lane's own registers and broadcast scalars.
     // The forward substitution rides along with the elimination.  No barriers, no LDS traffic after the row is loaded.
     if (!(RSP_LR_ABL & 4) && wv == 0) {
-      const int i = lane;
+      int i = lane;
+      asm volatile("" : "+v"(i));   // laundered per row: hipcc otherwise hoists the 64 load addresses below out of the row loop and spills them
       auto solve = [&](auto np_tag) {
         constexpr int NS = decltype(np_tag)::value;
         float r[NS];
@@ -317,6 +377,11 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
     }
     const float lsum = wave_sum(lt), ysum = wave_sum(yy);
     if (lane == 0) wloss += (double)lsum + a.lambda_loss * (double)ysum;
+    // shift the look-ahead
+    row_c = row_n; p1_c = p1_n; n_c = n_n;
+    row_n = row_nn; p1_n = p1_nn; n_n = n_nn;
+    row_nn = row_n3;
+    id_c = id_nx; c_c = c_nx;
   }
   __syncthreads();
   if (lane == 0) sRed[wv] = wloss;

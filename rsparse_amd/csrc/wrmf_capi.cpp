@@ -386,6 +386,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   if (const char* e = std::getenv("RSPARSE_HIP_NE_CHOL_MIN")) d.q_nec_min = std::min(kNeMinLen, std::max(kCholLrMax, std::atoi(e)));
   int n_nec = 0;
   while (n_nec < n && host_col_ptrs[order[(size_t)n_nec] + 1] - host_col_ptrs[order[(size_t)n_nec]] > d.q_nec_min) n_nec++;
+  d.q_n_nec = n_nec;
   if (n_nec == n_stream) {
     d.q_nec_rows = d.q_ne_rows; d.q_nec_ptr = d.q_ne_ptr; d.q_nec_wg = d.q_ne_wg; d.q_nec_segs = d.q_ne_segs;
     d.q_nec_nseg = d.q_ne_nseg; d.q_nec_entries = d.q_ne_entries; d.q_nec_split_rows = d.q_ne_split_rows;
@@ -491,6 +492,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.X = d_X; a.Y = d_Y; a.XtX = implicit ? d_XtX : nullptr;
   a.long_rows = d.long_rows; a.n_long = d.n_long; a.n_cols = d.n_cols;
   a.chol_long_rows = d.q_order; a.n_chol_long = d.q_order ? d.q_n_chol_long : 0;
+  a.chol_list = nullptr; a.chol_first = 0; a.chol_n_main = 0; a.chol_empty_first = 0;
   a.lr_rows = nullptr; a.n_lr = 0; a.lr_flags = nullptr; a.lr_M = nullptr;
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
@@ -505,6 +507,15 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.ne_segs = nullptr; a.ne_seg_scratch = nullptr; a.ne_seg_flags = nullptr;
   a.ne_chol = ne_chol ? 1 : 0;
   a.ne_chol_min = nec_lists ? d.q_nec_min : kNeMinLen;
+  if (d.q_order && solver == RSPARSE_SOLVER_CHOLESKY) {
+    // the k x k kernel's own rows as ranges of the length-sorted order: behind the prefix that the normal-equation launch
+    // (or the LONG launch) takes, down to the short rows of the low-rank kernel, and the empty rows at the end
+    const int first = ne_chol ? (nec_lists ? d.q_n_nec : d.q_off[1]) : d.q_n_chol_long;
+    a.chol_list = d.q_order;
+    a.chol_first = first;
+    a.chol_n_main = std::max(0, d.q_lr_first - first);
+    a.chol_empty_first = d.q_lr_first + d.q_n_lr;
+  }
   if ((cgq || ne_chol) && ne_nseg > 0 && ne_supported(rank)) {
     if ((rc = g_ws.ensure_ne_seg((size_t)ne_nseg))) return rc;
     a.ne_segs = ne_segs; a.ne_seg_scratch = g_ws.ne_seg_scratch; a.ne_seg_flags = g_ws.ne_seg_flags;

@@ -108,10 +108,38 @@ __global__ __launch_bounds__(256, LONG ? 2 : RSP_CHOL_MINW) void als_chol2_kerne
 
   // short rows belong to the low-rank kernel (wrmf_chol_lr.hip) unless it stood down (flag set on the device)
   const bool lr_on = !LONG && IMPLICIT && a.lr_flags && rfl((int)a.lr_flags[0]) == 0;
-  const int n_iter = LONG ? a.n_chol_long : a.n_cols;
+  // the main launch walks its own ranges of the length-sorted order (a.chol_list; see AlsArgs) instead of every column:
+  // on the bench matrix it owns 1.5 of the 10 million user rows, and every skipped column was a dependent load
+  const bool listed = !LONG && a.chol_list != nullptr;
+  const int n_tail = listed ? (lr_on ? a.n_cols - a.chol_empty_first : a.n_cols - a.chol_first - a.chol_n_main) : 0;
+  const int tail0 = listed ? (lr_on ? a.chol_empty_first : a.chol_first + a.chol_n_main) : 0;
+  const int n_iter = LONG ? a.n_chol_long : (listed ? a.chol_n_main + n_tail : a.n_cols);
+  auto row_at = [&](const int it2) {
+    if (LONG) return a.chol_long_rows[it2];
+    if (!listed) return it2;
+    return a.chol_list[it2 < a.chol_n_main ? a.chol_first + it2 : tail0 + (it2 - a.chol_n_main)];
+  };
+  // the row id runs two rows ahead of the solve, its pointers one ahead
+  int row_c = 0, pa_c = 0, pb_c = 0, row_n = 0;
+  if ((int)blockIdx.x < n_iter) {
+    row_c = row_at(blockIdx.x);
+    pa_c = a.col_ptrs[row_c];
+    pb_c = a.col_ptrs[row_c + 1];
+  }
+  if ((int)(blockIdx.x + gridDim.x) < n_iter) row_n = row_at(blockIdx.x + gridDim.x);
   for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
-    const int row = LONG ? rfl(a.chol_long_rows[it]) : it;
-    const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
+    const int row = rfl(row_c);
+    const int p1 = rfl(pa_c), p2 = rfl(pb_c);
+    {
+      int pa_n = 0, pb_n = 0, row_nn = 0;
+      if (it + (int)gridDim.x < n_iter) {
+        const int rn = rfl(row_n);
+        pa_n = a.col_ptrs[rn];
+        pb_n = a.col_ptrs[rn + 1];
+      }
+      if (it + 2 * (int)gridDim.x < n_iter) row_nn = row_at(it + 2 * gridDim.x);
+      row_c = row_n; pa_c = pa_n; pb_c = pb_n; row_n = row_nn;
+    }
     const int cnt = p2 - p1;
     if (!LONG && a.n_chol_long > 0 && cnt > kCholLongLen) continue;   // the LONG launch owns it
     if (lr_on && cnt >= 1 && cnt <= kCholLrMax) continue;

@@ -43,6 +43,7 @@ struct DevCSC {
   // longer prefix of q_order, dealt with the larger fixed cost of the exact solve); they alias the lists above when the
   // two thresholds coincide
   int q_nec_min = 0;
+  int q_n_nec = 0;      // rows of more than q_nec_min non-zeros (a prefix of q_order)
   bool q_nec_own = false;
   int32_t* q_nec_rows = nullptr;
   int32_t* q_nec_ptr = nullptr;
@@ -89,6 +90,12 @@ struct AlsArgs {
   // Cholesky: rows of more than kCholLongLen non-zeros = the first n_chol_long entries of the length-sorted row order
   const int32_t* chol_long_rows;
   int n_chol_long;
+  // ... and the main launch's rows as ranges of the same order (nullptr: it walks every column and skips what it does
+  // not own): [chol_first, chol_first + chol_n_main) = the rows of more than kCholLrMax non-zeros that no other launch
+  // takes, then, when the low-rank kernel stands down, the short rows behind them; the empty rows
+  // [chol_empty_first, n_cols) always
+  const int32_t* chol_list;
+  int chol_first, chol_n_main, chol_empty_first;
   // Cholesky, short rows: lr_rows = the n_lr rows of 1..kCholLrMax non-zeros; lr_flags (device word, nullable): 0 = the
   // low-rank kernel solves them and wrmf_chol.hip's skips them, else the other way round; lr_M = 2 x 128 x 128 floats
   const int32_t* lr_rows;

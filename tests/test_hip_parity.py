@@ -298,6 +298,30 @@ def test_cholesky_rows_of_every_length_class(k, implicit):
     assert abs(loss - lref) <= TOL * abs(lref)
 
 
+def test_cholesky_with_confidence_below_one_takes_the_general_kernels():
+    """The low-rank form of the short rows needs sqrt(c - 1) and the fp16 normal-equation products need c >= 1: a matrix
+    with some confidence below 1 is detected on the device; the low-rank kernel stands down and wrmf_chol.hip's kernel
+    takes the short rows too (its second range of the length-sorted order), the long rows go through the bf16 products."""
+    k = 128
+    n_fix, n_solve = 4000, 1500
+    d = synth.make_dataset(n_solve, n_fix, seed=7, mean_deg=150, d_max=700, feedback="implicit", device="cpu")
+    p, i, x = (t.numpy() for t in d["c_iu"])
+    x = x.astype(np.float64)
+    x[::9] = 0.5                                   # lhs = XtX - 0.5 x x^T for those: still positive definite here
+    lens = np.diff(p)
+    assert (lens == 0).sum() == 0 and ((lens >= 1) & (lens <= 64)).sum() > 100 and (lens > 512).sum() > 20
+    rng = np.random.default_rng(5)
+    X = np.asfortranarray((rng.standard_normal((k, n_fix)) * 0.1).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, n_solve)) * 0.1).astype(np.float32))
+    csc = (n_fix, n_solve, p, i, x)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 0, 3, True)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, 0.1, 1, 0, 3, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, (int(err.argmax()), float(err.max()), int(lens[err.argmax()]))
+    assert abs(loss - lref) <= TOL * abs(lref)
+
+
 @pytest.mark.parametrize("k", [128, 64])
 def test_implicit_cg_long_rows_with_confidence_below_one(k):
     """The fp16 normal-equation kernel takes sqrt(c - 1); a matrix with some confidence below 1 is detected on the device

@@ -136,7 +136,7 @@ size_t cgq_loss_slots(const QSchedule& q, int k);
 // long rows (bucket 0) by one-pass normal equations on the matrix cores (wrmf_ne.hip) instead of the streamed CG kernel
 bool ne_supported(int k);
 constexpr int kNeMinLen = 512;       // its rows: more non-zeros than the largest resident bucket of wrmf_cgq.hip holds
-constexpr int kNeCholMinLen = 128;   // solver == CHOLESKY: default threshold of the same launch (RSPARSE_HIP_NE_CHOL_MIN overrides, 64..512)
+constexpr int kNeCholMinLen = 64;   // solver == CHOLESKY: default threshold of the same launch (RSPARSE_HIP_NE_CHOL_MIN overrides, 64..512)
 constexpr int kNeMaxSeg = 16;        // segments per split row
 constexpr int kNeMaxSegTotal = 64;   // ... per matrix
 constexpr int kNeSegFloats = 4 * (11 * 16 * 64 + 128 + 2);   // per segment: 4 waves x (<= 11 accumulator tiles + b + sum c)

@@ -271,7 +271,7 @@ def test_cholesky_long_rows(k, implicit):
 @pytest.mark.parametrize("implicit", [True, False])
 def test_cholesky_rows_of_every_length_class(k, implicit):
     """solver == CHOLESKY dispatches by row length (and rank): <= 64 non-zeros in low-rank form (implicit, rank 98..128),
-    up to 128 (rank > 64) or 512 (rank <= 64) on wrmf_chol.hip's kernel, beyond that assembled by the normal-equation
+    up to 64 (rank > 64) or 512 (rank <= 64) on wrmf_chol.hip's kernel, beyond that assembled by the normal-equation
     kernel and solved by the blocked LDL^T in its LDS tiles.  Lengths 1..700 with every class well populated, and most
     of the long rows NOT split (enough rows per workgroup list); per-row bound."""
     fb = "implicit" if implicit else "explicit"

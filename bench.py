@@ -384,7 +384,15 @@ def main():
     tf = ROOT / "profiles" / "pmc_traffic.json"
     if tf.exists() and dom:
         try:
-            traffic = json.loads(tf.read_text()).get(dom["kernel"])
+            table = json.loads(tf.read_text())
+            traffic = table.get(dom["kernel"])
+            if traffic is None:
+                # the table is keyed by the name rocprof prints; trailing template arguments added since it was
+                # collected must not lose the entry ("als_ne_kernel<128, 2, true, true, true, false" matches both)
+                stem = dom["kernel"].rstrip(">")
+                hits = [v for kk, v in table.items() if isinstance(v, (int, float)) and
+                        (kk.rstrip(">").startswith(stem) or stem.startswith(kk.rstrip(">")))]
+                traffic = hits[0] if len(hits) == 1 else None
         except Exception:
             traffic = None
     achieved = dom["bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9 if dom and dom["avg_launch_ms"] > 0 else 0.0

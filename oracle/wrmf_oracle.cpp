@@ -130,6 +130,37 @@ void cg_solver_implicit(Scratch<T>& s, int k, int n, const T* XtX, unsigned n_it
   }
 }
 
+// inst/include/wrmf_implicit.hpp:35-57  cg_solver_implicit_global_bias<T> (call site :203)
+//   r = X_nnz*(c - c1 % (X_nnz^T x + global_bias)) - XtX*x + global_bias_base ; the loop is cg_solver_implicit's (:46-55)
+// (marked "very poor numerical precision" at :34 -- restated as written).  `n` may be 0: with a global bias every column
+// is solved (:178), an empty one against  r = global_bias_base - XtX*x.
+template <class T>
+void cg_solver_implicit_global_bias(Scratch<T>& s, int k, int n, const T* XtX, unsigned n_iter, const T* base, T gbias) {
+  T* x = s.x.data(); T* r = s.r.data(); T* p = s.p.data(); T* Ap = s.Ap.data();
+  T* t = s.t.data(); T* w = s.w.data(); T* tmp = s.tmp.data();
+  const T* Xn = s.Xn.data(); const T* c = s.conf.data();
+  gemv_t(Xn, x, t, k, n);
+  for (int j = 0; j < n; j++) w[j] = c[j] - (c[j] - (T)1.0) * (t[j] + gbias);
+  gemv_n(Xn, w, r, k, n, false);
+  gemv_sq(XtX, x, tmp, k);
+  for (int i = 0; i < k; i++) { r[i] = (r[i] - tmp[i]) + base[i]; p[i] = r[i]; }
+  double rsold = dot(r, r, k), rsnew, alpha;
+  for (unsigned it = 0; it < n_iter; it++) {
+    gemv_sq(XtX, p, Ap, k);
+    gemv_t(Xn, p, t, k, n);
+    for (int j = 0; j < n; j++) w[j] = (c[j] - (T)1.0) * t[j];
+    gemv_n(Xn, w, Ap, k, n, true);
+    alpha = rsold / dot(p, Ap, k);
+    const T a = (T)alpha;
+    for (int i = 0; i < k; i++) { x[i] += a * p[i]; r[i] -= a * Ap[i]; }
+    rsnew = dot(r, r, k);
+    if (rsnew < CG_TOL) break;
+    const T b = (T)(rsnew / rsold);
+    for (int i = 0; i < k; i++) p[i] = r[i] + p[i] * b;
+    rsold = rsnew;
+  }
+}
+
 // inst/include/wrmf_explicit.hpp:8-31  cg_solver_explicit<T>
 //   r = X_nnz*(c - X_nnz^T x) - lambda x ; Ap = X_nnz*(X_nnz^T p) + lambda p  (:15,21)
 template <class T>
@@ -607,13 +638,14 @@ double als_implicit_biases(int n_rows, int n_cols, const int32_t* col_ptrs, cons
   return loss / (double)nnz;
 }
 
-// als_implicit<T> with a global bias, no user/item biases, Cholesky / NNLS branch (inst/include/wrmf_implicit.hpp:
+// als_implicit<T> with a global bias, no user/item biases (inst/include/wrmf_implicit.hpp:
 // 108-112: global_bias_base = -global_bias * rowSums(X); :155-157 rhs_init = global_bias_base; :178 every column is
-// solved; :228-229 rhs = X_nnz c + rhs_init; :262-264 loss against 1 - global_bias).  base_out (k entries) may be null.
+// solved; Cholesky / NNLS :228-229 rhs = X_nnz c + rhs_init; conjugate gradient :203 cg_solver_implicit_global_bias from
+// the warm start; :262-264 loss against 1 - global_bias).  base_out (k entries) may be null.
 template <class T>
 double als_implicit_global(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
                            const double* values, const T* X, T* Y, const T* XtX, int k, double lambda, int n_threads,
-                           unsigned solver, double global_bias_in, T* base_out, int* status) {
+                           unsigned solver, double global_bias_in, T* base_out, int* status, unsigned cg_steps = 3) {
   double loss = 0;
   int bad = 0;
   const T gbias = global_bias_in < std::sqrt((double)std::numeric_limits<T>::epsilon()) ? (T)0 : (T)global_bias_in;
@@ -642,6 +674,22 @@ double als_implicit_global(int n_rows, int n_cols, const int32_t* col_ptrs, cons
         std::memcpy(&s.Xn[(size_t)j * k], X + (size_t)row_indices[p1 + j] * k, sizeof(T) * k);
       }
       std::vector<T> init(y, y + k);
+      if (solver == CONJUGATE_GRADIENT) {   // :199-204
+        std::memcpy(s.x.data(), init.data(), sizeof(T) * k);
+        if (gbias != (T)0) cg_solver_implicit_global_bias<T>(s, k, n, XtX, cg_steps, base.data(), gbias);
+        else cg_solver_implicit<T>(s, k, n, XtX, cg_steps);
+        std::memcpy(y, s.x.data(), sizeof(T) * k);
+        T lc = 0;
+        if (n > 0) {
+          gemv_t(s.Xn.data(), s.x.data(), s.t.data(), k, n);
+          for (int j = 0; j < n; j++) {
+            const T d = ((T)1.0 - gbias) - s.t[j];
+            lc += d * d * s.conf[j];
+          }
+        }
+        loss += lc + lambda * dot(s.x.data(), s.x.data(), k);
+        continue;
+      }
       T* lhs = s.lhs.data();
       std::memcpy(lhs, XtX, sizeof(T) * k * k);
       for (int j = 0; j < n; j++) {
@@ -854,22 +902,24 @@ double wrmf_oracle_als_implicit_bias_f64(int n_rows, int n_cols, const int32_t* 
 double wrmf_oracle_als_implicit_gbias_f32(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
                                           const double* values, const float* X, float* Y, const float* XtX, int k,
                                           double lambda, int n_threads, unsigned solver, int with_biases,
-                                          int is_x_bias_last_row, double global_bias, float* base_out, int* status) {
+                                          int is_x_bias_last_row, double global_bias, float* base_out, int* status,
+                                          unsigned cg_steps) {
   if (with_biases)
     return als_implicit_biases<float>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads,
                                       solver, is_x_bias_last_row, status, global_bias);
   return als_implicit_global<float>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads, solver,
-                                    global_bias, base_out, status);
+                                    global_bias, base_out, status, cg_steps);
 }
 double wrmf_oracle_als_implicit_gbias_f64(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
                                           const double* values, const double* X, double* Y, const double* XtX, int k,
                                           double lambda, int n_threads, unsigned solver, int with_biases,
-                                          int is_x_bias_last_row, double global_bias, double* base_out, int* status) {
+                                          int is_x_bias_last_row, double global_bias, double* base_out, int* status,
+                                          unsigned cg_steps) {
   if (with_biases)
     return als_implicit_biases<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads,
                                        solver, is_x_bias_last_row, status, global_bias);
   return als_implicit_global<double>(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, k, lambda, n_threads,
-                                     solver, global_bias, base_out, status);
+                                     solver, global_bias, base_out, status, cg_steps);
 }
 double wrmf_oracle_init_biases_implicit_f32(int n_items, const int32_t* csc_p, const int32_t* csc_i, const double* csc_x,
                                             int n_users, const int32_t* csr_p, const int32_t* csr_i, const double* csr_x,

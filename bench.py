@@ -200,8 +200,6 @@ def main():
     implicit = args.feedback == "implicit"
     solver = {"cholesky": 0, "cg": 1, "nnls": 2}[args.solver]          # inst/include/wrmf.hpp:16-20 codes
 
-    if args.serial_launches:
-        os.environ["RSPARSE_HIP_CONCURRENT"] = "0"   # read by the library at its first CG launch
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -232,6 +230,8 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device("cuda", local_rank))
     be = HipBackend(local_rank)
+    if args.serial_launches:
+        be.set_launch_mode(0)
     dev = be.device
     k, lam = args.rank, args.lam
 
@@ -468,10 +468,9 @@ def main():
                                      if (first_ref and losses) else None),
             "n_ranks_seen": n_ranks_seen, "shard_nnz_rank0": shard_nnz, "comm_ms": comm_ms,
             "partition": "contiguous blocks balanced by non-zeros, %d sub-blocks per rank and side (in-place slab all-gathers)" % lay_u.n_sub if ws > 1 else "single rank",
-            "launch_mode": {"0": "serial", "1": "every bucket on its own stream"}.get(
-                os.environ.get("RSPARSE_HIP_CONCURRENT", "2"),
-                "long-row launch alone, then the resident buckets on side streams (library default; the per-kernel "
-                "times under roofline are measured in a serialised pass)"),
+            "launch_mode": ("serial (--serial-launches)" if args.serial_launches else
+                            "long-row launch alone, then the resident buckets on side streams (library default; the "
+                            "per-kernel times under roofline are measured in a serialised pass)"),
             "datagen_s": t_gen,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -72,17 +72,24 @@ int rsparse_hip_set_device(int device);
  * dgCMatrix slots Dim[0], Dim[1], p, i, x.  rank = nrow(X).  n_threads is accepted and ignored.
  * with_biases: Cholesky and NNLS only (XtX is then (rank-1) x (rank-1)); with conjugate_gradient -> ERR_UNSUPPORTED
  * (the reference cannot run that combination either, wrmf_implicit.hpp:189,197).
- * global_bias >= sqrt(FLT_EPSILON) (wrmf_implicit.hpp:108-109): Cholesky and NNLS, with or without biases
- * (:146-153, 228-229, 262-270); with conjugate_gradient (cg_solver_implicit_global_bias, :35-57) -> ERR_UNSUPPORTED.
- * global_bias_base (rank entries, no biases only): written with -global_bias * rowSums(X) when initialize_bias_base
- * != 0 (:111-112), read otherwise; may be NULL.
+ * global_bias >= sqrt(epsilon of the element type) (wrmf_implicit.hpp:108-109; 3.45e-4 for _float, 1.49e-8 for _double;
+ * smaller values count as zero): every solver -- Cholesky and NNLS with or without biases (:146-153, 228-229, 262-270),
+ * conjugate gradient without biases (cg_solver_implicit_global_bias, :35-57, 203; marked "very poor numerical
+ * precision" in the reference and restated as written: note that it solves  lhs y = X_nnz c + base - g X_nnz (c - 1),
+ * the Cholesky branch  lhs y = X_nnz c + base).
+ * global_bias_base (no biases only; may be NULL): the vector -global_bias * rowSums(X), `rank` entries (:111-112).
+ * global_bias_base_len = the number of entries the caller's buffer holds.  The R driver allocates rank - 1
+ * (R/model_WRMF.R:292) while the reference's C++ assigns and reads `rank` (a local re-allocation on the write, one
+ * element past the R vector on the read); this library never touches more than the stated length: with
+ * initialize_bias_base != 0 it writes min(len, rank) entries, with initialize_bias_base == 0 it reads the vector only
+ * if len >= rank and otherwise recomputes it from X (its definition).
  * *loss_out = the value the reference returns (loss / nnz). */
 int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_ptrs,
                                    const int32_t* row_indices, const double* values,
                                    const float* X, float* Y, const float* XtX, int rank,
                                    double lambda, int n_threads, unsigned solver,
                                    unsigned cg_steps, int with_biases, int is_x_bias_last_row,
-                                   double global_bias, float* global_bias_base,
+                                   double global_bias, float* global_bias_base, int global_bias_base_len,
                                    int initialize_bias_base, double* loss_out);
 
 /* replaces als_implicit_double (src/wrmf_implicit.cpp:5-14).  Buffers are f64 like the reference's;
@@ -92,7 +99,7 @@ int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_p
                                     const double* X, double* Y, const double* XtX, int rank,
                                     double lambda, int n_threads, unsigned solver,
                                     unsigned cg_steps, int with_biases, int is_x_bias_last_row,
-                                    double global_bias, double* global_bias_base,
+                                    double global_bias, double* global_bias_base, int global_bias_base_len,
                                     int initialize_bias_base, double* loss_out);
 
 /* replaces als_explicit_float (src/wrmf_explicit.cpp:17-27 -> als_explicit<float>,
@@ -181,27 +188,25 @@ int rsparse_hip_gramian_device(const float* d_X, int rank, int64_t n, double lam
                                float* d_XtX_out, double* d_sumsq_out, void* stream);
 
 /* The same, and *d_absmax_inout = max(*d_absmax_inout, max |X|) (device float, nullable; the caller zeroes it before the
- * first block): the matrix is read here anyway.  What it is for: the long-row kernel of the implicit CG half-iteration
+ * first block): the matrix is read here anyway.  What it is for: the long-row kernel of the implicit half-iteration
  * (wrmf_ne.hip) scales its fp16 operands by a power of two taken from max |X|, which it otherwise finds by scanning X
- * once per half-iteration call. */
+ * once per half-iteration call -- see d_absmax of rsparse_hip_als_implicit_device. */
 int rsparse_hip_gramian_absmax_device(const float* d_X, int rank, int64_t n, double lambda, float* d_XtX_out,
                                       double* d_sumsq_out, float* d_absmax_inout, void* stream);
-
-/* Optional hint for rsparse_hip_als_implicit_device: while it is set, half-iterations whose fixed side is d_X take
- * max |X| from *d_absmax (device float; any value >= the true maximum is correct, a tight one is accurate) instead of
- * scanning X -- a sharded driver sets it once per half-iteration (all-reduced maximum of its ranks' blocks) and solves
- * its sub-blocks under it.  The caller keeps *d_absmax valid and current while the hint is set; (NULL, NULL) clears it. */
-int rsparse_hip_hint_factor_absmax(const float* d_X, const float* d_absmax);
 
 /* One implicit half-iteration over the columns of `conf` (als_implicit<float>, no-bias branch).
  * d_Y points at column 0 of this matrix's block (rank x n_cols).  Writes to d_loss_rows_out
  * (nullable, device double[1]) the un-normalised row part of the loss:
  *     sum_i [ sum_j c_ij (1 - y_i.x_j)^2 + lambda |y_i|^2 ]          (wrmf_implicit.hpp:259-261)
  * the caller adds lambda*sum(X^2) and divides by nnz (:286-304) -- kept separate so that shards
- * on several GPUs can be summed.  Asynchronous on `stream`. */
+ * on several GPUs can be summed.  Asynchronous on `stream`.
+ * d_absmax (nullable, device float[1]): max |X| if the caller knows it (rsparse_hip_gramian_absmax_device yields it; a
+ * sharded driver passes the all-reduced maximum of its ranks' blocks and solves all its sub-blocks under it).  Any
+ * value >= the true maximum is correct, a tight one is accurate; it must stay valid until the call has executed on
+ * `stream`.  NULL: the library scans X (0.5 ms per GB).  Per call, no state is kept. */
 int rsparse_hip_als_implicit_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
                                     const float* d_XtX, int rank, double lambda, unsigned solver,
-                                    unsigned cg_steps, double* d_loss_rows_out, void* stream);
+                                    unsigned cg_steps, const float* d_absmax, double* d_loss_rows_out, void* stream);
 
 /* One explicit half-iteration (als_explicit<float>, no-bias branch).  Loss row part:
  *     sum_i [ sum_j (r_ij - y_i.x_j)^2 + lambda_use_i |y_i|^2 ]      (wrmf_explicit.hpp:131-132) */
@@ -219,15 +224,18 @@ int rsparse_hip_als_implicit_bias_device(const rsparse_hip_csc* conf, const floa
                                          const float* d_XtX, int rank, double lambda, unsigned solver,
                                          int is_x_bias_last_row, double* d_loss_rows_out, void* stream);
 
-/* als_implicit<T> with a global bias (inst/include/wrmf_implicit.hpp:108-112,146-157,228-229,262-270), Cholesky or NNLS,
+/* als_implicit<T> with a global bias (inst/include/wrmf_implicit.hpp:108-112,146-157,228-229,262-270),
  * device-resident form; with_biases selects the user/item-bias layout of rsparse_hip_als_implicit_bias_device (then
- * rhs_init = -X' (x_b + global_bias), :152), otherwise X / Y / XtX are the plain rank x n matrices and every right-hand
- * side gets global_bias_base = -global_bias * rowSums(X) (:111-112, computed on the device).  The loss compares x_j.y
- * with 1 - global_bias (- x_b).  global_bias itself is the caller's: sum(x) / (sum(x) + n_user n_item - nnz),
- * R/model_WRMF.R:286-287.  solver = conjugate_gradient -> RSPARSE_HIP_ERR_UNSUPPORTED. */
+ * rhs_init = -X' (x_b + global_bias), :152; Cholesky / NNLS only), otherwise X / Y / XtX are the plain rank x n matrices
+ * and every right-hand side gets global_bias_base = -global_bias * rowSums(X) (:111-112, computed on the device); every
+ * column is solved, empty ones too (:178).  The loss compares x_j.y with 1 - global_bias (- x_b).  solver =
+ * conjugate_gradient (no biases): cg_solver_implicit_global_bias (:35-57, 203) from the warm start in d_Y, cg_steps
+ * steps.  global_bias itself is the caller's: sum(x) / (sum(x) + n_user n_item - nnz), R/model_WRMF.R:286-287.
+ * d_absmax: as for rsparse_hip_als_implicit_device. */
 int rsparse_hip_als_implicit_global_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
                                                 const float* d_XtX, int rank, double lambda, unsigned solver,
-                                                int with_biases, int is_x_bias_last_row, double global_bias,
+                                                unsigned cg_steps, int with_biases, int is_x_bias_last_row,
+                                                double global_bias, const float* d_absmax,
                                                 double* d_loss_rows_out, void* stream);
 
 /* initialize_biases_implicit (inst/include/wrmf_utils.hpp:86-165; .Call _rsparse_initialize_biases_{double,float} with
@@ -300,6 +308,11 @@ int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_use
  * fallback kernels: [0] short-row, [1] long-row, [2] loss); Cholesky -> [0]; Gramian -> [0] MFMA partial
  * kernel, [1] reduction. */
 int rsparse_hip_profile_enable(int on);
+/* How the launches of one conjugate-gradient half-iteration (one per row-length bucket, disjoint rows) are issued:
+ * 2 (default) = the long-row launch on the caller's stream, the others on side streams forked from / joined to it,
+ * 1 = every launch on a side stream, 0 = all back to back on the caller's stream -- what a profiler needs for
+ * well-defined per-kernel durations (bench.py --serial-launches).  Results do not depend on it. */
+int rsparse_hip_set_launch_mode(int mode);
 int rsparse_hip_profile_last(double ms_out[8]);
 
 /* number of per-row systems that failed (not positive definite) since the last call; resets. */

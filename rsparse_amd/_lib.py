@@ -23,9 +23,9 @@ SIGNATURES = {
     "rsparse_hip_device_count": (_c_int, []),
     "rsparse_hip_set_device": (_c_int, [_c_int]),
     "rsparse_hip_als_implicit_float": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_int,
-                                                _c_uint, _c_uint, _c_int, _c_int, _c_dbl, _vp, _c_int, _vp]),
+                                                _c_uint, _c_uint, _c_int, _c_int, _c_dbl, _vp, _c_int, _c_int, _vp]),
     "rsparse_hip_als_implicit_double": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_int,
-                                                 _c_uint, _c_uint, _c_int, _c_int, _c_dbl, _vp, _c_int, _vp]),
+                                                 _c_uint, _c_uint, _c_int, _c_int, _c_dbl, _vp, _c_int, _c_int, _vp]),
     "rsparse_hip_als_explicit_float": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint,
                                                 _c_uint, _c_uint, _c_int, _c_int, _c_int, _vp]),
     "rsparse_hip_als_explicit_double": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint,
@@ -34,12 +34,11 @@ SIGNATURES = {
     "rsparse_hip_csc_create_host": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "rsparse_hip_csc_create_device": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "rsparse_hip_gramian_absmax_device": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp, _vp, _vp, _vp]),
-    "rsparse_hip_hint_factor_absmax": (_c_int, [_vp, _vp]),
     "rsparse_hip_csc_destroy": (_c_int, [_vp]),
     "rsparse_hip_csc_info": (_c_int, [_vp, ctypes.POINTER(_c_i64)]),
     "rsparse_hip_als_implicit_bias_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_int, _vp, _vp]),
-    "rsparse_hip_als_implicit_global_bias_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_int, _c_int,
-                                                             _c_dbl, _vp, _vp]),
+    "rsparse_hip_als_implicit_global_bias_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_uint, _c_int,
+                                                             _c_int, _c_dbl, _vp, _vp, _vp]),
     "rsparse_hip_initialize_biases_implicit_device": (_c_int, [_vp, _vp, _vp, _vp, _c_dbl, _c_int, _c_int,
                                                                ctypes.POINTER(_c_dbl), _vp]),
     "rsparse_hip_initialize_biases_float": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_dbl, _c_int,
@@ -54,12 +53,13 @@ SIGNATURES = {
     "rsparse_hip_csc_transpose_device": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rsparse_hip_values_to_float_device": (_c_int, [_c_i64, _vp, _vp, _vp]),
     "rsparse_hip_gramian_device": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp, _vp, _vp]),
-    "rsparse_hip_als_implicit_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_uint, _vp, _vp]),
+    "rsparse_hip_als_implicit_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_uint, _vp, _vp, _vp]),
     "rsparse_hip_als_explicit_device": (_c_int, [_vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_uint, _c_int, _vp, _vp]),
     "rsparse_hip_weighted_sumsq_device": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp]),
     "rsparse_hip_top_product": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_uint, _c_uint, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp]),
     "rsparse_hip_top_product_device": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _vp]),
     "rsparse_hip_profile_enable": (_c_int, [_c_int]),
+    "rsparse_hip_set_launch_mode": (_c_int, [_c_int]),
     "rsparse_hip_profile_last": (_c_int, [ctypes.POINTER(_c_dbl)]),
     "rsparse_hip_take_numeric_failures": (_c_int, [ctypes.POINTER(_c_i64)]),
 }

@@ -66,11 +66,11 @@ def als_implicit(x, X, Y, lambda_, n_threads, solver_code, cg_steps, precision, 
         raise ValueError("X must be rank x nrow(x) and Y rank x ncol(x)")
     bias = bool(with_user_item_bias)
     fn = lib.rsparse_hip_als_implicit_float if precision == "float" else lib.rsparse_hip_als_implicit_double
-    if int(solver_code) == 1 and (bias or global_bias):
-        # the C ABI reports these as UNSUPPORTED (include/rsparse_wrmf_hip.h); ask it before computing a Gramian
+    if int(solver_code) == 1 and bias:
+        # the C ABI reports this as UNSUPPORTED (include/rsparse_wrmf_hip.h); ask it before computing a Gramian
         _lib.check(fn(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), None, rank, float(lambda_),
                       int(n_threads), int(solver_code), int(cg_steps), int(bias), int(bool(is_bias_last_row)),
-                      float(global_bias), None, int(bool(initialize_bias_base)), None))
+                      float(global_bias), None, 0, int(bool(initialize_bias_base)), None))
     if XtX is None:
         # R/model_WRMF.R:474-486: with biases the x_bias row is discarded before tcrossprod
         XX = X
@@ -79,13 +79,15 @@ def als_implicit(x, X, Y, lambda_, n_threads, solver_code, cg_steps, precision, 
         XtX = gramian(XX, lambda_, precision)
     _f_contig(XtX, dt, "XtX")
     if global_bias_base is not None:
-        # R/model_WRMF.R:470-472: numeric(rank) / float(rank), written when initialize_bias_base, read otherwise
-        if not isinstance(global_bias_base, np.ndarray) or global_bias_base.dtype != dt or global_bias_base.size != rank:
-            raise ValueError("global_bias_base must be a numpy vector of %d values of dtype %s" % (rank, np.dtype(dt)))
+        # self$global_bias_base: numeric(rank - 1) / float(rank - 1) in the R driver (R/model_WRMF.R:291-296) although the
+        # vector has `rank` entries; any length is accepted and its length is passed on (the library never touches more)
+        if not isinstance(global_bias_base, np.ndarray) or global_bias_base.dtype != dt or global_bias_base.ndim != 1:
+            raise ValueError("global_bias_base must be a numpy vector of dtype %s" % np.dtype(dt))
     loss = ctypes.c_double(0.0)
     _lib.check(fn(n_rows, n_cols, _vp(p), _vp(i), _vp(v), _vp(X), _vp(Y), _vp(XtX), rank, float(lambda_),
                   int(n_threads), int(solver_code), int(cg_steps), int(bias), int(bool(is_bias_last_row)),
-                  float(global_bias), _vp(global_bias_base), int(bool(initialize_bias_base)), ctypes.addressof(loss)))
+                  float(global_bias), _vp(global_bias_base), 0 if global_bias_base is None else int(global_bias_base.size),
+                  int(bool(initialize_bias_base)), ctypes.addressof(loss)))
     return loss.value
 
 

@@ -62,6 +62,10 @@ struct Workspace {
   size_t tscr_floats = 0;
   float* bias_buf = nullptr;   // explicit + biases: X', Y', shifted ratings
   size_t bias_floats = 0;
+  float* gb_r0 = nullptr;      // global bias + CG: per long row, base - g X_nnz (c - 1)  (launch_gb_row_terms)
+  size_t gb_r0_floats = 0;
+  int32_t* gb_slot = nullptr;  // ... and the slot of every row in it
+  size_t gb_slot_ints = 0;
   int device = -1;
 
   int ensure_device() {
@@ -135,6 +139,21 @@ struct Workspace {
     }
     return RSPARSE_HIP_OK;
   }
+  int ensure_gb(size_t floats, size_t ints) {
+    if (floats > gb_r0_floats) {
+      if (gb_r0) (void)hipFree(gb_r0);
+      gb_r0 = nullptr; gb_r0_floats = 0;
+      HIP_TRY(hipMalloc(&gb_r0, floats * sizeof(float)));
+      gb_r0_floats = floats;
+    }
+    if (ints > gb_slot_ints) {
+      if (gb_slot) (void)hipFree(gb_slot);
+      gb_slot = nullptr; gb_slot_ints = 0;
+      HIP_TRY(hipMalloc(&gb_slot, ints * sizeof(int32_t)));
+      gb_slot_ints = ints;
+    }
+    return RSPARSE_HIP_OK;
+  }
   int ensure_tscr(size_t floats) {
     if (floats > tscr_floats) {
       if (tscr) (void)hipFree(tscr);
@@ -146,6 +165,9 @@ struct Workspace {
     return RSPARSE_HIP_OK;
   }
   void release() {
+    if (gb_r0) (void)hipFree(gb_r0);
+    if (gb_slot) (void)hipFree(gb_slot);
+    gb_r0 = nullptr; gb_slot = nullptr; gb_r0_floats = 0; gb_slot_ints = 0;
     if (tscr) (void)hipFree(tscr);
     tscr = nullptr;
     tscr_floats = 0;
@@ -383,7 +405,9 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   }
   // solver == CHOLESKY: its normal-equation launch may take shorter rows too (RSPARSE_HIP_NE_CHOL_MIN, 64..512)
   d.q_nec_min = kNeCholMinLen;
+#ifdef RSP_AB   // dev builds: the threshold sweep behind DESIGN.md 3.3
   if (const char* e = std::getenv("RSPARSE_HIP_NE_CHOL_MIN")) d.q_nec_min = std::min(kNeMinLen, std::max(kCholLrMax, std::atoi(e)));
+#endif
   int n_nec = 0;
   while (n_nec < n && host_col_ptrs[order[(size_t)n_nec] + 1] - host_col_ptrs[order[(size_t)n_nec]] > d.q_nec_min) n_nec++;
   d.q_n_nec = n_nec;
@@ -400,9 +424,6 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   }
   return RSPARSE_HIP_OK;
 }
-
-// max |X| supplied by the caller for the half-iterations on X (rsparse_hip_hint_factor_absmax)
-struct AbsmaxHint { const float* X = nullptr; const float* absmax = nullptr; } g_absmax_hint;
 
 // the register-resident quad-layout CG kernels need rank % 4 == 0 and 16-byte aligned factor matrices; other ranks take
 // the LDS-tile kernels of wrmf_kernels.hip
@@ -422,18 +443,20 @@ int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_i
   return RSPARSE_HIP_OK;
 }
 
-// wrmf_implicit.hpp:108-109: a global bias below sqrt(eps) is treated as zero
-bool has_global_bias(double global_bias) { return global_bias >= std::sqrt((double)FLT_EPSILON); }
+// wrmf_implicit.hpp:108-109: a global bias below sqrt(eps) of the element type T is treated as zero (float: 3.45e-4,
+// double: 1.49e-8; the device layer holds floats, the stateless *_double entry point passes dbl = true)
+bool has_global_bias(double global_bias, bool dbl = false) {
+  return global_bias >= std::sqrt(dbl ? DBL_EPSILON : (double)FLT_EPSILON);
+}
 
 int check_variant(unsigned solver, int with_biases, double global_bias, bool implicit = true) {
   if (solver > RSPARSE_SOLVER_NNLS) return fail(RSPARSE_HIP_ERR_INVALID, "unknown solver code");
   if (with_biases && implicit && solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT)
     // the reference drops a row of the warm start twice on this path (wrmf_implicit.hpp:189,197) and cannot run it
     return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "with_user_item_bias + conjugate_gradient with implicit feedback is not on the device path");
-  if (has_global_bias(global_bias) && (!implicit || solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT))
-    // implicit global bias: the Cholesky / NNLS branches (wrmf_implicit.hpp:228-229,262-270) are on the device; the
-    // conjugate-gradient variant (cg_solver_implicit_global_bias, :35-57, "very poor numerical precision") is not
-    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "global_bias with the conjugate-gradient solver is not on the device path");
+  // (a global bias goes with every solver: Cholesky / NNLS wrmf_implicit.hpp:228-229,262-270, conjugate gradient
+  // cg_solver_implicit_global_bias :35-57; with explicit feedback it is removed from the data by the R driver)
+  (void)global_bias;
   return RSPARSE_HIP_OK;
 }
 
@@ -442,11 +465,14 @@ struct BiasTerms {   // implicit feedback with user/item biases and / or a globa
   const float* loss_tgt;
   const float* rhs_init;
   float tgt_const = 1.f;
+  float gbias = 0.f;   // conjugate gradient with a global bias: the bias itself (rhs_init = global_bias_base)
 };
 
+// d_absmax (nullable, device float): max |X| supplied by the caller -- X is then not scanned for the fp16 operand scales
 int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* d_X, float* d_Y,
                        const float* d_XtX, int rank, double lambda, unsigned solver, unsigned cg_steps,
-                       int dynamic_lambda, double* d_loss_rows_out, hipStream_t s, const BiasTerms* bias = nullptr) {
+                       int dynamic_lambda, double* d_loss_rows_out, hipStream_t s, const BiasTerms* bias = nullptr,
+                       const float* d_absmax = nullptr) {
   if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
   if (!d_X || !d_Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
   if (implicit && !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "XtX is NULL");
@@ -501,6 +527,9 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.loss_tgt = bias ? bias->loss_tgt : nullptr;
   a.rhs_init = bias ? bias->rhs_init : nullptr;
   a.loss_tgt_const = bias ? bias->tgt_const : 1.f;
+  const bool gb_cg = cg && implicit && bias && bias->gbias != 0.f;   // cg_solver_implicit_global_bias
+  a.gbias = gb_cg ? bias->gbias : 0.f;
+  a.ne_r0 = nullptr; a.ne_r0_slot = nullptr;
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
   a.ne_prof = nullptr;
   a.ne_stats = nullptr;
@@ -520,12 +549,18 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     if ((rc = g_ws.ensure_ne_seg((size_t)ne_nseg))) return rc;
     a.ne_segs = ne_segs; a.ne_seg_scratch = g_ws.ne_seg_scratch; a.ne_seg_flags = g_ws.ne_seg_flags;
   }
-  if ((cgq || ne_chol) && implicit && qs.ne_wg > 0 && ne_supported(rank) && !bias) {
+  if ((cgq || ne_chol) && implicit && qs.ne_wg > 0 && ne_supported(rank) && (!bias || gb_cg)) {
     // operand scales of the fp16 normal-equation kernel (and whether it may run at all), decided on the device
-    const float* hint = (g_absmax_hint.X == d_X && g_absmax_hint.absmax) ? g_absmax_hint.absmax : nullptr;
-    hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, hint);
+    hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax);
     if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
     a.ne_stats = g_ws.ne_stats;
+    if (gb_cg && cgq) {   // the long rows' share of the first residual: base - g X_nnz (c - 1), one more pass over them
+      const int n_ne = d.q_off[1];
+      if ((rc = g_ws.ensure_gb((size_t)n_ne * rank, (size_t)d.n_cols))) return rc;
+      hipError_t ge = launch_gb_row_terms(a, d.q_order, n_ne, g_ws.gb_r0, g_ws.gb_slot, s);
+      if (ge != hipSuccess) return hip_fail(ge, "launch_gb_row_terms");
+      a.ne_r0 = g_ws.gb_r0; a.ne_r0_slot = g_ws.gb_slot;
+    }
   }
 #ifdef RSP_NE_PROF
   static unsigned long long* prof_buf = nullptr;
@@ -640,7 +675,8 @@ int run_half_iteration_explicit_biased(const rsparse_hip_csc* conf, const float*
 // (rank-1) x (rank-1) Gramian of X without its x_bias row, ridge included (R/model_WRMF.R:474-486).
 int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, const float* d_XtX,
                                        int rank, double lambda, unsigned solver, int is_x_bias_last_row,
-                                       double* d_loss_rows_out, hipStream_t s, double global_bias = 0.0) {
+                                       double* d_loss_rows_out, hipStream_t s, double global_bias = 0.0,
+                                       bool dbl_threshold = false) {
   if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
   if (!d_X || !d_Y || !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "X, Y or XtX is NULL");
   if (rank < 2) return fail(RSPARSE_HIP_ERR_INVALID, "with_biases needs rank >= 2 (a row of ones and a bias row)");
@@ -666,7 +702,7 @@ int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float*
   if (d.n_cols > 0)
     HIP_TRY(hipMemcpy2DAsync(Yp, (size_t)k1 * 4, d_Y + ioff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_cols,
                              hipMemcpyDeviceToDevice, s));
-  const float gb = has_global_bias(global_bias) ? (float)global_bias : 0.f;
+  const float gb = has_global_bias(global_bias, dbl_threshold) ? (float)global_bias : 0.f;
   hipError_t e = launch_bias_implicit_terms(d.vals, d.row_idx, d_X, rank, xb, d.nnz, gb, rcoef, tgt, s);
   if (e != hipSuccess) return hip_fail(e, "launch_bias_implicit_terms");
   if ((e = launch_bias_rhs_init(d_X, rank, xoff, k1, xb, gb, d.n_rows, scratch, rinit, s)) != hipSuccess)
@@ -685,9 +721,9 @@ int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float*
 // (computed here when d_base_in is NULL -- initialize_bias_base -- and returned through d_base_out if given), every row
 // is solved (empty ones too, :178), and the loss compares x_j.y with 1 - global_bias.
 int run_half_iteration_implicit_global(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, const float* d_XtX,
-                                       int rank, double lambda, unsigned solver, double global_bias,
+                                       int rank, double lambda, unsigned solver, unsigned cg_steps, double global_bias,
                                        const float* d_base_in, float* d_base_out, double* d_loss_rows_out,
-                                       hipStream_t s) {
+                                       hipStream_t s, const float* d_absmax = nullptr) {
   if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
   if (!d_X || !d_Y || !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "X, Y or XtX is NULL");
   if (rank <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive");
@@ -706,8 +742,11 @@ int run_half_iteration_implicit_global(const rsparse_hip_csc* conf, const float*
     if (e != hipSuccess) return hip_fail(e, "launch_bias_rhs_init");
   }
   if (d_base_out) HIP_TRY(hipMemcpyAsync(d_base_out, rinit, (size_t)rank * 4, hipMemcpyDeviceToDevice, s));
-  BiasTerms bt{nullptr, nullptr, rinit, (float)(1.0 - global_bias)};
-  return run_half_iteration(conf, true, d_X, d_Y, d_XtX, rank, lambda, solver, 0, 0, d_loss_rows_out, s, &bt);
+  // conjugate gradient: cg_solver_implicit_global_bias (wrmf_implicit.hpp:35-57,203) from the warm start in d_Y
+  const bool cg = solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT;
+  BiasTerms bt{nullptr, nullptr, rinit, (float)(1.0 - global_bias), cg ? (float)global_bias : 0.f};
+  return run_half_iteration(conf, true, d_X, d_Y, d_XtX, rank, lambda, solver, cg ? cg_steps : 0, 0, d_loss_rows_out, s,
+                            &bt, d_absmax);
 }
 
 // Shared body of the four stateless drop-ins.  TX = float or double (host element type).
@@ -716,7 +755,7 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
               const double* values, const TX* X, TX* Y, const TX* XtX, const TX* cnt_X, int rank, double lambda,
               unsigned solver, unsigned cg_steps, int dynamic_lambda, double* loss_out, int with_biases = 0,
               int is_x_bias_last_row = 0, double global_bias = 0.0, TX* global_bias_base = nullptr,
-              int initialize_bias_base = 1) {
+              int global_bias_base_len = 0, int initialize_bias_base = 1) {
   rsparse_hip_csc* conf = nullptr;
   int rc = rsparse_hip_csc_create_host(n_rows, n_cols, col_ptrs, row_indices, values, &conf);
   if (rc) return rc;
@@ -747,23 +786,30 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
     HIP_TRY(upload(dW, cnt_X, (size_t)n_rows));
   }
   if ((rc = g_ws.ensure_device())) return rc;
-  const bool gbias = implicit && has_global_bias(global_bias);
+  const bool gbias = implicit && has_global_bias(global_bias, sizeof(TX) == sizeof(double));
   DevBuf dBase;
-  if (gbias && !with_biases) {   // global_bias_base: rank entries, read (initialize_bias_base == 0) or written
+  if (gbias && !with_biases) {
+    // global_bias_base = -global_bias * rowSums(X), `rank` entries (wrmf_implicit.hpp:111-112).  The caller's buffer holds
+    // global_bias_base_len entries -- the R driver allocates rank - 1 (R/model_WRMF.R:292) although the reference's C++ reads
+    // and assigns `rank`; here never more than the stated length is touched: it is READ (initialize_bias_base == 0) only
+    // when it holds the whole vector, otherwise the vector is recomputed from X (its definition); it is WRITTEN up to
+    // min(len, rank) entries
     HIP_TRY(dBase.alloc((size_t)rank * 4));
-    const bool given = !initialize_bias_base && global_bias_base;
+    const int blen = global_bias_base ? std::max(global_bias_base_len, 0) : 0;
+    const bool given = !initialize_bias_base && blen >= rank;
     if (given) HIP_TRY(upload(dBase, global_bias_base, (size_t)rank));
     rc = run_half_iteration_implicit_global(conf, dX.as<float>(), dY.as<float>(), dG.as<float>(), rank, lambda, solver,
-                                            global_bias, given ? dBase.as<float>() : nullptr,
+                                            cg_steps, global_bias, given ? dBase.as<float>() : nullptr,
                                             given ? nullptr : dBase.as<float>(), g_ws.scalars, nullptr);
-    if (!rc && !given && global_bias_base) {
+    if (!rc && !given && initialize_bias_base && blen > 0) {
       std::vector<float> hb((size_t)rank);
       HIP_TRY(hipMemcpy(hb.data(), dBase.p, (size_t)rank * 4, hipMemcpyDeviceToHost));
-      for (int t = 0; t < rank; t++) global_bias_base[t] = (TX)hb[(size_t)t];
+      for (int t = 0; t < std::min(blen, rank); t++) global_bias_base[t] = (TX)hb[(size_t)t];
     }
   } else if (with_biases && implicit)
     rc = run_half_iteration_implicit_biased(conf, dX.as<float>(), dY.as<float>(), dG.as<float>(), rank, lambda, solver,
-                                            is_x_bias_last_row, g_ws.scalars, nullptr, global_bias);
+                                            is_x_bias_last_row, g_ws.scalars, nullptr, global_bias,
+                                            sizeof(TX) == sizeof(double));
   else if (with_biases)
     rc = run_half_iteration_explicit_biased(conf, dX.as<float>(), dY.as<float>(), rank, lambda, solver, cg_steps,
                                             dynamic_lambda, is_x_bias_last_row, g_ws.scalars, nullptr);
@@ -815,7 +861,7 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
 extern "C" {
 
 const char* rsparse_hip_last_error(void) { return g_err.c_str(); }
-int rsparse_hip_abi_version(void) { return 2; }
+int rsparse_hip_abi_version(void) { return 3; }
 
 int rsparse_hip_device_count(void) {
   int n = 0;
@@ -980,6 +1026,12 @@ int rsparse_hip_csc_info(const rsparse_hip_csc* m, int64_t info_out[40]) {
   return RSPARSE_HIP_OK;
 }
 
+int rsparse_hip_set_launch_mode(int mode) {
+  if (mode < 0 || mode > 2) return fail(RSPARSE_HIP_ERR_INVALID, "launch mode must be 0, 1 or 2");
+  cgq_set_launch_mode(mode);
+  return RSPARSE_HIP_OK;
+}
+
 int rsparse_hip_profile_enable(int on) {
   g_prof.on = on != 0;
   g_prof.have = false;
@@ -1002,12 +1054,6 @@ int rsparse_hip_profile_last(double ms_out[8]) {
 int rsparse_hip_gramian_device(const float* d_X, int rank, int64_t n, double lambda, float* d_XtX_out,
                                double* d_sumsq_out, void* stream) {
   return rsparse_hip_gramian_absmax_device(d_X, rank, n, lambda, d_XtX_out, d_sumsq_out, nullptr, stream);
-}
-
-int rsparse_hip_hint_factor_absmax(const float* d_X, const float* d_absmax) {
-  g_absmax_hint.X = d_X;
-  g_absmax_hint.absmax = d_X ? d_absmax : nullptr;
-  return RSPARSE_HIP_OK;
 }
 
 int rsparse_hip_gramian_absmax_device(const float* d_X, int rank, int64_t n, double lambda, float* d_XtX_out,
@@ -1046,9 +1092,9 @@ int rsparse_hip_gramian_float(const float* X, int rank, int64_t n, double lambda
 
 int rsparse_hip_als_implicit_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, const float* d_XtX,
                                     int rank, double lambda, unsigned solver, unsigned cg_steps,
-                                    double* d_loss_rows_out, void* stream) {
+                                    const float* d_absmax, double* d_loss_rows_out, void* stream) {
   return run_half_iteration(conf, true, d_X, d_Y, d_XtX, rank, lambda, solver, cg_steps, 0, d_loss_rows_out,
-                            (hipStream_t)stream);
+                            (hipStream_t)stream, nullptr, d_absmax);
 }
 
 int rsparse_hip_als_explicit_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, int rank,
@@ -1069,18 +1115,19 @@ int rsparse_hip_als_implicit_bias_device(const rsparse_hip_csc* conf, const floa
 
 int rsparse_hip_als_implicit_global_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
                                                 const float* d_XtX, int rank, double lambda, unsigned solver,
-                                                int with_biases, int is_x_bias_last_row, double global_bias,
-                                                double* d_loss_rows_out, void* stream) {
+                                                unsigned cg_steps, int with_biases, int is_x_bias_last_row,
+                                                double global_bias, const float* d_absmax, double* d_loss_rows_out,
+                                                void* stream) {
   int rc = check_variant(solver, with_biases, global_bias, true);
   if (rc) return rc;
   if (with_biases)
     return run_half_iteration_implicit_biased(conf, d_X, d_Y, d_XtX, rank, lambda, solver, is_x_bias_last_row,
                                               d_loss_rows_out, (hipStream_t)stream, global_bias);
   if (!has_global_bias(global_bias))
-    return run_half_iteration(conf, true, d_X, d_Y, d_XtX, rank, lambda, solver, 0, 0, d_loss_rows_out,
-                              (hipStream_t)stream);
-  return run_half_iteration_implicit_global(conf, d_X, d_Y, d_XtX, rank, lambda, solver, global_bias, nullptr, nullptr,
-                                            d_loss_rows_out, (hipStream_t)stream);
+    return run_half_iteration(conf, true, d_X, d_Y, d_XtX, rank, lambda, solver, cg_steps, 0, d_loss_rows_out,
+                              (hipStream_t)stream, nullptr, d_absmax);
+  return run_half_iteration_implicit_global(conf, d_X, d_Y, d_XtX, rank, lambda, solver, cg_steps, global_bias, nullptr,
+                                            nullptr, d_loss_rows_out, (hipStream_t)stream, d_absmax);
 }
 
 int rsparse_hip_initialize_biases_implicit_device(const rsparse_hip_csc* c_ui, const rsparse_hip_csc* c_iu,
@@ -1307,28 +1354,30 @@ int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_pt
                                    const double* values, const float* X, float* Y, const float* XtX, int rank,
                                    double lambda, int n_threads, unsigned solver, unsigned cg_steps,
                                    int with_biases, int is_x_bias_last_row, double global_bias,
-                                   float* global_bias_base, int initialize_bias_base, double* loss_out) {
+                                   float* global_bias_base, int global_bias_base_len, int initialize_bias_base,
+                                   double* loss_out) {
   (void)n_threads;
   int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
   if (rc) return rc;
   if ((rc = check_variant(solver, with_biases, global_bias))) return rc;
   return stateless<float>(true, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, nullptr, rank, lambda,
                           solver, cg_steps, 0, loss_out, with_biases, is_x_bias_last_row, global_bias, global_bias_base,
-                          initialize_bias_base);
+                          global_bias_base_len, initialize_bias_base);
 }
 
 int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
                                     const double* values, const double* X, double* Y, const double* XtX, int rank,
                                     double lambda, int n_threads, unsigned solver, unsigned cg_steps,
                                     int with_biases, int is_x_bias_last_row, double global_bias,
-                                    double* global_bias_base, int initialize_bias_base, double* loss_out) {
+                                    double* global_bias_base, int global_bias_base_len, int initialize_bias_base,
+                                    double* loss_out) {
   (void)n_threads;
   int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
   if (rc) return rc;
   if ((rc = check_variant(solver, with_biases, global_bias))) return rc;
   return stateless<double>(true, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, nullptr, rank, lambda,
                            solver, cg_steps, 0, loss_out, with_biases, is_x_bias_last_row, global_bias, global_bias_base,
-                           initialize_bias_base);
+                           global_bias_base_len, initialize_bias_base);
 }
 
 }  // extern "C"

@@ -157,7 +157,10 @@ struct QSmem {
   static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats + pre_floats + dmf_floats) * 4 + 16;
 };
 
-template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, bool DMF = false>
+// GB: implicit feedback with a global bias (cg_solver_implicit_global_bias, wrmf_implicit.hpp:35-57,203): the first
+// residual is  X_nnz (c - c1 % (X_nnz^T x + global_bias)) - XtX x + global_bias_base  (a.gbias, a.rhs_init), every row is
+// solved -- empty ones too (:178) -- and the loss compares x_j.y with 1 - global_bias (a.loss_tgt_const, :262-264).
+template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, bool DMF = false, bool GB = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
                                                              int rows_per_team, size_t loss_slot0) {
   using G_ = QG<KP>;
@@ -166,6 +169,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   using SM = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF>;
   static_assert(WAVES % WPR == 0, "teams must tile the workgroup");
   static_assert(!DMF || (IMPLICIT && KP == 128 && WAVES == 4 && WPR == 1 && STREAM == 0), "DMF geometry");
+  static_assert(!GB || IMPLICIT, "the global bias of explicit feedback is removed from the data (R/model_WRMF.R:278-282)");
+  const float gbias = GB ? a.gbias : 0.f, ltgt = GB ? a.loss_tgt_const : 1.f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sG = reinterpret_cast<float*>(smem);
   float* sVec = sG + SM::gram_floats;
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     }
     const int cnt = p2 - p1;
     float* yrow = a.Y + (size_t)row * k;
-    if (WPR == 1 && cnt <= 0) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
+    if (!GB && WPR == 1 && cnt <= 0) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
       if (!DMF || have)
         for (int e = lane; e < k; e += 64) yrow[e] = 0.f;
       if constexpr (!DMF) continue;   // DMF: the workgroup's waves share the dense products, so this wave keeps in step
@@ -460,11 +465,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
               trec[4 * q] = t[u];
             }
             if (mode == 2) {
-              const float d = IMPLICIT ? 1.f - t[u] : c - t[u];
+              const float d = IMPLICIT ? ltgt - t[u] : c - t[u];
               lacc += valid ? (IMPLICIT ? c * d * d : d * d) : 0.f;
             } else {
               float w;
-              if (mode == 0) w = IMPLICIT ? c - (c - 1.f) * t[u] : c - t[u];
+              if (mode == 0) w = IMPLICIT ? c - (c - 1.f) * (GB ? t[u] + gbias : t[u]) : c - t[u];
               else w = IMPLICIT ? (c - 1.f) * t[u] : t[u];
               w = valid ? w : 0.f;
 #pragma unroll
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
             // loss from t_acc = X_nnz^T y built up by the sweeps (the vectors are not touched again)
             wave_sync();
             const float t = tacc[lane & (CAP - 1)];
-            const float d = IMPLICIT ? 1.f - t : cl - t;
+            const float d = IMPLICIT ? ltgt - t : cl - t;
             const float e = IMPLICIT ? cl * d * d : d * d;
             lacc = row16_sum(lane < ccnt ? e : 0.f);  // groups_sum below finishes the wave sum
           }
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
               for (int s2 = 0; s2 < kMaxSavedSweeps; s2++)
                 if (s2 < a.cg_steps) t = fmaf(alph[s2], tscr[(size_t)(s2 + 1) * a.stream_nnz + pos], t);
               const float c = a.vals[p1 + pos];
-              const float d = IMPLICIT ? 1.f - t : c - t;
+              const float d = IMPLICIT ? ltgt - t : c - t;
               lacc += IMPLICIT ? c * d * d : d * d;
             }
           }
@@ -708,6 +713,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       if (mode != 2) {
 #pragma unroll
         for (int rr = 0; rr < RPN; rr++) out[rr] = acc[rr];
+        if constexpr (GB) {
+          if (mode == 0) {   // + global_bias_base (the same k floats for every row: L2)
+#pragma unroll
+            for (int b = 0; b < NV; b++) {
+              const int off = b * 16 * VW + i * VW;
+              const piece_t pc = *reinterpret_cast<const piece_t*>(a.rhs_init + min(off, k - VW));
+              const float* pf = reinterpret_cast<const float*>(&pc);
+#pragma unroll
+              for (int c = 0; c < VW; c++) out[b * VW + c] += off < k ? pf[c] : 0.f;
+            }
+          }
+        }
         if constexpr (!IMPLICIT) {
 #pragma unroll
           for (int rr = 0; rr < RPN; rr++) out[rr] = fmaf(mode == 0 ? -lam_use : lam_use, v[rr], out[rr]);
@@ -724,7 +741,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       return row16_sum(s);  // the 16 lanes of a group cover the whole vector; groups are replicas
     };
 
-    const bool live = have && cnt > 0;
+    const bool live = have && (GB || cnt > 0);
     float dummy = 0.f;
     sweep(x, 0, r, dummy, live);
     if constexpr (IDXPF && STREAM == 0) {
@@ -816,24 +833,29 @@ constexpr BucketDef kBuckets[kNCfg][kNB] = {
     {{8, 8, 16, 1, 0x7fffffff}, {8, 8, 16, 0, 512}, {4, 4, 16, 0, 256}, {4, 2, 16, 0, 128}, {4, 1, 16, 0, 64}, {4, 1, 8, 0, 32}},
 };
 
-// RSPARSE_HIP_DENSE_MFMA=0 keeps the one-wave rows of <= 32 non-zeros on the vector-unit G v product (A/B switch)
+// dev builds (-DRSP_AB): RSPARSE_HIP_DENSE_MFMA=0 keeps the one-wave rows of <= 32 non-zeros on the vector-unit G v
+// product (the A/B switch behind DESIGN.md 3.1)
 bool dense_mfma_enabled() {
+#ifdef RSP_AB
   static const bool on = [] {
     const char* e = std::getenv("RSPARSE_HIP_DENSE_MFMA");
     return !(e && e[0] == '0');
   }();
   return on;
+#else
+  return true;
+#endif
 }
 
-template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT, bool DMF = false>
+template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT, bool GB, bool DMF = false>
 hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int grid, size_t slot0, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   constexpr bool kDmfGeometry = IMPLICIT && KP == 128 && WAVES == 4 && WPR == 1 && CAPQ == 8 && STREAM == 0;
   if constexpr (kDmfGeometry && !DMF) {
-    if (dense_mfma_enabled()) return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, true>(a, rows, n_rows, grid, slot0, s);
+    if (dense_mfma_enabled()) return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, GB, true>(a, rows, n_rows, grid, slot0, s);
   }
   constexpr int TEAMS = WAVES / WPR;
-  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF>;
+  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF, GB>;
   const size_t lds = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF>::bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -869,12 +891,11 @@ BucketStreams g_bs;
 
 // 0: every launch on the caller's stream; 1: every bucket on its own side stream; 2: the long-row launch first on the
 // caller's stream (it occupies every CU's LDS: nothing runs beside it), the resident buckets on side streams after it
-int concurrent_buckets() {
-  static const char* env = std::getenv("RSPARSE_HIP_CONCURRENT");
-  return env ? (env[0] - '0') : 2;   // (measured on the bench line: 0 -> 165.5 ms, 2 -> 166.0 ms, 1 -> 171.8 ms per iteration)
-}
+// (rsparse_hip_set_launch_mode; measured on the bench line: 0 -> 165.5 ms, 2 -> 166.0 ms, 1 -> 171.8 ms per iteration)
+int g_launch_mode = 2;
+int concurrent_buckets() { return g_launch_mode; }
 
-template <int KP, int CFG, bool IMPLICIT>
+template <int KP, int CFG, bool IMPLICIT, bool GB>
 hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEvent_t* ev) {
   hipError_t err;
   size_t slot = 0;
@@ -908,7 +929,7 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
             return err;                                                                                     \
         } else if constexpr (D.stream && KP > 32) {   /* ranks above 32 always take the branch above */     \
           return hipErrorInvalidValue;                                                                      \
-        } else if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT>(a, q.order + q.off[B], n, grid, slot, \
+        } else if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT, GB>(a, q.order + q.off[B], n, grid, slot, \
                                                                                 bs)) != hipSuccess)         \
           return err;                                                                                       \
         if (side) {                                                                                         \
@@ -977,12 +998,14 @@ size_t cgq_loss_slots(const QSchedule& q, int k) {
 }
 
 int cgq_default_cfg() { return 0; }
+void cgq_set_launch_mode(int mode) { g_launch_mode = mode; }
 
 hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(a.k);
 #define RSP_DISPATCH(KPV)                                                                                   \
   if (KP == KPV) {                                                                                          \
-    return implicit ? launch_all<KPV, 0, true>(a, q, s, ev) : launch_all<KPV, 0, false>(a, q, s, ev);       \
+    if (implicit && a.gbias != 0.f) return launch_all<KPV, 0, true, true>(a, q, s, ev);                     \
+    return implicit ? launch_all<KPV, 0, true, false>(a, q, s, ev) : launch_all<KPV, 0, false, false>(a, q, s, ev); \
   }
   RSP_DISPATCH(32)
   RSP_DISPATCH(64)

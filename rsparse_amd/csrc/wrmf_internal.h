@@ -84,6 +84,13 @@ struct AlsArgs {
   const float* loss_tgt;   // per non-zero: target of the loss term, 1 - global_bias - x_b               (default: loss_tgt_const)
   float loss_tgt_const;    // target of the loss term when loss_tgt is nullptr: 1, or 1 - global_bias (wrmf_implicit.hpp:262-264)
   const float* rhs_init;   // k floats added to every right-hand side; non-null also means "solve empty rows too"
+  // implicit feedback, conjugate gradient with a global bias (cg_solver_implicit_global_bias, wrmf_implicit.hpp:35-57):
+  // gbias != 0 selects it; rhs_init = global_bias_base, loss_tgt_const = 1 - gbias.  The normal-equation kernel's rows
+  // (wrmf_ne.hip) take the extra term of their first residual, global_bias_base - gbias X_nnz (c - 1), from ne_r0
+  // [ne_r0_slot[row]][k] (launch_gb_row_terms)
+  float gbias;
+  const float* ne_r0;
+  const int32_t* ne_r0_slot;
   float* tscr;
   const int64_t* stream_off;
   int64_t stream_nnz;
@@ -125,6 +132,7 @@ struct QSchedule {
   int ne_nsplit;
 };
 int cgq_default_cfg();
+void cgq_set_launch_mode(int mode);   // rsparse_hip_set_launch_mode
 int cgq_num_buckets();               // 6
 int cgq_bucket_wpr(int cfg, int b);  // waves per row of bucket b (0 = unused)
 int cgq_bucket_capq(int cfg, int b);
@@ -145,6 +153,9 @@ hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_
                            const float* absmax_hint = nullptr);
 struct QSchedule;
 hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s);
+// global bias + conjugate gradient: out[r][:] = base - gbias * sum_j (c_j - 1) x_j for the n rows `rows` (one workgroup
+// per row), slot_of_row[rows[r]] = r
+hipError_t launch_gb_row_terms(const AlsArgs& a, const int32_t* rows, int n, float* out, int32_t* slot_of_row, hipStream_t s);
 // ev (optional): 7 events, ev[b] before bucket b's kernel, ev[6] after the last one
 hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 

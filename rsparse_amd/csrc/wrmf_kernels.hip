@@ -78,6 +78,11 @@ __global__ __launch_bounds__(W * 64) void als_cg_short_kernel(AlsArgs a) {
   const bool active = e0 < KP;
   const int jl = lane % T;
   double wloss = 0.0;
+  // implicit feedback with a global bias (cg_solver_implicit_global_bias, wrmf_implicit.hpp:35-57,203): a.gbias != 0, then
+  // the first residual takes  + global_bias inside c1 % (.)  and  + a.rhs_init (global_bias_base), empty rows are solved
+  // (:178) and the loss compares with a.loss_tgt_const = 1 - global_bias (:262-264)
+  const bool gb = IMPLICIT && a.gbias != 0.f;
+  const float gbias = gb ? a.gbias : 0.f, ltgt = gb ? a.loss_tgt_const : 1.f;
 
   while (true) {
     int rr = 0;
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(W * 64) void als_cg_short_kernel(AlsArgs a) {
     const int cnt = p2 - p1;
     if (cnt > T) continue;  // solved by the long-row kernel
     float* yrow = a.Y + (size_t)row * k;
-    if (cnt <= 0) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
+    if (cnt <= 0 && !gb) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
       for (int e = lane; e < k; e += 64) yrow[e] = 0.f;
       continue;
     }
@@ -108,12 +113,16 @@ __global__ __launch_bounds__(W * 64) void als_cg_short_kernel(AlsArgs a) {
     put_vec<KP>(vec, x, lane, active);
     wave_sync();
     float t = tile_dot<KP, T>(tile, vec, lane);
-    float wgt = jvalid ? (IMPLICIT ? c - (c - 1.f) * t : c - t) : 0.f;
+    float wgt = jvalid ? (IMPLICIT ? c - (c - 1.f) * (t + gbias) : c - t) : 0.f;
 #pragma unroll
     for (int u = 0; u < EPL; u++) r[u] = 0.f;
     tile_axpy<KP>(tile, wgt, cnt, lane, active, r);
     if constexpr (IMPLICIT) {
       gram_mv<KP>(sG, vec, 0, KP, lane, active, -1.f, r);
+      if (gb) {
+#pragma unroll
+        for (int u = 0; u < EPL; u++) r[u] += (active && e0 + u < k) ? a.rhs_init[e0 + u] : 0.f;
+      }
     } else {
 #pragma unroll
       for (int u = 0; u < EPL; u++) r[u] -= lam_use * x[u];
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(W * 64) void als_cg_short_kernel(AlsArgs a) {
     put_vec<KP>(vec, x, lane, active);
     wave_sync();
     t = tile_dot<KP, T>(tile, vec, lane);
-    const float d = IMPLICIT ? 1.f - t : c - t;
+    const float d = IMPLICIT ? ltgt - t : c - t;
     const float lj = (jvalid && lane < T) ? (IMPLICIT ? c * d * d : d * d) : 0.f;
     const float rl = wave_sum(lj);
     float xx = 0.f;
@@ -208,6 +217,8 @@ __global__ __launch_bounds__(W * 64) void als_cg_long_kernel(AlsArgs a, size_t l
   const int jl = lane % T;
   int buf = 0;
   double wloss = 0.0;
+  const bool gb = IMPLICIT && a.gbias != 0.f;   // global bias, see als_cg_short_kernel
+  const float gbias = gb ? a.gbias : 0.f, ltgt = gb ? a.loss_tgt_const : 1.f;
 
   for (int li = blockIdx.x; li < a.n_long; li += gridDim.x) {
     const int row = rfl(a.long_rows[li]);
@@ -259,11 +270,11 @@ __global__ __launch_bounds__(W * 64) void als_cg_long_kernel(AlsArgs a, size_t l
         const bool jvalid = jl < ccnt;
         const float t = tile_dot<KP, T>(tile, vec, lane);
         if (mode == 2) {
-          const float d = IMPLICIT ? 1.f - t : cval - t;
+          const float d = IMPLICIT ? ltgt - t : cval - t;
           lacc += (jvalid && lane < T) ? (IMPLICIT ? cval * d * d : d * d) : 0.f;
         } else {
           float wgt;
-          if (mode == 0) wgt = IMPLICIT ? cval - (cval - 1.f) * t : cval - t;
+          if (mode == 0) wgt = IMPLICIT ? cval - (cval - 1.f) * (t + gbias) : cval - t;
           else wgt = IMPLICIT ? (cval - 1.f) * t : t;
           wgt = jvalid ? wgt : 0.f;
           tile_axpy<KP>(tile, wgt, ccnt, lane, active, acc);
@@ -300,6 +311,9 @@ __global__ __launch_bounds__(W * 64) void als_cg_long_kernel(AlsArgs a, size_t l
         if constexpr (!IMPLICIT) {
 #pragma unroll
           for (int u = 0; u < EPL; u++) out[u] = fmaf(mode == 0 ? -lam_use : lam_use, v[u], out[u]);
+        } else if (gb && mode == 0) {
+#pragma unroll
+          for (int u = 0; u < EPL; u++) out[u] += (active && e0 + u < k) ? a.rhs_init[e0 + u] : 0.f;
         }
       }
       buf ^= 1;

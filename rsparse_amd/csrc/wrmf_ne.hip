@@ -338,7 +338,11 @@ struct NeParts {   // MFMA operands of one step: block t, term q
 // COLLECT: the second launch for the rows that were split across workgroups (see the publish step below): one workgroup
 // per split row, no streaming -- it sums the published partial sums of the row's segments in segment order (the same
 // per-wave register images, so every geometry above works unchanged) and runs the same per-row solve.
-template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD, bool COLLECT, bool CHOL>
+// GB (conjugate gradient, implicit feedback with a global bias: cg_solver_implicit_global_bias, wrmf_implicit.hpp:35-57):
+// the first residual is  X_nnz (c - c1 % (X_nnz^T x + g)) - XtX x + base  =  b - A x + [base - g X_nnz (c - 1)];  the term
+// in brackets comes per row from a.ne_r0 (launch_gb_row_terms, one more pass over these rows: a rare variant), the CG steps
+// are unchanged, and the loss  sum_j c_j (tau - x_j.y)^2,  tau = 1 - g,  is  tau^2 sum c - 2 tau y.b + y^T (M1 + M2) y.
+template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD, bool COLLECT, bool CHOL, bool GB = false>
 __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, const int32_t* __restrict__ wg_rows,
                                                                     const int32_t* __restrict__ wg_ptr, int slot0,
                                                                     double* __restrict__ row_loss, int only_if_lt1) {
@@ -1340,13 +1344,21 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
     float r[NB], p[NB], ap[NB];
 #pragma unroll
     for (int t = 0; t < NB; t++) p[t] = x[t];
+    float r0x[NB];   // GB: base - g X_nnz (c - 1) of this row
+#pragma unroll
+    for (int t = 0; t < NB; t++) r0x[t] = 0.f;
+    if constexpr (GB) {
+      const int sl = sload(a.ne_r0_slot + row);
+#pragma unroll
+      for (int t = 0; t < NB; t++) r0x[t] = (32 * t + d < k) ? a.ne_r0[(size_t)sl * k + 32 * t + d] : 0.f;
+    }
     double rsold = 0.0;
     bool conv = false;
     for (int it = 0; it <= a.cg_steps; ++it) {
       matvec(p, ap);  // uniform control flow: every wave runs the barrier inside
       if (it == 0) {
 #pragma unroll
-        for (int t = 0; t < NB; t++) p[t] = r[t] = b[t] - ap[t];
+        for (int t = 0; t < NB; t++) p[t] = r[t] = (b[t] - ap[t]) + r0x[t];
         rsold = (double)dot(r, r);
       } else if (!conv) {
         const float alpha = (float)(rsold / (double)dot(p, ap));
@@ -1384,7 +1396,8 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
     __syncthreads();
     if (wv == 0) {   // park the solved row in LDS; stores happen YB rows at a time
       const double q = ((double)sScal[16] + (double)sScal[17]) + ((double)sScal[18] + (double)sScal[19]);
-      const double fit = sc_row - 2.0 * (double)yb + q;
+      const double tau = GB ? (double)a.loss_tgt_const : 1.0;
+      const double fit = tau * tau * sc_row - 2.0 * tau * (double)yb + q;
       const double reg = IMPLICIT ? a.lambda_loss * (double)yy : (double)(lam_use * yy);
       if (lane == 0) {
         sYloss[nbuf] = fit + reg;
@@ -1427,10 +1440,10 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
 #endif
 }
 
-template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD, bool COLLECT, bool CHOL>
+template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD, bool COLLECT, bool CHOL, bool GB = false>
 hipError_t launch_ne_t(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int grid, double* row_loss,
                        hipStream_t s, int only_if_lt1) {
-  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM, QUAD, COLLECT, CHOL>;
+  auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM, QUAD, COLLECT, CHOL, GB>;
   constexpr int lds = NeGeo<KP, NeRoles<KP, NS, IMPLICIT, SYM, QUAD>::NROLES, IMPLICIT>::BYTES;
   hipError_t err =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1496,7 +1509,32 @@ __global__ __launch_bounds__(256) void ne_stats_kernel(const float* __restrict__
   }
 }
 
+// out[r][t] = base[t] - g * sum_j (c_j - 1) X[t, idx_j]  for row rows[r]; slot_of_row[rows[r]] = r.  One 256-thread workgroup
+// per row: thread (half, t) sums every second non-zero of element t (coalesced k-float reads), the halves meet in LDS.
+__global__ __launch_bounds__(256) void gb_row_terms_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n,
+                                                            float* __restrict__ out, int32_t* __restrict__ slot_of_row) {
+  __shared__ float part[128];
+  const int r = blockIdx.x;
+  if (r >= n) return;
+  const int row = rows[r], k = a.k;
+  const int t = threadIdx.x & 127, hf = threadIdx.x >> 7;
+  const int p1 = a.col_ptrs[row], p2 = a.col_ptrs[row + 1];
+  float acc = 0.f;
+  if (t < k)
+    for (int j = p1 + hf; j < p2; j += 2) acc = fmaf(a.vals[j] - 1.f, a.X[(size_t)a.row_idx[j] * k + t], acc);
+  if (hf == 1) part[t] = acc;
+  __syncthreads();
+  if (hf == 0 && t < k) out[(size_t)r * k + t] = a.rhs_init[t] - a.gbias * (acc + part[t]);
+  if (threadIdx.x == 0) slot_of_row[row] = r;
+}
+
 }  // namespace
+
+hipError_t launch_gb_row_terms(const AlsArgs& a, const int32_t* rows, int n, float* out, int32_t* slot_of_row, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gb_row_terms_kernel, dim3(n), dim3(256), 0, s, a, rows, n, out, slot_of_row);
+  return hipGetLastError();
+}
 
 bool ne_supported(int k) { return k > 32 && k <= 128 && k % 4 == 0; }
 
@@ -1513,19 +1551,22 @@ hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_
 // Implicit feedback with a.ne_stats: the fp16 SYM kernel and, behind it, the bf16 kernel that takes over when some
 // confidence is below 1 (exactly one of the two does the work; the other returns at once).  Explicit feedback, or no
 // stats: the bf16 kernel alone.
-template <bool COLLECT, bool CHOL>
+template <bool COLLECT, bool CHOL, bool GB = false>
 hipError_t launch_ne_mode(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
                           double* row_loss, hipStream_t s) {
   const int KP = padded_rank(a.k);
   hipError_t err;
 #define RSP_NE_DISPATCH(KPV)                                                                                           \
   if (KP == KPV) {                                                                                                     \
-    if (!implicit) return launch_ne_t<KPV, 3, false, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
-    if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
-    if ((err = launch_ne_t<KPV, 2, true, true, KPV == 128, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) !=      \
+    if constexpr (!GB) {                                                                                               \
+      if (!implicit) return launch_ne_t<KPV, 3, false, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
+      if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
+    }                                                                                                                  \
+    if (!implicit || !a.ne_stats) return hipErrorInvalidValue;   /* GB: implicit feedback with the value statistics */  \
+    if ((err = launch_ne_t<KPV, 2, true, true, KPV == 128, COLLECT, CHOL, GB>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) !=  \
         hipSuccess)                                                                                                    \
       return err;                                                                                                      \
-    return launch_ne_t<KPV, 3, true, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 1);                 \
+    return launch_ne_t<KPV, 3, true, false, false, COLLECT, CHOL, GB>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 1);             \
   }
   RSP_NE_DISPATCH(128)
   RSP_NE_DISPATCH(64)
@@ -1540,10 +1581,14 @@ hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, do
   if (q.ne_wg <= 0) return hipSuccess;
   // a.ne_chol (solver == CHOLESKY): the instantiations whose per-row solve is the blocked LDL^T instead of CG -- separate
   // kernels, so neither solve costs the other's streaming loops a register
+  const bool gb = !a.ne_chol && implicit && a.gbias != 0.f;   // conjugate gradient with a global bias
+  if (gb && !(a.ne_r0 && a.ne_r0_slot)) return hipErrorInvalidValue;
   hipError_t err = a.ne_chol ? launch_ne_mode<false, true>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s)
+                   : gb      ? launch_ne_mode<false, false, true>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s)
                              : launch_ne_mode<false, false>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s);
   if (err != hipSuccess || q.ne_nsplit <= 0) return err;
   return a.ne_chol ? launch_ne_mode<true, true>(a, q.ne_split_rows, q.ne_split_ptr, q.ne_nsplit, implicit, row_loss + q.ne_entries, s)
+         : gb      ? launch_ne_mode<true, false, true>(a, q.ne_split_rows, q.ne_split_ptr, q.ne_nsplit, implicit, row_loss + q.ne_entries, s)
                    : launch_ne_mode<true, false>(a, q.ne_split_rows, q.ne_split_ptr, q.ne_nsplit, implicit, row_loss + q.ne_entries, s);
 }
 

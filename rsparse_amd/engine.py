@@ -181,22 +181,18 @@ class HipBackend:
             F.data_ptr(), k, n, float(lambda_), out.data_ptr(), None if sumsq_out is None else sumsq_out.data_ptr(),
             None if absmax_inout is None else absmax_inout.data_ptr(), self._stream()))
 
-    def hint_absmax(self, F, absmax):
-        """While set, implicit half-iterations on F take max |F| from `absmax` (float32[1]) instead of scanning F;
-        hint_absmax(None, None) clears it."""
-        _lib.check(self.lib.rsparse_hip_hint_factor_absmax(None if F is None else F.data_ptr(),
-                                                           None if absmax is None else absmax.data_ptr()))
-
     def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out,
-                       bias_last_row=None, global_bias=0.0):
+                       bias_last_row=None, global_bias=0.0, absmax=None):
         """bias_last_row: None = no user/item biases; True/False = als_explicit's is_x_bias_last_row with
-        with_biases = TRUE (explicit feedback only)."""
+        with_biases = TRUE.  absmax (float32[1] on the device, optional): max |F| if the caller knows it (implicit
+        feedback; the Gramian pass yields it) -- F is then not scanned for the fp16 operand scales."""
         k = F.shape[1]
+        am = None if absmax is None else absmax.data_ptr()
         if implicit and global_bias:
-            # implicit feedback with a global bias, with or without user/item biases (Cholesky / NNLS)
+            # implicit feedback with a global bias: every solver without user/item biases, Cholesky / NNLS with them
             _lib.check(self.lib.rsparse_hip_als_implicit_global_bias_device(
-                csc.h, F.data_ptr(), S_block.data_ptr(), G.data_ptr(), k, float(lambda_), int(solver),
-                int(bias_last_row is not None), int(bool(bias_last_row)), float(global_bias), loss_out.data_ptr(),
+                csc.h, F.data_ptr(), S_block.data_ptr(), G.data_ptr(), k, float(lambda_), int(solver), int(cg_steps),
+                int(bias_last_row is not None), int(bool(bias_last_row)), float(global_bias), am, loss_out.data_ptr(),
                 self._stream()))
         elif bias_last_row is not None and implicit:
             # G: (k-1) x (k-1) Gramian of F without its bias row, ridge included (R/model_WRMF.R:463-486)
@@ -211,7 +207,7 @@ class HipBackend:
                                                                      loss_out.data_ptr(), self._stream()))
         elif implicit:
             _lib.check(self.lib.rsparse_hip_als_implicit_device(csc.h, F.data_ptr(), S_block.data_ptr(), G.data_ptr(),
-                                                                k, float(lambda_), int(solver), int(cg_steps),
+                                                                k, float(lambda_), int(solver), int(cg_steps), am,
                                                                 loss_out.data_ptr(), self._stream()))
         else:
             _lib.check(self.lib.rsparse_hip_als_explicit_device(csc.h, F.data_ptr(), S_block.data_ptr(), k,
@@ -251,6 +247,10 @@ class HipBackend:
         _lib.check(self.lib.rsparse_hip_weighted_sumsq_device(F.data_ptr(), k, n,
                                                               None if w is None else w.data_ptr(),
                                                               out.data_ptr(), self._stream()))
+
+    def set_launch_mode(self, mode):
+        """0 = the launches of a CG half-iteration back to back on one stream (profilers), 2 = the default overlap"""
+        _lib.check(self.lib.rsparse_hip_set_launch_mode(int(mode)))
 
     def profile(self, on):
         _lib.check(self.lib.rsparse_hip_profile_enable(int(bool(on))))
@@ -440,24 +440,26 @@ class ShardedALS:
         # user/item biases: solving the items means X = U = [1, ..., user_bias] (is_bias_last_row = TRUE), solving the
         # users X = components = [item_bias, ..., 1] (FALSE)  -- R/model_WRMF.R:321-329
         blr = (side == "items") if self.with_bias else None
-        if self.implicit and G is None:
+        own_gramian = self.implicit and G is None
+        if own_gramian:
             G = self.gramian_bias(F, layF, blr) if self.with_bias else self.gramian(F, layF)
         # solve sub-block j, start its exchange, solve sub-block j+1 meanwhile (both halves alike)
         works = []
         self.scal_sub.zero_()
-        hinted = self.implicit and getattr(self, "absmax_of", None) is F and hasattr(self.be, "hint_absmax")
-        if hinted:
-            self.be.hint_absmax(F, self.absmax)
+        # max |F| rides along with THIS call's own Gramian (gramian() above); a Gramian supplied by the caller says
+        # nothing about F's current content, so nothing is passed then and the library scans F itself
+        extra = {}
+        if self.implicit and own_gramian and self.absmax_of is F:
+            extra["absmax"] = self.absmax
+        self.absmax_of = None   # F's owner may change it before the next Gramian
+        if self.global_bias:
+            extra["global_bias"] = self.global_bias
         for j, (c0, c1, sub) in enumerate(subs):
             if c1 > c0:
                 a = layS.sub_start(self.me, j)
                 self.be.half_iteration(sub, self.implicit, F, S[a:a + (c1 - c0)], G, self.lambda_, solver,
-                                       self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1], blr,
-                                       **({"global_bias": self.global_bias} if self.global_bias else {}))
+                                       self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1], blr, **extra)
             works.append(self._gather_slab(S, layS, j))
-        if hinted:
-            self.be.hint_absmax(None, None)
-            self.absmax_of = None   # F's owner may change it before the next Gramian
         for w in works:
             if w is not None:
                 w.wait()

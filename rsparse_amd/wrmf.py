@@ -9,11 +9,16 @@ Differences forced by the host language, nothing else:
   * `lambda` is a Python keyword -> `lambda_`;
   * `x` is a scipy.sparse matrix (users x items) instead of a Matrix::sparseMatrix;
   * R's global RNG (large_rand_matrix / flrnorm, src/utils.cpp:131-143) -> `rng` (seed or Generator);
-  * not on the device path: the implicit-feedback global bias with the conjugate-gradient solver
-    (cg_solver_implicit_global_bias; the Cholesky / NNLS branches are), and user/item biases with implicit feedback and
-    the conjugate-gradient solver (a combination the reference itself cannot run, wrmf_implicit.hpp:189,197) -- the
-    C ABI answers RSPARSE_HIP_ERR_UNSUPPORTED and this class raises `UnsupportedOnDevice` (an R shim would keep
-    the package's CPU code for them).
+  * not on the device path: user/item biases with implicit feedback and the conjugate-gradient solver (a combination the
+    reference itself cannot run, wrmf_implicit.hpp:189,197) -- the C ABI answers RSPARSE_HIP_ERR_UNSUPPORTED and this
+    class raises `UnsupportedOnDevice`.
+Deliberate deviations from what the reference DOES (as opposed to what it means), both on the implicit global bias
+without user/item biases:
+  * `transform()` derives global_bias_base = -global_bias * rowSums(components) from the components; the reference passes
+    initialize_bias_base = FALSE there and reads self$global_bias_base, which the R side allocated with rank - 1 zeros and
+    never updates (R/model_WRMF.R:291-296, 131-132), i.e. it reads zeros and one element past the end of the vector;
+  * consequently `fit_transform(x) == transform(x)` holds here with a global bias too (the reference's own invariant,
+    tests/testthat/test-wrmf.R:57, is only tested without one).
 """
 import numpy as np
 import scipy.sparse as sp
@@ -52,10 +57,6 @@ class WRMF:
         self._non_negative = solver == "nnls"
         if self._non_negative and with_global_bias:
             with_global_bias = False                                              # :90-93 (the reference warns)
-        if with_global_bias and feedback != "explicit" and solver == "conjugate_gradient":
-            raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED,
-                                           "global bias + conjugate_gradient with implicit feedback "
-                                           "(cg_solver_implicit_global_bias) is not on the device path; use solver='cholesky'")
         if with_user_item_bias and feedback != "explicit" and solver == "conjugate_gradient":
             raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "user/item biases + conjugate_gradient with implicit "
                                            "feedback: the reference cannot run this combination either")

@@ -40,15 +40,13 @@ class OracleBackend:
         if sumsq_out is not None:
             sumsq_out[0] = float((Ff.astype(np.float64) ** 2).sum())
 
-    def hint_absmax(self, F, absmax):
-        """what the HIP backend passes on to the library; here: checked against the truth (the multi-rank tests thereby
-        verify that every rank holds the GLOBAL maximum when it solves)"""
-        self.hint = None if F is None else (F, float(absmax[0]))
-
     def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out,
-                       bias_last_row=None):
-        if getattr(self, "hint", None) is not None and self.hint[0] is F:
-            assert abs(self.hint[1] - float(F.abs().max())) <= 1e-6 * max(1.0, self.hint[1]), "stale or local absmax hint"
+                       bias_last_row=None, absmax=None):
+        # absmax = what the HIP backend passes on to the library as max |F|; here: checked against the truth (the
+        # multi-rank tests thereby verify that every rank holds the GLOBAL maximum when it solves, and that it is current)
+        if absmax is not None:
+            self.absmax_seen = getattr(self, "absmax_seen", 0) + 1
+            assert abs(float(absmax[0]) - float(F.abs().max())) <= 1e-6 * max(1.0, float(absmax[0])), "stale or local absmax"
         assert bias_last_row is None, "the CPU stand-in backend covers the no-bias control flow only"
         X = np.asfortranarray(self._f(F))
         Y = np.asfortranarray(self._f(S_block)).copy(order="F")

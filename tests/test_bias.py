@@ -300,8 +300,55 @@ def test_oracle_implicit_global_bias_matches_dense_solve(with_biases):
     else:
         tot += lam * np.sum(X ** 2)
     assert np.isclose(loss, tot / m.nnz, rtol=1e-10)
-    with pytest.raises(NotImplementedError):                 # the CG variant is not restated
-        O.als_implicit(p, i, x, X, Y, G, lam, 1, 3, with_biases=with_biases, is_x_bias_last_row=True, global_bias=gb)
+    if with_biases:
+        with pytest.raises(NotImplementedError):             # CG + user/item biases: the reference cannot run it
+            O.als_implicit(p, i, x, X, Y, G, lam, 1, 3, with_biases=True, is_x_bias_last_row=True, global_bias=gb)
+
+
+def test_oracle_implicit_global_bias_cg():
+    """cg_solver_implicit_global_bias (wrmf_implicit.hpp:35-57, call site :203): r0 = X_nnz (c - c1 % (X_nnz^T x + g)) -
+    XtX x + base, then cg_solver_implicit's loop; every column is solved (:178), the loss compares with 1 - g (:262-264).
+    Checked against a numpy restatement of the same recurrence (3 steps) and, with many steps, against the system it
+    solves:  (XtX + X_nnz C1 X_nnz^T) y = X_nnz c + base - g X_nnz (c - 1)  -- NOT the Cholesky branch's right-hand side
+    X_nnz c + base (:228-229): the two branches of the reference differ by g X_nnz (c - 1)."""
+    m, X, Y0 = _problem(37)
+    m.data[:] = np.abs(m.data) + 1.0
+    k, lam, gb = X.shape[0], 0.2, 0.013
+    p, i, x = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    G = O.gramian(X, lam)
+    base = -gb * X.sum(axis=1)
+    Y3 = Y0.copy(order="F")
+    loss = O.als_implicit(p, i, x, X, Y3, G, lam, 1, 3, global_bias=gb)
+    Yinf = Y0.copy(order="F")
+    O.als_implicit(p, i, x, X, Yinf, G, lam, 1, 60, global_bias=gb)
+    tot = 0.0
+    assert p[6] == p[5]                                      # the empty column is solved too
+    for c in range(m.shape[1]):
+        idx, val = i[p[c]:p[c + 1]], x[p[c]:p[c + 1]]
+        Xn, y = X[:, idx], Y0[:, c].copy()
+        r = Xn @ (val - (val - 1.0) * (Xn.T @ y + gb)) - G @ y + base
+        pp, rs = r.copy(), r @ r
+        for _ in range(3):
+            Ap = G @ pp + Xn @ ((val - 1.0) * (Xn.T @ pp))
+            a = rs / (pp @ Ap)
+            y += a * pp
+            r -= a * Ap
+            rn = r @ r
+            if rn < 1e-10:
+                break
+            pp = r + pp * (rn / rs)
+            rs = rn
+        assert np.allclose(Y3[:, c], y, rtol=1e-10, atol=1e-12), c
+        tot += np.sum(val * ((1.0 - gb) - y @ Xn) ** 2) + lam * y @ y
+        fix = np.linalg.solve(G + (Xn * (val - 1.0)) @ Xn.T, Xn @ val + base - gb * (Xn @ (val - 1.0)))
+        assert np.allclose(Yinf[:, c], fix, rtol=1e-4, atol=1e-5), c   # (stops at |r|^2 < 1e-10)
+    tot += lam * np.sum(X ** 2)
+    assert np.isclose(loss, tot / m.nnz, rtol=1e-10)
+    # below sqrt(eps) of the element type the bias counts as zero and empty columns become zeros again (:108-109,:178)
+    Ya, Yb = Y0.copy(order="F"), Y0.copy(order="F")
+    la = O.als_implicit(p, i, x, X, Ya, G, lam, 1, 3, global_bias=1e-9)
+    lb = O.als_implicit(p, i, x, X, Yb, G, lam, 1, 3)
+    assert np.array_equal(Ya, Yb) and la == lb and not Ya[:, 5].any()
 
 
 def test_oracle_init_biases_implicit_global():
@@ -368,13 +415,91 @@ def test_hip_implicit_global_bias_half_iteration(solver, with_biases, k, precisi
         loss2 = als.als_implicit(csc, Xd, Y2, 0.1, 1, solver, 3, precision, False, True, initialize_bias_base=False,
                                  global_bias=gb, global_bias_base=base.copy())
         assert np.array_equal(Y2, Y) and loss2 == loss
-    # below sqrt(eps) the global bias counts as zero (wrmf_implicit.hpp:108-109)
+    # below sqrt(eps) OF THE ELEMENT TYPE the global bias counts as zero (wrmf_implicit.hpp:108-109): 3.45e-4 for the
+    # float entry point, 1.49e-8 for the double one
+    tiny = 1e-5 if precision == "float" else 1e-9
     Ya, Yb = (np.asfortranarray(Y32, dtype=dt).copy(order="F") for _ in range(2))
-    la = als.als_implicit(csc, Xd, Ya, 0.1, 1, solver, 3, precision, with_biases, True, global_bias=1e-5)
+    la = als.als_implicit(csc, Xd, Ya, 0.1, 1, solver, 3, precision, with_biases, True, global_bias=tiny)
     lb = als.als_implicit(csc, Xd, Yb, 0.1, 1, solver, 3, precision, with_biases, True, global_bias=0.0)
     assert np.array_equal(Ya, Yb) and la == lb
-    with pytest.raises(NotImplementedError):                 # CG + global bias: UNSUPPORTED
-        als.als_implicit(csc, Xd, Y, 0.1, 1, 1, 3, precision, with_biases, True, global_bias=gb)
+    if precision == "double" and solver == 0 and not with_biases:
+        # ... and 1e-5 is a bias for als_implicit<double>: the empty column is solved against global_bias_base
+        Yc = np.asfortranarray(Y32, dtype=dt).copy(order="F")
+        als.als_implicit(csc, Xd, Yc, 0.1, 1, solver, 3, precision, False, True, global_bias=1e-5)
+        Yr = np.asfortranarray(Y32, dtype=np.float64).copy(order="F")
+        O.als_implicit(p, i, x, X64, Yr, O.gramian(X64, 0.1), 0.1, solver, 3, global_bias=1e-5)
+        assert Yr[:, 5].any() and not Yb[:, 5].any()
+        assert rel_fro(Yc[:, 5], Yr[:, 5]) < 1e-3 and rel_fro(Yc, Yr) < 1e-4
+    if with_biases:
+        with pytest.raises(NotImplementedError):             # CG + user/item biases: UNSUPPORTED (the reference cannot run it)
+            als.als_implicit(csc, Xd, Y, 0.1, 1, 1, 3, precision, with_biases, True, global_bias=gb)
+
+
+def _long_row_problem(seed, k, n_rows=2500, n_cols=260):
+    """implicit-feedback columns of every launch class: empty, 1..32, 33..512 and a few beyond 512 non-zeros (the
+    normal-equation kernel; with so few of them every one is split across workgroups)"""
+    rng = np.random.default_rng(seed)
+    lens = np.concatenate([[0, 1, 2, 31, 32, 33, 64, 65, 128, 129, 256, 257, 512, 513, 700, 1100, 2300],
+                           rng.integers(1, 90, n_cols - 17)])
+    cols, rows = [], []
+    for c, n in enumerate(lens):
+        rows.append(np.sort(rng.choice(n_rows, size=int(n), replace=False)))
+        cols.append(np.full(int(n), c))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    vals = 1.0 + rng.geometric(0.5, size=rows.size).astype(np.float64)
+    m = sp.csc_matrix((vals, (rows, cols)), shape=(n_rows, n_cols))
+    m.sort_indices()
+    X = np.asfortranarray((rng.standard_normal((k, n_rows)) * 0.1).astype(np.float32))
+    Y = np.asfortranarray((rng.standard_normal((k, n_cols)) * 0.1).astype(np.float32))
+    return m, X, Y
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cg_steps", [3, 0])
+@pytest.mark.parametrize("k", [6, 34, 36, 64, 128])
+@pytest.mark.parametrize("precision", ["float", "double"])
+def test_hip_implicit_global_bias_cg_half_iteration(k, precision, cg_steps):
+    """cg_solver_implicit_global_bias on the device (wrmf_implicit.hpp:35-57,203): the LDS-tile kernels (rank % 4 != 0), the
+    register-resident buckets, the matrix-core dense product (rank 128, <= 32 non-zeros), the normal-equation kernel with
+    its per-row term from launch_gb_row_terms (> 512 non-zeros, incl. rows split across workgroups) and empty columns,
+    against the oracle in double; yardstick for the bound = the oracle in float (three CG steps from a warm start)."""
+    from rsparse_amd import als
+    if precision == "double" and (k in (34, 64) or cg_steps == 0):
+        pytest.skip("same kernels as float")
+    dt = np.float32 if precision == "float" else np.float64
+    m, X32, Y32 = _long_row_problem(900 + k, k)
+    p, i, x = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    gb, lam = 0.037, 0.1
+    X64, Y64 = np.asfortranarray(X32, dtype=np.float64), np.asfortranarray(Y32, dtype=np.float64).copy(order="F")
+    base_ref = np.zeros(k)
+    lref = O.als_implicit(p, i, x, X64, Y64, O.gramian(X64, lam), lam, 1, cg_steps, global_bias=gb, base_out=base_ref, n_threads=8)
+    Yo32 = Y32.copy(order="F")
+    O.als_implicit(p, i, x, X32, Yo32, O.gramian(X32, lam), lam, 1, cg_steps, global_bias=gb, n_threads=8)
+    norm = np.maximum(np.linalg.norm(Y64, axis=0), 1e-30)
+    err32 = np.linalg.norm(Yo32 - Y64, axis=0) / norm
+    Xd, Y = np.asfortranarray(X32, dtype=dt), np.asfortranarray(Y32, dtype=dt).copy(order="F")
+    base = np.zeros(k - 1, dtype=dt)         # the R driver's allocation: rank - 1 entries (R/model_WRMF.R:292)
+    csc = (m.shape[0], m.shape[1], p, i, x)
+    loss = als.als_implicit(csc, Xd, Y, lam, 1, 1, cg_steps, precision, False, True, initialize_bias_base=True,
+                            global_bias=gb, global_bias_base=base)
+    err = np.linalg.norm(Y - Y64, axis=0) / norm
+    bound = np.maximum(1e-4, 3.0 * err32)
+    worst = int(np.argmax(err / bound))
+    assert np.all(err <= bound), (worst, int(np.diff(p)[worst]), float(err[worst]), float(err32[worst]))
+    assert abs(loss - lref) <= 1e-4 * abs(lref)
+    assert Y[:, 0].any() == Y64[:, 0].any()                  # the empty column (solved when cg_steps > 0 moves it)
+    assert rel_fro(base, base_ref[:k - 1]) < 1e-5            # min(len, rank) entries written, nothing beyond
+    # initialize_bias_base = FALSE with the short R vector: recomputed from X, same result (include/rsparse_wrmf_hip.h)
+    Y2 = np.asfortranarray(Y32, dtype=dt).copy(order="F")
+    loss2 = als.als_implicit(csc, Xd, Y2, lam, 1, 1, cg_steps, precision, False, True, initialize_bias_base=False,
+                             global_bias=gb, global_bias_base=np.zeros(k - 1, dtype=dt))
+    assert np.array_equal(Y2, Y) and loss2 == loss
+    # ... and with the whole vector it is read: a different base gives a different solve
+    if cg_steps:
+        Y3 = np.asfortranarray(Y32, dtype=dt).copy(order="F")
+        als.als_implicit(csc, Xd, Y3, lam, 1, 1, cg_steps, precision, False, True, initialize_bias_base=False,
+                         global_bias=gb, global_bias_base=np.zeros(k, dtype=dt))
+        assert not np.array_equal(Y3, Y)
 
 
 @pytest.mark.gpu
@@ -409,37 +534,42 @@ def test_hip_stateless_initialize_biases(ml_train, explicit, global_bias, dtype)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("solver", ["cholesky", "nnls"])
+@pytest.mark.parametrize("solver", ["cholesky", "nnls", "conjugate_gradient"])
 @pytest.mark.parametrize("bias", [False, True])
 def test_hip_wrmf_implicit_global_bias(ml_train, solver, bias):
     """WRMF$new(feedback = "implicit", with_global_bias = TRUE) (R/model_WRMF.R:128-131, :262-272, :317-318) against the
     oracle driver, same initial factors."""
-    from rsparse_amd import WRMF
+    from rsparse_amd import WRMF, _lib
     n_user, n_item, p, i, x = ml_train
     train = sp.csc_matrix((x, i, p), shape=(n_user, n_item))
+    cg = solver == "conjugate_gradient"
+    if cg and bias:       # the reference cannot run CG with user/item biases (wrmf_implicit.hpp:189,197)
+        with pytest.raises(_lib.UnsupportedOnDevice):
+            WRMF(rank=8, feedback="implicit", solver=solver, with_user_item_bias=True, with_global_bias=True, precision="float")
+        return
     rng = np.random.default_rng(77 + bias)
     rank0 = 8
     rank = rank0 + 2 * bias
     U0 = np.abs(rng.standard_normal((n_user, rank)) * 0.01).astype(np.float32)
     V0 = np.abs(rng.standard_normal((rank, n_item)) * 0.01).astype(np.float32)
     model = WRMF(rank=rank0, lambda_=0.1, feedback="implicit", solver=solver, with_user_item_bias=bias,
-                 with_global_bias=True, precision="float", init=V0.copy())
+                 with_global_bias=True, precision="float", init=None if cg else V0.copy())
     model._init_user_factors = U0
     emb = model.fit_transform(train, n_iter=3, convergence_tol=-1)
     ref = O.OracleWRMF(rank0, lam=0.1, feedback="implicit", solver=solver, dtype=np.float64, n_threads=8,
                        with_user_item_bias=bias, with_global_bias=True)
     ref_emb = ref.fit_transform(n_user, n_item, p, i, x, U0.T.astype(np.float64), n_iter=3, convergence_tol=-1,
-                                init_components=V0.astype(np.float64))
+                                init_components=None if cg else V0.astype(np.float64))
     if solver == "nnls":                                     # R/model_WRMF.R:90-93: nnls switches the global bias off
         assert model.global_bias == 0.0 and ref.global_bias == 0.0
     else:
         assert model.global_bias > 0 and abs(model.global_bias - ref.global_bias) < 1e-6 * ref.global_bias
     tol = 1e-4
-    if solver == "nnls":
+    if solver != "cholesky":     # yardstick: the same fit on the oracle in float
         ref32 = O.OracleWRMF(rank0, lam=0.1, feedback="implicit", solver=solver, dtype=np.float32, n_threads=8,
                              with_user_item_bias=bias, with_global_bias=True)
         e32 = ref32.fit_transform(n_user, n_item, p, i, x, U0.T.copy(), n_iter=3, convergence_tol=-1,
-                                  init_components=V0.copy())
+                                  init_components=None if cg else V0.copy())
         tol = max(tol, 3 * rel_fro(e32, ref_emb), 3 * rel_fro(ref32.components, ref.components))
     assert rel_fro(emb, ref_emb) < tol and rel_fro(model.components, ref.components) < tol
     assert np.allclose([l[1] for l in model.losses], [l[1] for l in ref.losses], rtol=max(tol, 1e-4))

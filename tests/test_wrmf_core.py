@@ -118,12 +118,9 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
 def test_wrmf_implicit_cg_with_biases_is_rejected():
     """Outside the reference's grid (test-wrmf.R:16-21 keeps with_user_item_bias = FALSE for conjugate_gradient): the
     reference drops a row of the warm start twice on that path (wrmf_implicit.hpp:189,197) and cannot run it; the
-    device path answers UNSUPPORTED, and so does the conjugate-gradient variant of the implicit-feedback global bias
-    (cg_solver_implicit_global_bias, wrmf_implicit.hpp:34 "very poor numerical precision").  The Cholesky / NNLS global
-    bias is on the device path (tests/test_bias.py)."""
+    device path answers UNSUPPORTED.  The global bias goes with every solver (tests/test_bias.py)."""
     from rsparse_amd import WRMF, _lib
     with pytest.raises(_lib.UnsupportedOnDevice):
         WRMF(rank=6, lambda_=0.1, feedback="implicit", solver="conjugate_gradient", with_user_item_bias=True)
-    with pytest.raises(_lib.UnsupportedOnDevice):
-        WRMF(rank=6, lambda_=0.1, feedback="implicit", solver="conjugate_gradient", with_global_bias=True)
+    WRMF(rank=6, lambda_=0.1, feedback="implicit", solver="conjugate_gradient", with_global_bias=True)   # the default solver
     WRMF(rank=6, lambda_=0.1, feedback="implicit", solver="cholesky", with_global_bias=True)

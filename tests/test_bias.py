@@ -493,8 +493,8 @@ def test_hip_implicit_global_bias_cg_half_iteration(k, precision, cg_steps):
     Y2 = np.asfortranarray(Y32, dtype=dt).copy(order="F")
     loss2 = als.als_implicit(csc, Xd, Y2, lam, 1, 1, cg_steps, precision, False, True, initialize_bias_base=False,
                              global_bias=gb, global_bias_base=np.zeros(k - 1, dtype=dt))
-    assert np.array_equal(Y2, Y) and loss2 == loss
-    # ... and with the whole vector it is read: a different base gives a different solve
+    assert np.array_equal(Y2, Y) and abs(loss2 - loss) <= 1e-12 * abs(loss)   # (the LDS-tile kernels claim rows dynamically:
+    # ... and with the whole vector it is read                                   #  their loss partials sum in claim order): a different base gives a different solve
     if cg_steps:
         Y3 = np.asfortranarray(Y32, dtype=dt).copy(order="F")
         als.als_implicit(csc, Xd, Y3, lam, 1, 1, cg_steps, precision, False, True, initialize_bias_base=False,

@@ -4,7 +4,7 @@ TAG=${1:-q}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider -x ${PYTEST_ARGS:-} > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee $OUT/summary.txt
+timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider ${PYTEST_ARGS:-} > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee $OUT/summary.txt
 grep -v "Warning\|warnings.warn\|^$\|model = WRMF\|WRMF(rank" $OUT/pytest_gpu.log | tail -${TAILN:-25} >> $OUT/summary.txt
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt

@@ -310,10 +310,15 @@ def main():
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
 
     # ---- per-kernel durations (HIP events inside the library, same stream), separate pass ----
+    # segments of rsparse_hip_profile_last: CG -> one per row-length bucket; Cholesky -> [0] normal-equation launch (long
+    # rows, exact solve), [1] low-rank kernel (short rows), [2] k x k kernel; NNLS -> [0].  The kernel NAMES come from the
+    # library too (rsparse_hip_profile_last_names: the runtime's symbol table, i.e. what rocprofv3 prints).
+    import re
     be.profile(True)
     nb = 6
-    kern = {sd: {"bucket": [[] for _ in range(nb)], "gram": []} for sd in ("items", "users")}
+    kern = {sd: {"bucket": [[] for _ in range(nb)], "gram": [], "names": [""] * nb} for sd in ("items", "users")}
     half_ms = {"items": [], "users": []}
+    short = lambda full: (re.search(r"(\w+<[^()]*>)\s*\(", full) or re.search(r"(\w+)\s*\(", full) or [None, full])[1] if full else ""
     for _ in range(max(1, min(args.steps, 3))):
         for side in ("items", "users"):
             F, layF = (U, lay_u) if side == "items" else (V, lay_i)
@@ -325,93 +330,132 @@ def main():
                 gm = be.profile_last()
             als.half_iteration(side, U, V, solver, G=G, want_loss=True)
             pm = be.profile_last()
+            nm = be.profile_last_names()
             torch.cuda.synchronize()
             half_ms[side].append(1e3 * (time.perf_counter() - th))
             kern[side]["gram"].append(gm[0] + gm[1])
             for b in range(nb):
                 kern[side]["bucket"][b].append(pm[b])
+                if b < len(nm) and nm[b]:
+                    kern[side]["names"][b] = short(nm[b])
     be.profile(False)
     mean = lambda v: float(np.mean(v)) if len(v) else 0.0
     info = {"users": als.csc_users.info(), "items": als.csc_items.info()}
-    # per bucket: launches (one per half-iteration that has rows in it), mean duration, algorithmic bytes
+    sides = ("items", "users")
     buckets = []
-    kp = 32 if k <= 32 else (64 if k <= 64 else 128)
-    tf_flag = "true" if implicit else "false"
-    if solver != 1:
-        # one kernel per half-iteration; no warm-start read (Cholesky ignores it): drop one N*k*4 from B_half
-        ms = [mean(kern[sd]["bucket"][0]) for sd in ("items", "users")]
-        by = [algorithmic_bytes(info[sd]["n_cols"], info[sd]["nnz"], k, info[sd]["n_empty"]) -
-              (info[sd]["n_cols"] - info[sd]["n_empty"]) * 4 * k for sd in ("items", "users")]
-        per_row = (k ** 3 / 3.0 + 2.0 * k * k) if solver == 0 else (2.0 * k ** 3 + 4.0 * k * k)
-        fl = [2.0 * k * k * info[sd]["nnz"] + (info[sd]["n_cols"] - info[sd]["n_empty"]) * per_row
-              for sd in ("items", "users")]
-        buckets.append({"kernel": ("als_chol2_kernel<%d, %s, true>" if solver == 0 else "als_nnls_kernel<%d, %s, true>") % (kp, tf_flag),
-                        "what": "one 256-thread workgroup per row: normal equations assembled in registers, " +
-                                ("blocked Cholesky, two triangular solves" if solver == 0 else
-                                 "squared in LDS, sequential coordinate descent on one wave (flops below count the "
-                                 "assembly and the squaring, not the data-dependent sweeps)") +
-                                " (compute/LDS bound, see roofline.compute)",
-                        "launches_per_iteration": 2, "avg_launch_ms": float(np.mean(ms)),
-                        "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms)),
-                        "flops_per_launch": float(np.mean(fl))})
-    def dmf(kp_, capq, waves, wpr_, tf):   # launch_bucket's choice of the matrix-core dense product (wrmf_cgq.hip)
-        return (kp_ == 128 and capq == 8 and waves == 4 and wpr_ == 1 and tf == "true"
-                and os.environ.get("RSPARSE_HIP_DENSE_MFMA", "1")[:1] != "0")
-    for b in range(nb if solver == 1 else 0):
-        wpr = int(info["users"]["bucket_wpr"][b])
-        if wpr <= 0:
-            continue
-        ms = [mean(kern[sd]["bucket"][b]) for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
-        by = [algorithmic_bytes(info[sd]["bucket_rows"][b], info[sd]["bucket_nnz"][b], k,
-                                info[sd]["n_empty"] if b == nb - 1 or info["users"]["bucket_wpr"][min(b + 1, nb - 1)] <= 0 else 0)
-              for sd in ("items", "users") if info[sd]["bucket_rows"][b] > 0]
-        if ms:
-            iu = info["users"]
-            ne = bool(iu["bucket_stream"][b]) and k > 32 and k % 4 == 0
-            buckets.append({"kernel": ("als_ne_kernel<%d, %s>" % (kp, ("2, true, true, true, false, false" if kp == 128 else "2, true, true, false, false, false") if tf_flag == "true" else "3, false, false, false, false, false")) if ne else
-                                      "als_cgq_kernel<%d, %d, %d, %d, %d, %s, %s>" % (kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, iu["bucket_stream"][b], tf_flag,
-                                                                                   "true" if dmf(kp, iu["bucket_capq"][b], iu["bucket_waves"][b], wpr, tf_flag) else "false"),
-                            "what": "rows beyond 512 non-zeros: one pass, normal equations on the matrix cores (operands split exactly into fp16 / bf16 terms), CG on the k x k system in LDS" if ne else
-                                    "rows on teams of %d wave(s)%s" % (wpr, ", streamed (longer than the workgroup's resident capacity)" if iu["bucket_stream"][b] else ", register-resident"),
+    if solver == 1:
+        # one launch per row-length bucket and half-iteration that has rows in it
+        for b in range(nb):
+            if int(info["users"]["bucket_wpr"][b]) <= 0:
+                continue
+            live = [sd for sd in sides if info[sd]["bucket_rows"][b] > 0]
+            if not live:
+                continue
+            last = b == nb - 1 or info["users"]["bucket_wpr"][min(b + 1, nb - 1)] <= 0
+            ms = [mean(kern[sd]["bucket"][b]) for sd in live]
+            by = [algorithmic_bytes(info[sd]["bucket_rows"][b], info[sd]["bucket_nnz"][b], k, info[sd]["n_empty"] if last else 0)
+                  for sd in live]
+            name = kern[live[0]]["names"][b]
+            ne = name.startswith("als_ne_kernel")
+            wpr = int(info["users"]["bucket_wpr"][b])
+            buckets.append({"kernel": name,
+                            "what": "rows beyond 512 non-zeros: one pass, normal equations on the matrix cores (fp32 operands as "
+                                    "2 fp16 / 3 bf16 split terms, fp32 accumulation), CG on the k x k system in LDS" if ne else
+                                    "rows on teams of %d wave(s), register-resident" % wpr,
                             "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),
                             "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms))})
+    else:
+        # Cholesky / NNLS: which rows a launch takes (wrmf_capi.cpp run_half_iteration).  Length classes of csc_info:
+        # [> 512, 257-512, 129-256, 65-128, 33-64, <= 32 (incl. empty)] non-zeros
+        def rows_of(sd, seg):
+            r, z = info[sd]["bucket_rows"], info[sd]["bucket_nnz"]
+            emp = info[sd]["n_empty"]
+            if solver == 2:
+                return (sum(r), sum(z), emp) if seg == 0 else (0, 0, 0)
+            ne_ok = k > 32 and k % 4 == 0
+            lr_ok = implicit and 96 < k <= 128 and k % 2 == 0
+            cut = 4 if k > 64 else 1                # the normal-equation launch takes the classes [0, cut)
+            if seg == 0:
+                return (sum(r[:cut]), sum(z[:cut]), 0) if ne_ok else (0, 0, 0)
+            lo = cut if ne_ok else 0
+            if seg == 1:
+                return (r[4] + r[5] - emp, z[4] + z[5], 0) if lr_ok else (0, 0, 0)
+            hi = 4 if lr_ok else 6
+            return (sum(r[lo:hi]) + (emp if lr_ok else 0), sum(z[lo:hi]), emp)
+        what = {0: "normal-equation launch: rows beyond %d non-zeros assembled on the matrix cores in one pass, blocked LDL^T in LDS" % (64 if k > 64 else 512),
+                1: "low-rank form of the exact solve for rows of 1..64 non-zeros (Woodbury on XtX = L L^T; matrix cores)",
+                2: "k x k kernel: normal equations in registers, blocked Cholesky, two triangular solves"}
+        if solver == 2:
+            what = {0: "one 256-thread workgroup per row: normal equations assembled in registers, squared in LDS, sequential "
+                       "coordinate descent on one wave (flops count the assembly and the squaring, not the data-dependent sweeps)"}
+        for seg in range(3 if solver == 0 else 1):
+            live = [sd for sd in sides if rows_of(sd, seg)[0] > 0 and mean(kern[sd]["bucket"][seg]) > 0]
+            if not live:
+                continue
+            ms = [mean(kern[sd]["bucket"][seg]) for sd in live]
+            by, fl = [], []
+            for sd in live:
+                nr, nz, emp = rows_of(sd, seg)
+                # no warm-start read (the exact solvers ignore it): drop one N*k*4 from B_half
+                by.append(algorithmic_bytes(nr, nz, k, emp) - (nr - emp) * 4 * k)
+                # nominal flops of the reference's formulation for these rows: lhs assembly 2 k^2 n_i, rhs 2 k n_i,
+                # potrf k^3 / 3 + two triangular solves 2 k^2  (NNLS: the squaring 2 k^3 + 4 k^2 instead)
+                per_row = (k ** 3 / 3.0 + 2.0 * k * k) if solver == 0 else (2.0 * k ** 3 + 4.0 * k * k)
+                fl.append((2.0 * k * k + 2.0 * k) * nz + (nr - emp) * per_row)
+            buckets.append({"kernel": kern[live[0]]["names"][seg], "what": what[seg],
+                            "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),
+                            "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms)),
+                            "flops_per_launch": float(np.mean(fl)),
+                            "rows_per_launch": float(np.mean([rows_of(sd, seg)[0] for sd in live]))})
     dom = max(buckets, key=lambda d: d["total_ms_per_iteration"]) if buckets else None
     solve_ms = sum(d["total_ms_per_iteration"] for d in buckets)
     solve_bytes = sum(d["bytes_per_launch"] * d["launches_per_iteration"] for d in buckets)
     b_iter = (algorithmic_bytes(info["users"]["n_cols"], info["users"]["nnz"], k, info["users"]["n_empty"]) +
               algorithmic_bytes(info["items"]["n_cols"], info["items"]["nnz"], k, info["items"]["n_empty"]))
-    traffic = None
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is the one
+    # collected by tools/gpu_pmc_full.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) for THIS workload --
+    # the table records the workload it was collected on; for any other workload the field is null
+    this_workload = {"users": n_user, "items": n_item, "nnz": nnz, "rank": k, "feedback": args.feedback, "solver": args.solver,
+                     "cg_steps": args.cg_steps, "n_gpus": ws}
+    traffic, traffic_source = None, "no PMC table (profiles/pmc_traffic.json)"
     tf = ROOT / "profiles" / "pmc_traffic.json"
     if tf.exists() and dom:
         try:
             table = json.loads(tf.read_text())
-            traffic = table.get(dom["kernel"])
-            if traffic is None:
-                # the table is keyed by the name rocprof prints; trailing template arguments added since it was
-                # collected must not lose the entry ("als_ne_kernel<128, 2, true, true, true, false" matches both)
-                stem = dom["kernel"].rstrip(">")
-                hits = [v for kk, v in table.items() if isinstance(v, (int, float)) and
-                        (kk.rstrip(">").startswith(stem) or stem.startswith(kk.rstrip(">")))]
-                traffic = hits[0] if len(hits) == 1 else None
-        except Exception:
-            traffic = None
+            if table.get("workload") == this_workload:
+                traffic = table.get("kernels", {}).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+                traffic_source = {"file": "profiles/pmc_traffic.json", "collected_on": table["workload"],
+                                  "how": table.get("how"), "kernel_found": traffic is not None}
+            else:
+                traffic_source = {"file": "profiles/pmc_traffic.json", "collected_on": table.get("workload"),
+                                  "note": "collected on a different workload than this run: not applicable, traffic = null"}
+        except Exception as e:
+            traffic_source = "unreadable PMC table: %r" % (e,)
     achieved = dom["bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9 if dom and dom["avg_launch_ms"] > 0 else 0.0
     roofline = {
         "bound": "hbm", "kernel": dom["kernel"] if dom else None, "achieved": achieved,
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "traffic_source": traffic_source,
         "bytes_per_launch": dom["bytes_per_launch"] if dom else None,
         "avg_launch_ms": dom["avg_launch_ms"] if dom else None,
-        "all_cg_kernels_GBps": solve_bytes / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else None,
+        "all_solve_kernels_GBps": solve_bytes / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else None,
         "whole_iteration_algorithmic_GBps_per_gpu": b_iter / (ms_per_step * 1e-3) / 1e9,
-        "cg_kernels": buckets,
+        "solve_kernels": buckets,
         "gramian_ms": {sd: mean(kern[sd]["gram"]) for sd in kern},
         "half_iteration_ms": {sd: mean(v) for sd, v in half_ms.items()},
     }
     if solver != 1 and dom:
+        # the exact solvers are compute / LDS bound (about 2 k^2 n_i + k^3/3 flops per row against ~n_i (4k+8) bytes): the
+        # fraction below is THAT launch's nominal flops over THAT launch's time, and the line's whole-iteration figure
         tfl = dom["flops_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e12
-        roofline["compute"] = {"achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_PEAK_TFLOPS,
-                               "note": "the Cholesky solver is compute/LDS bound (about 2 k^2 n_i + k^3/3 flops per row "
-                                       "against ~n_i (4k+8) bytes); the hbm figures above are reported as the contract asks"}
+        all_fl = sum(d["flops_per_launch"] * d["launches_per_iteration"] for d in buckets)
+        roofline["compute"] = {"kernel": dom["kernel"], "achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tfl / FP32_PEAK_TFLOPS,
+                               "whole_iteration_tflops": all_fl / (ms_per_step * 1e-3) / 1e12,
+                               "whole_iteration_frac": all_fl / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                               "note": "nominal flops of the reference's formulation (assembly 2 k^2 n_i + potrf k^3/3 + solves) "
+                                       "for the rows each launch takes, over that launch's own event-timed duration; the "
+                                       "hbm figures above are reported as the contract asks"}
 
     comm_ms = None
     if ws > 1:   # exchange alone: the slab all-gathers of both sides, back to back (the timed steps overlap them with solves)
@@ -446,12 +490,37 @@ def main():
         except Exception as e:
             parity = {"rows_checked": 0, "max_row_err": None, "error": repr(e)}
 
+    transform = None
+    if rank == 0 and ws == 1 and implicit and k <= 128:
+        # WRMF$transform / the last step of every fit_transform (R/model_WRMF.R:359,412-452): one EXACT user half-iteration
+        # against the final item factors, Gramian precomputed (private$XtX).  Not part of the timed iterations; last,
+        # because it overwrites U
+        try:
+            Gt = als.gramian(V, lay_i).clone()
+            tms = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                tt = time.perf_counter()
+                als.half_iteration("users", U, V, 0, G=Gt, want_loss=False)
+                torch.cuda.synchronize()
+                tms.append(1e3 * (time.perf_counter() - tt))
+            be.check_numeric()
+            transform = {"rows_per_sec": n_user / (min(tms) * 1e-3), "ms": min(tms), "rows": n_user, "solver": "cholesky",
+                         "what": "WRMF$transform of every user: one exact user half-iteration from the final item factors"}
+        except Exception as e:
+            transform = {"rows_per_sec": None, "error": repr(e)}
+
     if rank == 0:
         user_half_ms = mean(half_ms["users"])
         line = {
             "metric": "als_iterations_per_sec", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": ("f32 (Gram products of rows > 512 / <= 32 non-zeros as 2 x fp16 / 3 x bf16 split terms of the fp32 operands, "
+                      "fp32 accumulate; everything else fp32)" if (solver == 1 and k > 32 and k % 4 == 0) else
+                      ("f32 (normal equations of rows beyond 64 / 512 non-zeros assembled from 2 x fp16 / 3 x bf16 split terms, "
+                       "fp32 accumulate; factorisations fp32)" if solver == 0 else "f32")),
+            "data": "synthetic",
             "config": {"workload": "WRMF %s ALS, %s, synthetic %dx%d, %d nnz, rank %d, lambda %g%s"
                                    % (args.feedback, "CG(%d)" % args.cg_steps if solver == 1 else ("Cholesky" if solver == 0 else "NNLS"), n_user, n_item,
                                       nnz, k, lam, "" if implicit else ", dynamic_lambda"),
@@ -460,6 +529,7 @@ def main():
                        "solver": {0: "cholesky", 1: "conjugate_gradient", 2: "nnls"}[solver],
                        "cg_steps": args.cg_steps, "parallelism": "rows sharded x%d, factors replicated" % ws},
             "user_rows_per_sec": n_user / (user_half_ms * 1e-3) if user_half_ms > 0 else None,
+            "transform": transform,
             "loss_users_last": losses[-1][1] if losses else None,
             "loss_first_iteration": list(losses[0]) if losses else None,
             # N > 1: the first iteration's losses against the committed N = 1 values of the same configuration (the

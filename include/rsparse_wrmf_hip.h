@@ -303,11 +303,18 @@ int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_use
 
 /* Kernel timing for measurement harnesses (bench.py): when enabled, every device-layer call brackets
  * its kernels with HIP events on the caller's stream.  rsparse_hip_profile_last() waits for the last
- * call and returns milliseconds per kernel in launch order: CG half-iterations -> [0..5] the
- * als_cgq_kernel launches (one per bucket of rsparse_hip_csc_info), [6] loss reduction (with the LDS-tile
- * fallback kernels: [0] short-row, [1] long-row, [2] loss); Cholesky -> [0]; Gramian -> [0] MFMA partial
- * kernel, [1] reduction. */
+ * call and returns milliseconds per segment in launch order:
+ *   CG half-iterations -> [0..5] the launches of the row-length buckets of rsparse_hip_csc_info ([0] = the
+ *     normal-equation kernel for the rows beyond 512 non-zeros), [6] loss reduction (with the LDS-tile fallback kernels
+ *     for ranks that are not a multiple of 4: [0] short-row, [1] long-row, [2] loss);
+ *   Cholesky -> [0] the normal-equation launch with the exact solve (long rows), [1] the low-rank kernel (short rows,
+ *     incl. its one-workgroup preparation), [2] the k x k kernel, [3] loss reduction;
+ *   NNLS -> [0] kernel, [2] loss reduction;   Gramian -> [0] MFMA partial kernel, [1] reduction.
+ * rsparse_hip_profile_last_names() gives, for the same call, the name of the kernel each segment timed -- newline
+ * separated, an empty line for a segment that launched nothing -- taken from the runtime's own symbol table
+ * (hipKernelNameRefByPtr, demangled), i.e. exactly what rocprofv3 prints for it. */
 int rsparse_hip_profile_enable(int on);
+int rsparse_hip_profile_last_names(char* buf, int cap);
 /* How the launches of one conjugate-gradient half-iteration (one per row-length bucket, disjoint rows) are issued:
  * 2 (default) = the long-row launch on the caller's stream, the others on side streams forked from / joined to it,
  * 1 = every launch on a side stream, 0 = all back to back on the caller's stream -- what a profiler needs for

@@ -6,6 +6,8 @@
 // wrmf_kernels.hip.  No torch, no R, no Armadillo types anywhere.
 #include "../../include/rsparse_wrmf_hip.h"
 
+#include <cxxabi.h>
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -197,11 +199,13 @@ struct Profiler {
   bool have = false;
   int nseg = 0;
   hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const void* kern[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t* begin() {
     have = false;
     if (!on) return nullptr;
     for (auto& e : ev)
       if (!e && hipEventCreate(&e) != hipSuccess) return nullptr;
+    for (auto& k : kern) k = nullptr;
     return ev;
   }
 } g_prof;
@@ -584,15 +588,17 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     a.lr_rows = d.q_order + d.q_lr_first; a.n_lr = d.q_n_lr; a.lr_flags = g_ws.ne_stats + 2; a.lr_M = g_ws.lr_M;
   }
   hipEvent_t* ev = g_prof.begin();
+  const bool chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY;
+  if (chol && ev) HIP_TRY(hipEventRecord(ev[0], s));   // Cholesky: [0] normal-equation launch, [1] low-rank, [2] k x k, [3] loss
   if (ne_chol) {
-    hipError_t ne = launch_als_ne(a, qs, implicit, g_ws.partials + chol_base, s);
+    hipError_t ne = launch_als_ne(a, qs, implicit, g_ws.partials + chol_base, s, ev);
     if (ne != hipSuccess) return hip_fail(ne, "launch_als_ne");
   }
   hipError_t e = cgq ? launch_als_cgq(a, qs, implicit, s, ev)
                      : (cg ? launch_als_cg(a, implicit, s, ev)
                            : (solver == RSPARSE_SOLVER_NNLS
                                   ? launch_als_nnls(a, implicit, s, ev)
-                                  : launch_als_chol2(a, implicit, s, ev)));
+                                  : launch_als_chol2(a, implicit, s, ev ? ev + 1 : nullptr)));
   if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
   e = launch_sum_partials(g_ws.partials, slots, out, s, g_ws.partials + g_ws.partial_slots);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
@@ -614,7 +620,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   }
 #endif
   if (ev) {
-    const int last = cgq ? 7 : 3;
+    const int last = cgq ? 7 : (chol ? 4 : 3);
     HIP_TRY(hipEventRecord(ev[last], s));
     g_prof.have = true;
     g_prof.nseg = last;
@@ -858,6 +864,14 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
 
 }  // namespace
 
+namespace rsparse_hip {
+void prof_note(hipEvent_t* ev_slot, const void* kernel_fn) {
+  if (!ev_slot || !g_prof.on) return;
+  const ptrdiff_t i = ev_slot - g_prof.ev;
+  if (i >= 0 && i < 10 && !g_prof.kern[i]) g_prof.kern[i] = kernel_fn;   // the first launch of a segment names it
+}
+}  // namespace rsparse_hip
+
 extern "C" {
 
 const char* rsparse_hip_last_error(void) { return g_err.c_str(); }
@@ -1035,6 +1049,26 @@ int rsparse_hip_set_launch_mode(int mode) {
 int rsparse_hip_profile_enable(int on) {
   g_prof.on = on != 0;
   g_prof.have = false;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_profile_last_names(char* buf, int cap) {
+  if (!buf || cap <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "buf is NULL or empty");
+  buf[0] = 0;
+  if (!g_prof.on || !g_prof.have) return fail(RSPARSE_HIP_ERR_INVALID, "no profiled call to report");
+  std::string out;
+  for (int i = 0; i < g_prof.nseg; i++) {
+    if (i) out += '\n';
+    if (!g_prof.kern[i]) continue;
+    const char* mangled = hipKernelNameRefByPtr(g_prof.kern[i], nullptr);
+    if (!mangled) continue;
+    int st = 0;
+    char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+    out += (st == 0 && dem) ? dem : mangled;
+    std::free(dem);
+  }
+  if ((int)out.size() + 1 > cap) return fail(RSPARSE_HIP_ERR_INVALID, "buffer too small for the kernel names");
+  std::memcpy(buf, out.c_str(), out.size() + 1);
   return RSPARSE_HIP_OK;
 }
 

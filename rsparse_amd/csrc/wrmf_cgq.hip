@@ -848,11 +848,12 @@ bool dense_mfma_enabled() {
 }
 
 template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT, bool GB, bool DMF = false>
-hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int grid, size_t slot0, hipStream_t s) {
+hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int grid, size_t slot0, hipStream_t s,
+                         hipEvent_t* ev_slot) {
   if (n_rows <= 0) return hipSuccess;
   constexpr bool kDmfGeometry = IMPLICIT && KP == 128 && WAVES == 4 && WPR == 1 && CAPQ == 8 && STREAM == 0;
   if constexpr (kDmfGeometry && !DMF) {
-    if (dense_mfma_enabled()) return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, GB, true>(a, rows, n_rows, grid, slot0, s);
+    if (dense_mfma_enabled()) return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, GB, true>(a, rows, n_rows, grid, slot0, s, ev_slot);
   }
   constexpr int TEAMS = WAVES / WPR;
   auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF, GB>;
@@ -862,6 +863,7 @@ hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int 
   if (err != hipSuccess) return err;
   const int total_teams = grid * TEAMS;
   const int rpt = (n_rows + total_teams - 1) / total_teams;
+  prof_note(ev_slot, reinterpret_cast<const void*>(kern));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a, rows, n_rows, rpt, slot0);
   return hipGetLastError();
 }
@@ -925,12 +927,12 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
           if ((err = hipStreamWaitEvent(bs, g_bs.fork, 0)) != hipSuccess) return err;                       \
         }                                                                                                   \
         if (D.stream && ne_supported(a.k)) {                                                                \
-          if ((err = launch_als_ne(a, q, IMPLICIT, a.loss_partials + slot, bs)) != hipSuccess)                  \
+          if ((err = launch_als_ne(a, q, IMPLICIT, a.loss_partials + slot, bs, ev ? ev + B : nullptr)) != hipSuccess) \
             return err;                                                                                     \
         } else if constexpr (D.stream && KP > 32) {   /* ranks above 32 always take the branch above */     \
           return hipErrorInvalidValue;                                                                      \
         } else if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT, GB>(a, q.order + q.off[B], n, grid, slot, \
-                                                                                bs)) != hipSuccess)         \
+                                                                                bs, ev ? ev + B : nullptr)) != hipSuccess) \
           return err;                                                                                       \
         if (side) {                                                                                         \
           if ((err = hipEventRecord(g_bs.done[B], bs)) != hipSuccess) return err;                           \

@@ -438,15 +438,17 @@ hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
       return err;
   if ((err = hipMemsetAsync(a.loss_partials + grid, 0, (size_t)kCholLongGrid * sizeof(double), s)) != hipSuccess)
     return err;
+  // per-kernel timing: ev[0] | low-rank kernel for the short rows (+ its one-workgroup prep) | ev[1] | k x k kernel(s) | ev[2]
   if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
   if (a.lr_flags) {   // the short rows first (its prep kernel also settles lr_flags before the launches below read it)
-    if ((err = launch_als_chol_lr(a, a.lr_rows, a.n_lr, a.lr_M, a.lr_M + 128 * 128, a.lr_flags, grid + kCholLongGrid, s)) !=
-        hipSuccess)
+    if ((err = launch_als_chol_lr(a, a.lr_rows, a.n_lr, a.lr_M, a.lr_M + 128 * 128, a.lr_flags, grid + kCholLongGrid, s,
+                                  ev)) != hipSuccess)
       return err;
   } else if ((err = hipMemsetAsync(a.loss_partials + grid + kCholLongGrid, 0, (size_t)kCholLrGrid * sizeof(double), s)) !=
              hipSuccess) {
     return err;
   }
+  if (ev && (err = hipEventRecord(ev[1], s)) != hipSuccess) return err;
   // The long rows are few and the longest of them decides when the half-iteration ends: their launch runs on a side
   // stream next to the main one (disjoint rows), forked from / joined to the caller's stream with events.  With
   // per-kernel timing (ev) both go back to back on the caller's stream.
@@ -465,12 +467,10 @@ hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
       if ((err = hipStreamWaitEvent(s, g_long_stream.done, 0)) != hipSuccess) return err;
     }
   }
+  prof_note(ev ? ev + 1 : nullptr, reinterpret_cast<const void*>(kc));
   hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a, 0);
   if ((err = hipGetLastError()) != hipSuccess) return err;
-  if (ev) {
-    if ((err = hipEventRecord(ev[1], s)) != hipSuccess) return err;
-    if ((err = hipEventRecord(ev[2], s)) != hipSuccess) return err;
-  }
+  if (ev && (err = hipEventRecord(ev[2], s)) != hipSuccess) return err;
   return hipSuccess;
 }
 

@@ -400,7 +400,7 @@ bool chol_lr_supported(const AlsArgs& a, bool implicit) {
 // scratch; flags: the device word launch_ne_stats leaves in stats[2] (some confidence < 1) -- the prep kernel ORs its own
 // verdict into the same word.  Loss partials of its kCholLrGrid workgroups from loss_slot0 on.
 hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows, float* M, float* Mt, unsigned* flags,
-                              int loss_slot0, hipStream_t s) {
+                              int loss_slot0, hipStream_t s, hipEvent_t* ev_slot) {
   hipError_t err;
   if ((err = hipMemsetAsync(a.loss_partials + loss_slot0, 0, (size_t)kCholLrGrid * sizeof(double), s)) != hipSuccess)
     return err;
@@ -418,6 +418,7 @@ hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows,
                                  (int)LrSmem<KP>::bytes)) != hipSuccess)
     return err;
   const int grid = n_rows < kCholLrGrid ? n_rows : kCholLrGrid;
+  prof_note(ev_slot, reinterpret_cast<const void*>(kern));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LrSmem<KP>::bytes, s, a, rows, n_rows, M, Mt, flags, loss_slot0);
   return hipGetLastError();
 }

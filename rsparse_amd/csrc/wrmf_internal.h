@@ -152,7 +152,8 @@ constexpr int kNeSegFloats = 4 * (11 * 16 * 64 + 128 + 2);   // per segment: 4 w
 hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s,
                            const float* absmax_hint = nullptr);
 struct QSchedule;
-hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s);
+hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s,
+                         hipEvent_t* ev_slot = nullptr);
 // global bias + conjugate gradient: out[r][:] = base - gbias * sum_j (c_j - 1) x_j for the n rows `rows` (one workgroup
 // per row), slot_of_row[rows[r]] = r
 hipError_t launch_gb_row_terms(const AlsArgs& a, const int32_t* rows, int n, float* out, int32_t* slot_of_row, hipStream_t s);
@@ -184,7 +185,7 @@ constexpr int kCholLrGrid = 512;
 size_t chol2_loss_slots(int n_cols);
 bool chol_lr_supported(const AlsArgs& a, bool implicit);
 hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows, float* M, float* Mt, unsigned* flags,
-                              int loss_slot0, hipStream_t s);
+                              int loss_slot0, hipStream_t s, hipEvent_t* ev_slot = nullptr);
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 constexpr int kSumStageBlocks = 256;
@@ -226,5 +227,10 @@ hipError_t launch_top_product(const float* U, const float* V, int n_users, int n
                               float glob_mean, int32_t* res, float* scores, hipStream_t s);
 
 int padded_rank(int k);  // 32 / 64 / 128, or 0 if unsupported
+
+// Measurement harness (rsparse_hip_profile_*): the launcher that records the event `ev_slot` in front of a kernel also
+// says which kernel it is about to launch (host function pointer); rsparse_hip_profile_last_names resolves the pointers
+// to the names a profiler prints.  No-op when ev_slot is null.
+void prof_note(hipEvent_t* ev_slot, const void* kernel_fn);
 
 }  // namespace rsparse_hip

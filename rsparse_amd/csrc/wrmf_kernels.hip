@@ -512,6 +512,7 @@ hipError_t launch_cg_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   if (grid_s > 0) {
     auto ks = als_cg_short_kernel<KP, T, W, IMPLICIT, VEC>;
     if ((err = set_lds(ks, SM::short_bytes)) != hipSuccess) return err;
+    prof_note(ev, reinterpret_cast<const void*>(ks));
     hipLaunchKernelGGL(ks, dim3(grid_s), dim3(W * 64), SM::short_bytes, s, a);
     if ((err = hipGetLastError()) != hipSuccess) return err;
   }
@@ -520,6 +521,7 @@ hipError_t launch_cg_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
     const int grid_l = (a.n_long + kRowsPerWGLong - 1) / kRowsPerWGLong;
     auto kl = als_cg_long_kernel<KP, T, W, IMPLICIT, VEC>;
     if ((err = set_lds(kl, SM::long_bytes)) != hipSuccess) return err;
+    prof_note(ev ? ev + 1 : nullptr, reinterpret_cast<const void*>(kl));
     hipLaunchKernelGGL(kl, dim3(grid_l), dim3(W * 64), SM::long_bytes, s, a, (size_t)grid_s * W);
     if ((err = hipGetLastError()) != hipSuccess) return err;
   }
@@ -598,6 +600,10 @@ hipError_t launch_gramian(const float* X, int k, int64_t n, float ridge, float* 
   double* diag = reinterpret_cast<double*>(scratch + (((size_t)waves * KP * KP + 1) & ~(size_t)1));
   const int grid = waves / 4;
   if (ev) (void)hipEventRecord(ev[0], s);
+  prof_note(ev, KP == 32 ? reinterpret_cast<const void*>(gramian_partial_kernel<32>)
+                         : (KP == 64 ? reinterpret_cast<const void*>(gramian_partial_kernel<64>)
+                                     : reinterpret_cast<const void*>(gramian_partial_kernel<128>)));
+  prof_note(ev ? ev + 1 : nullptr, reinterpret_cast<const void*>(gramian_reduce_kernel));
   if (KP == 32) hipLaunchKernelGGL(gramian_partial_kernel<32>, dim3(grid), dim3(256), 0, s, X, k, n, partials, absmax_bits);
   else if (KP == 64) hipLaunchKernelGGL(gramian_partial_kernel<64>, dim3(grid), dim3(256), 0, s, X, k, n, partials, absmax_bits);
   else hipLaunchKernelGGL(gramian_partial_kernel<128>, dim3(grid), dim3(256), 0, s, X, k, n, partials, absmax_bits);

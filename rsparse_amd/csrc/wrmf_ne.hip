@@ -1442,12 +1442,13 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
 
 template <int KP, int NS, bool IMPLICIT, bool SYM, bool QUAD, bool COLLECT, bool CHOL, bool GB = false>
 hipError_t launch_ne_t(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int grid, double* row_loss,
-                       hipStream_t s, int only_if_lt1) {
+                       hipStream_t s, int only_if_lt1, hipEvent_t* ev_slot = nullptr) {
   auto kern = als_ne_kernel<KP, NS, IMPLICIT, SYM, QUAD, COLLECT, CHOL, GB>;
   constexpr int lds = NeGeo<KP, NeRoles<KP, NS, IMPLICIT, SYM, QUAD>::NROLES, IMPLICIT>::BYTES;
   hipError_t err =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (err != hipSuccess) return err;
+  if (!COLLECT && !only_if_lt1) prof_note(ev_slot, reinterpret_cast<const void*>(kern));   // the launch that does the work
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, wg_rows, wg_ptr, 0, row_loss, only_if_lt1);
   return hipGetLastError();
 }
@@ -1553,17 +1554,17 @@ hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_
 // stats: the bf16 kernel alone.
 template <bool COLLECT, bool CHOL, bool GB = false>
 hipError_t launch_ne_mode(const AlsArgs& a, const int32_t* wg_rows, const int32_t* wg_ptr, int n_wg, bool implicit,
-                          double* row_loss, hipStream_t s) {
+                          double* row_loss, hipStream_t s, hipEvent_t* ev_slot = nullptr) {
   const int KP = padded_rank(a.k);
   hipError_t err;
 #define RSP_NE_DISPATCH(KPV)                                                                                           \
   if (KP == KPV) {                                                                                                     \
     if constexpr (!GB) {                                                                                               \
-      if (!implicit) return launch_ne_t<KPV, 3, false, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
-      if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0); \
+      if (!implicit) return launch_ne_t<KPV, 3, false, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0, ev_slot); \
+      if (!a.ne_stats) return launch_ne_t<KPV, 3, true, false, false, COLLECT, CHOL>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0, ev_slot); \
     }                                                                                                                  \
     if (!implicit || !a.ne_stats) return hipErrorInvalidValue;   /* GB: implicit feedback with the value statistics */  \
-    if ((err = launch_ne_t<KPV, 2, true, true, KPV == 128, COLLECT, CHOL, GB>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0)) !=  \
+    if ((err = launch_ne_t<KPV, 2, true, true, KPV == 128, COLLECT, CHOL, GB>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 0, ev_slot)) !=  \
         hipSuccess)                                                                                                    \
       return err;                                                                                                      \
     return launch_ne_t<KPV, 3, true, false, false, COLLECT, CHOL, GB>(a, wg_rows, wg_ptr, n_wg, row_loss, s, 1);             \
@@ -1577,15 +1578,16 @@ hipError_t launch_ne_mode(const AlsArgs& a, const int32_t* wg_rows, const int32_
 // The long rows of one half-iteration: the streaming launch over the per-workgroup lists (q.ne_rows / ne_ptr; an entry is
 // a row or a segment of a split row), then, if rows were split, the COLLECT launch (one workgroup per split row).
 // row_loss: one double per list entry, then one per split row.
-hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s) {
+hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s,
+                         hipEvent_t* ev_slot) {
   if (q.ne_wg <= 0) return hipSuccess;
   // a.ne_chol (solver == CHOLESKY): the instantiations whose per-row solve is the blocked LDL^T instead of CG -- separate
   // kernels, so neither solve costs the other's streaming loops a register
   const bool gb = !a.ne_chol && implicit && a.gbias != 0.f;   // conjugate gradient with a global bias
   if (gb && !(a.ne_r0 && a.ne_r0_slot)) return hipErrorInvalidValue;
-  hipError_t err = a.ne_chol ? launch_ne_mode<false, true>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s)
-                   : gb      ? launch_ne_mode<false, false, true>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s)
-                             : launch_ne_mode<false, false>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s);
+  hipError_t err = a.ne_chol ? launch_ne_mode<false, true>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s, ev_slot)
+                   : gb      ? launch_ne_mode<false, false, true>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s, ev_slot)
+                             : launch_ne_mode<false, false>(a, q.ne_rows, q.ne_ptr, q.ne_wg, implicit, row_loss, s, ev_slot);
   if (err != hipSuccess || q.ne_nsplit <= 0) return err;
   return a.ne_chol ? launch_ne_mode<true, true>(a, q.ne_split_rows, q.ne_split_ptr, q.ne_nsplit, implicit, row_loss + q.ne_entries, s)
          : gb      ? launch_ne_mode<true, false, true>(a, q.ne_split_rows, q.ne_split_ptr, q.ne_nsplit, implicit, row_loss + q.ne_entries, s)

@@ -291,6 +291,7 @@ hipError_t launch_nnls_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
                                  (int)SM::bytes)) != hipSuccess)
     return err;
   if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
+  prof_note(ev, reinterpret_cast<const void*>(kc));
   hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   if (ev) {

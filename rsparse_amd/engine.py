@@ -261,6 +261,12 @@ class HipBackend:
         _lib.check(self.lib.rsparse_hip_profile_last(buf))
         return list(buf)
 
+    def profile_last_names(self):
+        """kernel names of the segments of the last profiled call, as the runtime's symbol table has them"""
+        buf = ctypes.create_string_buffer(8192)
+        _lib.check(self.lib.rsparse_hip_profile_last_names(buf, 8192))
+        return buf.value.decode().split("\n")
+
     def check_numeric(self):
         c = ctypes.c_int64(0)
         _lib.check(self.lib.rsparse_hip_take_numeric_failures(ctypes.byref(c)))

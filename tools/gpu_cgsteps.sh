@@ -10,7 +10,7 @@ for n in 0 1 2 3; do
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
-    print("cg_steps %s  ms %.1f  " % (sys.argv[2], d["ms_per_step"]) + "  ".join("%.2f" % c["avg_launch_ms"] for c in d["roofline"]["cg_kernels"]))
+    print("cg_steps %s  ms %.1f  " % (sys.argv[2], d["ms_per_step"]) + "  ".join("%.2f" % c["avg_launch_ms"] for c in d["roofline"]["solve_kernels"]))
 except Exception as e:
     print(sys.argv[2], "no json:", e)
 PY

@@ -15,7 +15,7 @@ import json, sys
 try:
     d = json.load(open(sys.argv[1]))
     print("it/s %.3f  ms %.1f  parity %s" % (d["value"], d["ms_per_step"], json.dumps(d.get("parity", {}))[:300]))
-    for c in d["roofline"]["cg_kernels"]:
+    for c in d["roofline"]["solve_kernels"]:
         print("   %-55s %7.2f ms  %6.0f GB/s" % (c["kernel"], c["avg_launch_ms"], c["bytes_per_launch"] / c["avg_launch_ms"] / 1e6))
 except Exception as e:
     print("no json:", e)

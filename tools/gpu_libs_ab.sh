@@ -11,7 +11,7 @@ for v in "$@"; do
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
-    print("%-8s it/s %.3f ms %.1f  " % (sys.argv[2], d["value"], d["ms_per_step"]) + "  ".join("%.2f" % c["avg_launch_ms"] for c in d["roofline"]["cg_kernels"]))
+    print("%-8s it/s %.3f ms %.1f  " % (sys.argv[2], d["value"], d["ms_per_step"]) + "  ".join("%.2f" % c["avg_launch_ms"] for c in d["roofline"]["solve_kernels"]))
 except Exception as e:
     print(sys.argv[2], "no json:", e)
 PY

@@ -14,7 +14,7 @@ import json
 try:
     d=json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1])
     print("it/s %.3f ms %.1f loss %.6f"%(d["value"],d["ms_per_step"],d["loss_users_last"]))
-    for kk in d["roofline"]["cg_kernels"]: print("  %-52s n=%d %.2f ms  %.1f GB/launch -> %.2f TB/s"%(kk["kernel"],kk["launches_per_iteration"],kk["avg_launch_ms"],kk["bytes_per_launch"]/1e9,kk["bytes_per_launch"]/kk["avg_launch_ms"]/1e9))
+    for kk in d["roofline"]["solve_kernels"]: print("  %-52s n=%d %.2f ms  %.1f GB/launch -> %.2f TB/s"%(kk["kernel"],kk["launches_per_iteration"],kk["avg_launch_ms"],kk["bytes_per_launch"]/1e9,kk["bytes_per_launch"]/kk["avg_launch_ms"]/1e9))
     print("  half ms", d["roofline"]["half_iteration_ms"], "gram", d["roofline"]["gramian_ms"])
 except Exception as e:
     print("bench parse failed", e); print(open("$OUT/bench.err").read()[-1500:])

@@ -13,3 +13,4 @@ done
 python tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 grep -A14 "als_cgq\|als_ne" $OUT/summary.txt | cut -c1-200 | head -120
 find $OUT -name "*kernel_trace.csv" -size +5M -delete
+python tools/pmc_traffic.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1; tail -12 $OUT/pmc_traffic.txt

@@ -13,7 +13,7 @@ try:
     d=json.load(open("$OUT/bench_full.json"))
     r=d["roofline"]
     print("  full: it/s %.3f ms/step %.1f  half %s  frac %.3f dom %s" % (d["value"], d["ms_per_step"], {k: round(v,1) for k,v in r["half_iteration_ms"].items()}, r["frac"], r["kernel"]))
-    for c in r.get("cg_kernels", []): print("   ", c["kernel"], "launches", c["launches_per_iteration"], "ms/iter %.2f" % c["total_ms_per_iteration"], "GB/s %.0f" % (c["bytes_per_launch"]/c["avg_launch_ms"]/1e6))
+    for c in r.get("solve_kernels", []): print("   ", c["kernel"], "launches", c["launches_per_iteration"], "ms/iter %.2f" % c["total_ms_per_iteration"], "GB/s %.0f" % (c["bytes_per_launch"]/c["avg_launch_ms"]/1e6))
     print("   gram", r["gramian_ms"], "cpu", d.get("cpu_baseline"))
 except Exception as e:
     print("  (no json)", e); print(open("$OUT/bench_full.err").read()[-800:])

@@ -12,7 +12,7 @@ python - $OUT/bench.json >> $OUT/summary.txt 2>&1 <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]
 print("it/s %.3f ms %.1f half %s" % (d["value"], d["ms_per_step"], r["half_iteration_ms"]))
-for kx in r["cg_kernels"]:
+for kx in r["solve_kernels"]:
     print("  %-60s %6.2f ms x%d  %.0f GB/s" % (kx["kernel"], kx["avg_launch_ms"], kx["launches_per_iteration"], kx["bytes_per_launch"] / kx["avg_launch_ms"] / 1e6))
 PY
 tail -3 $OUT/bench.err >> $OUT/summary.txt

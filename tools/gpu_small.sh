@@ -6,5 +6,5 @@ python - <<PY
 import json
 d=json.loads(open("$OUT/small.json").read().strip().splitlines()[-1])
 print(d["value"], d["ms_per_step"])
-for kk in d["roofline"]["cg_kernels"]: print("  %-52s n=%d %.3f ms  %.2f GB/launch -> %.2f TB/s"%(kk["kernel"],kk["launches_per_iteration"],kk["avg_launch_ms"],kk["bytes_per_launch"]/1e9,kk["bytes_per_launch"]/kk["avg_launch_ms"]/1e9))
+for kk in d["roofline"]["solve_kernels"]: print("  %-52s n=%d %.3f ms  %.2f GB/launch -> %.2f TB/s"%(kk["kernel"],kk["launches_per_iteration"],kk["avg_launch_ms"],kk["bytes_per_launch"]/1e9,kk["bytes_per_launch"]/kk["avg_launch_ms"]/1e9))
 PY

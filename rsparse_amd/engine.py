@@ -308,13 +308,16 @@ class ShardedALS:
 
     def __init__(self, backend, n_user, n_item, rank_k, c_ui_block, c_iu_block, total_nnz, feedback="implicit",
                  lambda_=0.0, dynamic_lambda=True, cg_steps=3, group=None, world_size=1, my_rank=0, with_bias=False,
-                 lay_user=None, lay_item=None):
+                 lay_user=None, lay_item=None, force_collectives=False):
         self.be, self.k = backend, int(rank_k)
         self.n_user, self.n_item, self.total_nnz = int(n_user), int(n_item), int(total_nnz)
         self.implicit = feedback == "implicit"
         self.with_bias = bool(with_bias)     # rank_k counts the row of ones and the bias row (R/model_WRMF.R:160)
         self.lambda_, self.dynamic_lambda, self.cg_steps = float(lambda_), bool(dynamic_lambda), int(cg_steps)
         self.group, self.ws, self.me = group, int(world_size), int(my_rank)
+        # collectives are issued when there is more than one rank -- or when a test asks for them on a one-rank group
+        # (the RCCL branches can then be executed on a single GPU: tests/test_nccl_single_rank.py)
+        self.coll = self.ws > 1 or bool(force_collectives)
         if lay_user is None or lay_item is None:
             lay_user, lay_item = self.layouts(n_user, n_item, self.ws)
         self.lay_user, self.lay_item = lay_user, lay_item
@@ -326,6 +329,10 @@ class ShardedALS:
         self.G = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
         self.Gpart = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float64, device=dev)   # [0] sumsq, [1] loss rows, [2] spare
+        # one collective per Gramian: every rank contributes [k x k partial, sum(F^2), max |F|] (doubles), all ranks get
+        # all contributions and reduce them locally in rank order (sums and the maximum: deterministic, identical everywhere)
+        self.red_in = torch.zeros(self.k * self.k + 2, dtype=torch.float64, device=dev)
+        self.red_all = torch.zeros((self.ws, self.k * self.k + 2), dtype=torch.float64, device=dev)
         self.absmax = torch.zeros(1, dtype=torch.float32, device=dev)   # max |F| of the fixed side (gramian())
         self.absmax_of = None
         self.global_bias = 0.0 # implicit feedback: the model's global bias (R/model_WRMF.R:285-287); explicit: data are shifted
@@ -362,12 +369,12 @@ class ShardedALS:
         return whole, subs
 
     def _all_reduce(self, t):
-        if self.ws > 1:
+        if self.coll:
             torch.distributed.all_reduce(t, group=self.group)
 
     def _gather_slab(self, S, lay, j):
         """In-place all-gather of sub-block j of every rank (one contiguous slab of S); returns a work handle or None."""
-        if self.ws == 1:
+        if not self.coll:
             return None
         a, b = lay.slab(j)
         out = S[a:b]
@@ -401,7 +408,7 @@ class ShardedALS:
         # ranks below; half_iteration() hands it to the library so that no half-iteration call scans F again
         self.absmax.zero_()
         self.absmax_of = None
-        if self.ws == 1 and len(pieces) == 1:
+        if not self.coll and len(pieces) == 1:
             a, b = pieces[0]
             self.be.gramian(F[a:b], self.lambda_, self.G, self.scal[0:1], self.absmax)
             self.absmax_of = F
@@ -412,10 +419,21 @@ class ShardedALS:
             self.be.gramian(F[a:b], 0.0, self.Gpart, self.scal[2:3], self.absmax)
             self.G += self.Gpart
             self.scal[0:1] += self.scal[2:3]
-        self._all_reduce(self.G)
-        self._all_reduce(self.scal[0:1])
-        if self.ws > 1:
-            torch.distributed.all_reduce(self.absmax, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        if self.coll:   # ONE collective for the k x k partial, sum(F^2) and max |F| (see red_in / red_all)
+            kk = self.k * self.k
+            self.red_in[:kk] = self.G.reshape(-1)
+            self.red_in[kk] = self.scal[0]
+            self.red_in[kk + 1] = self.absmax[0]
+            if self.red_in.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+                host = self.red_all.cpu()   # dry-run configuration only (ranks sharing one GPU under gloo)
+                torch.distributed.all_gather_into_tensor(host.view(-1), self.red_in.cpu(), group=self.group)
+                self.red_all.copy_(host)
+            else:
+                torch.distributed.all_gather_into_tensor(self.red_all.view(-1), self.red_in, group=self.group)
+            tot = self.red_all[:, :kk + 1].sum(dim=0)
+            self.G.copy_(tot[:kk].view(self.k, self.k))
+            self.scal[0] = tot[kk]
+            self.absmax[0] = self.red_all[:, kk + 1].max()
         self.absmax_of = F
         self.G.diagonal().add_(float(np.float32(self.lambda_)))   # fl(diag(lambda)), R/model_WRMF.R:476
         return self.G
@@ -489,7 +507,8 @@ class ShardedALS:
                     Freg = (Freg[:, 1:] if blr else Freg[:, :self.k - 1]).contiguous()   # x bias is last, else last
                 self.be.weighted_sumsq(Freg, w, self.scal[2:3])
                 self.scal[0:1] += self.scal[2:3]
-            self._all_reduce(self.scal[0:1])
-        self._all_reduce(self.scal[1:2])
+            self._all_reduce(self.scal[0:2])   # regulariser and row part of the loss in ONE all-reduce
+        else:
+            self._all_reduce(self.scal[1:2])
         loss = (self.scal[1] + self.lambda_ * self.scal[0]) / float(self.total_nnz)
         return loss.clone() if want_loss == "device" else float(loss)

@@ -41,7 +41,8 @@ class TopItems(np.ndarray):
 class WRMF:
     def __init__(self, rank=10, lambda_=0.0, dynamic_lambda=True, init=None, preprocess=_identity,
                  feedback="implicit", solver="conjugate_gradient", with_user_item_bias=False,
-                 with_global_bias=False, cg_steps=3, precision="double", rng=None, device=None):
+                 with_global_bias=False, cg_steps=3, precision="double", rng=None, device=None, group=None,
+                 backend=None):
         if init is not None and not isinstance(init, np.ndarray):
             raise TypeError("init must be NULL or a matrix")                      # :84
         if solver not in SOLVER_CODES:
@@ -76,7 +77,8 @@ class WRMF:
         self.global_bias = 0.0
         self._rng = rng if isinstance(rng, np.random.Generator) else np.random.default_rng(rng)
         self._device = device
-        self._be = None
+        self._be = backend   # None = HipBackend on first use; tests inject the CPU stand-in for the multi-rank control flow
+        self._group = group  # torch.distributed process group to shard over (None = the default group if initialised)
         self._V = None       # item factors on the device, (n_item, rank)
         self._XtX = None
         self._cnt_item = None
@@ -97,10 +99,26 @@ class WRMF:
         return (be.to_device(m.indptr, torch.int32), be.to_device(m.indices, torch.int32),
                 be.to_device(m.data, torch.float32))
 
+    def _dist(self):
+        """(world size, my rank) of the group this model shards over; (1, 0) without torch.distributed."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self._group), dist.get_rank(self._group)
+        return 1, 0
+
     def fit_transform(self, x, n_iter=10, convergence_tol=None):
-        """R/model_WRMF.R:173-360.  Returns the user embeddings (n_user x rank)."""
+        """R/model_WRMF.R:173-360.  Returns the user embeddings (n_user x rank).
+
+        Under torch.distributed (one process per GPU, e.g. `torchrun --nproc-per-node 8`; backend "nccl" = RCCL) with more
+        than one rank, every rank calls this with the SAME matrix and the same model arguments: users and items are
+        sharded over the ranks in contiguous blocks balanced by non-zeros, every rank uploads and solves only its own
+        blocks, the k x k Gramians are all-reduced and the solved factor blocks all-gathered each half-iteration
+        (rsparse_amd/engine.py), and every rank returns the same embeddings / holds the same `components`."""
         if convergence_tol is None:
             convergence_tol = 0.005 if self._feedback == "implicit" else 0.001
+        ws, me = self._dist()
+        if ws > 1:
+            return self._fit_transform_sharded(x, n_iter, convergence_tol, ws, me)
         be = self._backend()
         c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))               # :184-188
         c_ui.sort_indices()
@@ -184,11 +202,123 @@ class WRMF:
         # the returned embeddings come from one more exact solve, not from U (:355-359)
         return self._transform(als.csc_users, n_user)
 
+    def _fit_transform_sharded(self, x, n_iter, convergence_tol, ws, me):
+        """fit_transform over `ws` ranks (see fit_transform).  Same sequence of half-iterations, initial factors and
+        stopping rule as the one-rank path; the factors of a row do not depend on the number of ranks (only the order of
+        the Gramian / loss sums does)."""
+        import torch.distributed as dist
+        if self._with_bias:
+            raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "with_user_item_bias is single-rank only: its initialisation "
+                                           "sweeps (initialize_biases_*) alternate over the WHOLE matrix")
+        be = self._backend()
+        c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))
+        c_ui.sort_indices()
+        if (self._feedback != "explicit" or self._non_negative) and c_ui.nnz and c_ui.data.min() < 0:
+            raise ValueError("all(c_ui@x >= 0) is not TRUE")
+        n_user, n_item = c_ui.shape
+        k = self._rank
+        # the SAME initial factors on every rank: drawn once from the model's generator ...
+        if self._init_user_factors is not None:
+            U0 = np.ascontiguousarray(self._init_user_factors, dtype=np.float32)
+        else:
+            U0 = (self._rng.standard_normal((n_user, k)) * 0.01).astype(np.float32)
+        if self.components is None:
+            V0 = (np.zeros((n_item, k), dtype=np.float32) if self._solver_code == 1 else
+                  (self._rng.standard_normal((n_item, k)) * 0.01).astype(np.float32))
+        else:
+            if self.components.shape != (k, n_item):
+                raise ValueError("init must be rank x n_item")
+            V0 = np.ascontiguousarray(self.components.T, dtype=np.float32)
+        if self._non_negative:
+            U0, V0 = np.abs(U0), np.abs(V0)
+        dev0 = be.to_device(np.zeros(1, dtype=np.float32), torch.float32).device
+        for buf in (U0, V0):   # ... and rank 0's copy wins if the ranks were seeded differently
+            t = torch.from_numpy(buf).to(dev0)
+            dist.broadcast(t, src=dist.get_global_rank(self._group, 0) if self._group is not None else 0, group=self._group)
+            buf[...] = t.cpu().numpy()
+        self.global_bias = 0.0
+        if self._with_global_bias and self._feedback == "explicit":                # :278-282, on the host: the mean is global
+            self.global_bias = float(np.mean(c_ui.data)) if c_ui.nnz else 0.0
+            c_ui = c_ui.copy()
+            c_ui.data -= self.global_bias
+        elif self._with_global_bias:                                               # :285-287
+            sm = float(c_ui.data.sum())
+            self.global_bias = sm / (sm + float(n_user) * float(n_item) - float(c_ui.nnz))
+        c_iu = sp.csc_matrix(c_ui.T)          # t_shallow(as.csr.matrix(c_ui)), :190 (host side: only blocks are uploaded)
+        c_iu.sort_indices()
+        cnt_item = torch.from_numpy(np.diff(c_ui.indptr).astype(np.int64))
+        cnt_user = torch.from_numpy(np.diff(c_iu.indptr).astype(np.int64))
+        lay_u, lay_i = ShardedALS.layouts(n_user, n_item, ws, cnt_user, cnt_item)
+
+        def block(m, lo, hi):
+            b = m[:, lo:hi]
+            return (be.to_device(b.indptr, torch.int32), be.to_device(b.indices, torch.int32),
+                    be.to_device(b.data.astype(np.float32), torch.float32))
+        als = ShardedALS(be, n_user, n_item, k, block(c_ui, *lay_i.bounds[me]), block(c_iu, *lay_u.bounds[me]), c_ui.nnz,
+                         feedback=self._feedback, lambda_=self._lambda, dynamic_lambda=self._dynamic_lambda,
+                         cg_steps=self._cg_steps, group=self._group, world_size=ws, my_rank=me, lay_user=lay_u,
+                         lay_item=lay_i)
+        als.cnt_user = be.to_device(cnt_user.numpy().astype(np.float32), torch.float32)
+        als.cnt_item = be.to_device(cnt_item.numpy().astype(np.float32), torch.float32)
+        U = lay_u.from_global(lay_u.alloc(k, dev0), be.to_device(U0, torch.float32))
+        V = lay_i.from_global(lay_i.alloc(k, dev0), be.to_device(V0, torch.float32))
+        if self._feedback == "implicit":
+            als.global_bias = self.global_bias
+        loss_prev = float("inf")
+        self.losses = []
+        for it in range(int(n_iter)):
+            li = als.half_iteration("items", U, V, self._solver_code)
+            lu = als.half_iteration("users", U, V, self._solver_code)
+            self.losses.append((li, lu))
+            if (loss_prev / lu if lu != 0 else float("inf")) - 1 < convergence_tol:   # every rank sees the same loss
+                break
+            loss_prev = lu
+        be.check_numeric()
+        # the returned embeddings: one more exact solve from zeros against the final item factors (:355-359), sharded like
+        # a user half-iteration
+        XtX = als.gramian(V, lay_i).clone() if self._feedback == "implicit" else None
+        res = lay_u.alloc(k, dev0)
+        solver = 0 if self._solver_code == 1 else self._solver_code
+        als.half_iteration("users", res, V, solver, G=XtX, want_loss=False)
+        be.check_numeric()
+        # what transform() / predict() need afterwards: a plain (n_item, rank) replica of the item factors on every rank
+        self._V = lay_i.to_global(V).contiguous()
+        self._XtX = XtX
+        self._cnt_item = als.cnt_item
+        self.components = np.asfortranarray(self._V.cpu().numpy().T.astype(self._np_dtype()))
+        return lay_u.to_global(res).cpu().numpy().astype(self._np_dtype())
+
     def _transform(self, csc_users, n_new):
         return self._transform_dev(csc_users, n_new).cpu().numpy().astype(self._np_dtype())     # t(res), :444
 
+    def _my_rows(self, x_csr):
+        """multi-rank transform / predict: (first, one past the last) row of x this rank solves -- contiguous blocks
+        balanced by non-zeros; (0, n) on one rank"""
+        ws, me = self._dist()
+        if ws <= 1:
+            return 0, x_csr.shape[0], ws
+        from .engine import balanced_bounds
+        a, b = balanced_bounds(torch.from_numpy(np.diff(x_csr.indptr).astype(np.int64)), ws)[me]
+        return a, b, ws
+
+    def _share_rows(self, block, a, n_new, fill=0):
+        """every rank computed rows [a, a + len(block)) of an (n_new, ...) result: assemble the whole on every rank (one
+        all-reduce of a tensor that is `fill`-free outside the rank's own rows)"""
+        import torch.distributed as dist
+        full = torch.zeros((n_new,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        full[a:a + block.shape[0]] = block
+        if full.is_cuda and dist.get_backend(self._group) == "gloo":   # dry-run configuration (ranks sharing one GPU)
+            host = full.cpu()
+            dist.all_reduce(host, group=self._group)
+            full.copy_(host)
+        else:
+            dist.all_reduce(full, group=self._group)
+        return full
+
     def _transform_device(self, x_csr):
-        xt = sp.csc_matrix(x_csr.T, dtype=np.float64)
+        a, b, ws = self._my_rows(x_csr)
+        mine = x_csr[a:b] if ws > 1 else x_csr
+        xt = sp.csc_matrix(mine.T, dtype=np.float64)
         xt = self._preprocess(xt)
         if self.global_bias != 0.0 and self._feedback == "explicit":                          # :381-382
             xt = xt.copy()
@@ -196,7 +326,8 @@ class WRMF:
         xt.sort_indices()
         be = self._backend()
         csc = be.make_csc(xt.shape[0], xt.shape[1], *self._upload_csc(xt))
-        return self._transform_dev(csc, x_csr.shape[0])
+        res = self._transform_dev(csc, mine.shape[0])
+        return self._share_rows(res, a, x_csr.shape[0]) if ws > 1 else res
 
     def _transform_dev(self, csc_users, n_new):
         """R/model_WRMF.R:412-452: one user half-iteration from zeros against the final item factors,
@@ -236,25 +367,33 @@ class WRMF:
         if not_recommend is not None and not sp.issparse(not_recommend):
             raise TypeError("'not_recommend' should be NULL or 'sparseMatrix'")                     # R/utils.R:47
         be = self._backend()
-        emb = self._transform_device(x)
+        emb = self._transform_device(x)             # (n_new, rank), complete on every rank
+        # several ranks: every rank scores its own block of rows (the same blocks as transform), then the blocks are shared
+        a, b, ws = self._my_rows(x)
+        n_mine = b - a
         nr_p = nr_j = None
         if not_recommend is not None:
             nr = sp.csr_matrix(not_recommend)
             if nr.shape != (n_new, n_item):
                 raise ValueError("not_recommend must have the shape of x")                          # R/utils.R:55-56
+            nr = nr[a:b]
             nr.sort_indices()
             if nr.nnz:
                 nr_p = be.to_device(nr.indptr, torch.int32)
                 nr_j = be.to_device(nr.indices, torch.int32)
         d_ex = be.to_device(excl, torch.int32) if excl.size else None
-        res = torch.empty((n_new, k), dtype=torch.int32, device=emb.device)
-        sc = torch.empty((n_new, k), dtype=torch.float32, device=emb.device)
+        res = torch.empty((n_mine, k), dtype=torch.int32, device=emb.device)
+        sc = torch.empty((n_mine, k), dtype=torch.float32, device=emb.device)
         lib = be.lib
-        _lib.check(lib.rsparse_hip_top_product_device(
-            emb.data_ptr(), self._V.data_ptr(), n_new, n_item, self._rank, k,
-            None if nr_p is None else nr_p.data_ptr(), None if nr_j is None else nr_j.data_ptr(),
-            None if d_ex is None else d_ex.data_ptr(), int(excl.size), float(self.global_bias),
-            res.data_ptr(), sc.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)))
+        if n_mine > 0:
+            emb_mine = emb[a:b]
+            _lib.check(lib.rsparse_hip_top_product_device(
+                emb_mine.data_ptr(), self._V.data_ptr(), n_mine, n_item, self._rank, k,
+                None if nr_p is None else nr_p.data_ptr(), None if nr_j is None else nr_j.data_ptr(),
+                None if d_ex is None else d_ex.data_ptr(), int(excl.size), float(self.global_bias),
+                res.data_ptr(), sc.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)))
+        if ws > 1:
+            res, sc = self._share_rows(res, a, n_new), self._share_rows(sc, a, n_new)
         idx = res.cpu().numpy().astype(np.int64)
         idx = np.where(idx == -2147483648, -1, idx - 1)       # R is 1-based with NA_integer_
         out = idx.view(TopItems)

@@ -41,7 +41,7 @@ class OracleBackend:
             sumsq_out[0] = float((Ff.astype(np.float64) ** 2).sum())
 
     def half_iteration(self, csc, implicit, F, S_block, G, lambda_, solver, cg_steps, dynamic_lambda, loss_out,
-                       bias_last_row=None, absmax=None):
+                       bias_last_row=None, absmax=None, global_bias=0.0):
         # absmax = what the HIP backend passes on to the library as max |F|; here: checked against the truth (the
         # multi-rank tests thereby verify that every rank holds the GLOBAL maximum when it solves, and that it is current)
         if absmax is not None:
@@ -55,11 +55,11 @@ class OracleBackend:
             return
         if implicit:
             Gn = np.asfortranarray(G.numpy().T)
-            O.als_implicit(csc.p, csc.i, csc.x, X, Y, Gn, lambda_, solver, cg_steps)
+            O.als_implicit(csc.p, csc.i, csc.x, X, Y, Gn, lambda_, solver, cg_steps, global_bias=global_bias)
         else:
             cnt = np.zeros(X.shape[1], dtype=X.dtype)   # regulariser on X is added by the engine
             O.als_explicit(csc.p, csc.i, csc.x, X, Y, cnt, lambda_, solver, cg_steps, dynamic_lambda)
-        rows = _row_loss(csc, X, Y, implicit, lambda_, dynamic_lambda)
+        rows = _row_loss(csc, X, Y, implicit, lambda_, dynamic_lambda, 1.0 - global_bias if implicit else 1.0)
         S_block.copy_(torch.from_numpy(np.ascontiguousarray(Y.T)))
         loss_out[0] = rows
 
@@ -72,7 +72,7 @@ class OracleBackend:
         pass
 
 
-def _row_loss(csc, X, Y, implicit, lambda_, dynamic_lambda):
+def _row_loss(csc, X, Y, implicit, lambda_, dynamic_lambda, target=1.0):
     """un-normalised row part of the loss (wrmf_implicit.hpp:259-261 / wrmf_explicit.hpp:131-132), float64"""
     X = X.astype(np.float64)
     Y = Y.astype(np.float64)
@@ -80,12 +80,14 @@ def _row_loss(csc, X, Y, implicit, lambda_, dynamic_lambda):
     for c in range(csc.n_cols):
         p1, p2 = csc.p[c], csc.p[c + 1]
         if p1 == p2:
+            if implicit and target != 1.0:      # with a global bias empty columns are solved and regularised (:178, :257)
+                tot += lambda_ * float(Y[:, c] @ Y[:, c])
             continue
         t = Y[:, c] @ X[:, csc.i[p1:p2]]
         v = csc.x[p1:p2]
         yy = float(Y[:, c] @ Y[:, c])
         if implicit:
-            tot += float(((1.0 - t) ** 2) @ v) + lambda_ * yy
+            tot += float(((target - t) ** 2) @ v) + lambda_ * yy
         else:
             tot += float(((v - t) ** 2).sum()) + lambda_ * ((p2 - p1) if dynamic_lambda else 1.0) * yy
     return tot

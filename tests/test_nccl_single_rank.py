@@ -1,0 +1,75 @@
+"""RCCL's API contract, as far as ONE GPU allows: a one-rank `nccl` process group on the device, with ShardedALS told to issue
+its collectives anyway (force_collectives) -- the asynchronous IN-PLACE all_gather_into_tensor of a solved sub-block into the
+slab it is a slice of, the fused Gramian all-gather (k x k partial + sum(F^2) + max |F| as one buffer) and the fused loss
+all-reduce run on device tensors through RCCL -- and the result must equal the run that issues no collective at all.  (What
+this cannot show is more than one rank: the driver's N = 2, 4, 8 runs are the first time RCCL moves data between GPUs.)"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from rsparse_amd import synth
+    from rsparse_amd.engine import HipBackend, Layout, ShardedALS
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        be = HipBackend(0)
+        dev = be.device
+        n_user, n_item, k, lam = 6000, 700, 64, 0.1
+        d = synth.make_dataset(n_user, n_item, seed=3, mean_deg=40, d_max=1500, device=dev)
+        out = {}
+        for mode in ("plain", "rccl"):
+            coll = mode == "rccl"
+            lay_u = Layout(n_user, [(0, n_user)], 4 if coll else 1)
+            lay_i = Layout(n_item, [(0, n_item)], 4 if coll else 1)
+            als = ShardedALS(be, n_user, n_item, k, d["c_ui"], d["c_iu"], d["nnz"], feedback="implicit", lambda_=lam,
+                             cg_steps=3, group=None, world_size=1, my_rank=0, lay_user=lay_u, lay_item=lay_i,
+                             force_collectives=coll)
+            g = torch.Generator(device=dev).manual_seed(1)
+            U = lay_u.from_global(lay_u.alloc(k, dev), torch.randn(n_user, k, generator=g, device=dev) * 0.01)
+            V = lay_i.alloc(k, dev)
+            losses = []
+            for _ in range(2):
+                losses.append((als.half_iteration("items", U, V, 1), als.half_iteration("users", U, V, 1)))
+            # the exact solver through the same exchange (the sharded final solve of WRMF.fit_transform)
+            res = lay_u.alloc(k, dev)
+            als.half_iteration("users", res, V, 0, G=als.gramian(V, lay_i).clone(), want_loss=False)
+            be.check_numeric()
+            torch.cuda.synchronize()
+            out[mode] = {"U": lay_u.to_global(U).cpu(), "V": lay_i.to_global(V).cpu(), "res": lay_u.to_global(res).cpu(),
+                         "losses": losses}
+        # collectives with the other reduce op and dtype the drivers use (bench.py: MAX of the elapsed time)
+        t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        out["max"] = float(t.item())
+        torch.save(out, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_branches_on_a_one_rank_nccl_group(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_worker, args=(port, path), nprocs=1, join=True)
+    out = torch.load(path, weights_only=False)
+    a, b = out["plain"], out["rccl"]
+    # sub-blocked storage + collectives change nothing but the order of the Gramian / loss sums (k x k through doubles)
+    for key in ("U", "V", "res"):
+        err = float((a[key] - b[key]).norm() / a[key].norm())
+        assert err < 2e-5, (key, err)
+    for (x1, y1), (x2, y2) in zip(a["losses"], b["losses"]):
+        assert abs(x1 - x2) <= 1e-6 * abs(x1) and abs(y1 - y2) <= 1e-6 * abs(y1)
+    assert out["max"] == 3.5

@@ -1,0 +1,103 @@
+"""`WRMF.fit_transform / transform` under torch.distributed (north star: "users and items shard across the GPUs" behind the
+R6 API): world_size-2 gloo run through the WRMF class == the one-process oracle driver.  The numerics are the CPU stand-in
+backend (tests/oracle_backend.py) -- what is under test is the class's multi-rank control flow: nnz-balanced blocks cut on
+the host, broadcast initial factors, ShardedALS with sub-block-major storage, the sharded final exact solve, the row-sharded
+transform of new data and its all-reduce assembly."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import rel_fro
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _problem():
+    rng = np.random.default_rng(11)
+    n_user, n_item = 211, 67
+    lens = np.clip(rng.lognormal(1.5, 1.0, n_user).astype(int), 0, 50)
+    rows = np.repeat(np.arange(n_user), lens)
+    cols = np.concatenate([rng.choice(n_item, size=l, replace=False) for l in lens])
+    vals = 1.0 + rng.geometric(0.5, size=rows.size)
+    m = sp.csr_matrix((vals, (rows, cols)), shape=(n_user, n_item))
+    new = sp.csr_matrix((rng.random((23, n_item)) < 0.15) * 2.0)
+    return m, new
+
+
+def _fit(feedback, solver, with_global_bias, group_ready):
+    from oracle_backend import OracleBackend
+    from rsparse_amd import WRMF
+    m, new = _problem()
+    rng = np.random.default_rng(5)
+    k = 8
+    model = WRMF(rank=k, lambda_=0.1, feedback=feedback, solver=solver, with_global_bias=with_global_bias,
+                 precision="float", backend=OracleBackend(), rng=123 if group_ready else 123)
+    model._init_user_factors = (rng.standard_normal((m.shape[0], k)) * 0.01).astype(np.float32)
+    if solver != "conjugate_gradient":
+        model.components = (rng.standard_normal((k, m.shape[1])) * 0.01).astype(np.float32)
+    emb = model.fit_transform(m, n_iter=3, convergence_tol=-1)
+    return model, emb, model.transform(new)
+
+
+def _worker(rank, ws, port, feedback, solver, gb, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        model, emb, emb_new = _fit(feedback, solver, gb, True)
+        be = model._backend()
+        torch.save({"emb": emb, "new": emb_new, "components": model.components, "losses": model.losses,
+                    "global_bias": model.global_bias, "absmax_seen": getattr(be, "absmax_seen", 0)},
+                   os.path.join(out_dir, "r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("feedback,solver,gb", [("implicit", "conjugate_gradient", False), ("implicit", "cholesky", True),
+                                                ("implicit", "conjugate_gradient", True), ("explicit", "cholesky", True)])
+def test_wrmf_two_ranks_match_the_oracle_driver(tmp_path, feedback, solver, gb):
+    import torch.multiprocessing as mp
+    from oracle import wrmf_oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, feedback, solver, gb, str(tmp_path)), nprocs=2, join=True)
+    rs = [torch.load(tmp_path / ("r%d.pt" % r), weights_only=False) for r in range(2)]
+    for key in ("emb", "new", "components"):
+        assert np.array_equal(rs[0][key], rs[1][key]), key      # every rank returns / holds the same thing
+    assert rs[0]["losses"] == rs[1]["losses"]
+    if feedback == "implicit":
+        assert rs[0]["absmax_seen"] > 0                         # max |F| travelled with the fused Gramian collective
+    # one-process oracle driver, same initial factors, float arithmetic
+    m, new = _problem()
+    rng = np.random.default_rng(5)
+    k = 8
+    U0 = (rng.standard_normal((m.shape[0], k)) * 0.01).astype(np.float32)
+    V0 = None if solver == "conjugate_gradient" else (rng.standard_normal((k, m.shape[1])) * 0.01).astype(np.float32)
+    c = sp.csc_matrix(m); c.sort_indices()
+    ref = O.OracleWRMF(k, lam=0.1, feedback=feedback, solver=solver, dtype=np.float32, n_threads=4, with_global_bias=gb)
+    ref_emb = ref.fit_transform(m.shape[0], m.shape[1], c.indptr.astype(np.int32), c.indices.astype(np.int32),
+                                c.data.astype(np.float64), U0.T.copy(), n_iter=3, convergence_tol=-1, init_components=V0)
+    assert abs(rs[0]["global_bias"] - ref.global_bias) <= 1e-12 * max(1.0, abs(ref.global_bias))
+    assert rel_fro(rs[0]["components"], ref.components) < 5e-5
+    assert rel_fro(rs[0]["emb"], ref_emb) < 5e-5
+    assert np.allclose([l[1] for l in rs[0]["losses"]], [l[1] for l in ref.losses], rtol=5e-5)
+    nt = sp.csc_matrix(new.T); nt.sort_indices()
+    ref_new = ref.transform(nt.indptr.astype(np.int32), nt.indices.astype(np.int32), nt.data.astype(np.float64))
+    assert rs[0]["new"].shape == (new.shape[0], k) and rel_fro(rs[0]["new"], ref_new) < 5e-5
+
+
+def test_wrmf_sharded_rejects_user_item_biases(tmp_path):
+    """(the bias initialisation alternates over the whole matrix: single-rank only, stated in the error)"""
+    from rsparse_amd import WRMF, _lib
+    from oracle_backend import OracleBackend
+    m, _ = _problem()
+    model = WRMF(rank=4, feedback="explicit", solver="cholesky", with_user_item_bias=True, precision="float",
+                 backend=OracleBackend())
+    with pytest.raises(_lib.UnsupportedOnDevice):
+        model._fit_transform_sharded(m, 1, -1, 2, 0)

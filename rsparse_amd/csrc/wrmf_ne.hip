@@ -66,10 +66,16 @@ struct NeUnit { int kind, t, pair; };             // a pair of floats to split: 
 //   M1 = a' a'^T with a' = sqrt(c - 1) s1 x,   M2 = (s2 x)(s2 x)^T     (s1, s2: powers of two, see ne_scales),
 // split exactly into 2 fp16 terms (22 bits) with 3 products kept (2^-21 per product): half the matrix-core work of the
 // bf16 path and, in a PAIR, half the split arithmetic per wave -- role 0 = M1 (needs only a'), role 1 = M2 + b (only x).
-// QUAD (SYM at rank 128): all four waves of the workgroup consume the same steps, five tiles each -- roles 0, 1 the two
-// halves of M1, roles 2, 3 those of M2 (role 3 also b).  80 accumulator registers per wave and one ring instead of
-// two: the workgroup fits the CU twice, and the two resident workgroups overlap each other's matrix, vector, copy and
-// per-row solve phases -- inside ONE wave they add up (measured: MFMA + split + copy issue = the step time).
+// QUAD (SYM at rank 128): all four waves of the workgroup consume the same steps, five tiles each.  80 accumulator
+// registers per wave and one ring instead of two: the workgroup fits the CU twice, and the two resident workgroups
+// overlap each other's matrix, vector, copy and per-row solve phases -- inside ONE wave they add up (measured: MFMA +
+// split + copy issue = the step time).
+// M2 = X_nnz X_nnz^T feeds ONLY the loss term y^T M2 y = sum_j (x_j.y)^2 (the system matrix is XtX + M1), so in the SYM
+// path it is accumulated from the leading fp16 term alone (ONE product, 2^-11 per product, unbiased rounding: the row's
+// loss moves by ~1e-5 relative, far inside the 1e-4 the tests hold the loss to; factors are untouched) while M1 keeps
+// its three products (2^-21).  That is 40 instead of 60 MFMAs per step; the QUAD tiles are dealt so that every wave
+// still owns five tiles and 9..11 MFMAs: wave 0 = M1 tiles 0-2 + M2 tiles 0-1, wave 1 = M1 3-5 + M2 2-3, wave 2 = M1 6-7 +
+// M2 4-6 (and b, sum c: it reads every block of x anyway), wave 3 = M1 8-9 + M2 7-9.
 template <int KP, int NS, bool IMPLICIT, bool SYM = false, bool QUAD = false>
 struct NeRoles {
   static_assert(!SYM || (IMPLICIT && NS == 2), "SYM: implicit feedback, two fp16 terms");
@@ -79,13 +85,22 @@ struct NeRoles {
   static constexpr bool PAIR = IMPLICIT && KP == 128 && !QUAD;
   static constexpr int NROLES = QUAD ? 4 : (PAIR ? 2 : 1);   // waves that consume the same steps
   static constexpr int NSETS = 4 / NROLES;                   // ring groups
-  static constexpr int QH = 5;                               // QUAD: tiles 0..4 = half 0 (blocks 0..2), 5..9 = half 1
+  static constexpr int QH = 5;                               // QUAD: accumulator tiles per wave
+  static constexpr int M2P = SYM ? 1 : 3;                    // products kept for the loss-only matrix M2 (see above)
+  // QUAD: first M1 / M2 tile of wave w (tiles in the order of tile(R, C)); wave w owns [first(w), first(w + 1))
+  __host__ __device__ static constexpr int q_first(int m, int w) {
+    return m == 0 ? (w == 0 ? 0 : w == 1 ? 3 : w == 2 ? 6 : w == 3 ? 8 : 10) : (w == 0 ? 0 : w == 1 ? 2 : w == 2 ? 4 : w == 3 ? 7 : 10);
+  }
   // Accumulator slot of tile (R, C) of matrix m (0 = the matrix of the system: implicit M1, explicit M2; 1 = implicit M2,
   // loss only) for a wave of the given role, or -1 if that wave does not accumulate the tile
   __host__ __device__ static constexpr int tile(int R, int C) { return R * (R + 1) / 2 + C; }
   __host__ __device__ static constexpr int slot(int role, int m, int R, int C) {
     if (!IMPLICIT) return m == 0 ? tile(R, C) : -1;
-    if (QUAD) return (m == role / 2 && tile(R, C) / QH == role % 2) ? tile(R, C) % QH : -1;
+    if (QUAD) {
+      const int t = tile(R, C);
+      if (t < q_first(m, role) || t >= q_first(m, role + 1)) return -1;
+      return m == 0 ? t - q_first(0, role) : (q_first(0, role + 1) - q_first(0, role)) + t - q_first(1, role);
+    }
     if (!PAIR) return m * NT + tile(R, C);
     if (NS >= 3 && !SYM) {
       // role 0: M1 tile rows 2, 3 (slots 0..6, 42 products) + M2 tiles (0,0), (1,1) (slots 7, 8; 6 products)
@@ -100,7 +115,14 @@ struct NeRoles {
   }
   static constexpr int NSLOT = !IMPLICIT ? NT : (QUAD ? QH : (!PAIR ? 2 * NT : (NS >= 3 && !SYM ? 11 : 10)));
   __host__ __device__ static constexpr bool owns_row(int role, int R) { return IMPLICIT && slot(role, 0, R, 0) >= 0; }
-  __host__ __device__ static constexpr int rhs_role() { return QUAD ? 3 : (PAIR ? 1 : 0); }  // who accumulates b and sum c
+  __host__ __device__ static constexpr int rhs_role() { return QUAD ? 2 : (PAIR ? 1 : 0); }  // who accumulates b and sum c
+  // QUAD: does wave `role` need block t of the operand a' = sqrt(c - 1) s1 x (m = 0) / of s2 x (m = 1)?
+  __host__ __device__ static constexpr bool q_needs(int role, int m, int t) {
+    for (int R = 0; R < NB; R++)
+      for (int C = 0; C <= R; C++)
+        if (slot(role, m, R, C) >= 0 && (R == t || C == t)) return true;
+    return false;
+  }
 
   // The MFMAs of one step in issue order: product-major, so that two MFMAs on the same accumulator are a whole sweep over
   // the tiles apart.  M2 (implicit) takes the products of its first two terms, the system matrix those of total order < NS.
@@ -109,7 +131,7 @@ struct NeRoles {
     for (int R = 0; R < NB; R++)
       for (int C = 0; C <= R; C++) {
         if (slot(role, 0, R, C) >= 0) n += NS * (NS + 1) / 2;
-        if (IMPLICIT && slot(role, 1, R, C) >= 0) n += 3;
+        if (IMPLICIT && slot(role, 1, R, C) >= 0) n += M2P;
       }
     return n;
   }
@@ -125,8 +147,8 @@ struct NeRoles {
               n++;
             }
     if (IMPLICIT)
-      for (int pa = 0; pa < 2; pa++)
-        for (int pb = 0; pb + pa < 2; pb++)
+      for (int pa = 0; pa < (M2P == 1 ? 1 : 2); pa++)
+        for (int pb = 0; pb + pa < (M2P == 1 ? 1 : 2); pb++)
           for (int R = 0; R < NB; R++)
             for (int C = 0; C <= R; C++)
               if (slot(role, 1, R, C) >= 0) {
@@ -613,8 +635,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
     auto accumulate = [&](auto role_tag) {
       constexpr int ROLE = decltype(role_tag)::value;
       constexpr bool RHS = ROLE == RL::rhs_role();
-      // QUAD: the two M2 roles share b (role 2: its blocks 0..2 and sum c; role 3: block 3) -- role 3 splits one block more
-      constexpr bool ANYRHS = QUAD ? ROLE >= 2 : RHS, SCR = QUAD ? ROLE == 2 : RHS;
+      constexpr bool ANYRHS = RHS, SCR = RHS;
       constexpr int NMFMA = RL::mfma_count(ROLE), NU = RL::unit_count(ROLE), NHU = 2 * NU;
       constexpr int BARE = 4;   // MFMAs issued before the first split slice: they cover the latency of the ring reads
       using Parts = NeParts<NB, NS>;
@@ -789,7 +810,6 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
       // Split the step's operands, start the look-ahead copies, then the 15 MFMAs back to back.
       auto step_quad = [&](auto masked_tag, const int i) {
         constexpr bool masked = decltype(masked_tag)::value;
-        constexpr int NBLK = NU / 4, KIND = RL::unit(ROLE, 0).kind;
         const int rem = cnt - i * kStepNnz;
         const char* slot = ring + cslot * G_::SLOT_BYTES;
         cslot = cslot + 1 == D ? 0 : cslot + 1;
@@ -805,57 +825,63 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
           for (int e = 0; e < 8; e++) c[e] = (8 * h + e < rem) ? c[e] : 0.f;
         }
         const char* lbase = slot + h * (8 / NI) * (KP * 4) + d * 4;
-        float raw[NBLK][8];
+        // the blocks of the factor dimension this wave touches: as a' = s1 sqrt(c - 1) x (its M1 tiles), as s2 x (its M2
+        // tiles: leading fp16 term only) and, the right-hand-side wave, raw for b
+        float raw[NB][8];
+        static_for<NB>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          if constexpr (RL::q_needs(ROLE, 0, t) || RL::q_needs(ROLE, 1, t) || RHS) {
 #pragma unroll
-        for (int t = 0; t < NBLK; t++) {
+            for (int e = 0; e < 8; e++)
+              raw[t][e] = *reinterpret_cast<const float*>(lbase + (e % NI) * 1024 + (e / NI) * (KP * 4) + t * 128);
+            if constexpr (masked) {
 #pragma unroll
-          for (int e = 0; e < 8; e++)
-            raw[t][e] = *reinterpret_cast<const float*>(lbase + (e % NI) * 1024 + (e / NI) * (KP * 4) + t * 128);
-          if constexpr (masked) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) raw[t][e] = (32 * t + d < k && 8 * h + e < rem) ? raw[t][e] : 0.f;
+              for (int e = 0; e < 8; e++) raw[t][e] = (32 * t + d < k && 8 * h + e < rem) ? raw[t][e] : 0.f;
+            }
           }
-        }
+        });
         prepare(std::integral_constant<int, ROLE>{});
         static_for<G_::GROUP>([&](auto nc) { piece(std::integral_constant<int, ROLE>{}, nc); });
-        f32x2 mul[4];   // per pair: s1 sqrt(c - 1) (M1 roles) or s2 (M2 roles)
+        f32x2 mul[4];   // per pair: s1 sqrt(c - 1)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          if constexpr (KIND == 1)
-            mul[q] = f32x2{__builtin_amdgcn_sqrtf(__builtin_fabsf(fmaf(c[2 * q], scl.s1sq, -scl.s1sq))),
-                           __builtin_amdgcn_sqrtf(__builtin_fabsf(fmaf(c[2 * q + 1], scl.s1sq, -scl.s1sq)))};
-          else
-            mul[q] = f32x2{scl.s2, scl.s2};
-        }
-        u32x4 op[NBLK][2];
-#pragma unroll
-        for (int t = 0; t < NBLK; t++)
+        for (int q = 0; q < 4; q++)
+          mul[q] = f32x2{__builtin_amdgcn_sqrtf(__builtin_fabsf(fmaf(c[2 * q], scl.s1sq, -scl.s1sq))),
+                         __builtin_amdgcn_sqrtf(__builtin_fabsf(fmaf(c[2 * q + 1], scl.s1sq, -scl.s1sq)))};
+        const f32x2 s2v = {scl.s2, scl.s2};
+        u32x4 opa[NB][2], opx[NB];
+        static_for<NB>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            f32x2 r = {raw[t][2 * q], raw[t][2 * q + 1]};
-            if ((ROLE == 2 && t < 3) || (ROLE == 3 && t == 3)) bp[t] += f32x2{c[2 * q], c[2 * q + 1]} * r;
-            r = pk_mul(r, mul[q]);
-            op[t][0][q] = split_stage_h(r, false);
-            op[t][1][q] = split_stage_h(r, true);
+            const f32x2 r0 = {raw[t][2 * q], raw[t][2 * q + 1]};
+            if constexpr (RHS) bp[t] += f32x2{c[2 * q], c[2 * q + 1]} * r0;
+            if constexpr (RL::q_needs(ROLE, 0, t)) {
+              f32x2 r = pk_mul(r0, mul[q]);
+              opa[t][0][q] = split_stage_h(r, false);
+              opa[t][1][q] = split_stage_h(r, true);
+            }
+            if constexpr (RL::q_needs(ROLE, 1, t)) {
+              f32x2 r = pk_mul(r0, s2v);
+              opx[t][q] = split_stage_h(r, true);
+            }
           }
+        });
         static_for<NMFMA>([&](auto jc) {
           constexpr auto o = RL::mfma_op(ROLE, decltype(jc)::value);
-          acc[o.slot] = mfma_f16(op[o.R][o.pa], op[o.C][o.pb], acc[o.slot]);
+          if constexpr (o.m == 0) acc[o.slot] = mfma_f16(opa[o.R][o.pa], opa[o.C][o.pb], acc[o.slot]);
+          else acc[o.slot] = mfma_f16(opx[o.R], opx[o.C], acc[o.slot]);
         });
-        if constexpr (SCR) {
+        if constexpr (RHS) {
           float s = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; e++) s += c[e];
           sc += (double)s;
-        }
-        if constexpr (ANYRHS) {
           const float fm = (i & 63) == 63 ? 1.f : 0.f;
 #pragma unroll
-          for (int t = 0; t < NB; t++)
-            if ((ROLE == 2 && t < 3) || (ROLE == 3 && t == 3)) {
-              bp_hi[t] += f32x2{fm, fm} * bp[t];
-              bp[t] -= f32x2{fm, fm} * bp[t];
-            }
+          for (int t = 0; t < NB; t++) {
+            bp_hi[t] += f32x2{fm, fm} * bp[t];
+            bp[t] -= f32x2{fm, fm} * bp[t];
+          }
         }
         NE_T(3)
       };
@@ -911,40 +937,35 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
     // together (plain loads: hipcc drains the queue for them, look-ahead copies included), then G + M1 straight into the tile
     auto chain_add_quad = [&](auto role_tag) {
       constexpr int ROLE = decltype(role_tag)::value;
-      if constexpr (ROLE < 2) {
-        int h4 = 4 * h;
-        asm volatile("" : "+v"(h4));   // keeps the 80 offsets out of the row loop's preheader (they would be spilled)
-        // in two batches (3 + 2 tiles): 48 loads in flight next to the 80 accumulator registers
-        static_for<2>([&](auto bc) {
-          constexpr int T0 = decltype(bc)::value * 3, TN = decltype(bc)::value == 0 ? 3 : RL::QH - 3;
-          float g[TN][16];
-          static_for<TN>([&](auto tc) {
-            constexpr int T = RL::QH * ROLE + T0 + decltype(tc)::value;
-            constexpr int R = T >= 6 ? 3 : (T >= 3 ? 2 : (T >= 1 ? 1 : 0)), C = T - R * (R + 1) / 2;
-            const int gj = min(32 * C + d, k - 1);
+      constexpr int T0 = RL::q_first(0, ROLE), TN = RL::q_first(0, ROLE + 1) - T0;   // this wave's M1 tiles (2 or 3)
+      int h4 = 4 * h;
+      asm volatile("" : "+v"(h4));   // keeps the offsets out of the row loop's preheader (they would be spilled)
+      float g[TN][16];
+      static_for<TN>([&](auto tc) {
+        constexpr int T = T0 + decltype(tc)::value;
+        constexpr int R = T >= 6 ? 3 : (T >= 3 ? 2 : (T >= 1 ? 1 : 0)), C = T - R * (R + 1) / 2;
+        const int gj = min(32 * C + d, k - 1);
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-              const int gi = min(32 * R + 8 * (e >> 2) + (e & 3) + h4, k - 1);
-              g[decltype(tc)::value][e] = a.XtX[(unsigned)(gi * k + gj)];
-            }
-          });
-          static_for<TN>([&](auto tc) {
-            constexpr int TL = T0 + decltype(tc)::value, T = RL::QH * ROLE + TL;
-            constexpr int R = T >= 6 ? 3 : (T >= 3 ? 2 : (T >= 1 ? 1 : 0)), C = T - R * (R + 1) / 2;
-            int toff = T * 32 * TLD + 4 * h * TLD + d;
-            asm volatile("" : "+v"(toff));
-            float* ta = sA + toff;
-            const float cm = (32 * C + d < k) ? 1.f : 0.f;   // rank < 128: the padding of the tile is zero, not a clamped copy
-            const f32x16 v = acc[TL] * scl.inv1;
+        for (int e = 0; e < 16; e++) {
+          const int gi = min(32 * R + 8 * (e >> 2) + (e & 3) + h4, k - 1);
+          g[decltype(tc)::value][e] = a.XtX[(unsigned)(gi * k + gj)];
+        }
+      });
+      static_for<TN>([&](auto tc) {
+        constexpr int TL = decltype(tc)::value, T = T0 + TL;
+        constexpr int R = T >= 6 ? 3 : (T >= 3 ? 2 : (T >= 1 ? 1 : 0)), C = T - R * (R + 1) / 2;
+        int toff = T * 32 * TLD + 4 * h * TLD + d;
+        asm volatile("" : "+v"(toff));
+        float* ta = sA + toff;
+        const float cm = (32 * C + d < k) ? 1.f : 0.f;   // rank < 128: the padding of the tile is zero, not a clamped copy
+        const f32x16 v = acc[TL] * scl.inv1;             // (slot of M1 tile T0 + TL = TL)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-              const float rm = (32 * R + 8 * (e >> 2) + (e & 3) + h4 < k) ? cm : 0.f;
-              ta[(8 * (e >> 2) + (e & 3)) * TLD] = fmaf(g[decltype(tc)::value][e], rm, v[e]);
-            }
-          });
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
+        for (int e = 0; e < 16; e++) {
+          const float rm = (32 * R + 8 * (e >> 2) + (e & 3) + h4 < k) ? cm : 0.f;
+          ta[(8 * (e >> 2) + (e & 3)) * TLD] = fmaf(g[TL][e], rm, v[e]);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
     };
     auto chain_add = [&](auto role_tag, const int ph) {
       constexpr int ROLE = decltype(role_tag)::value;

@@ -7,13 +7,17 @@
 // stays), emit them best first -- equal scores come out with the larger index first, because the heap pops
 // (score, index) pairs in ascending pair order and the output is filled from the end (:88-95).
 //
-// One 256-thread workgroup per block of 32 users.  The user block is the MFMA A operand and stays in
-// registers (k/2 VGPRs); each of the 4 waves walks its own 32-item tiles: the tile is loaded with coalesced
-// 16-byte reads, staged in LDS with an odd row stride, read back as B fragments, and multiplied with
-// v_mfma_f32_32x32x2_f32 (exact fp32).  A score survives only if it beats the user's current k-th best
-// (threshold in LDS); survivors that pass the exclusion checks (binary searches) are appended to the user's
-// LDS buffer; once per round of 4 tiles, buffers holding more than k entries are reduced to their top k by
-// rank counting and the threshold is raised.  After the first few tiles almost nothing survives.
+// One 256-thread workgroup per block of 32 * UB users (UB = 2 when the candidate buffers fit LDS, i.e. k <= 16).  The
+// user blocks are the MFMA A operands and stay in registers (UB * k/2 VGPRs); each of the 4 waves walks its own 32-item
+// tiles: while the matrix cores work on tile n, the 16-byte coalesced loads of tile n + 1 are in flight into registers
+// (one wave per SIMD: nothing else would hide them), then the tile goes to LDS (row stride k + 4: aligned 16-byte
+// stores; the 4-way bank conflict of the fragment reads is invisible next to a 64-cycle MFMA), is read back as B
+// fragments -- each fragment feeds UB MFMAs -- and multiplied with v_mfma_f32_32x32x2_f32 (exact fp32).  A score survives
+// only if it beats the user's current k-th best (threshold in LDS); survivors that pass the exclusion checks (binary
+// searches) are appended to the user's LDS buffer; once per round of 4 tiles, buffers holding more than k entries are
+// reduced to their top k by rank counting and the threshold is raised.  After the first few tiles almost nothing
+// survives.  (Round 3: the staging loop used to be 4-byte loads with a run-time division per element and no load in
+// flight during the MFMAs -- 8.6 TFLOP/s at 1M x 1M, rank 128; see profiles/r03.)
 #include "wrmf_internal.h"
 #include "wrmf_device.h"
 
@@ -24,17 +28,21 @@ using namespace dev;
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-constexpr int kTopUsers = 32;    // users per workgroup
-constexpr int kTopCap = 256;     // candidate buffer per user (k <= kTopCap - 128)
+constexpr int kTopBlock = 32;    // users per MFMA block
+constexpr int kTopMaxK = 128;    // RSPARSE_HIP_MAX_TOPK
 constexpr int kTopWaves = 4;
+// candidate buffer per user: the heap (k entries) + everything one round of 4 tiles can add (4 x 32 items)
+__host__ __device__ constexpr int top_cap(int topk) { return ((topk + 128 + 15) / 16) * 16; }
 
-template <int KP>
+template <int KP, int UB>
 struct TopSmem {
-  static constexpr int LDT = KP + 1;  // odd stride: conflict-free column reads (ds_read_b32)
+  static constexpr int LDT = KP + 4;  // rows 16-byte aligned (ds_write_b128); fragment reads: 4-way conflict, hidden
+  static constexpr int USERS = kTopBlock * UB;
   static constexpr size_t tile_floats = (size_t)kTopWaves * 32 * LDT;
-  static constexpr size_t buf_floats = (size_t)kTopUsers * kTopCap;           // values
-  static constexpr size_t bytes = (tile_floats + 2 * buf_floats + 8 * kTopUsers) * 4 + 64 +
-                                  (size_t)kTopWaves * kTopCap * 8;            // compaction scratch
+  static size_t bytes(int topk) {
+    const size_t cap = (size_t)top_cap(topk);
+    return (tile_floats + 2 * (size_t)USERS * cap + 8 * USERS) * 4 + 64 + (size_t)kTopWaves * cap * 8;   // + compaction scratch
+  }
 };
 
 // is `item` in the sorted list a[0..n) ?
@@ -54,7 +62,7 @@ __device__ __forceinline__ bool sel_before(float va, int ia, float vb, int ib) {
   return va > vb || (va == vb && ia < ib);
 }
 
-template <int KP>
+template <int KP, int UB, bool VEC>
 __global__ __launch_bounds__(256) void top_product_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                           int n_users, int n_items, int k_rank, int topk,
                                                           const int32_t* __restrict__ nr_ptr,
@@ -62,15 +70,16 @@ __global__ __launch_bounds__(256) void top_product_kernel(const float* __restric
                                                           const int32_t* __restrict__ excl, int n_excl,
                                                           float glob_mean, int32_t* __restrict__ res,
                                                           float* __restrict__ scores_out) {
-  using SM = TopSmem<KP>;
-  constexpr int LDT = SM::LDT, NK2 = KP / 2;
+  using SM = TopSmem<KP, UB>;
+  constexpr int LDT = SM::LDT, NK2 = KP / 2, kTopUsers = SM::USERS;
+  const int kTopCap = top_cap(topk);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sTile = reinterpret_cast<float*>(smem);
-  float* sVal = sTile + SM::tile_floats;                            // [32][CAP]
-  int* sIdx = reinterpret_cast<int*>(sVal + SM::buf_floats);        // [32][CAP]
-  int* sCnt = sIdx + SM::buf_floats;                                // [32]
-  float* sThr = reinterpret_cast<float*>(sCnt + kTopUsers);         // [32]
-  int* sNeed = reinterpret_cast<int*>(sThr + kTopUsers);            // [32] spare / flags
+  float* sVal = sTile + SM::tile_floats;                            // [USERS][CAP]
+  int* sIdx = reinterpret_cast<int*>(sVal + (size_t)kTopUsers * kTopCap);   // [USERS][CAP]
+  int* sCnt = sIdx + (size_t)kTopUsers * kTopCap;                   // [USERS]
+  float* sThr = reinterpret_cast<float*>(sCnt + kTopUsers);         // [USERS]
+  int* sNeed = reinterpret_cast<int*>(sThr + kTopUsers);            // [USERS] spare / flags
   float* sTmpV = reinterpret_cast<float*>(sNeed + 2 * kTopUsers + 4);  // [4][CAP]
   int* sTmpI = reinterpret_cast<int*>(sTmpV + kTopWaves * kTopCap);    // [4][CAP]
 
@@ -82,14 +91,15 @@ __global__ __launch_bounds__(256) void top_product_kernel(const float* __restric
     sThr[tid] = -INFINITY;
     sNeed[tid] = 0;   // entries [0, sNeed) of the user's buffer are the heap as the last reduction left it
   }
-  // A operand: lane holds U[u0 + (lane & 31)][2t + half], t = 0..KP/2-1 (zero beyond the matrix)
-  float afrag[NK2];
-  {
-    const int u = u0 + col;
+  // A operands: lane holds U[u0 + 32 ub + (lane & 31)][2t + half], t = 0..KP/2-1 (zero beyond the matrix)
+  float afrag[UB][NK2];
+#pragma unroll
+  for (int ub = 0; ub < UB; ub++) {
+    const int u = u0 + 32 * ub + col;
 #pragma unroll
     for (int t = 0; t < NK2; t++) {
       const int kk = 2 * t + half;
-      afrag[t] = (u < n_users && kk < k_rank) ? U[(size_t)u * k_rank + kk] : 0.f;
+      afrag[ub][t] = (u < n_users && kk < k_rank) ? U[(size_t)u * k_rank + kk] : 0.f;
     }
   }
   float* tile = sTile + wv * 32 * LDT;
@@ -98,49 +108,83 @@ __global__ __launch_bounds__(256) void top_product_kernel(const float* __restric
 
   const int n_tiles = (n_items + 31) / 32;
   const int rounds = (n_tiles + kTopWaves - 1) / kTopWaves;
+  // item tile tl -> registers: VEC = rank a multiple of 4 and V 16-byte aligned: NLD 16-byte loads per lane, all in
+  // flight together (piece e4 = j * 64 + lane: item e4 / (KP / 4), floats 4 (e4 % (KP / 4)) ..+3)
+  constexpr int NLD = KP / 8;
+  float4 pf[VEC ? NLD : 1];
+  auto load_tile = [&](const int tl) {
+    if constexpr (VEC) {
+      const int i0 = tl * 32;
+#pragma unroll
+      for (int j = 0; j < NLD; j++) {
+        const int e4 = j * 64 + lane, it = e4 / (KP / 4), c4 = e4 % (KP / 4);
+        pf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tl < n_tiles && i0 + it < n_items && 4 * c4 < k_rank)
+          pf[j] = *reinterpret_cast<const float4*>(V + (size_t)(i0 + it) * k_rank + 4 * c4);
+      }
+    }
+  };
+  auto store_tile = [&](const int tl) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < NLD; j++) {
+        const int e4 = j * 64 + lane, it = e4 / (KP / 4), c4 = e4 % (KP / 4);
+        *reinterpret_cast<float4*>(tile + it * LDT + 4 * c4) = pf[j];
+      }
+    } else {   // any rank / alignment: scalar staging (slow path)
+      const int i0 = tl * 32;
+      for (int it = 0; it < 32; it++)
+        for (int kk = lane; kk < k_rank; kk += 64)
+          tile[it * LDT + kk] = (tl < n_tiles && i0 + it < n_items) ? V[(size_t)(i0 + it) * k_rank + kk] : 0.f;
+    }
+  };
+  load_tile(wv);
+  store_tile(wv);
+  wave_sync();
   for (int rd = 0; rd < rounds; rd++) {
     const int tl = rd * kTopWaves + wv;
+    load_tile(tl + kTopWaves);   // the next tile's loads fly during this tile's MFMAs
     if (tl < n_tiles) {
       const int i0 = tl * 32;
-      // stage the item tile: coalesced reads of 32 consecutive item vectors
-      for (int e = lane; e < 32 * k_rank; e += 64) {
-        const int it = e / k_rank, kk = e - it * k_rank;
-        tile[it * LDT + kk] = (i0 + it < n_items) ? V[(size_t)(i0 + it) * k_rank + kk] : 0.f;
-      }
-      wave_sync();
-      f32x16_t acc;
+      f32x16_t acc[UB];
 #pragma unroll
-      for (int e = 0; e < 16; e++) acc[e] = 0.f;
+      for (int ub = 0; ub < UB; ub++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[ub][e] = 0.f;
 #pragma unroll
       for (int t = 0; t < NK2; t++) {
         const float b = tile[col * LDT + 2 * t + half];  // B[kk = 2t + half][item = col]
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[t], b, acc, 0, 0, 0);
+#pragma unroll
+        for (int ub = 0; ub < UB; ub++) acc[ub] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[ub][t], b, acc[ub], 0, 0, 0);
       }
-      wave_sync();
-      // lane holds item `col` for users row(e) = (e & 3) + 8 (e >> 2) + 4 half
+      // lane holds item `col` for users row(e) = (e & 3) + 8 (e >> 2) + 4 half of each block
       const int item = i0 + col;
       const bool item_ok = item < n_items && !(n_excl > 0 && sorted_contains(excl, n_excl, item));
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int ul = (e & 3) + 8 * (e >> 2) + 4 * half;
-        const int u = u0 + ul;
-        const float s = acc[e];
-        if (item_ok && u < n_users && s > sThr[ul]) {
-          bool skip = false;
-          if (nr_ptr) {
-            const int p1 = nr_ptr[u], p2 = nr_ptr[u + 1];
-            skip = sorted_contains(nr_idx + p1, p2 - p1, item);
-          }
-          if (!skip) {
-            const int pos = atomicAdd(&sCnt[ul], 1);
-            if (pos < kTopCap) {
-              sVal[ul * kTopCap + pos] = s;
-              sIdx[ul * kTopCap + pos] = item;
+      for (int ub = 0; ub < UB; ub++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int ul = 32 * ub + (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int u = u0 + ul;
+          const float s = acc[ub][e];
+          if (item_ok && u < n_users && s > sThr[ul]) {
+            bool skip = false;
+            if (nr_ptr) {
+              const int p1 = nr_ptr[u], p2 = nr_ptr[u + 1];
+              skip = sorted_contains(nr_idx + p1, p2 - p1, item);
+            }
+            if (!skip) {
+              const int pos = atomicAdd(&sCnt[ul], 1);
+              if (pos < kTopCap) {
+                sVal[ul * kTopCap + pos] = s;
+                sIdx[ul * kTopCap + pos] = item;
+              }
             }
           }
         }
-      }
     }
+    wave_sync();                 // this wave has read its tile for the last time
+    store_tile(tl + kTopWaves);
     __syncthreads();
     // reduce over-full buffers to their top k (one wave per user, rank counting), raise the threshold
     for (int ul = wv; ul < kTopUsers; ul += kTopWaves) {
@@ -271,35 +315,38 @@ __global__ __launch_bounds__(256) void top_product_kernel(const float* __restric
 
 }  // namespace
 
-size_t top_product_lds_bytes(int k_rank) {
-  const int KP = padded_rank(k_rank);
-  if (KP == 32) return TopSmem<32>::bytes;
-  if (KP == 64) return TopSmem<64>::bytes;
-  return TopSmem<128>::bytes;
-}
-
 hipError_t launch_top_product(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
                               const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
                               float glob_mean, int32_t* res, float* scores, hipStream_t s) {
   const int KP = padded_rank(k_rank);
-  if (!KP || topk < 1 || topk > kTopCap - 128) return hipErrorInvalidValue;
+  if (!KP || topk < 1 || topk > kTopMaxK) return hipErrorInvalidValue;
   if (n_users <= 0) return hipSuccess;
-  const int grid = (n_users + kTopUsers - 1) / kTopUsers;
+  const bool vec = k_rank % 4 == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0;
   hipError_t err;
+#define RSP_TOPK_L(KPV, UBV, VECV)                                                                           \
+  {                                                                                                          \
+    auto kern = top_product_kernel<KPV, UBV, VECV>;                                                          \
+    const size_t lds = TopSmem<KPV, UBV>::bytes(topk);                                                       \
+    if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)lds)) != hipSuccess)                                                 \
+      return err;                                                                                            \
+    const int users = 32 * UBV, grid = (n_users + users - 1) / users;                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, U, V, n_users, n_items, k_rank, topk, nr_ptr, nr_idx, \
+                       excl, n_excl, glob_mean, res, scores);                                                \
+    return hipGetLastError();                                                                                \
+  }
+  // two user blocks per workgroup halve the passes over V; they need 64 candidate buffers in LDS next to the tiles
 #define RSP_TOPK(KPV)                                                                                        \
   if (KP == KPV) {                                                                                           \
-    auto kern = top_product_kernel<KPV>;                                                                     \
-    if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                   (int)TopSmem<KPV>::bytes)) != hipSuccess)                                 \
-      return err;                                                                                            \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), TopSmem<KPV>::bytes, s, U, V, n_users, n_items, k_rank, topk, \
-                       nr_ptr, nr_idx, excl, n_excl, glob_mean, res, scores);                                \
-    return hipGetLastError();                                                                                \
+    const bool two = TopSmem<KPV, 2>::bytes(topk) <= 156 * 1024 && n_users > 32;                             \
+    if (two) { if (vec) RSP_TOPK_L(KPV, 2, true) else RSP_TOPK_L(KPV, 2, false) }                            \
+    if (vec) RSP_TOPK_L(KPV, 1, true) else RSP_TOPK_L(KPV, 1, false)                                         \
   }
   RSP_TOPK(32)
   RSP_TOPK(64)
   RSP_TOPK(128)
 #undef RSP_TOPK
+#undef RSP_TOPK_L
   return hipErrorInvalidValue;
 }
 

@@ -35,12 +35,19 @@ def build(force=False, verbose=False, defines=(), out=None):
     objdir.mkdir(parents=True, exist_ok=True)
     src = [s for s in SRC if s.exists()]
     hdr_m = max(h.stat().st_mtime for h in HEADERS)
-    todo = []
+    todo, objs = [], []
+    names = [d.split("=")[0] for d in defines]
+    hdr_text = "".join(h.read_text() for h in HEADERS if h.suffix == ".h")
     for s in src:
         o = objdir / (s.stem + ".o")
+        if defines and not any(n in s.read_text() or n in hdr_text for n in names):
+            rel = OUT.parent / "obj" / "release" / (s.stem + ".o")   # a dev define this source never mentions: the release object
+            if rel.exists() and rel.stat().st_mtime >= max(s.stat().st_mtime, hdr_m):
+                objs.append(rel)
+                continue
+        objs.append(o)
         if force or not o.exists() or o.stat().st_mtime < max(s.stat().st_mtime, hdr_m):
             todo.append((s, o))
-    objs = [objdir / (s.stem + ".o") for s in src]
     if not todo and out.exists() and all(out.stat().st_mtime >= o.stat().st_mtime for o in objs):
         return out
 

@@ -582,7 +582,8 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     // low-rank form for the short rows; "some confidence < 1" comes from the values scan of launch_ne_stats (word 2)
     if ((rc = g_ws.ensure_lr())) return rc;
     if (!a.ne_stats) {   // (with the long rows on the normal-equation kernel the full statistics were just taken)
-      hipError_t se = launch_ne_stats(nullptr, 0, d.vals, d.nnz, g_ws.ne_stats, s, nullptr);
+      // max |X| too: the low-rank kernel scales its fp16 operand terms by it
+      hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax);
       if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
     }
     a.lr_rows = d.q_order + d.q_lr_first; a.n_lr = d.q_n_lr; a.lr_flags = g_ws.ne_stats + 2; a.lr_M = g_ws.lr_M;
@@ -1064,6 +1065,12 @@ int rsparse_hip_profile_last_names(char* buf, int cap) {
     if (!mangled) continue;
     int st = 0;
     char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+    if (st != 0 || !dem) {   // this libstdc++ does not know _Float16 ("DF16_"): demangle it as half ("Dh")
+      std::string alt(mangled);
+      for (size_t p2; (p2 = alt.find("DF16_")) != std::string::npos;) alt.replace(p2, 5, "Dh");
+      std::free(dem);
+      dem = abi::__cxa_demangle(alt.c_str(), nullptr, nullptr, &st);
+    }
     out += (st == 0 && dem) ? dem : mangled;
     std::free(dem);
   }

@@ -9,8 +9,11 @@
 //     lhs = L (I_k + W^T W) L^T,   W = D^1/2 V',  V' = X_nnz M  (n x k),  D = diag(c - 1)
 //     (I_k + W^T W)^-1 = I_k - W^T S^-1 W,        S = I_n + W W^T  (n x n, eigenvalues >= 1)
 //     y = M (g - W^T S^-1 W g),                   g = M^T rhs = V'^T c
-// so the per-row work is two small GEMMs on the matrix cores (V' = X_nnz M and V' V'^T, exact fp32 MFMA), an n x n
-// LDL^T instead of a k x k Cholesky, and a handful of matrix-vector products.  The loss needs no second gather:
+// so the per-row work is two small GEMMs on the matrix cores, an n x n LDL^T instead of a k x k Cholesky, and a handful of
+// matrix-vector products.  The GEMMs (V' = X_nnz M and W W^T) run as fp16-term products like the long-row kernel's
+// (wrmf_ne.hip): every fp32 operand is split exactly into two fp16 terms of a power-of-two multiple of itself and the three
+// products of order < 2 are accumulated in fp32 by v_mfma_f32_32x32x16_f16 -- 2^-21 per product, 5x the rate of the fp32
+// matrix instruction (round 3: V' 73 -> and S 56 -> ms of the user half of config 4; the fp32 version is the git history).  The loss needs no second gather:
 // x_j . y = v_j . q with q = g - W^T S^-1 W g.  Any exact method satisfies the reference's `solve`; the parity bound
 // (1e-4 against the fp64 oracle) is the same as for wrmf_chol.hip and is checked by the same tests.
 //
@@ -27,17 +30,39 @@ namespace {
 using namespace dev;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// x (already scaled) -> fl16(x), fl16(x - fl16(x)) for a pair; the residual is exact in fp32
+__device__ __forceinline__ void lr_split(const float x0, const float x1, unsigned& hi, unsigned& lo) {
+  const f32x2 v = {x0, x1};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// biased exponent e (1..253) of the power of two that brings `vmax` into [2^13, 2^14); 2^(e - 127) is the scale
+__device__ __forceinline__ int lr_scale_exp(float vmax) {
+  const int eb = (int)((__float_as_uint(vmax) >> 23) & 0xffu);
+  return min(253, max(1, 267 - eb));
+}
+__device__ __forceinline__ float lr_pow2(int biased) { return __uint_as_float((unsigned)biased << 23); }
 
 #ifndef RSP_LR_ABL
 #define RSP_LR_ABL 0   // dev builds: timing-only ablations (1 no V' GEMM, 2 no S GEMM, 4 no LDL^T, 8 no substitution, 16 no y = M q, 32 no gather)
 #endif
-constexpr int kLrLd = 130;   // LDS row stride of the n x k operands: conflict-free for the MFMA operand reads (2 i + c)
+constexpr int kLrLd = 130;   // LDS row stride (floats) of V' (fp32)
+constexpr int kLrLh = 136;   // ... (halves) of the fp16 terms of X_nnz and of W: 16-byte aligned rows for the operand reads
 constexpr int kLrLs = 65;    // ... of the n x n system
 
 // ---- XtX = L L^T, M = L^-T, Mt = M^T = L^-1: one workgroup, once per half-iteration ----------------------------------
 // M and Mt are written KP x KP, zero padded.  flags[0] |= 1 when XtX is not positive definite.
+// Also written: the two fp16 terms of Mt * 2^e (the B operand of V' = X_nnz M: M[kk][col] = Mt[col][kk], 8 consecutive kk
+// per lane) into M16 = [2][KP][KP] halves, and e (biased exponent) into flags[1].
 template <int KP>
-__global__ __launch_bounds__(256) void chol_lr_prep_kernel(const float* __restrict__ G, int k, float* __restrict__ M,
+__global__ __launch_bounds__(256) void chol_lr_prep_kernel(const float* __restrict__ G, int k, _Float16* __restrict__ M16,
                                                            float* __restrict__ Mt, unsigned* __restrict__ flags) {
   constexpr int LD = KP + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -84,11 +109,29 @@ __global__ __launch_bounds__(256) void chol_lr_prep_kernel(const float* __restri
     }
   }
   __syncthreads();
+  float mx = 0.f;
+  for (int e = tid; e < KP * KP; e += 256) {
+    const int r = e / KP, c = e % KP;
+    if (r < k && c <= r) mx = fmaxf(mx, fabsf(sZ[r * LD + c]));
+  }
+  __shared__ float smx[256];
+  smx[tid] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) smx[tid] = fmaxf(smx[tid], smx[tid + o]);
+    __syncthreads();
+  }
+  const int eM = lr_scale_exp(fmaxf(smx[0], 1e-30f));
+  const float sM = lr_pow2(eM);
+  if (tid == 0) flags[1] = (unsigned)eM;
   for (int e = tid; e < KP * KP; e += 256) {
     const int r = e / KP, c = e % KP;
     const bool in = r < k && c < k;
-    Mt[e] = (in && c <= r) ? sZ[r * LD + c] : 0.f;   // Mt = L^-1 (lower)
-    M[e] = (in && r <= c) ? sZ[c * LD + r] : 0.f;    // M = L^-T (upper)
+    const float v = (in && c <= r) ? sZ[r * LD + c] : 0.f;   // Mt = L^-1 (lower)
+    Mt[e] = v;
+    const _Float16 h = (_Float16)(v * sM);
+    M16[e] = h;
+    M16[KP * KP + e] = (_Float16)(v * sM - (float)h);
   }
 }
 
@@ -96,7 +139,7 @@ __global__ __launch_bounds__(256) void chol_lr_prep_kernel(const float* __restri
 template <int KP>
 struct LrSmem {
   static constexpr int NP = 64;
-  static constexpr size_t x_floats = (size_t)NP * kLrLd;   // X_nnz, later S (NP x kLrLs fits)
+  static constexpr size_t x_floats = (size_t)NP * kLrLh;   // fp16 terms of X_nnz ([2][NP][kLrLh] halves), then of W, then S (NP x kLrLs floats)
   static constexpr size_t v_floats = (size_t)NP * kLrLd;   // V'
   static constexpr size_t vec_floats = 4 * NP + 4 * KP + 64;
   static constexpr size_t bytes = (x_floats + v_floats + vec_floats) * 4 + 64;
@@ -104,14 +147,16 @@ struct LrSmem {
 
 template <int KP>
 __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
-                                                             const float* __restrict__ M, const float* __restrict__ Mt,
+                                                             const _Float16* __restrict__ M16, const float* __restrict__ Mt,
                                                              const unsigned* __restrict__ flags, int loss_slot0) {
   using SM = LrSmem<KP>;
-  constexpr int NP = SM::NP, LD = kLrLd, LS = kLrLs, NKS = KP / 2;
+  constexpr int NP = SM::NP, LD = kLrLd, LS = kLrLs, LH = kLrLh;
   static_assert(KP == 128, "written for rank 97..128");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sX = reinterpret_cast<float*>(smem);
   float* sS = sX;                        // alias: X_nnz is dead once V' exists
+  _Float16* sXh = reinterpret_cast<_Float16*>(sX);   // [NP][LH] leading fp16 terms of X_nnz * 2^ex, later of W * 2^ew
+  _Float16* sXl = sXh + NP * LH;                     // [NP][LH] second terms
   float* sV = sX + SM::x_floats;
   float* sC = sV + SM::v_floats;         // [NP] confidences
   float* sQ = sC + NP;                   // [NP] sqrt(c - 1)
@@ -126,6 +171,10 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
   const int col = lane & 31, half = lane >> 5;
   const int k = a.k;
   if (flags[0] != 0) return;   // some confidence < 1 or XtX not positive definite: wrmf_chol.hip takes these rows
+  // operand scales: max |X| from the statistics block in front of the flags (launch_ne_stats: flags = stats + 2), the
+  // exponent of Mt from the prep kernel
+  const int ex = lr_scale_exp(fmaxf(__uint_as_float(flags[-2]), 1e-30f)), eM = (int)flags[1];
+  const float sx = lr_pow2(ex), inv_xm = lr_pow2(254 - ex) * lr_pow2(254 - eM);   // 2^-(ex - 127) * 2^-(eM - 127)
 
   // B operand of V' = X_nnz M for this wave's column block: M[kk][32 wv + col], kk = 2 t + half; M is upper
   // triangular: nothing below row 32 (wv + 1).  Re-read from L2 for every row: keeping the 64 registers for the whole launch
@@ -155,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
     id_c = a.row_idx[p1_c + lane];
     c_c = a.vals[p1_c + lane];
   }
-  for (; it < n_rows; it += G) {
+  for (int rot = 0; it < n_rows; it += G, rot++) {
     const int row = rfl(row_c);
     const int p1 = rfl(p1_c), n = rfl(n_c);   // 1 <= n <= 64 (launcher)
     const int nrt = n <= 32 ? 1 : 2;   // 32-row tiles
@@ -198,51 +247,78 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
         sC[lane] = lane < n ? c : 0.f;
         sQ[lane] = lane < n ? sqrtf(fmaxf(c - 1.f, 0.f)) : 0.f;
       }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
+      auto put = [&](const int u) {
         const int j = wv + 4 * u;
-        *reinterpret_cast<float2*>(sX + j * LD + 2 * lane) = j < n ? v[u] : float2{0.f, 0.f};
-      }
+        unsigned hi = 0u, lo = 0u;
+        if (j < n) lr_split(v[u].x * sx, v[u].y * sx, hi, lo);
+        *reinterpret_cast<unsigned*>(sXh + j * LH + 2 * lane) = hi;
+        *reinterpret_cast<unsigned*>(sXl + j * LH + 2 * lane) = lo;
+      };
+#pragma unroll
+      for (int u = 0; u < 8; u++) put(u);
       if (nrt == 2) {
 #pragma unroll
-        for (int u = 8; u < 16; u++) {
-          const int j = wv + 4 * u;
-          *reinterpret_cast<float2*>(sX + j * LD + 2 * lane) = j < n ? v[u] : float2{0.f, 0.f};
-        }
+        for (int u = 8; u < 16; u++) put(u);
       }
     }
     __syncthreads();
-    // 2. V' = X_nnz M on the matrix cores: this wave's 32 columns, all row tiles.  (The pointer is made opaque so that
-    // the loads stay inside the row loop -- hoisted, they pin 64 registers for the whole launch -- and the triangular
-    // cut-off is taken per chunk of 16 k-steps: one uniform branch per chunk instead of one per MFMA.)
+    // 2. V' = X_nnz M on the matrix cores: this wave's 32 columns, all row tiles, 16 factor dimensions per instruction.
+    // B fragments: lane (n = col, kg = half) holds Mt16[32 wv + col][16 ch + 8 kg .. + 7] = M[those kk][that column]; M is
+    // upper triangular, so the chunks beyond 2 wv + 1 are zero and skipped.  (The pointer is made opaque so that the loads
+    // stay inside the row loop -- hoisted, they pin 64 registers for the whole launch.)
+    float wmax = 0.f;   // max |W| of this wave's part (for the scale of the second product)
     if (!(RSP_LR_ABL & 1)) {
-      const float* Mp = M + (size_t)half * KP + 32 * wv + col;
+      const _Float16* Mp = M16 + (size_t)(32 * wv + col) * KP + 8 * half;
       asm volatile("" : "+v"(Mp));
-      float breg[4][16];
+      f16x8 bh[8], bl[8];
 #pragma unroll
-      for (int ch = 0; ch < 4; ch++)
-        if (ch <= wv) {
-#pragma unroll
-          for (int t = 0; t < 16; t++) breg[ch][t] = Mp[(size_t)(2 * (16 * ch + t)) * KP];
+      for (int ch = 0; ch < 8; ch++)
+        if (ch <= 2 * wv + 1) {
+          bh[ch] = *reinterpret_cast<const f16x8*>(Mp + 16 * ch);
+          bl[ch] = *reinterpret_cast<const f16x8*>(Mp + KP * KP + 16 * ch);
         }
       for (int rt = 0; rt < nrt; rt++) {
-        f32x16 acc;
+        f32x16 acc, acc2;
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = 0.f;
-        const float* xa = sX + (32 * rt + col) * LD + half;
+        for (int e = 0; e < 16; e++) acc[e] = acc2[e] = 0.f;
+        const _Float16* xa = sXh + (32 * rt + col) * LH + 8 * half;
 #pragma unroll
-        for (int ch = 0; ch < 4; ch++)
-          if (ch <= wv) {
-#pragma unroll
-            for (int t = 0; t < 16; t++)
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * (16 * ch + t)], breg[ch][t], acc, 0, 0, 0);
+        for (int ch = 0; ch < 8; ch++)
+          if (ch <= 2 * wv + 1) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(xa + 16 * ch);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(xa + NP * LH + 16 * ch);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ch], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ch], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ch], acc2, 0, 0, 0);
           }
 #pragma unroll
-        for (int e = 0; e < 16; e++)
-          sV[(32 * rt + (e & 3) + 8 * (e >> 2) + 4 * half) * LD + 32 * wv + col] = acc[e];
+        for (int e = 0; e < 16; e++) {
+          const int i = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * half;
+          const float vv = (acc[e] + acc2[e]) * inv_xm;
+          sV[i * LD + 32 * wv + col] = vv;
+          wmax = fmaxf(wmax, fabsf(vv) * sQ[i]);
+        }
       }
     }
-    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) sT[wv] = wmax;
+    __syncthreads();   // V' complete, every wave is done with the fp16 terms of X_nnz
+    // 2b. the fp16 terms of W = D^1/2 V' * 2^ew over the X_nnz terms (thread t: row t / 4, 32 columns)
+    const int ew = lr_scale_exp(fmaxf(fmaxf(fmaxf(sT[0], sT[1]), fmaxf(sT[2], sT[3])), 1e-30f));
+    if (!(RSP_LR_ABL & 2)) {
+      const int j = tid >> 2, part = tid & 3;
+      if (j < 32 * nrt) {
+        const float sw = lr_pow2(ew) * sQ[j];
+        const float* vr = sV + j * LD + 32 * part;
+#pragma unroll
+        for (int e = 0; e < 32; e += 2) {
+          unsigned hi, lo;
+          lr_split(vr[e] * sw, vr[e + 1] * sw, hi, lo);
+          *reinterpret_cast<unsigned*>(sXh + j * LH + 32 * part + e) = hi;
+          *reinterpret_cast<unsigned*>(sXl + j * LH + 32 * part + e) = lo;
+        }
+      }
+    }
     // 3. g = V'^T c
     if (tid < KP) {
       float s = 0.f;
@@ -263,22 +339,33 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
       s += __shfl_xor(s, 2);
       if (part == 0 && j < NP) sH[j] = s * sQ[j];
     }
-    // 5. S = I + D^1/2 V' V'^T D^1/2 (lower tiles) on the matrix cores -> sS (over X_nnz)
+    // 5. S = I + W W^T (lower tiles) on the matrix cores from the fp16 terms of W, then -> sS (over those terms)
+    __syncthreads();   // the terms of W are complete (and g, h above have been formed from V')
     {
       const int rt = wv == 0 ? 0 : 1, ct = wv == 2 ? 1 : 0;
-      if (!(RSP_LR_ABL & 2) && wv < (nrt == 1 ? 1 : 3)) {
-        f32x16 acc;
+      const bool mine = !(RSP_LR_ABL & 2) && wv < (nrt == 1 ? 1 : 3);
+      f32x16 acc, acc2;
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = 0.f;
-        const float* va = sV + (32 * rt + col) * LD + half;
-        const float* vb = sV + (32 * ct + col) * LD + half;
+      for (int e = 0; e < 16; e++) acc[e] = acc2[e] = 0.f;
+      if (mine) {
+        const _Float16* wa = sXh + (32 * rt + col) * LH + 8 * half;
+        const _Float16* wb = sXh + (32 * ct + col) * LH + 8 * half;
 #pragma unroll
-        for (int t = 0; t < NKS; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * t], vb[2 * t], acc, 0, 0, 0);
-        const float qc = sQ[32 * ct + col];
+        for (int ch = 0; ch < 8; ch++) {
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(wa + 16 * ch), al = *reinterpret_cast<const f16x8*>(wa + NP * LH + 16 * ch);
+          const f16x8 bh2 = *reinterpret_cast<const f16x8*>(wb + 16 * ch), bl2 = *reinterpret_cast<const f16x8*>(wb + NP * LH + 16 * ch);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh2, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl2, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh2, acc2, 0, 0, 0);
+        }
+      }
+      __syncthreads();   // every wave has read its operands: the region becomes S
+      if (mine) {
+        const float inv_w2 = lr_pow2(254 - ew) * lr_pow2(254 - ew);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int i = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * half, c2 = 32 * ct + col;
-          sS[i * LS + c2] = (i == c2 ? 1.f : 0.f) + sQ[i] * qc * acc[e];
+          sS[i * LS + c2] = (i == c2 ? 1.f : 0.f) + (acc[e] + acc2[e]) * inv_w2;
         }
       }
     }
@@ -289,7 +376,9 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
     // diagonal, column values frozen at their pivot steps (row i of L times D) and, right of it, its own pivot row
     // (column i of L times d_i) -- both triangular solves read nothing but the lane's own registers and broadcast scalars.
     // The forward substitution rides along with the elimination.  No barriers, no LDS traffic after the row is loaded.
-    if (!(RSP_LR_ABL & 4) && wv == 0) {
+    // (the solving wave rotates from row to row, offset by the workgroup: the two workgroups of a CU would otherwise both
+    // solve on the SIMD that holds their wave 0 while the other three idle)
+    if (!(RSP_LR_ABL & 4) && wv == ((blockIdx.x + rot) & 3)) {
       int i = lane;
       asm volatile("" : "+v"(i));   // laundered per row: hipcc otherwise hoists the 64 load addresses below out of the row loop and spills them
       auto solve = [&](auto np_tag) {
@@ -397,8 +486,9 @@ bool chol_lr_supported(const AlsArgs& a, bool implicit) {
 }
 
 // rows: the n_rows rows of 1..kCholLrMax non-zeros (a suffix of the length-sorted order); M / Mt: 2 x 128 x 128 floats of
-// scratch; flags: the device word launch_ne_stats leaves in stats[2] (some confidence < 1) -- the prep kernel ORs its own
-// verdict into the same word.  Loss partials of its kCholLrGrid workgroups from loss_slot0 on.
+// scratch (M: the two fp16 terms of Mt, Mt: fp32); flags: word 2 of the statistics block launch_ne_stats leaves (word 0 =
+// bits of max |X| -- X must have been scanned --, word 2 = some confidence < 1, word 3 = the prep kernel's exponent) -- the
+// prep kernel ORs its own verdict into word 2.  Loss partials of its kCholLrGrid workgroups from loss_slot0 on.
 hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows, float* M, float* Mt, unsigned* flags,
                               int loss_slot0, hipStream_t s, hipEvent_t* ev_slot) {
   hipError_t err;
@@ -411,7 +501,7 @@ hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows,
   if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(prep), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  prep_lds)) != hipSuccess)
     return err;
-  hipLaunchKernelGGL(prep, dim3(1), dim3(256), prep_lds, s, a.XtX, a.k, M, Mt, flags);
+  hipLaunchKernelGGL(prep, dim3(1), dim3(256), prep_lds, s, a.XtX, a.k, reinterpret_cast<_Float16*>(M), Mt, flags);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   auto kern = als_chol_lr_kernel<KP>;
   if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -419,7 +509,8 @@ hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows,
     return err;
   const int grid = n_rows < kCholLrGrid ? n_rows : kCholLrGrid;
   prof_note(ev_slot, reinterpret_cast<const void*>(kern));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LrSmem<KP>::bytes, s, a, rows, n_rows, M, Mt, flags, loss_slot0);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LrSmem<KP>::bytes, s, a, rows, n_rows,
+                     reinterpret_cast<const _Float16*>(M), Mt, flags, loss_slot0);
   return hipGetLastError();
 }
 

@@ -47,8 +47,8 @@ extern "C" {
 #define RSPARSE_HIP_ERR_INVALID 1     /* bad argument (NULL pointer, negative size, rank <= 0 ...) */
 #define RSPARSE_HIP_ERR_UNSUPPORTED 2 /* variant not on the device path: caller keeps its CPU path   */
 #define RSPARSE_HIP_ERR_RUNTIME 3     /* HIP runtime / out of memory / no device                    */
-#define RSPARSE_HIP_ERR_NUMERIC 4     /* a per-row system was not positive definite (the reference's */
-                                      /* arma::solve would throw -> R error, RcppExports.cpp:374,392) */
+#define RSPARSE_HIP_ERR_NUMERIC 4     /* a per-row system was singular for the general solver too (the   */
+                                      /* reference's arma::solve throws -> R error, RcppExports.cpp:374,392) */
 
 /* solver codes: inst/include/wrmf.hpp:16-18 */
 #define RSPARSE_SOLVER_CHOLESKY 0
@@ -322,8 +322,14 @@ int rsparse_hip_profile_last_names(char* buf, int cap);
 int rsparse_hip_set_launch_mode(int mode);
 int rsparse_hip_profile_last(double ms_out[8]);
 
-/* number of per-row systems that failed (not positive definite) since the last call; resets. */
-int rsparse_hip_take_numeric_failures(int64_t* count_out);
+/* The exact (Cholesky) solver's bookkeeping since the last call of this function; resets.  A per-row system whose
+ * factorisation meets a non-positive pivot is re-solved on the device by Gaussian elimination with partial pivoting -- what
+ * arma::solve(lhs, rhs, fast + likely_sympd) falls back to behind a warning (inst/include/wrmf_implicit.hpp:236,
+ * wrmf_explicit.hpp:108): *fallback_out (nullable) = the number of such rows, the reference's warnings.  *unresolved_out =
+ * the rows whose general solve failed too (an exactly singular system; their solution was set to zero): the half-iteration
+ * entry points report them as RSPARSE_HIP_ERR_NUMERIC (the stateless ones at once, the device-resident ones through this
+ * call).  Reads device memory: synchronises. */
+int rsparse_hip_take_numeric_failures(int64_t* unresolved_out, int64_t* fallback_out);
 
 #ifdef __cplusplus
 }

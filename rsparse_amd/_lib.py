@@ -62,7 +62,7 @@ SIGNATURES = {
     "rsparse_hip_set_launch_mode": (_c_int, [_c_int]),
     "rsparse_hip_profile_last": (_c_int, [ctypes.POINTER(_c_dbl)]),
     "rsparse_hip_profile_last_names": (_c_int, [ctypes.c_char_p, _c_int]),
-    "rsparse_hip_take_numeric_failures": (_c_int, [ctypes.POINTER(_c_i64)]),
+    "rsparse_hip_take_numeric_failures": (_c_int, [ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
 }
 
 

@@ -81,9 +81,9 @@ struct Workspace {
       HIP_TRY(hipMalloc(&scalars, 16 * sizeof(double)));
       HIP_TRY(hipMemset(scalars, 0, 16 * sizeof(double)));
     }
-    if (!fails) {
-      HIP_TRY(hipMalloc(&fails, sizeof(int)));
-      HIP_TRY(hipMemset(fails, 0, sizeof(int)));
+    if (!fails) {   // see launch_fail_roll
+      HIP_TRY(hipMalloc(&fails, (size_t)(4 + kFailCap) * sizeof(int)));
+      HIP_TRY(hipMemset(fails, 0, 4 * sizeof(int)));
     }
     if (!ne_stats) {
       HIP_TRY(hipMalloc(&ne_stats, 4 * sizeof(unsigned)));
@@ -510,7 +510,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   const size_t chol_base = chol2_loss_slots(d.n_cols);
   const size_t slots = cgq ? cgq_loss_slots(qs, rank) : (cg ? cg_loss_slots(d.n_cols, d.n_long)
                                    : (solver == RSPARSE_SOLVER_NNLS ? chol_loss_slots(d.n_cols)
-                                      : chol_base + (ne_chol ? (size_t)(qs.ne_entries + qs.ne_nsplit) : 0)));
+                                      : chol_base + (ne_chol ? (size_t)(qs.ne_entries + qs.ne_nsplit) : 0) + (size_t)kLuGrid));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
   double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
   if (d.n_cols == 0) {
@@ -527,6 +527,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails; a.zero_row = g_ws.zero_row;
+  a.fail_rows = g_ws.fails + 4; a.fail_cap = kFailCap;
   a.rhs_vals = bias ? bias->rhs_vals : nullptr;
   a.loss_tgt = bias ? bias->loss_tgt : nullptr;
   a.rhs_init = bias ? bias->rhs_init : nullptr;
@@ -588,8 +589,12 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     }
     a.lr_rows = d.q_order + d.q_lr_first; a.n_lr = d.q_n_lr; a.lr_flags = g_ws.ne_stats + 2; a.lr_M = g_ws.lr_M;
   }
-  hipEvent_t* ev = g_prof.begin();
   const bool chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY;
+  if (chol) {
+    hipError_t fe = launch_fail_roll(g_ws.fails, s);
+    if (fe != hipSuccess) return hip_fail(fe, "launch_fail_roll");
+  }
+  hipEvent_t* ev = g_prof.begin();
   if (chol && ev) HIP_TRY(hipEventRecord(ev[0], s));   // Cholesky: [0] normal-equation launch, [1] low-rank, [2] k x k, [3] loss
   if (ne_chol) {
     hipError_t ne = launch_als_ne(a, qs, implicit, g_ws.partials + chol_base, s, ev);
@@ -601,6 +606,12 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
                                   ? launch_als_nnls(a, implicit, s, ev)
                                   : launch_als_chol2(a, implicit, s, ev ? ev + 1 : nullptr)));
   if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
+  if (chol) {
+    // rows whose factorisation met a non-positive pivot: the general solver, as arma::solve falls back to (wrmf_lu.hip).
+    // The counters are per call: a previous call's count was taken by rsparse_hip_take_numeric_failures or is added to.
+    if ((e = launch_als_lu_fallback(a, implicit, slots - (size_t)kLuGrid, s)) != hipSuccess)
+      return hip_fail(e, "launch_als_lu_fallback");
+  }
   e = launch_sum_partials(g_ws.partials, slots, out, s, g_ws.partials + g_ws.partial_slots);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
 #ifdef RSP_NE_PROF
@@ -843,7 +854,7 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
   }
   HIP_TRY(hipDeviceSynchronize());
   int64_t nfail = 0;
-  rsparse_hip_take_numeric_failures(&nfail);
+  rsparse_hip_take_numeric_failures(&nfail, nullptr);
   double host_scalars[2] = {0, 0};
   HIP_TRY(hipMemcpy(host_scalars, g_ws.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost));
   if (lambda > 0 && nx > 0) reg = lambda * host_scalars[1];
@@ -859,7 +870,8 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
   const double nnz = (double)conf->d.nnz;
   if (loss_out) *loss_out = (host_scalars[0] + reg) / nnz;  // wrmf_implicit.hpp:304
   if (nfail)
-    return fail(RSPARSE_HIP_ERR_NUMERIC, std::to_string(nfail) + " per-row systems were not positive definite");
+    return fail(RSPARSE_HIP_ERR_NUMERIC, std::to_string(nfail) + " per-row systems were singular (not positive definite, and "
+                                         "the general solver found a zero pivot column)");
   return RSPARSE_HIP_OK;
 }
 
@@ -1380,14 +1392,19 @@ int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, in
   return RSPARSE_HIP_OK;
 }
 
-int rsparse_hip_take_numeric_failures(int64_t* count_out) {
-  if (!count_out) return fail(RSPARSE_HIP_ERR_INVALID, "count_out is NULL");
-  *count_out = 0;
+int rsparse_hip_take_numeric_failures(int64_t* unresolved_out, int64_t* fallback_out) {
+  if (!unresolved_out) return fail(RSPARSE_HIP_ERR_INVALID, "unresolved_out is NULL");
+  *unresolved_out = 0;
+  if (fallback_out) *fallback_out = 0;
   if (!g_ws.fails) return RSPARSE_HIP_OK;
-  int v = 0;
-  HIP_TRY(hipMemcpy(&v, g_ws.fails, sizeof(int), hipMemcpyDeviceToHost));
-  if (v) HIP_TRY(hipMemset(g_ws.fails, 0, sizeof(int)));
-  *count_out = v;
+  int v[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(v, g_ws.fails, sizeof(v), hipMemcpyDeviceToHost));   // (synchronises with the device)
+  if (v[0] | v[1] | v[2] | v[3]) HIP_TRY(hipMemset(g_ws.fails, 0, sizeof(v)));
+  const int64_t sent = (int64_t)v[0] + v[2];
+  // rows beyond the list's capacity could not be handed over: they count as unresolved
+  const int64_t lost = v[0] > kFailCap ? (int64_t)v[0] - kFailCap : 0;
+  *unresolved_out = (int64_t)v[1] + v[3] + lost;
+  if (fallback_out) *fallback_out = sent;
   return RSPARSE_HIP_OK;
 }
 

@@ -368,6 +368,17 @@ __global__ __launch_bounds__(256, LONG ? 2 : RSP_CHOL_MINW) void als_chol2_kerne
     }
     __syncthreads();
     if (tid < k) yrow[tid] = sV[tid];
+    // a non-positive pivot: the row goes to the general solver (wrmf_lu.hip), which also owns its loss term
+    const bool rowbad = *sFlag != 0;
+    if (rowbad) {
+      __syncthreads();
+      if (tid == 0) {
+        const int pos = atomicAdd(a.fail_counter, 1);
+        if (pos < a.fail_cap) a.fail_rows[pos] = row;
+        *sFlag = 0;
+      }
+      continue;   // (uniform; the assembly of the next row has barriers before the flag can be set again)
+    }
 
     // ---------------- loss row term (wrmf_implicit.hpp:259-261 / wrmf_explicit.hpp:131-132) ----------------
     // second pass over the row's chunks: t_j = y . x_j with the lane-per-non-zero dot of the CG kernels
@@ -405,7 +416,6 @@ __global__ __launch_bounds__(256, LONG ? 2 : RSP_CHOL_MINW) void als_chol2_kerne
   __syncthreads();
   if (tid == 0) {
     a.loss_partials[loss_slot0 + blockIdx.x] = (sLoss[0] + sLoss[1]) + (sLoss[2] + sLoss[3]);
-    if (*sFlag) atomicAdd(a.fail_counter, 1);
   }
 }
 

@@ -75,7 +75,11 @@ struct AlsArgs {
   double lambda_loss;  // lambda of the loss term (double, wrmf_implicit.hpp:259-261)
   int dynamic_lambda;
   double* loss_partials;  // one double per wave (short kernel) / per workgroup (long kernel)
-  int* fail_counter;      // Cholesky: rows whose system was not positive definite
+  // Cholesky: fail_counter[0] = rows whose factorisation met a non-positive pivot (they are appended to fail_rows, at most
+  // fail_cap of them, and re-solved by the general solver, wrmf_lu.hip), fail_counter[1] = rows that one could not solve either
+  int* fail_counter;
+  int* fail_rows;
+  int fail_cap;
   // streamed CG rows: scratch [cg_steps+1][stream_nnz] for the per-non-zero dot products of every sweep,
   // stream_off[r] = first slot of the r-th streamed row (rows in schedule order); nullptr = re-gather for the loss
   const float* zero_row;  // >= 128 zero floats: what the padding slots of a gather read
@@ -188,6 +192,12 @@ hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows,
                               int loss_slot0, hipStream_t s, hipEvent_t* ev_slot = nullptr);
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
+constexpr int kLuGrid = 64;          // workgroups (and loss slots) of the general-solver fallback
+constexpr int kFailCap = 1 << 16;    // rows it can take per half-iteration call
+hipError_t launch_als_lu_fallback(const AlsArgs& a, bool implicit, size_t loss_slot0, hipStream_t s);
+// the failure block: [0] rows sent to the general solver by the current call, [1] of them unresolved, [2], [3] the same
+// summed over the earlier calls since rsparse_hip_take_numeric_failures, [4 ..] the current call's row ids
+hipError_t launch_fail_roll(int* fails, hipStream_t s);
 constexpr int kSumStageBlocks = 256;
 hipError_t launch_sum_partials(const double* partials, size_t n, double* out, hipStream_t s, double* tail = nullptr);
 hipError_t launch_bias_shift_values(const float* vals, const int32_t* row_idx, const float* X, int k, int bias_row,

@@ -1179,6 +1179,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
       return wave_sum_all(s) * 0.5f;  // the two halves of the wave hold identical values
     };
 
+    bool row_bad = false;   // CHOL: a non-positive pivot (known to wave 0, which also writes the loss)
     if constexpr (CHOL) {
       // solver == CHOLESKY (wrmf_implicit.hpp:231,236 / wrmf_explicit.hpp:103-108: y = solve(lhs, rhs)) on the system
       // assembled above: LDL^T blocked on the 32 x 32 tiles, in place.  Per block column J:
@@ -1326,7 +1327,11 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
         __syncthreads();
         NE_T(15)
       }
-      if (bad && tid == 0) atomicAdd(a.fail_counter, 1);
+      if (bad && tid == 0) {   // the row goes to the general solver (wrmf_lu.hip), which also owns its loss term
+        const int pos = atomicAdd(a.fail_counter, 1);
+        if (pos < a.fail_cap) a.fail_rows[pos] = row;
+      }
+      row_bad = bad;
       if (!(RSP_NECH_ABL & 8) && wv == 0) {   // D L^T y = u, last block first
         for (int J = NB - 1; J >= 0; J--) {
           int dd = d;
@@ -1421,7 +1426,7 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
       const double fit = tau * tau * sc_row - 2.0 * tau * (double)yb + q;
       const double reg = IMPLICIT ? a.lambda_loss * (double)yy : (double)(lam_use * yy);
       if (lane == 0) {
-        sYloss[nbuf] = fit + reg;
+        sYloss[nbuf] = row_bad ? 0.0 : fit + reg;
         sYrow[nbuf] = row;
         sYli[nbuf] = li;
       }

@@ -268,10 +268,17 @@ class HipBackend:
         return buf.value.decode().split("\n")
 
     def check_numeric(self):
-        c = ctypes.c_int64(0)
-        _lib.check(self.lib.rsparse_hip_take_numeric_failures(ctypes.byref(c)))
-        if c.value:
-            raise _lib.RsparseHipError(_lib.ERR_NUMERIC, "%d per-row systems were not positive definite" % c.value)
+        """Raises if per-row systems of the exact solver were singular for the general-solver fallback too; systems that
+        were merely not positive definite were re-solved on the device and are reported like the reference's warning."""
+        bad, fell = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(self.lib.rsparse_hip_take_numeric_failures(ctypes.byref(bad), ctypes.byref(fell)))
+        self.last_fallback_rows = fell.value
+        if fell.value:
+            import warnings
+            warnings.warn("rsparse_amd: %d per-row systems were not positive definite; solved by the general (LU) solver "
+                          "(the reference's arma::solve warns likewise)" % fell.value, RuntimeWarning, stacklevel=2)
+        if bad.value:
+            raise _lib.RsparseHipError(_lib.ERR_NUMERIC, "%d per-row systems were singular" % bad.value)
 
 
 class _CscHandle:

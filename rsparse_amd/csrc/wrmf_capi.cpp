@@ -368,6 +368,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   d.q_nec_split_rows = nullptr; d.q_nec_split_ptr = nullptr; d.q_nec_nsplit = 0; d.q_nec_own = false; d.q_nec_min = kNeCholMinLen;
   d.q_n_chol_long = 0;
   d.q_lr_first = 0; d.q_n_lr = 0;
+  d.q_pair_first = 0;
   d.q_cfg = cgq_default_cfg();
   if (n <= 0) return RSPARSE_HIP_OK;
   const int max_len = d.max_len;
@@ -378,6 +379,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     start[(size_t)(max_len - len) + 1]++;
     const int b = cgq_bucket_of(len, d.q_cfg);
     if (len > kCholLongLen) d.q_n_chol_long++;
+    if (len > 16) d.q_pair_first++;                // the order is longest first: the rows of <= 16 non-zeros are a suffix
     if (len > kCholLrMax) d.q_lr_first++;          // the order is longest first: the short rows are a suffix
     else if (len >= 1) d.q_n_lr++;
     cnt_b[b]++;
@@ -491,6 +493,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   QSchedule qs;
   qs.order = d.q_order;
   qs.cfg = d.q_cfg;
+  qs.pair_first = d.q_pair_first;
   for (int b = 0; b < 7; b++) qs.off[b] = d.q_off[b];
   qs.ne_rows = d.q_ne_rows; qs.ne_ptr = d.q_ne_ptr; qs.ne_wg = d.q_ne_wg; qs.ne_entries = d.q_ne_entries;
   qs.ne_split_rows = d.q_ne_split_rows; qs.ne_split_ptr = d.q_ne_split_ptr; qs.ne_nsplit = d.q_ne_nsplit;
@@ -508,7 +511,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   const int ne_nseg = (ne_chol && nec_lists) ? d.q_nec_nseg : d.q_ne_nseg;
   const int32_t* ne_segs = (ne_chol && nec_lists) ? d.q_nec_segs : d.q_ne_segs;
   const size_t chol_base = chol2_loss_slots(d.n_cols);
-  const size_t slots = cgq ? cgq_loss_slots(qs, rank) : (cg ? cg_loss_slots(d.n_cols, d.n_long)
+  const size_t slots = cgq ? cgq_loss_slots(qs, rank, implicit) : (cg ? cg_loss_slots(d.n_cols, d.n_long)
                                    : (solver == RSPARSE_SOLVER_NNLS ? chol_loss_slots(d.n_cols)
                                       : chol_base + (ne_chol ? (size_t)(qs.ne_entries + qs.ne_nsplit) : 0) + (size_t)kLuGrid));
   if ((rc = g_ws.ensure_partials(slots))) return rc;

@@ -22,6 +22,7 @@
 // waves of one workgroup: every wave keeps its own chunk resident, partial vectors are combined through
 // LDS with one barrier per CG sweep.  Rows beyond the workgroup's capacity are streamed (STREAM = 1
 // instantiation): the first 16 non-zeros per wave stay in LDS, the rest is re-gathered in every sweep.
+#include <algorithm>
 #include <cstdlib>
 
 #include "wrmf_internal.h"
@@ -1037,6 +1038,19 @@ BucketStreams g_bs;
 int g_launch_mode = 2;
 int concurrent_buckets() { return g_launch_mode; }
 
+// loss slots of bucket b: one per list entry of the normal-equation launch, else one per wave of the bucket's launch(es)
+size_t bucket_slots(const QSchedule& q, int b, int k, bool implicit) {
+  const BucketDef d = kBuckets[q.cfg][b];
+  if (d.wpr <= 0) return 0;
+  if (d.stream && ne_supported(k)) return (size_t)(q.ne_entries + q.ne_nsplit);
+  const int rows = q.off[b + 1] - q.off[b];
+  if (b == kNB - 1 && rows > 0 && cgp_supported(k, implicit) && dense_mfma_enabled()) {
+    const int split = std::min(std::max(q.pair_first, q.off[b]), q.off[b + 1]);
+    return (size_t)cgq_bucket_grid(split - q.off[b], b, q.cfg) * d.waves + (size_t)cgp_grid(q.off[b + 1] - split) * 4;
+  }
+  return (size_t)cgq_bucket_grid(rows, b, q.cfg) * d.waves;
+}
+
 template <int KP, int CFG, bool IMPLICIT, bool GB>
 hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEvent_t* ev) {
   hipError_t err;
@@ -1071,6 +1085,17 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
             return err;                                                                                     \
         } else if constexpr (D.stream && KP > 32) {   /* ranks above 32 always take the branch above */     \
           return hipErrorInvalidValue;                                                                      \
+        } else if (B == kNB - 1 && cgp_supported(a.k, IMPLICIT) && dense_mfma_enabled()) {                    \
+          /* the last bucket in two launches: rows of 17..32 non-zeros one per wave, the rest two per wave (wrmf_cgp.hip) */ \
+          const int first = q.off[B], split = std::min(std::max(q.pair_first, first), q.off[B + 1]);         \
+          const int n_main = split - first, n_pair = q.off[B + 1] - split;                                   \
+          const int g_main = cgq_bucket_grid(n_main, B, CFG);                                                \
+          if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT, GB>(a, q.order + first, n_main, g_main, slot, \
+                                                                                  bs, ev ? ev + B : nullptr)) != hipSuccess) \
+            return err;                                                                                     \
+          if ((err = launch_als_cgp(a, q.order + split, n_pair, slot + (size_t)g_main * D.waves, bs,          \
+                                    n_main > 0 ? nullptr : (ev ? ev + B : nullptr))) != hipSuccess)           \
+            return err;                                                                                     \
         } else if ((err = launch_bucket<KP, D.waves, D.capq, D.wpr, D.stream, IMPLICIT, GB>(a, q.order + q.off[B], n, grid, slot, \
                                                                                 bs, ev ? ev + B : nullptr)) != hipSuccess) \
           return err;                                                                                       \
@@ -1079,7 +1104,7 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
           if ((err = hipStreamWaitEvent(s, g_bs.done[B], 0)) != hipSuccess) return err;                     \
         }                                                                                                   \
       }                                                                                                     \
-      slot += (D.stream && ne_supported(a.k)) ? (size_t)(q.ne_entries + q.ne_nsplit) : (size_t)grid * D.waves; \
+      slot += bucket_slots(q, B, a.k, IMPLICIT);                                                             \
     }                                                                                                       \
   }
   RSP_BUCKET(0)
@@ -1129,13 +1154,9 @@ int cgq_bucket_of(int len, int cfg) {  // last (smallest-team) bucket whose capa
   return best;
 }
 
-size_t cgq_loss_slots(const QSchedule& q, int k) {
+size_t cgq_loss_slots(const QSchedule& q, int k, bool implicit) {
   size_t n = 0;
-  for (int b = 0; b < kNB; b++) {
-    const int rows = q.off[b + 1] - q.off[b];
-    if (kBuckets[q.cfg][b].stream && ne_supported(k)) n += (size_t)(q.ne_entries + q.ne_nsplit);  // one slot per list entry and split row (wrmf_ne.hip)
-    else n += (size_t)cgq_bucket_grid(rows, b, q.cfg) * kBuckets[q.cfg][b].waves;
-  }
+  for (int b = 0; b < kNB; b++) n += bucket_slots(q, b, k, implicit);
   return n;
 }
 

@@ -24,6 +24,7 @@ struct DevCSC {
   int32_t* q_order = nullptr;
   int q_off[7] = {0, 0, 0, 0, 0, 0, 0};
   int q_cfg = 0;
+  int q_pair_first = 0;   // position in q_order of the first row with at most 16 non-zeros (wrmf_cgp.hip: two rows per wave)
   int64_t q_nnz[6] = {0, 0, 0, 0, 0, 0};
   int64_t* q_stream_off = nullptr;  // prefix sums of the streamed bucket's row lengths (device)
   // normal-equation kernel (wrmf_ne.hip): the long rows (bucket 0) dealt to q_ne_wg workgroups, longest processing
@@ -126,6 +127,7 @@ struct AlsArgs {
 struct QSchedule {
   const int32_t* order;
   int off[7];
+  int pair_first;   // see DevCSC::q_pair_first
   int cfg;  // geometry the schedule was built for (see wrmf_cgq.hip kBuckets)
   const int32_t* ne_rows;  // see DevCSC::q_ne_*
   const int32_t* ne_ptr;
@@ -144,7 +146,12 @@ int cgq_bucket_waves(int cfg, int b);  // waves per workgroup of bucket b's kern
 int cgq_bucket_stream(int cfg, int b);
 int cgq_bucket_grid(int n_rows, int bucket, int cfg);
 int cgq_bucket_of(int len, int cfg);
-size_t cgq_loss_slots(const QSchedule& q, int k);
+size_t cgq_loss_slots(const QSchedule& q, int k, bool implicit);
+// the rows of at most 16 non-zeros of the last bucket, two per wave (wrmf_cgp.hip): rank 65..128, implicit feedback
+bool cgp_supported(int k, bool implicit);
+int cgp_grid(int n_rows);
+hipError_t launch_als_cgp(const AlsArgs& a, const int32_t* rows, int n_rows, size_t loss_slot0, hipStream_t s,
+                          hipEvent_t* ev_slot);
 // long rows (bucket 0) by one-pass normal equations on the matrix cores (wrmf_ne.hip) instead of the streamed CG kernel
 bool ne_supported(int k);
 constexpr int kNeMinLen = 512;       // its rows: more non-zeros than the largest resident bucket of wrmf_cgq.hip holds

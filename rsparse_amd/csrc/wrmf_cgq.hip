@@ -165,9 +165,13 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
-template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, bool DMF = false>
+// DMF: 0 = dense product on the vector units (G in LDS as fp32), 1 = on the matrix cores with this wave's rows of G as fp16
+// terms in REGISTERS (rows <= 32 non-zeros: 64 registers are free), 2 = the same with the fp16 terms in LDS, stored in
+// fragment order (rows of 33..64 non-zeros: the gathered vectors take 128 registers, G's 64 KB of LDS hold the terms instead
+// of the fp32 matrix: 16 conflict-free 16-byte reads per wave and sweep instead of 72 + 128 packed FMAs)
+template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, int DMF = 0>
 struct QSmem {
-  static constexpr size_t gram_floats = (IMPLICIT && !DMF) ? (size_t)KP * KP : 0;
+  static constexpr size_t gram_floats = (IMPLICIT && DMF != 1) ? (size_t)KP * KP : 0;   // (DMF 2: 4 x 2 x 4 x 2 KB fragments)
   static constexpr size_t vec_floats = IMPLICIT ? (size_t)WAVES * KP : 0;
   static constexpr size_t red_floats = WPR > 1 ? (size_t)2 * WAVES * KP + 2 * WAVES : 0;
   // resident rows: per wave, t_acc[CAP] = x_j . y accumulated over the CG steps and t_cur[CAP] = x_j . p of the
@@ -190,7 +194,7 @@ struct QSmem {
 // GB: implicit feedback with a global bias (cg_solver_implicit_global_bias, wrmf_implicit.hpp:35-57,203): the first
 // residual is  X_nnz (c - c1 % (X_nnz^T x + global_bias)) - XtX x + global_bias_base  (a.gbias, a.rhs_init), every row is
 // solved -- empty ones too (:178) -- and the loss compares x_j.y with 1 - global_bias (a.loss_tgt_const, :262-264).
-template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, bool DMF = false, bool GB = false>
+template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, int DMF = 0, bool GB = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
                                                              int rows_per_team, size_t loss_slot0) {
   using G_ = QG<KP>;
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   using SM = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF>;
   static_assert(WAVES % WPR == 0, "teams must tile the workgroup");
   static_assert(!DMF || (IMPLICIT && KP == 128 && WAVES == 4 && WPR == 1 && STREAM == 0), "DMF geometry");
+  static_assert(DMF != 1 || CAPQ == 8, "register-resident G terms: only the 8-quad kernel has the 64 registers");
   static_assert(!GB || IMPLICIT, "the global bias of explicit feedback is removed from the data (R/model_WRMF.R:278-282)");
   const float gbias = GB ? a.gbias : 0.f, ltgt = GB ? a.loss_tgt_const : 1.f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   const int g = lane >> 4, i = lane & 15;
   const int team = wv / WPR, tw = wv % WPR;
   const int k = a.k;
-  if constexpr (IMPLICIT && !DMF) {
+  if constexpr (IMPLICIT && DMF == 0) {
     for (int e = tid; e < KP * KP; e += WAVES * 64) {
       const int r = e / KP, c = e % KP;
       sG[e] = (r < k && c < k) ? a.XtX[(size_t)r * k + c] : 0.f;
@@ -243,7 +248,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   }
   // DMF: this wave's 32 rows of G as A operands (tile t = rows 32 wv + 16 t + (lane & 15), step ks = columns
   // 32 ks + 8 (lane >> 4) + 0..7), two fp16 terms of G * 2^ge; ginv = 2^-ge
-  f16x8 gAh[DMF ? 2 : 1][DMF ? 4 : 1], gAl[DMF ? 2 : 1][DMF ? 4 : 1];
+  f16x8 gAh[DMF == 1 ? 2 : 1][DMF == 1 ? 4 : 1], gAl[DMF == 1 ? 2 : 1][DMF == 1 ? 4 : 1];
+  // DMF 2: the same fragments in LDS, [wave][tile][step][term] x 1 KB (lane l's 16 bytes at l * 16: conflict-free)
+  char* sGf = reinterpret_cast<char*>(sG) + (size_t)wv * 16 * 1024;
   float ginv = 1.f;
   if constexpr (DMF) {
     const int m = lane & 15, kb = lane >> 4;
@@ -274,9 +281,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           split_f16(g0 * gs, g1 * gs, hi[e / 2], lo[e / 2]);
         }
         const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, l4 = {lo[0], lo[1], lo[2], lo[3]};
-        gAh[t][ks] = __builtin_bit_cast(f16x8, h4);
-        gAl[t][ks] = __builtin_bit_cast(f16x8, l4);
+        if constexpr (DMF == 1) {
+          gAh[t][ks] = __builtin_bit_cast(f16x8, h4);
+          gAl[t][ks] = __builtin_bit_cast(f16x8, l4);
+        } else {
+          *reinterpret_cast<uint4*>(sGf + ((t * 4 + ks) * 2 + 0) * 1024 + lane * 16) = h4;
+          *reinterpret_cast<uint4*>(sGf + ((t * 4 + ks) * 2 + 1) * 1024 + lane * 16) = l4;
+        }
       }
+    if constexpr (DMF == 2) wave_sync();   // (each wave reads back only what it wrote)
   }
   float* vec = sVec + wv * KP;
   // this wave's staging area as an LDS byte address in an SGPR; everything lane-dependent is re-derived at the point of use
@@ -643,9 +656,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
             const f16x8 bl = *reinterpret_cast<const f16x8*>(sPl + nb + 32 * ks);
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-              d0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gAh[t][ks], bh, d0[t], 0, 0, 0);
-              d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gAh[t][ks], bl, d1[t], 0, 0, 0);
-              d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gAl[t][ks], bh, d1[t], 0, 0, 0);
+              f16x8 ah, al;
+              if constexpr (DMF == 1) {
+                ah = gAh[t][ks];
+                al = gAl[t][ks];
+              } else {
+                ah = *reinterpret_cast<const f16x8*>(sGf + ((t * 4 + ks) * 2 + 0) * 1024 + lane * 16);
+                al = *reinterpret_cast<const f16x8*>(sGf + ((t * 4 + ks) * 2 + 1) * 1024 + lane * 16);
+              }
+              d0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, d0[t], 0, 0, 0);
+              d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, d1[t], 0, 0, 0);
+              d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, d1[t], 0, 0, 0);
             }
           }
           if ((lane & 15) < 4) {   // D: column = lane & 15, rows 4 (lane >> 4) + 0..3 of the tile
@@ -988,13 +1009,14 @@ bool dense_mfma_enabled() {
 #endif
 }
 
-template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT, bool GB, bool DMF = false>
+template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT, bool GB, int DMF = 0>
 hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int grid, size_t slot0, hipStream_t s,
                          hipEvent_t* ev_slot) {
   if (n_rows <= 0) return hipSuccess;
-  constexpr bool kDmfGeometry = IMPLICIT && KP == 128 && WAVES == 4 && WPR == 1 && CAPQ == 8 && STREAM == 0;
+  constexpr bool kDmfGeometry = IMPLICIT && KP == 128 && WAVES == 4 && WPR == 1 && (CAPQ == 8 || CAPQ == 16) && STREAM == 0;
   if constexpr (kDmfGeometry && !DMF) {
-    if (dense_mfma_enabled()) return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, GB, true>(a, rows, n_rows, grid, slot0, s, ev_slot);
+    if (dense_mfma_enabled())
+      return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, GB, CAPQ == 8 ? 1 : 2>(a, rows, n_rows, grid, slot0, s, ev_slot);
   }
   constexpr int TEAMS = WAVES / WPR;
   auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF, GB>;

@@ -412,7 +412,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     // 8-wave teams with the staged prefix: the confidences live in LDS during the sweeps (slot 4q+g of the wave's area),
     // 16 registers this kernel does not have next to the copy addresses
     constexpr bool CVL = LPFQ > 0;
-    float cl = 0.f;       // resident rows: confidence / rating of non-zero `lane` of the chunk (loss)
+    constexpr int NSL = (CAP + 63) / 64;   // slots of the chunk per lane (2 only for the rank <= 64 geometry, CAP = 128)
+    float cl[NSL];        // resident rows: confidence / rating of non-zero `lane` (+ 64) of the chunk (loss)
+#pragma unroll
+    for (int s2 = 0; s2 < NSL; s2++) cl[s2] = 0.f;
     int ccnt = 0;
 
     // Gather n (1..CAP) non-zeros starting at `base` into the registers: all index loads, then all vector
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     constexpr bool ZPAD = STREAM == 0 && CAPQ >= RSP_ZPAD_MINCAPQ;
     constexpr bool TSAVE = STREAM == 0 && CAPQ >= RSP_TSAVE_MINCAPQ;
     constexpr bool GVFIRST = STREAM == 0 && CAPQ >= RSP_GVFIRST_MINCAPQ;
-    constexpr bool IDXPF = (STREAM == 0 && WPR <= RSP_IDX_PREFETCH_MAXWPR) || (STREAM == 1 && IMPLICIT && RSP_STREAM_IDX_PREFETCH);
+    constexpr bool IDXPF = CAP <= 64 && ((STREAM == 0 && WPR <= RSP_IDX_PREFETCH_MAXWPR) || (STREAM == 1 && IMPLICIT && RSP_STREAM_IDX_PREFETCH));
     int pf_pos = -1;   // streamed rows: chunk the prefetch registers belong to
     auto gather_q = [&](auto nq_tag, const int base, const int n, const bool from_pf = false) {
       constexpr int NQG = decltype(nq_tag)::value;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           id[q] = xi[j];
           cv[q] = (!ZPAD || 4 * q + g < n) ? tcur[j] : 0.f;
         }
-        if constexpr (TSAVE) cl = lane < n ? pf_c : 0.f;
+        if constexpr (TSAVE) cl[0] = lane < n ? pf_c : 0.f;
         wave_sync();
       } else {
 #pragma unroll
@@ -452,7 +455,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           const float c = a.vals[base + j];
           cv[q] = (!ZPAD || 4 * q + g < n) ? c : 0.f;
         }
-        if constexpr (TSAVE && !(SM::lpfq > 0)) cl = lane < n ? a.vals[base + lane] : 0.f;   // (staged kernels: from LDS at the loss)
+        if constexpr (TSAVE && !(SM::lpfq > 0)) {   // (staged kernels: from LDS at the loss)
+#pragma unroll
+          for (int s2 = 0; s2 < NSL; s2++) cl[s2] = lane + 64 * s2 < n ? a.vals[base + lane + 64 * s2] : 0.f;
+        }
       }
       if constexpr (LPFQ > 0 && NQG == CAPQ) {   // the staged quads: copied into LDS during the previous row's sweeps
         int gi = g * KP + i * VW;   // one laundered lane offset; the (q, b) parts fit the DS instructions' immediate field
@@ -741,16 +747,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           } else {
             // loss from t_acc = X_nnz^T y built up by the sweeps (the vectors are not touched again)
             wave_sync();
-            const float t = tacc[lane & (CAP - 1)];
-            float clv = cl;
-            if constexpr (SM::lpfq > 0) {   // the confidences were parked in LDS in exactly this order (slot = non-zero of the chunk)
-              int l4 = (lane & (CAP - 1)) * 4;
-              asm volatile("" : "+v"(l4));
-              clv = *reinterpret_cast<const float*>(lpf_ptr(kLpfValOff + 256) + l4);
+            float esum = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < NSL; s2++) {
+              const int sl = NSL == 1 ? (lane & (CAP - 1)) : lane + 64 * s2;
+              const float t = tacc[sl];
+              float clv = cl[s2];
+              if constexpr (SM::lpfq > 0) {   // the confidences were parked in LDS in exactly this order (slot = non-zero of the chunk)
+                int l4 = sl * 4;
+                asm volatile("" : "+v"(l4));
+                clv = *reinterpret_cast<const float*>(lpf_ptr(kLpfValOff + 256) + l4);
+              }
+              const float d = IMPLICIT ? ltgt - t : clv - t;
+              const float e = IMPLICIT ? clv * d * d : d * d;
+              esum += lane + 64 * s2 < ccnt ? e : 0.f;
             }
-            const float d = IMPLICIT ? ltgt - t : clv - t;
-            const float e = IMPLICIT ? clv * d * d : d * d;
-            lacc = row16_sum(lane < ccnt ? e : 0.f);  // groups_sum below finishes the wave sum
+            lacc = row16_sum(esum);  // groups_sum below finishes the wave sum
           }
         } else if (mode == 2 && tscr) {
           // streamed rows: t_final = t_0 + sum_s alpha_s t_s from the scratch written by the sweeps -- 20 bytes
@@ -937,8 +949,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           if (s2 == itc) alph[s2] = alpha;
         if constexpr (TSAVE) {  // t_acc += alpha * t_cur  (x += alpha p  =>  X_nnz^T x += alpha X_nnz^T p)
           wave_sync();
-          const int sl = lane & (CAP - 1);
-          tacc[sl] = fmaf(alpha, tcur[sl], tacc[sl]);
+#pragma unroll
+          for (int s2 = 0; s2 < NSL; s2++) {
+            const int sl = NSL == 1 ? (lane & (CAP - 1)) : lane + 64 * s2;
+            tacc[sl] = fmaf(alpha, tcur[sl], tacc[sl]);
+          }
           wave_sync();
         }
 #pragma unroll
@@ -990,10 +1005,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 // Every instantiation is capped at 256 VGPRs (2 waves per SIMD, 8 waves per CU).
 struct BucketDef { int waves, wpr, capq, stream, max_len; };
 constexpr int kNB = 6;
-constexpr int kNCfg = 1;
+// Geometry 1 (rank 33..64, round 3): a rank-64 vector is 4 registers of a lane, so the 128 registers that hold 64 vectors at
+// rank 128 hold 128 -- the same row-length classes run on HALF the waves: 257..512 on 4-wave teams of 256-thread
+// workgroups (two per CU: gather and sweeps of the two overlap, which the one 512-thread workgroup per CU of geometry 0
+// cannot), 129..256 on 2 waves, 65..128 on one.  The class boundaries are those of geometry 0: the schedule is built once
+// per matrix, before the rank is known.
+constexpr int kNCfg = 2;
 constexpr BucketDef kBuckets[kNCfg][kNB] = {
     {{8, 8, 16, 1, 0x7fffffff}, {8, 8, 16, 0, 512}, {4, 4, 16, 0, 256}, {4, 2, 16, 0, 128}, {4, 1, 16, 0, 64}, {4, 1, 8, 0, 32}},
+    {{8, 8, 16, 1, 0x7fffffff}, {4, 4, 32, 0, 512}, {4, 2, 32, 0, 256}, {4, 1, 32, 0, 128}, {4, 1, 16, 0, 64}, {4, 1, 8, 0, 32}},
 };
+constexpr int cfg_of_kp(int KP) { return KP == 64 ? 1 : 0; }
 
 // dev builds (-DRSP_AB): RSPARSE_HIP_DENSE_MFMA=0 keeps the one-wave rows of <= 32 non-zeros on the vector-unit G v
 // product (the A/B switch behind DESIGN.md 3.1)
@@ -1062,15 +1084,16 @@ int concurrent_buckets() { return g_launch_mode; }
 
 // loss slots of bucket b: one per list entry of the normal-equation launch, else one per wave of the bucket's launch(es)
 size_t bucket_slots(const QSchedule& q, int b, int k, bool implicit) {
-  const BucketDef d = kBuckets[q.cfg][b];
+  const int cfg = cfg_of_kp(padded_rank(k));
+  const BucketDef d = kBuckets[cfg][b];
   if (d.wpr <= 0) return 0;
   if (d.stream && ne_supported(k)) return (size_t)(q.ne_entries + q.ne_nsplit);
   const int rows = q.off[b + 1] - q.off[b];
   if (b == kNB - 1 && rows > 0 && cgp_supported(k, implicit) && dense_mfma_enabled()) {
     const int split = std::min(std::max(q.pair_first, q.off[b]), q.off[b + 1]);
-    return (size_t)cgq_bucket_grid(split - q.off[b], b, q.cfg) * d.waves + (size_t)cgp_grid(q.off[b + 1] - split) * 4;
+    return (size_t)cgq_bucket_grid(split - q.off[b], b, cfg) * d.waves + (size_t)cgp_grid(q.off[b + 1] - split) * 4;
   }
-  return (size_t)cgq_bucket_grid(rows, b, q.cfg) * d.waves;
+  return (size_t)cgq_bucket_grid(rows, b, cfg) * d.waves;
 }
 
 template <int KP, int CFG, bool IMPLICIT, bool GB>
@@ -1189,8 +1212,9 @@ hipError_t launch_als_cgq(const AlsArgs& a, const QSchedule& q, bool implicit, h
   const int KP = padded_rank(a.k);
 #define RSP_DISPATCH(KPV)                                                                                   \
   if (KP == KPV) {                                                                                          \
-    if (implicit && a.gbias != 0.f) return launch_all<KPV, 0, true, true>(a, q, s, ev);                     \
-    return implicit ? launch_all<KPV, 0, true, false>(a, q, s, ev) : launch_all<KPV, 0, false, false>(a, q, s, ev); \
+    if (implicit && a.gbias != 0.f) return launch_all<KPV, cfg_of_kp(KPV), true, true>(a, q, s, ev);        \
+    return implicit ? launch_all<KPV, cfg_of_kp(KPV), true, false>(a, q, s, ev)                             \
+                    : launch_all<KPV, cfg_of_kp(KPV), false, false>(a, q, s, ev);                           \
   }
   RSP_DISPATCH(32)
   RSP_DISPATCH(64)

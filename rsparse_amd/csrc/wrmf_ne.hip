@@ -35,6 +35,7 @@
 
 #include "wrmf_internal.h"
 #include "wrmf_device.h"
+#include "wrmf_ldlt.h"
 
 namespace rsparse_hip {
 namespace {
@@ -1179,191 +1180,32 @@ __global__ __launch_bounds__(256, QUAD ? 2 : 1) void als_ne_kernel(AlsArgs a, co
       return wave_sum_all(s) * 0.5f;  // the two halves of the wave hold identical values
     };
 
-    bool row_bad = false;   // CHOL: a non-positive pivot (known to wave 0, which also writes the loss)
+    bool row_bad = false;   // CHOL: a non-positive pivot (known to every wave; wave 0 writes the loss)
     if constexpr (CHOL) {
       // solver == CHOLESKY (wrmf_implicit.hpp:231,236 / wrmf_explicit.hpp:103-108: y = solve(lhs, rhs)) on the system
-      // assembled above: LDL^T blocked on the 32 x 32 tiles, in place.  Per block column J:
-      //   (1) the diagonal tile by ONE wave in registers (lane i = row i, pivot rows broadcast by v_readlane, as in
-      //       wrmf_chol_lr.hip), the forward substitution of the block riding along; written back as L_JJ below and
-      //       L_JJ^T above the diagonal, pivots and their inverses to sD / sDi;
-      //   (2) the panel: one half-wave per tile (I, J), lane = row, L_IJ = A_IJ L_JJ^-T D_J^-1 by substitution in
-      //       registers (the rows of L_JJ^T are broadcast reads), and b_I -= L_IJ u_J;
-      //   (3) the trailing tiles (I, K) -= (L_IJ D_J) L_KJ^T on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
-      //       products), dealt to the four waves.
-      // Then D L^T y = u backwards by one wave.  A pivot that is not positive bumps the failure counter
-      // (RSPARSE_HIP_ERR_NUMERIC), as in wrmf_chol.hip.
-      constexpr int TS = 32 * TLD;
-      auto tile = [&](const int R2, const int C2) { return sA + (R2 * (R2 + 1) / 2 + C2) * TS; };
-      float* sD = sPart;         // [KP] pivots
-      float* sDi = sPart + KP;   // [KP] 1 / pivot
-      float* sU = sPub;          // [KP] right-hand side -> u -> solution
-      bool bad = false;
-      if (tid >= k && tid < KP) tile(tid >> 5, tid >> 5)[(tid & 31) * (TLD + 1)] = 1.f;   // padding: unit diagonal
+      // assembled above: LDL^T with the matrix in the waves' registers (wrmf_ldlt.h; its scratch overlays the tiles, which
+      // are dead once every wave has its columns).  A pivot that is not positive sends the row to the general solver
+      // (wrmf_lu.hip), which also owns its loss term.
+      using LD = Ldlt<KP, TLD>;
+      static_assert(LD::FLOATS <= G_::A_FLOATS, "the LDL^T scratch overlays the tiles");
+      float* sU = sPub;          // [KP] right-hand side -> solution
+      if (tid >= k && tid < KP) sA[((tid >> 5) * ((tid >> 5) + 1) / 2 + (tid >> 5)) * 32 * TLD + (tid & 31) * (TLD + 1)] = 1.f;   // padding: unit diagonal
       if (wv == 0 && h == 0) {
 #pragma unroll
         for (int t = 0; t < NB; t++) sU[32 * t + d] = b[t];
       }
       __syncthreads();
-      // Look-ahead: the first trailing tile of a block column is the one that holds the NEXT diagonal block; wave 0 takes
-      // it, then factors that block while waves 1..3 finish the other trailing tiles.  J2 = -1 is the start-up pass
-      // (diagonal block 0 only).
-      for (int J2 = -1; J2 < 2 * NB; J2++) {   // block columns of 16 inside the 32 x 32 tiles
-        const int JT = max(J2, 0) >> 1, hc = max(J2, 0) & 1, c0 = 16 * hc, jb = 16 * max(J2, 0);
-        float* TJ = tile(JT, JT);
-        const int JN = J2 + 1, cn = 16 * (JN & 1), jn = 16 * JN;
-        float* TN = tile(min(JN >> 1, NB - 1), min(JN >> 1, NB - 1));
-        if (J2 >= 0) {
-        {   // (2) the rows below the block: rows 16..31 of the diagonal tile (first block column of a tile), then the tiles
-            // under it; one half-wave each, lane = row
-          const int unit = ((wv + 3) & 3) * 2 + h;   // wave 1 first: wave 0 has just done the diagonal block
-          const int unit0 = ((wv + 3) & 3) * 2;      // the wave's first half
-          const int n_units = (NB - 1 - JT) + (1 - hc);
-          if (!(RSP_NECH_ABL & 2) && unit0 < n_units) {   // wave-uniform
-            int dd = d;
-            asm volatile("" : "+v"(dd));
-            // row (lane & 15) of the block's L in registers (every 16-lane group alike): the multipliers of the
-            // substitution are lane broadcasts (v_readlane)
-            float lr[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) lr[c] = TJ[(c0 + (dd & 15)) * TLD + c0 + c];
-            const bool mine = unit < n_units;
-            const bool diag_half = hc == 0 && unit == 0;             // rows 16..31 of tile (JT, JT)
-            const int I = hc == 0 ? JT + unit : JT + 1 + unit;       // tile row of this half's unit
-            const int trow_i = diag_half ? 16 + (dd & 15) : dd;
-            float* TI = tile(mine ? I : JT, JT) + trow_i * TLD + c0;
-            const bool act = mine && (!diag_half || dd < 16);
-            float y[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) y[c] = TI[c];
-#pragma unroll
-            for (int c = 0; c < 15; c++) {
-              const float yc = y[c];
-#pragma unroll
-              for (int c2 = c + 1; c2 < 16; c2++) y[c2] = fmaf(-yc, readlane_f(lr[c], c2), y[c2]);   // L[c2][c]
-            }
-            if (act) {
-              float dot_u = 0.f;
-#pragma unroll
-              for (int c = 0; c < 16; c++) {
-                const float l = y[c] * sDi[jb + c];
-                TI[c] = l;
-                dot_u = fmaf(l, sU[jb + c], dot_u);
-              }
-              sU[32 * I + trow_i] -= dot_u;
-            }
-          }
-        }
-        __syncthreads();
-        NE_T(16)
-        {   // (3) trailing tiles (I, K), K >= JT (first block column of a tile: the tile column JT itself, right half only)
-          int idx = 0;
-          for (int I = JT; I < NB; I++)
-            for (int K2 = JT + hc; K2 <= I; K2++) {
-              if (I == JT && hc == 1) continue;             // nothing left of the diagonal tile
-              const bool here = idx == 0 ? wv == 0 : (idx - 1) % 3 + 1 == wv;   // wave 0: the tile of the next diagonal block only
-              idx++;
-              if ((RSP_NECH_ABL & 4) || !here) continue;
-              int dd = d;
-              asm volatile("" : "+v"(dd));
-              float* C = tile(I, K2) + 4 * h * TLD + dd;
-              const float* LI = tile(I, JT) + dd * TLD + c0 + h;
-              const float* LK = tile(K2, JT) + dd * TLD + c0 + h;
-              const float* dj = sD + jb + h;
-              f32x16 acc;
-#pragma unroll
-              for (int e = 0; e < 16; e++) acc[e] = C[((e & 3) + 8 * (e >> 2)) * TLD];
-#pragma unroll
-              for (int kk = 0; kk < 8; kk++)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-LI[2 * kk] * dj[2 * kk], LK[2 * kk], acc, 0, 0, 0);
-              const bool col_ok = K2 > JT || dd >= 16;      // tile column JT: its left half is final L
-              const bool low_only = I == JT;                // diagonal tile: its upper-left block is final too
-              if (col_ok) {
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                  if (e >= 8 || !low_only) C[((e & 3) + 8 * (e >> 2)) * TLD] = acc[e];
-              }
-            }
-        }
-        }
-        if (!(RSP_NECH_ABL & 1) && wv == 0 && J2 + 1 < 2 * NB) {   // (1) of the NEXT block column; the four 16-lane groups compute the same, lanes 0..15 write
-          // (the lane's offsets are laundered per block: hipcc otherwise hoists the address pieces out of the row
-          // loop and spills them into the streaming loops)
-          int dd = lane & 15;
-          asm volatile("" : "+v"(dd));
-          float* trow = TN + (cn + dd) * TLD + cn;   // own row of the block: left of the diagonal
-          const float* tcol = TN + cn * TLD + cn + dd;   // own column: the transposed entries right of it (lower triangle only)
-          float r[16];
-#pragma unroll
-          for (int c = 0; c < 16; c++) r[c] = *(c <= dd ? trow + c : tcol + c * TLD);
-          float u = sU[jn + dd], dinv = 1.f, dii = 1.f;
-#pragma unroll
-          for (int j = 0; j < 16; j++) {
-            const float pj = readlane_f(r[j], j);
-            if (!(pj > 0.f)) bad = true;
-            // 1 / pivot: v_rcp_f32 and one Newton step (<= 1 ulp) -- the IEEE division sequence is three times as long,
-            // and the sixteen of them are the serial spine of this block
-            const float r0 = __builtin_amdgcn_rcpf(pj);
-            const float inv = fmaf(fmaf(-pj, r0, 1.f), r0, r0);
-            const float uj = readlane_f(u, j);
-            if (dd == j) { dinv = inv; dii = pj; }
-            const float lij = dd > j ? r[j] * inv : 0.f;   // L_ij; rows <= j are finished
-            u = fmaf(-lij, uj, u);
-#pragma unroll
-            for (int c = j + 1; c < 16; c++) r[c] = fmaf(-lij, readlane_f(r[c], j), r[c]);
-          }
-          // lane i now holds L_ic d_c left of the diagonal; the block is kept as its lower triangle (unit L, pivot on
-          // the diagonal)
-          if (lane < 16) {
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-              const float dc = readlane_f(dinv, c);
-              if (c <= dd) trow[c] = c < dd ? r[c] * dc : dii;
-            }
-            sD[jn + dd] = dii;
-            sDi[jn + dd] = dinv;
-            sU[jn + dd] = u;
-          }
-        }
-        __syncthreads();
-        NE_T(15)
-      }
-      if (bad && tid == 0) {   // the row goes to the general solver (wrmf_lu.hip), which also owns its loss term
+      NE_T(15)
+      row_bad = LD::solve(sA, sA, sU, reinterpret_cast<int*>(sScal + 32), wv, lane);
+      if (row_bad && tid == 0) {
         const int pos = atomicAdd(a.fail_counter, 1);
         if (pos < a.fail_cap) a.fail_rows[pos] = row;
       }
-      row_bad = bad;
-      if (!(RSP_NECH_ABL & 8) && wv == 0) {   // D L^T y = u, last block first
-        for (int J = NB - 1; J >= 0; J--) {
-          int dd = d;
-          asm volatile("" : "+v"(dd));
-          const float* TJ0 = tile(J, J);
-          float t2 = sU[32 * J + dd] * sDi[32 * J + dd];
-          for (int I = J + 1; I < NB; I++) {
-            const float* TI = tile(I, J) + dd;
-            const float* yI = sU + 32 * I;
-#pragma unroll
-            for (int r2 = 0; r2 < 32; r2++) t2 = fmaf(-TI[r2 * TLD], yI[r2], t2);
-          }
-          float lc[32];
-#pragma unroll
-          for (int c = 0; c < 32; c++) lc[c] = TJ0[c * TLD + dd];   // column d of L_JJ, read below the diagonal (c > d)
-          float accb = 0.f, z = 0.f;
-#pragma unroll
-          for (int c = 31; c >= 0; c--) {
-            if (d == c) z = t2 - accb;
-            const float zc = readlane_f(z, c);
-            accb = fmaf(d < c ? lc[c] : 0.f, zc, accb);
-          }
-          wave_sync();
-          if (h == 0) sU[32 * J + dd] = z;
-          wave_sync();
-        }
-      }
-      __syncthreads();
-      NE_T(18)
+      NE_T(16)
 #pragma unroll
       for (int t = 0; t < NB; t++) x[t] = (32 * t + d < k) ? sU[32 * t + d] : 0.f;
       __syncthreads();   // sPub is per-wave scratch again below
+      NE_T(18)
     } else {
     // cg_solver_implicit / cg_solver_explicit on the assembled operator (one matrix-vector product per pass: pass 0
     // forms r = b - A x); rsold / alpha in double like the reference (wrmf_implicit.hpp:18)

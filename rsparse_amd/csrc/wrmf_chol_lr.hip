@@ -20,6 +20,7 @@
 // Needs every confidence >= 1 (D^1/2) and XtX positive definite: both are decided on the device (flags[0] != 0 ->
 // this kernel returns at once and wrmf_chol.hip's kernel, which otherwise skips the short rows, takes them).
 #include <type_traits>
+#include <utility>
 
 #include "wrmf_internal.h"
 #include "wrmf_device.h"
@@ -49,6 +50,15 @@ __device__ __forceinline__ int lr_scale_exp(float vmax) {
   return min(253, max(1, 267 - eb));
 }
 __device__ __forceinline__ float lr_pow2(int biased) { return __uint_as_float((unsigned)biased << 23); }
+
+template <class F, int... I>
+__device__ __forceinline__ void lr_sfor_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void lr_sfor(F&& f) {
+  lr_sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 #ifndef RSP_LR_ABL
 #define RSP_LR_ABL 0   // dev builds: timing-only ablations (1 no V' GEMM, 2 no S GEMM, 4 no LDL^T, 8 no substitution, 16 no y = M q, 32 no gather)
@@ -388,18 +398,32 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
         for (int c = 0; c < NS; c++) r[c] = (i < n && c < n) ? sS[(i >= c ? i * LS + c : c * LS + i)] : (i == c ? 1.f : 0.f);
         float u = i < n ? sH[i] : 0.f;
         float dinv = 1.f;   // 1 / d_i, set when row i is the pivot row
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-          const float pj = readlane_f(r[j], j);   // >= 1 (S = I + W W^T)
-          const float r0 = __builtin_amdgcn_rcpf(pj);
-          const float inv = fmaf(fmaf(-pj, r0, 1.f), r0, r0);   // v_rcp_f32 + one Newton step: the pivots' serial spine
+        // Pivot step j: r[c] -= l_ij S[j][c] for the columns c > j.  S[j][c] = S[c][j] is lane c of register r[j]: its rows
+        // of 16 lanes are copied into every row once per pivot (rows_to_all) and the multiplier is then a DPP row broadcast
+        // inside the FMA -- one 4.8-cycle instruction per entry instead of v_readlane + v_fma (12.7).  Column j + 1, the next
+        // pivot column, is served first and by v_readlane, so that the next pivot's chain (broadcast, reciprocal, scale) starts
+        // before this pivot's other columns are done.
+        float pj = readlane_f(r[0], 0);
+        lr_sfor<NS>([&](auto jt) {
+          constexpr int j = decltype(jt)::value;
+          const float inv = __builtin_amdgcn_rcpf(pj);   // (>= 1: S = I + W W^T; 1 ulp)
           const float uj = readlane_f(u, j);
           if (i == j) dinv = inv;
           const float lij = i > j ? r[j] * inv : 0.f;   // L_ij; rows <= j are finished
           u = fmaf(-lij, uj, u);
-#pragma unroll
-          for (int c = j + 1; c < NS; c++) r[c] = fmaf(-lij, readlane_f(r[c], j), r[c]);
-        }
+          if constexpr (j + 1 < NS) {
+            r[j + 1] = fmaf(-lij, readlane_f(r[j], j + 1), r[j + 1]);
+            pj = readlane_f(r[j + 1], j + 1);
+            if constexpr (j + 2 < NS) {
+              float rep[4];
+              rows_to_all<(NS > 32 ? 4 : 2)>(r[j], rep);
+              lr_sfor<NS - j - 2>([&](auto ct) {
+                constexpr int c = j + 2 + decltype(ct)::value;
+                fnma_row_bcast<c % 16>(r[c], rep[c / 16], lij);
+              });
+            }
+          }
+        });
         // backward: z_c = (u_c - sum_{c' > c} d_c L[c'][c] z_c') / d_c, largest index first
         float acc = 0.f, z = 0.f;
 #pragma unroll

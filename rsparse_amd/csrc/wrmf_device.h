@@ -36,6 +36,29 @@ __device__ __forceinline__ float dpp(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
+// acc -= u(lane E of the row of 16 lanes this lane sits in) * l: v_fmac_f32 with a DPP row broadcast on its first operand.
+// 4.8 cycles per wave against 8.4 + 4.3 for v_readlane + v_fma (tools/probes/valu_rate_probe.hip).  Needs EXEC = all ones.
+template <int E>
+__device__ __forceinline__ void fnma_row_bcast(float& acc, const float u, const float l) {
+  asm("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(l), "n"(E));
+}
+// rep[g] = row g (lanes 16 g .. 16 g + 15) of v in every row of 16 lanes, g < NG (two or three lane-swap instructions)
+template <int NG>
+__device__ __forceinline__ void rows_to_all(const float v, float (&rep)[4]) {
+  const unsigned u = __float_as_uint(v);
+  const auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // h[0] = rows (0, 1, 0, 1), h[1] = rows (2, 3, 2, 3)
+  const auto lo = __builtin_amdgcn_permlane16_swap(h[0], h[0], false, false);   // rows (0, 0, 0, 0), (1, 1, 1, 1)
+  rep[0] = __uint_as_float(lo[0]);
+  rep[1] = __uint_as_float(lo[1]);
+  if constexpr (NG > 2) {
+    const auto hi = __builtin_amdgcn_permlane16_swap(h[1], h[1], false, false);
+    rep[2] = __uint_as_float(hi[0]);
+    rep[3] = __uint_as_float(hi[1]);
+  } else {
+    rep[2] = rep[3] = 0.f;
+  }
+}
+
 // Sum over the 64 lanes, result uniform.  Needs EXEC = all ones.  Fixed order -> deterministic.
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp<0xB1>(v);   // quad_perm:[1,0,3,2]

@@ -64,11 +64,8 @@ struct Ldlt {
     sfor_impl(f, std::make_integer_sequence<int, N>{});
   }
 
-  // acc -= u(lane E of the row of 16 lanes) * l   (v_fmac_f32 with a DPP row broadcast on its first operand)
   template <int E>
-  static __device__ __forceinline__ void fnma_bcast(float& acc, const float u, const float l) {
-    asm("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(l), "n"(E));
-  }
+  static __device__ __forceinline__ void fnma_bcast(float& acc, const float u, const float l) { fnma_row_bcast<E>(acc, u, l); }
   static __device__ __forceinline__ float swap32_add(float a, float b) {   // lanes < 32: sum of a's halves, >= 32: of b's
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);

@@ -146,18 +146,31 @@ __global__ __launch_bounds__(256) void chol_lr_prep_kernel(const float* __restri
 }
 
 // ---- the rows ----------------------------------------------------------------------------------------------------
+// One PASS of a workgroup = 64 slots of non-zeros: one row of 33..64 non-zeros, two rows of 17..32 (32 slots each) or four
+// rows of <= 16 (16 slots each; a slot beyond its row's length is a zero vector with confidence 0).  The per-pass fixed
+// costs (a dozen barriers, the M fragments and the rows of M^T from L2, the gather round trip) are what a short row costs
+// -- its arithmetic is nothing -- and half of the bench matrix's users have <= 24 non-zeros, so they share them.  The
+// packed rows' S = I + W W^T is block diagonal (the cross blocks are dropped when it is written), i.e. independent systems
+// living in disjoint groups of 16 or 32 lanes, and their LDL^T runs for all of them at once on lane-group-local DPP
+// broadcasts (no v_readlane at all).
 template <int KP>
 struct LrSmem {
-  static constexpr int NP = 64;
+  static constexpr int NP = 64, RMAX = 4;
   static constexpr size_t x_floats = (size_t)NP * kLrLh;   // fp16 terms of X_nnz ([2][NP][kLrLh] halves), then of W, then S (NP x kLrLs floats)
   static constexpr size_t v_floats = (size_t)NP * kLrLd;   // V'
-  static constexpr size_t vec_floats = 4 * NP + 4 * KP + 64;
+  static constexpr size_t vec_floats = 4 * NP + 4 * RMAX * KP + 64;
   static constexpr size_t bytes = (x_floats + v_floats + vec_floats) * 4 + 64;
 };
 
+template <int E>
+__device__ __forceinline__ float lr_row_bcast(const float v) {   // lane E of this lane's row of 16 lanes
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + E, 0xf, 0xf, true));
+}
+
 template <int KP>
 __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
-                                                             const _Float16* __restrict__ M16, const float* __restrict__ Mt,
+                                                             int n64, int n32, const _Float16* __restrict__ M16,
+                                                             const float* __restrict__ Mt,
                                                              const unsigned* __restrict__ flags, int loss_slot0) {
   using SM = LrSmem<KP>;
   constexpr int NP = SM::NP, LD = kLrLd, LS = kLrLs, LH = kLrLh;
@@ -172,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
   float* sQ = sC + NP;                   // [NP] sqrt(c - 1)
   float* sH = sQ + NP;                   // [NP] h = W g, then sqrt(c - 1) z
   float* sT = sH + NP;                   // [NP] spare
-  float* sGv = sT + NP;                  // [KP] g
-  float* sQv = sGv + KP;                 // [KP] q
-  float* sY = sQv + KP;                  // [KP] y (two partial halves are added through sP)
-  float* sP = sY + KP;                   // [KP] second half of y
-  double* sRed = reinterpret_cast<double*>(sP + KP);   // [8]
+  float* sGv = sT + NP;                  // [4][KP] g of the pass's rows
+  float* sQv = sGv + 4 * KP;             // [4][KP] q
+  float* sY = sQv + 4 * KP;              // [4][KP] y (two partial halves are added through sP)
+  float* sP = sY + 4 * KP;               // [4][KP] second half of y
+  double* sRed = reinterpret_cast<double*>(sP + 4 * KP);   // [8]
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   const int k = a.k;
@@ -186,81 +199,100 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
   const int ex = lr_scale_exp(fmaxf(__uint_as_float(flags[-2]), 1e-30f)), eM = (int)flags[1];
   const float sx = lr_pow2(ex), inv_xm = lr_pow2(254 - ex) * lr_pow2(254 - eM);   // 2^-(ex - 127) * 2^-(eM - 127)
 
-  // B operand of V' = X_nnz M for this wave's column block: M[kk][32 wv + col], kk = 2 t + half; M is upper
-  // triangular: nothing below row 32 (wv + 1).  Re-read from L2 for every row: keeping the 64 registers for the whole launch
-  // (or across the gather) spills.
+  // the passes: [0, P64) one row each, [P64, P64 + P32) two rows, then four; the list is longest first
+  const int n16 = n_rows - n64 - n32;
+  const int P64 = n64, P32 = (n32 + 1) >> 1, P16 = (n16 + 3) >> 2, n_pass = P64 + P32 + P16;
+  // slot -> (row of the pass, non-zero of the row) for pass pp: lsh = log2(slots per row); li = list index of this lane's row
+  struct PassGeo { int lsh, li, lim; };
+  auto geo = [&](const int pp) {
+    PassGeo g;
+    if (pp < P64) { g.lsh = 6; g.li = pp; g.lim = n64; }
+    else if (pp < P64 + P32) { g.lsh = 5; g.li = n64 + 2 * (pp - P64) + (lane >> 5); g.lim = n64 + n32; }
+    else { g.lsh = 4; g.li = n64 + n32 + 4 * (pp - P64 - P32) + (lane >> 4); g.lim = n_rows; }
+    if (pp >= n_pass) g.lim = 0;
+    return g;
+  };
 
   double wloss = 0.0;
-  // Row metadata runs ahead of the solves so that the gather of a row is ONE memory round trip (it was a chain of four:
-  // row id -> pointers -> index -> vector, and that per vector): the row id three rows ahead, its pointers two ahead,
-  // its indices and confidences (lane j holds non-zero j) one ahead.
+  // Row metadata runs ahead of the solves so that the gather of a pass is ONE memory round trip (it was a chain of four:
+  // row id -> pointers -> index -> vector, and that per vector): the row ids three passes ahead, their pointers two ahead,
+  // the indices and confidences (lane j holds slot j) one ahead.  All per lane: lane j works for the row of slot j.
   const int G = gridDim.x;
   int it = blockIdx.x;
-  int row_c = 0, p1_c = 0, n_c = 0, row_n = 0, p1_n = 0, n_n = 0, row_nn = 0;
-  if (it < n_rows) {
-    row_c = rows[it];
-    p1_c = a.col_ptrs[row_c];
-    n_c = a.col_ptrs[row_c + 1] - p1_c;
-  }
-  if (it + G < n_rows) {
-    row_n = rows[it + G];
-    p1_n = a.col_ptrs[row_n];
-    n_n = a.col_ptrs[row_n + 1] - p1_n;
-  }
-  if (it + 2 * G < n_rows) row_nn = rows[it + 2 * G];
+  int rid_c = -1, n_c = 0, rid_n = -1, p1_n = 0, n_n = 0, rid_nn = -1;
   int id_c = 0;
   float c_c = 1.f;
-  if (it < n_rows && lane < n_c) {
-    id_c = a.row_idx[p1_c + lane];
-    c_c = a.vals[p1_c + lane];
+  {
+    const PassGeo g0 = geo(it), g1 = geo(it + G), g2 = geo(it + 2 * G);
+    int p1_c = 0;
+    if (g0.li < g0.lim) {
+      rid_c = rows[g0.li];
+      p1_c = a.col_ptrs[rid_c];
+      n_c = a.col_ptrs[rid_c + 1] - p1_c;
+    }
+    if (g1.li < g1.lim) {
+      rid_n = rows[g1.li];
+      p1_n = a.col_ptrs[rid_n];
+      n_n = a.col_ptrs[rid_n + 1] - p1_n;
+    }
+    if (g2.li < g2.lim) rid_nn = rows[g2.li];
+    const int nz = lane & ((1 << g0.lsh) - 1);
+    if (nz < n_c) {
+      id_c = a.row_idx[p1_c + nz];
+      c_c = a.vals[p1_c + nz];
+    }
   }
-  for (int rot = 0; it < n_rows; it += G, rot++) {
-    const int row = rfl(row_c);
-    const int p1 = rfl(p1_c), n = rfl(n_c);   // 1 <= n <= 64 (launcher)
-    const int nrt = n <= 32 ? 1 : 2;   // 32-row tiles
-    __syncthreads();                   // the previous row's buffers are free
-    // requests for the rows to come (consumed at the bottom of this iteration)
-    int id_nx = 0, p1_nn = 0, n_nn = 0, row_n3 = 0;
+  for (; it < n_pass; it += G) {
+    const int lsh = it < P64 ? 6 : (it < P64 + P32 ? 5 : 4);   // log2 of the slots per row
+    const int nz_c = lane & ((1 << lsh) - 1);
+    const bool valid = nz_c < n_c;
+    const unsigned long long vmask = __ballot(valid);
+    const int nrt = (vmask >> 32) ? 2 : 1;   // 32-slot tiles in use
+    __syncthreads();                   // the previous pass's buffers are free
+    // requests for the passes to come (consumed at the bottom of this iteration)
+    int id_nx = 0, p1_nn = 0, n_nn = 0, rid_n3 = -1;
     float c_nx = 1.f;
     {
-      const int p1n = rfl(p1_n), nn = rfl(n_n);
-      if (it + G < n_rows && lane < nn) {
-        id_nx = a.row_idx[p1n + lane];
-        c_nx = a.vals[p1n + lane];
+      const PassGeo g1 = geo(it + G), g3 = geo(it + 3 * G);
+      const int nz1 = lane & ((1 << g1.lsh) - 1);
+      if (nz1 < n_n) {
+        id_nx = a.row_idx[p1_n + nz1];
+        c_nx = a.vals[p1_n + nz1];
       }
-      if (it + 2 * G < n_rows) {
-        const int rnn = rfl(row_nn);
-        p1_nn = a.col_ptrs[rnn];
-        n_nn = a.col_ptrs[rnn + 1] - p1_nn;
+      if (rid_nn >= 0) {
+        p1_nn = a.col_ptrs[rid_nn];
+        n_nn = a.col_ptrs[rid_nn + 1] - p1_nn;
       }
-      if (it + 3 * G < n_rows) row_n3 = rows[it + 3 * G];
+      if (g3.li < g3.lim) rid_n3 = rows[g3.li];
     }
-    // 1. gather: wave w takes vectors w, w + 4, ...; a lane copies 2 floats of each.  All of a wave's loads are issued
-    // before the first LDS store (slots past the row repeat its last vector and are stored as zeros).
+    // 1. gather: wave w takes slots w, w + 4, ...; a lane copies 2 floats of each.  All of a wave's loads are issued
+    // before the first LDS store (empty slots are stored as zeros).
     {
       float2 v[16];
       const bool on = !(RSP_LR_ABL & 32);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const int id = __builtin_amdgcn_readlane(id_c, min(wv + 4 * u, n - 1));
-        v[u] = (on && 2 * lane < k) ? *reinterpret_cast<const float2*>(a.X + (size_t)id * k + 2 * lane) : float2{0.f, 0.f};
+        const int j = wv + 4 * u;
+        const int id = __builtin_amdgcn_readlane(id_c, j);
+        v[u] = (on && ((vmask >> j) & 1) && 2 * lane < k) ? *reinterpret_cast<const float2*>(a.X + (size_t)id * k + 2 * lane) : float2{0.f, 0.f};
       }
       if (nrt == 2) {
 #pragma unroll
         for (int u = 8; u < 16; u++) {
-          const int id = __builtin_amdgcn_readlane(id_c, min(wv + 4 * u, n - 1));
-          v[u] = (on && 2 * lane < k) ? *reinterpret_cast<const float2*>(a.X + (size_t)id * k + 2 * lane) : float2{0.f, 0.f};
+          const int j = wv + 4 * u;
+          const int id = __builtin_amdgcn_readlane(id_c, j);
+          v[u] = (on && ((vmask >> j) & 1) && 2 * lane < k) ? *reinterpret_cast<const float2*>(a.X + (size_t)id * k + 2 * lane) : float2{0.f, 0.f};
         }
       }
-      if (wv == 0 && lane < 32 * nrt) {
+      if (wv == 0) {
         const float c = on ? c_c : 1.f;
-        sC[lane] = lane < n ? c : 0.f;
-        sQ[lane] = lane < n ? sqrtf(fmaxf(c - 1.f, 0.f)) : 0.f;
+        sC[lane] = valid ? c : 0.f;
+        sQ[lane] = valid ? sqrtf(fmaxf(c - 1.f, 0.f)) : 0.f;
       }
       auto put = [&](const int u) {
         const int j = wv + 4 * u;
         unsigned hi = 0u, lo = 0u;
-        if (j < n) lr_split(v[u].x * sx, v[u].y * sx, hi, lo);
+        if ((vmask >> j) & 1) lr_split(v[u].x * sx, v[u].y * sx, hi, lo);
         *reinterpret_cast<unsigned*>(sXh + j * LH + 2 * lane) = hi;
         *reinterpret_cast<unsigned*>(sXl + j * LH + 2 * lane) = lo;
       };
@@ -313,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
     for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
     if (lane == 0) sT[wv] = wmax;
     __syncthreads();   // V' complete, every wave is done with the fp16 terms of X_nnz
-    // 2b. the fp16 terms of W = D^1/2 V' * 2^ew over the X_nnz terms (thread t: row t / 4, 32 columns)
+    // 2b. the fp16 terms of W = D^1/2 V' * 2^ew over the X_nnz terms (thread t: slot t / 4, 32 columns)
     const int ew = lr_scale_exp(fmaxf(fmaxf(fmaxf(sT[0], sT[1]), fmaxf(sT[2], sT[3])), 1e-30f));
     if (!(RSP_LR_ABL & 2)) {
       const int j = tid >> 2, part = tid & 3;
@@ -329,31 +361,37 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
         }
       }
     }
-    // 3. g = V'^T c
-    if (tid < KP) {
-      float s = 0.f;
-      for (int j = 0; j < n; j++) s = fmaf(sC[j], sV[j * LD + tid], s);
-      sGv[tid] = s;
+    // 3. g_r = V'_r^T c_r for the rows r of the pass: thread (t, hh) takes the rows r = hh, hh + 2
+    {
+      const int t = tid & (KP - 1), hh = tid >> 7, sl = 1 << lsh;
+      for (int r = hh; r < (64 >> lsh); r += 2) {
+        float s = 0.f;
+        const int j0 = r << lsh, j1 = min(j0 + sl, 32 * nrt);
+        for (int j = j0; j < j1; j++) s = fmaf(sC[j], sV[j * LD + t], s);
+        sGv[r * KP + t] = s;
+      }
     }
     __syncthreads();
-    // 4. h = D^1/2 V' g  (4 threads per row)
+    // 4. h = D^1/2 V' g  (4 threads per slot)
     {
       const int j = tid >> 2, part = tid & 3;
       float s = 0.f;
       if (j < 32 * nrt) {
         const float* vr = sV + j * LD + 32 * part;
+        const float* gr = sGv + (j >> lsh) * KP + 32 * part;
 #pragma unroll 8
-        for (int e = 0; e < 32; e++) s = fmaf(vr[e], sGv[32 * part + e], s);
+        for (int e = 0; e < 32; e++) s = fmaf(vr[e], gr[e], s);
       }
       s += __shfl_xor(s, 1);
       s += __shfl_xor(s, 2);
       if (part == 0 && j < NP) sH[j] = s * sQ[j];
     }
-    // 5. S = I + W W^T (lower tiles) on the matrix cores from the fp16 terms of W, then -> sS (over those terms)
+    // 5. S = I + W W^T (lower tiles) on the matrix cores from the fp16 terms of W, then -> sS (over those terms); entries
+    // between slots of different rows are dropped (the off-diagonal tile is such entries only unless the pass is one row)
     __syncthreads();   // the terms of W are complete (and g, h above have been formed from V')
     {
       const int rt = wv == 0 ? 0 : 1, ct = wv == 2 ? 1 : 0;
-      const bool mine = !(RSP_LR_ABL & 2) && wv < (nrt == 1 ? 1 : 3);
+      const bool mine = !(RSP_LR_ABL & 2) && wv < (nrt == 1 ? 1 : 3) && (lsh == 6 || wv != 1);
       f32x16 acc, acc2;
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[e] = acc2[e] = 0.f;
@@ -370,29 +408,29 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
         }
       }
       __syncthreads();   // every wave has read its operands: the region becomes S
+      const float inv_w2 = lr_pow2(254 - ew) * lr_pow2(254 - ew);
       if (mine) {
-        const float inv_w2 = lr_pow2(254 - ew) * lr_pow2(254 - ew);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int i = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * half, c2 = 32 * ct + col;
-          sS[i * LS + c2] = (i == c2 ? 1.f : 0.f) + (acc[e] + acc2[e]) * inv_w2;
+          const bool same = (i >> lsh) == (c2 >> lsh);
+          sS[i * LS + c2] = (i == c2 ? 1.f : 0.f) + (same ? (acc[e] + acc2[e]) * inv_w2 : 0.f);
         }
       }
     }
     __syncthreads();
-    // 6 + 7. z = S^-1 h by ONE wave, in registers: lane i holds row i of the (full, symmetric) matrix.  Right-looking
-    // LDL^T: at step j the pivot row is broadcast entry by entry (v_readlane of lane j's registers: S[c][j] = S[j][c]) and
-    // every lane updates its own row; the Schur complements stay symmetric, so at the end lane i holds, left of the
-    // diagonal, column values frozen at their pivot steps (row i of L times D) and, right of it, its own pivot row
-    // (column i of L times d_i) -- both triangular solves read nothing but the lane's own registers and broadcast scalars.
-    // The forward substitution rides along with the elimination.  No barriers, no LDS traffic after the row is loaded.
-    // (the solving wave rotates from row to row, offset by the workgroup: the two workgroups of a CU would otherwise both
-    // solve on the SIMD that holds their wave 0 while the other three idle)
-    if (!(RSP_LR_ABL & 4) && wv == ((blockIdx.x + rot) & 3)) {
+    // 6 + 7. z = S^-1 h by ONE wave, in registers, lane i = slot i.  Right-looking LDL^T: the Schur complements stay
+    // symmetric, so the pivot row's entry for column c is lane c of the pivot COLUMN's register, and at the end lane i holds,
+    // left of the diagonal, column values frozen at their pivot steps (row i of L times D) and, right of it, its own pivot row
+    // (column i of L times d_i) -- both triangular solves read nothing but the lane's own registers and broadcasts.  The
+    // forward substitution rides along with the elimination.  No barriers, no LDS traffic after the system is loaded.
+    if (!(RSP_LR_ABL & 4) && wv == ((blockIdx.x + (it / G)) & 3)) {
       int i = lane;
-      asm volatile("" : "+v"(i));   // laundered per row: hipcc otherwise hoists the 64 load addresses below out of the row loop and spills them
+      asm volatile("" : "+v"(i));   // laundered per pass: hipcc otherwise hoists the 64 load addresses below out of the loop and spills them
+      // one row of 33..64 non-zeros: the whole wave is one system
       auto solve = [&](auto np_tag) {
         constexpr int NS = decltype(np_tag)::value;
+        const int n = rfl(n_c);
         float r[NS];
 #pragma unroll
         for (int c = 0; c < NS; c++) r[c] = (i < n && c < n) ? sS[(i >= c ? i * LS + c : c * LS + i)] : (i == c ? 1.f : 0.f);
@@ -416,7 +454,9 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
             pj = readlane_f(r[j + 1], j + 1);
             if constexpr (j + 2 < NS) {
               float rep[4];
-              rows_to_all<(NS > 32 ? 4 : 2)>(r[j], rep);
+              dpp_ready(r[j]);
+              rows_to_all<4>(r[j], rep);
+              dpp_ready(rep[0], rep[1], rep[2], rep[3]);
               lr_sfor<NS - j - 2>([&](auto ct) {
                 constexpr int c = j + 2 + decltype(ct)::value;
                 fnma_row_bcast<c % 16>(r[c], rep[c / 16], lij);
@@ -434,43 +474,125 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
         }
         sH[i] = i < n ? z * sQ[i] : 0.f;   // D^1/2 z
       };
+      // packed rows: 64 / SL independent SL x SL systems, one per group of SL lanes; register t = column t OF THE GROUP.
+      // Every broadcast is local to the group: a DPP row broadcast (SL = 16: the group is one row of 16 lanes), or one
+      // v_permlane16_swap that lays the group's two rows side by side, then the row broadcast (SL = 32)
+      auto solve_packed = [&](auto sl_tag) {
+        constexpr int SL = decltype(sl_tag)::value;
+        const int il = i & (SL - 1), base = i - il;
+        const bool live = i < 32 * nrt;   // (the second tile of slots is not even computed when it is empty)
+        float r[SL];
+#pragma unroll
+        for (int t = 0; t < SL; t++) r[t] = live ? sS[(il >= t ? i * LS + base + t : (base + t) * LS + i)] : (il == t ? 1.f : 0.f);
+        float u = live ? sH[i] : 0.f;
+        float dinv = 1.f;
+        // lane t of the group, of the value v held one per lane
+        auto grp = [&](const float v, float (&rep)[2]) {
+          if constexpr (SL == 32) {
+            const unsigned uu = __float_as_uint(v);
+            const auto sw = __builtin_amdgcn_permlane16_swap(uu, uu, false, false);   // rows (0, 0, 2, 2) and (1, 1, 3, 3)
+            rep[0] = __uint_as_float(sw[0]);
+            rep[1] = __uint_as_float(sw[1]);
+          } else {
+            rep[0] = rep[1] = v;
+          }
+        };
+        lr_sfor<SL>([&](auto tt) {
+          constexpr int t = decltype(tt)::value;
+          float rep[2], ur[2];
+          dpp_ready(r[t], u);   // (both were last written by the FMAs of the step before, which hipcc cannot see into)
+          grp(r[t], rep);
+          grp(u, ur);
+          dpp_ready(rep[0], rep[1], ur[0], ur[1]);
+          const float pv = lr_row_bcast<t % 16>(rep[t / 16]);
+          const float inv = __builtin_amdgcn_rcpf(pv);
+          if (il == t) dinv = inv;
+          const float lij = il > t ? r[t] * inv : 0.f;
+          fnma_row_bcast<t % 16>(u, ur[t / 16], lij);
+          lr_sfor<SL - t - 1>([&](auto ct) {
+            constexpr int c = t + 1 + decltype(ct)::value;
+            fnma_row_bcast<c % 16>(r[c], rep[c / 16], lij);
+          });
+        });
+        float acc = 0.f, z = 0.f;
+        lr_sfor<SL>([&](auto tt) {
+          constexpr int c = SL - 1 - decltype(tt)::value;
+          if (il == c) z = (u - acc) * dinv;
+          float zr[2];
+          grp(z, zr);
+          dpp_ready(zr[0], zr[1]);
+          const float m = il < c ? -r[c] : 0.f;
+          fnma_row_bcast<c % 16>(acc, zr[c / 16], m);   // acc += r[c] z_c
+        });
+        sH[i] = live ? z * sQ[i] : 0.f;   // D^1/2 z (empty slots: sQ = 0)
+      };
       if (!(RSP_LR_ABL & 8)) {
-        if (n <= 16) solve(std::integral_constant<int, 16>{});
-        else if (n <= 32) solve(std::integral_constant<int, 32>{});
-        else if (n <= 48) solve(std::integral_constant<int, 48>{});
+        if (lsh == 4) solve_packed(std::integral_constant<int, 16>{});
+        else if (lsh == 5) solve_packed(std::integral_constant<int, 32>{});
+        else if (rfl(n_c) <= 48) solve(std::integral_constant<int, 48>{});
         else solve(std::integral_constant<int, NP>{});
       }
     }
     __syncthreads();
-    // 8. q = g - V'^T (D^1/2 z)
-    if (tid < KP) {
-      float s = sGv[tid];
-      for (int j = 0; j < n; j++) s = fmaf(-sH[j], sV[j * LD + tid], s);
-      sQv[tid] = s;
+    // 8. q_r = g_r - V'_r^T (D^1/2 z)_r
+    {
+      const int t = tid & (KP - 1), hh = tid >> 7, sl = 1 << lsh;
+      for (int r = hh; r < (64 >> lsh); r += 2) {
+        float s = sGv[r * KP + t];
+        const int j0 = r << lsh, j1 = min(j0 + sl, 32 * nrt);
+        for (int j = j0; j < j1; j++) s = fmaf(-sH[j], sV[j * LD + t], s);
+        sQv[r * KP + t] = s;
+      }
     }
     __syncthreads();
-    // 9. y = M q = sum_j Mt[j][.] q_j  (rows of Mt are coalesced; the two halves of the workgroup split j)
+    // 9. y_r = M q_r = sum_j Mt[j][.] q_r[j]  (rows of Mt are coalesced and read once for all rows of the pass; the two halves of
+    // the workgroup split j)
     {
-      const int i = tid & (KP - 1), hj = tid >> 7;
-      const float* Mtp = Mt + (size_t)(64 * hj) * KP + i;
+      const int i2 = tid & (KP - 1), hj = tid >> 7;
+      const float* Mtp = Mt + (size_t)(64 * hj) * KP + i2;
       asm volatile("" : "+v"(Mtp));   // (opaque: these loads must not be hoisted out of the row loop either)
-      float s = 0.f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
       for (int j0 = 0; j0 < ((RSP_LR_ABL & 16) ? 0 : 64); j0 += 32) {   // 32 independent L2 reads in flight per thread
         float m[32];
 #pragma unroll
         for (int e = 0; e < 32; e++) m[e] = Mtp[(size_t)(j0 + e) * KP];
+        const float* qv = sQv + 64 * hj + j0;
+        if (lsh == 6) {
 #pragma unroll
-        for (int e = 0; e < 32; e++) s = fmaf(m[e], sQv[64 * hj + j0 + e], s);
+          for (int e = 0; e < 32; e++) s0 = fmaf(m[e], qv[e], s0);
+        } else if (lsh == 5) {
+#pragma unroll
+          for (int e = 0; e < 32; e++) {
+            s0 = fmaf(m[e], qv[e], s0);
+            s1 = fmaf(m[e], qv[KP + e], s1);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 32; e++) {
+            s0 = fmaf(m[e], qv[e], s0);
+            s1 = fmaf(m[e], qv[KP + e], s1);
+            s2 = fmaf(m[e], qv[2 * KP + e], s2);
+            s3 = fmaf(m[e], qv[3 * KP + e], s3);
+          }
+        }
       }
-      (hj ? sP : sY)[i] = s;
+      float* dst = (hj ? sP : sY) + i2;
+      dst[0] = s0; dst[KP] = s1; dst[2 * KP] = s2; dst[3 * KP] = s3;
     }
     __syncthreads();
     float lt = 0.f, yy = 0.f;
     if (tid < KP) {
-      const float y = sY[tid] + sP[tid];
-      if (tid < k) a.Y[(size_t)row * k + tid] = y;
-      yy = tid < k ? y * y : 0.f;
+      for (int r = 0; r < (64 >> lsh); r++) {
+        const int rid = __builtin_amdgcn_readlane(rid_c, r << lsh);
+        if (rid >= 0) {
+          const float y = sY[r * KP + tid] + sP[r * KP + tid];
+          if (tid < k) {
+            a.Y[(size_t)rid * k + tid] = y;
+            yy = fmaf(y, y, yy);
+          }
+        }
+      }
     }
     // 10. loss: x_j . y = v_j . q
     {
@@ -478,22 +600,23 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
       float s = 0.f;
       if (j < 32 * nrt) {
         const float* vr = sV + j * LD + 32 * part;
+        const float* qr = sQv + (j >> lsh) * KP + 32 * part;
 #pragma unroll 8
-        for (int e = 0; e < 32; e++) s = fmaf(vr[e], sQv[32 * part + e], s);
+        for (int e = 0; e < 32; e++) s = fmaf(vr[e], qr[e], s);
       }
       s += __shfl_xor(s, 1);
       s += __shfl_xor(s, 2);
-      if (part == 0 && j < n) {
+      if (part == 0 && j < 32 * nrt) {
         const float dlt = 1.f - s;
-        lt = sC[j] * dlt * dlt;
+        lt = sC[j] * dlt * dlt;   // (empty slots: c = 0)
       }
     }
     const float lsum = wave_sum(lt), ysum = wave_sum(yy);
     if (lane == 0) wloss += (double)lsum + a.lambda_loss * (double)ysum;
     // shift the look-ahead
-    row_c = row_n; p1_c = p1_n; n_c = n_n;
-    row_n = row_nn; p1_n = p1_nn; n_n = n_nn;
-    row_nn = row_n3;
+    rid_c = rid_n; n_c = n_n;
+    rid_n = rid_nn; p1_n = p1_nn; n_n = n_nn;
+    rid_nn = rid_n3;
     id_c = id_nx; c_c = c_nx;
   }
   __syncthreads();
@@ -515,6 +638,13 @@ bool chol_lr_supported(const AlsArgs& a, bool implicit) {
 // prep kernel ORs its own verdict into word 2.  Loss partials of its kCholLrGrid workgroups from loss_slot0 on.
 hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows, float* M, float* Mt, unsigned* flags,
                               int loss_slot0, hipStream_t s, hipEvent_t* ev_slot) {
+  // the list is longest first: lr_n_gt32 rows of 33..64 non-zeros, then (lr_n_gt16 - lr_n_gt32) of 17..32, then the rest;
+  // without the counts every row is a pass of its own
+  int n64 = n_rows, n32 = 0;
+  if (a.lr_n_gt32 >= 0 && a.lr_n_gt16 >= a.lr_n_gt32 && a.lr_n_gt16 <= n_rows) {
+    n64 = a.lr_n_gt32;
+    n32 = a.lr_n_gt16 - a.lr_n_gt32;
+  }
   hipError_t err;
   if ((err = hipMemsetAsync(a.loss_partials + loss_slot0, 0, (size_t)kCholLrGrid * sizeof(double), s)) != hipSuccess)
     return err;
@@ -531,9 +661,10 @@ hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows,
   if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)LrSmem<KP>::bytes)) != hipSuccess)
     return err;
-  const int grid = n_rows < kCholLrGrid ? n_rows : kCholLrGrid;
+  const int n_pass = n64 + (n32 + 1) / 2 + (n_rows - n64 - n32 + 3) / 4;
+  const int grid = n_pass < kCholLrGrid ? n_pass : kCholLrGrid;
   prof_note(ev_slot, reinterpret_cast<const void*>(kern));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LrSmem<KP>::bytes, s, a, rows, n_rows,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LrSmem<KP>::bytes, s, a, rows, n_rows, n64, n32,
                      reinterpret_cast<const _Float16*>(M), Mt, flags, loss_slot0);
   return hipGetLastError();
 }

@@ -42,6 +42,15 @@ template <int E>
 __device__ __forceinline__ void fnma_row_bcast(float& acc, const float u, const float l) {
   asm("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(l), "n"(E));
 }
+// A register that a DPP operand (or a lane swap) is about to read must not have been written by the one or two vector
+// instructions before it (2 wait states).  hipcc inserts them between instructions it knows; it does not look inside inline
+// asm, neither as the writer nor as the reader -- these tie an s_nop to the registers (the asm "rewrites" them, so the real
+// writers stay in front of it and the readers behind).
+__device__ __forceinline__ void dpp_ready(float& a) { asm("s_nop 1" : "+v"(a)); }
+__device__ __forceinline__ void dpp_ready(float& a, float& b) { asm("s_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void dpp_ready(float& a, float& b, float& c, float& d) {
+  asm("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 // rep[g] = row g (lanes 16 g .. 16 g + 15) of v in every row of 16 lanes, g < NG (two or three lane-swap instructions)
 template <int NG>
 __device__ __forceinline__ void rows_to_all(const float v, float (&rep)[4]) {

@@ -96,6 +96,41 @@ def test_cholesky_half_iteration(k, implicit):
     assert abs(loss - lref) <= TOL * abs(lref)
 
 
+def _rows_of_lengths(lengths, n_item, k, seed, scale=0.3):
+    """a CSC (columns = the rows to solve) whose column j has lengths[j] distinct random items, confidences >= 1"""
+    rng = np.random.default_rng(seed)
+    p = np.zeros(len(lengths) + 1, dtype=np.int32)
+    p[1:] = np.cumsum(lengths)
+    idx = np.concatenate([np.sort(rng.choice(n_item, size=int(n), replace=False)) for n in lengths] or [np.zeros(0)]).astype(np.int32)
+    x = (1.0 + rng.gamma(1.0, 2.0, size=idx.size)).astype(np.float32).astype(np.float64)
+    X = np.asfortranarray((rng.standard_normal((k, n_item)) * scale).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, len(lengths))) * scale).astype(np.float32))
+    return (n_item, len(lengths), p, idx, x), X, Y0
+
+
+@pytest.mark.parametrize("k", [128, 100])
+@pytest.mark.parametrize("classes", ["short5", "mid3", "short+long", "all", "one"])
+def test_cholesky_short_rows_share_a_pass(k, classes):
+    """wrmf_chol_lr.hip packs four rows of <= 16 non-zeros / two of <= 32 into one pass: class sizes that are not multiples
+    of the packing, empty classes, the class boundaries (16 / 17, 32 / 33, 64 / 65) and empty rows in between"""
+    rng = np.random.default_rng(7)
+    lens = {
+        "short5": [16, 1, 9, 16, 3],
+        "mid3": [17, 32, 25],
+        "short+long": [16, 15, 2, 1, 1, 1, 40, 64, 33, 65, 130, 0],
+        "all": list(rng.integers(0, 70, size=301)) + [16, 17, 32, 33, 64, 65],
+        "one": [7],
+    }[classes]
+    csc, X, Y0 = _rows_of_lengths(np.asarray(lens, dtype=np.int64), 400, k, seed=11 + k)
+    lam = 0.1
+    Yref, lref = _oracle64(csc, X, Y0, lam, 0, 3, True)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, lam, 1, 0, 3, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, (int(np.argmax(err)), lens[int(np.argmax(err))])
+    assert abs(loss - lref) <= TOL * abs(lref)
+
+
 @pytest.mark.parametrize("k", [128, 96, 64, 20])
 @pytest.mark.parametrize("implicit", [True, False])
 def test_cg_long_rows_all_buckets(k, implicit):

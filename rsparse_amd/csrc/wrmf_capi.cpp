@@ -273,9 +273,14 @@ int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_pt
   int dev = 0, cus = 256;
   HIP_TRY(hipGetDevice(&dev));
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  // two lists per CU: the rank-128 fp16 kernel runs two workgroups per CU; the one-per-CU kernels work through two
-  // lists each, one after the other
-  const int n_wg = std::min(n_prefix, 2 * std::max(cus, 1));
+  // Many more lists than workgroup slots (eight rows or more per list, up to 256 lists per CU; two workgroups of the
+  // rank-128 fp16 kernel are resident per CU): the
+  // hardware hands the next list to whichever slot frees up.  With exactly one list per slot the launch ended 13 % after
+  // its mean workgroup (round 3, in-kernel counters): of the two workgroups that share a CU's SIMDs the one dispatched
+  // first wins the issue arbitration and runs 27 % faster -- every workgroup of index < 256 took 63.9 M ticks for its
+  // list, every one of index >= 256 81.4 M for an equal list, the last 17 M of them alone on its CU.
+  const int n_slots = std::min(n_prefix, 2 * std::max(cus, 1));           // what the share of the split rule refers to
+  const int n_wg = std::max(n_slots, std::min(n_prefix / 8, 256 * std::max(cus, 1)));
   // Items of the deal: whole rows, and SEGMENTS of the rows that are too long to balance (the 5e5-non-zero item of the
   // bench matrix is by itself an average workgroup's share; on a rank of an 8-GPU run it is eight shares).  A row
   // whose cost exceeds half a share is cut into up to kNeMaxSeg runs of whole steps of about a quarter share; the
@@ -285,7 +290,7 @@ int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_pt
   auto steps_of = [](int64_t len) { return (len + 15) / 16; };
   int64_t total = 0;
   for (int r = 0; r < n_prefix; r++) total += steps_of(len_of(r)) + fixed;
-  const int64_t share = std::max<int64_t>(1, total / n_wg);
+  const int64_t share = std::max<int64_t>(1, total / n_slots);
   struct Item { int64_t cost; int32_t entry; };
   std::vector<Item> items;
   items.reserve((size_t)n_prefix + 64);
@@ -295,7 +300,7 @@ int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_pt
     const int64_t len = len_of(r);
     const int64_t st = steps_of(len);
     int parts = 1;
-    if (n_wg >= 8 && 2 * (st + fixed) > share) parts = (int)std::min<int64_t>(kNeMaxSeg, (4 * st + share - 1) / share);
+    if (n_slots >= 8 && 2 * (st + fixed) > share) parts = (int)std::min<int64_t>(kNeMaxSeg, (4 * st + share - 1) / share);
     if (parts < 2 || n_seg + parts > kNeMaxSegTotal) {
       items.push_back({st + fixed, order[(size_t)r]});
       continue;
@@ -573,8 +578,8 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   }
 #ifdef RSP_NE_PROF
   static unsigned long long* prof_buf = nullptr;
-  if (!prof_buf) { HIP_TRY(hipMalloc(&prof_buf, 1024 * 4 * 20 * 8)); }
-  HIP_TRY(hipMemsetAsync(prof_buf, 0, 1024 * 4 * 20 * 8, s));
+  if (!prof_buf) { HIP_TRY(hipMalloc(&prof_buf, (size_t)65536 * 4 * 20 * 8)); }
+  HIP_TRY(hipMemsetAsync(prof_buf, 0, (size_t)65536 * 4 * 20 * 8, s));
   a.ne_prof = prof_buf;
 #endif
   // ranks the normal-equation kernel does not take (<= 32): the streamed CG bucket keeps its per-sweep dot products in
@@ -633,6 +638,15 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
         std::fprintf(stderr, " %s %.2f/%.2f", nm[j], sum / qs.ne_wg / 1e6, mx / 1e6);
       }
       std::fprintf(stderr, " Mcycles (mean/max over %d workgroups)\n", qs.ne_wg);
+    }
+    if (const char* dump = std::getenv("RSPARSE_NE_PROF_DUMP")) {   // per workgroup: total, rows, consume, wait_vm of wave 0
+      if (FILE* f = std::fopen(dump, "a")) {
+        std::fprintf(f, "# launch n_cols %d wgs %d\n", d.n_cols, qs.ne_wg);
+        for (int b = 0; b < qs.ne_wg; b++)
+          std::fprintf(f, "%d %llu %llu %llu %llu\n", b, hp[((size_t)b * 4) * 20 + 5], hp[((size_t)b * 4) * 20 + 6],
+                       hp[((size_t)b * 4) * 20 + 3], hp[((size_t)b * 4) * 20 + 0]);
+        std::fclose(f);
+      }
     }
   }
 #endif

@@ -194,7 +194,7 @@ constexpr int kCholLongLen = 4096;
 constexpr int kCholLongGrid = 512;
 // rows of 1..kCholLrMax non-zeros, implicit feedback, rank 98..128: the low-rank form of the exact solve (wrmf_chol_lr.hip)
 constexpr int kCholLrMax = 64;
-constexpr int kCholLrGrid = 512;
+constexpr int kCholLrGrid = 65536;   // (many more than workgroup slots: the hardware deals them as slots free up, see build_ne_lists)
 size_t chol2_loss_slots(int n_cols);
 bool chol_lr_supported(const AlsArgs& a, bool implicit);
 hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows, float* M, float* Mt, unsigned* flags,

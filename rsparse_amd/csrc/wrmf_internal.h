@@ -179,7 +179,7 @@ constexpr int kWavesPerWG = 4;
 constexpr int kRowsPerWGShort = 64;  // rows handed to one short-row workgroup
 constexpr int kRowsPerWGLong = 8;    // rows handed to one long-row workgroup
 
-constexpr int kCholMaxGrid = 256 * 8;  // Cholesky workgroups (grid-stride over rows)
+constexpr int kCholMaxGrid = 256 * 96;  // Cholesky / NNLS workgroups (grid-stride over rows); many more than slots (3 per CU): the hardware deals them as slots free up
 
 // number of loss partial slots each launcher writes
 size_t cg_loss_slots(int n_cols, int n_long);

@@ -263,7 +263,8 @@ struct NeLists {
 
 // Lists of the normal-equation launch over the n_prefix longest rows (order = every row, longest first); `fixed` = the
 // per-row cost of the solve in 16-non-zero steps (CG: 12; the exact solve of solver == CHOLESKY: 72).
-int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_ptrs, int n_prefix, int64_t fixed, NeLists& L) {
+int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_ptrs, int n_prefix, int64_t fixed, NeLists& L,
+                   bool fine = true) {
   if (n_prefix <= 0) return RSPARSE_HIP_OK;
   auto len_of = [&](int r) { return (int64_t)(host_col_ptrs[order[(size_t)r] + 1] - host_col_ptrs[order[(size_t)r]]); };
   {
@@ -280,7 +281,9 @@ int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_pt
   // first wins the issue arbitration and runs 27 % faster -- every workgroup of index < 256 took 63.9 M ticks for its
   // list, every one of index >= 256 81.4 M for an equal list, the last 17 M of them alone on its CU.
   const int n_slots = std::min(n_prefix, 2 * std::max(cus, 1));           // what the share of the split rule refers to
-  const int n_wg = std::max(n_slots, std::min(n_prefix / 8, 256 * std::max(cus, 1)));
+  // (`fine` = false: one list per slot, for the kernels that are resident once per CU -- no such asymmetry there, and a
+  //  workgroup start costs more: XtX tiles into LDS; many short lists cost them 1..7 %)
+  const int n_wg = fine ? std::max(n_slots, std::min(n_prefix / 8, 256 * std::max(cus, 1))) : n_slots;
   // Items of the deal: whole rows, and SEGMENTS of the rows that are too long to balance (the 5e5-non-zero item of the
   // bench matrix is by itself an average workgroup's share; on a rank of an 8-GPU run it is eight shares).  A row
   // whose cost exceeds half a share is cut into up to kNeMaxSeg runs of whole steps of about a quarter share; the
@@ -367,6 +370,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   d.q_order = nullptr;
   d.q_stream_off = nullptr;
   d.q_ne_rows = nullptr; d.q_ne_ptr = nullptr; d.q_ne_wg = 0;
+  d.q_ne1_rows = nullptr; d.q_ne1_ptr = nullptr; d.q_ne1_wg = 0;
   d.q_ne_segs = nullptr; d.q_ne_nseg = 0; d.q_ne_entries = 0;
   d.q_ne_split_rows = nullptr; d.q_ne_split_ptr = nullptr; d.q_ne_nsplit = 0;
   d.q_nec_rows = nullptr; d.q_nec_ptr = nullptr; d.q_nec_wg = 0; d.q_nec_segs = nullptr; d.q_nec_nseg = 0; d.q_nec_entries = 0;
@@ -414,6 +418,13 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     if (int rc2 = build_ne_lists(order, host_col_ptrs, n_stream, 12, L)) return rc2;
     d.q_ne_rows = L.rows; d.q_ne_ptr = L.ptr; d.q_ne_wg = L.wg; d.q_ne_segs = L.segs; d.q_ne_nseg = L.nseg;
     d.q_ne_entries = L.entries; d.q_ne_split_rows = L.split_rows; d.q_ne_split_ptr = L.split_ptr; d.q_ne_nsplit = L.nsplit;
+    // the same rows and segments as one list per workgroup slot, for the ranks whose kernel is resident once per CU
+    NeLists L1;
+    if (int rc2 = build_ne_lists(order, host_col_ptrs, n_stream, 12, L1, false)) return rc2;
+    d.q_ne1_rows = L1.rows; d.q_ne1_ptr = L1.ptr; d.q_ne1_wg = L1.wg;
+    if (L1.segs) (void)hipFree(L1.segs);   // (identical to the tables above: the deal does not change the cut)
+    if (L1.split_rows) (void)hipFree(L1.split_rows);
+    if (L1.split_ptr) (void)hipFree(L1.split_ptr);
   }
   // solver == CHOLESKY: its normal-equation launch may take shorter rows too (RSPARSE_HIP_NE_CHOL_MIN, 64..512)
   d.q_nec_min = kNeCholMinLen;
@@ -501,7 +512,10 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   qs.cfg = d.q_cfg;
   qs.pair_first = d.q_pair_first;
   for (int b = 0; b < 7; b++) qs.off[b] = d.q_off[b];
-  qs.ne_rows = d.q_ne_rows; qs.ne_ptr = d.q_ne_ptr; qs.ne_wg = d.q_ne_wg; qs.ne_entries = d.q_ne_entries;
+  // (two workgroups per CU only for implicit feedback at rank 97..128: the fp16 QUAD kernel of wrmf_ne.hip)
+  const bool ne_fine = implicit && padded_rank(rank) == 128;
+  qs.ne_rows = ne_fine ? d.q_ne_rows : d.q_ne1_rows; qs.ne_ptr = ne_fine ? d.q_ne_ptr : d.q_ne1_ptr;
+  qs.ne_wg = ne_fine ? d.q_ne_wg : d.q_ne1_wg; qs.ne_entries = d.q_ne_entries;
   qs.ne_split_rows = d.q_ne_split_rows; qs.ne_split_ptr = d.q_ne_split_ptr; qs.ne_nsplit = d.q_ne_nsplit;
   // solver == CHOLESKY: the rows beyond 512 non-zeros are assembled by the normal-equation kernel (matrix cores, one pass)
   // and solved exactly there (a.ne_chol); wrmf_chol.hip's kernel then skips them
@@ -1032,6 +1046,8 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
   if (d.q_order) (void)hipFree(d.q_order);
   if (d.q_stream_off) (void)hipFree(d.q_stream_off);
   if (d.q_ne_rows) (void)hipFree(d.q_ne_rows);
+  if (d.q_ne1_rows) (void)hipFree(d.q_ne1_rows);
+  if (d.q_ne1_ptr) (void)hipFree(d.q_ne1_ptr);
   if (d.q_ne_ptr) (void)hipFree(d.q_ne_ptr);
   if (d.q_ne_segs) (void)hipFree(d.q_ne_segs);
   if (d.q_ne_split_rows) (void)hipFree(d.q_ne_split_rows);

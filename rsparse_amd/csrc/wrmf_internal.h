@@ -35,6 +35,9 @@ struct DevCSC {
   int32_t* q_ne_rows = nullptr;
   int32_t* q_ne_ptr = nullptr;
   int q_ne_wg = 0;
+  int32_t* q_ne1_rows = nullptr;   // the same rows dealt to one list per workgroup slot (kernels resident once per CU)
+  int32_t* q_ne1_ptr = nullptr;
+  int q_ne1_wg = 0;
   int32_t* q_ne_segs = nullptr;   // [q_ne_nseg][6]: segments of the rows split across workgroups (wrmf_capi.cpp)
   int q_ne_nseg = 0;
   int q_ne_entries = 0;           // list entries = rows that are not split + segments

@@ -365,10 +365,19 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
     {
       const int t = tid & (KP - 1), hh = tid >> 7, sl = 1 << lsh;
       for (int r = hh; r < (64 >> lsh); r += 2) {
-        float s = 0.f;
-        const int j0 = r << lsh, j1 = min(j0 + sl, 32 * nrt);
-        for (int j = j0; j < j1; j++) s = fmaf(sC[j], sV[j * LD + t], s);
-        sGv[r * KP + t] = s;
+        // (eight slots per trip, their reads issued together: one read-wait-FMA per slot made these two loops -- this one and
+        //  step 8 -- a fifth of the pass)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const int j0 = r << lsh, j1 = min(j0 + sl, 32 * nrt);   // (multiples of 16)
+        for (int j = j0; j < j1; j += 8) {
+          const float4 ca = *reinterpret_cast<const float4*>(sC + j), cb = *reinterpret_cast<const float4*>(sC + j + 4);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = sV[(j + e) * LD + t];
+          s0 = fmaf(ca.x, v[0], s0); s1 = fmaf(ca.y, v[1], s1); s2 = fmaf(ca.z, v[2], s2); s3 = fmaf(ca.w, v[3], s3);
+          s0 = fmaf(cb.x, v[4], s0); s1 = fmaf(cb.y, v[5], s1); s2 = fmaf(cb.z, v[6], s2); s3 = fmaf(cb.w, v[7], s3);
+        }
+        sGv[r * KP + t] = (s0 + s1) + (s2 + s3);
       }
     }
     __syncthreads();
@@ -538,10 +547,17 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
     {
       const int t = tid & (KP - 1), hh = tid >> 7, sl = 1 << lsh;
       for (int r = hh; r < (64 >> lsh); r += 2) {
-        float s = sGv[r * KP + t];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         const int j0 = r << lsh, j1 = min(j0 + sl, 32 * nrt);
-        for (int j = j0; j < j1; j++) s = fmaf(-sH[j], sV[j * LD + t], s);
-        sQv[r * KP + t] = s;
+        for (int j = j0; j < j1; j += 8) {
+          const float4 ha = *reinterpret_cast<const float4*>(sH + j), hb = *reinterpret_cast<const float4*>(sH + j + 4);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = sV[(j + e) * LD + t];
+          s0 = fmaf(ha.x, v[0], s0); s1 = fmaf(ha.y, v[1], s1); s2 = fmaf(ha.z, v[2], s2); s3 = fmaf(ha.w, v[3], s3);
+          s0 = fmaf(hb.x, v[4], s0); s1 = fmaf(hb.y, v[5], s1); s2 = fmaf(hb.z, v[6], s2); s3 = fmaf(hb.w, v[7], s3);
+        }
+        sQv[r * KP + t] = sGv[r * KP + t] - ((s0 + s1) + (s2 + s3));
       }
     }
     __syncthreads();

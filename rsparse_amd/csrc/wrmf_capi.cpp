@@ -653,6 +653,14 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
       }
       std::fprintf(stderr, " Mcycles (mean/max over %d workgroups)\n", qs.ne_wg);
     }
+#ifdef RSP_CGQ_PROF
+    {
+      unsigned long long cq[6];
+      HIP_TRY(hipMemcpy(cq, prof_buf + (size_t)65536 * 80 - 16, sizeof(cq), hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "[cgq_prof] 8-wave launch (n_cols %d), G ticks summed over its waves: gather %.2f setup %.2f sweeps %.2f issue %.2f cg %.2f tail %.2f\n",
+                   d.n_cols, cq[0] / 1e9, cq[1] / 1e9, cq[2] / 1e9, cq[3] / 1e9, cq[4] / 1e9, cq[5] / 1e9);
+    }
+#endif
     if (const char* dump = std::getenv("RSPARSE_NE_PROF_DUMP")) {   // per workgroup: total, rows, consume, wait_vm of wave 0
       if (FILE* f = std::fopen(dump, "a")) {
         std::fprintf(f, "# launch n_cols %d wgs %d\n", d.n_cols, qs.ne_wg);

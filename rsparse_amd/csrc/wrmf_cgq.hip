@@ -337,6 +337,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   float* tcur = tacc + CAP;
   int buf = 0;
   double wloss = 0.0;
+#ifdef RSP_CGQ_PROF   // dev builds: ticks per phase, summed over the waves of the 8-wave launch (wrmf_capi.cpp prints them)
+  unsigned long long cq_t[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long cq_l = __builtin_amdgcn_s_memtime();
+#define CQ_T(j) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); cq_t[j] += t1_ - cq_l; cq_l = t1_; }
+#else
+#define CQ_T(j)
+#endif
   int pf_id = 0, pf_cnt = -1;   // next row's share of this wave, lane-major (RSP_IDX_PREFETCH)
   float pf_c = 0.f;
   const int team_global = blockIdx.x * TEAMS + team;
@@ -549,6 +556,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       }
     }
 
+    CQ_T(0)   // row switch + gather
     float x[RPN], r[RPN], p[RPN], ap[RPN];
 #pragma unroll
     for (int b = 0; b < NV; b++) {
@@ -904,7 +912,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 
     const bool live = have && (GB || cnt > 0);
     float dummy = 0.f;
+    CQ_T(1)   // warm start, setup
     sweep(x, 0, r, dummy, live);
+    CQ_T(2)   // sweeps
     int lpf_n = -1;   // >= 0: the next row's staged copy is under way (count of its share of this wave)
     if constexpr (LPFQ > 0) {
       // the next row's pointers were requested at the top of this iteration and have arrived by now
@@ -929,16 +939,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         }
       }
     }
+    CQ_T(3)   // staging issue / index prefetch
 #pragma unroll
     for (int rr = 0; rr < RPN; rr++) p[rr] = r[rr];
     float rsold = dot16(r, r);
     bool conv = false;
     for (int itc = 0; itc < a.cg_steps; ++itc) {
       if (WPR == 1 && !DMF && conv) break;
+      CQ_T(4)   // CG scalars and updates
       sweep(p, 1, ap, dummy, live && !conv, itc + 1);
+      CQ_T(2)
       if constexpr (LPFQ > 0) {
         if (itc == 0 && lpf_n >= 0) lpf_issue_vec(lpf_n);   // lands during the remaining sweeps
       }
+      CQ_T(3)
       if (!conv) {
         const float pap = dot16(p, ap);
         // rsold / alpha / beta as the reference holds them: double scalars fed by T-valued dot products
@@ -973,7 +987,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       }
     }
     float rl = 0.f;
+    CQ_T(4)
     sweep(x, 2, ap, rl, live);
+    CQ_T(2)
     if (live && tw == 0) {
       const float xx = dot16(x, x);
       wloss += IMPLICIT ? (double)rl + a.lambda_loss * (double)xx : (double)(rl + lam_use * xx);
@@ -992,6 +1008,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       }
     }
   }
+  CQ_T(5)   // loss, store of the row
+#ifdef RSP_CGQ_PROF
+  if (WAVES == 8 && WPR == 8 && !STREAM && a.ne_prof && lane == 0)
+    for (int j = 0; j < 6; j++) atomicAdd(a.ne_prof + (size_t)65536 * 80 - 16 + j, cq_t[j]);
+#endif
   if (lane == 0) a.loss_partials[loss_slot0 + (size_t)blockIdx.x * WAVES + wv] = wloss;
 }
 

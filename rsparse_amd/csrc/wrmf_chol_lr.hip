@@ -17,6 +17,9 @@
 // x_j . y = v_j . q with q = g - W^T S^-1 W g.  Any exact method satisfies the reference's `solve`; the parity bound
 // (1e-4 against the fp64 oracle) is the same as for wrmf_chol.hip and is checked by the same tests.
 //
+// Round 3: the n x n systems are solved by one wave in registers with the pivot-row multipliers as DPP row broadcasts inside
+// the FMAs, and rows of <= 16 / <= 32 non-zeros share a pass four / two at a time (see "the rows" below).
+//
 // Needs every confidence >= 1 (D^1/2) and XtX positive definite: both are decided on the device (flags[0] != 0 ->
 // this kernel returns at once and wrmf_chol.hip's kernel, which otherwise skips the short rows, takes them).
 #include <type_traits>

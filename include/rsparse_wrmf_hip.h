@@ -28,9 +28,11 @@
  *   Y       rank x n_cols  column-major, in: CG warm start, out: solution
  *   XtX     rank x rank, must already contain + lambda*I (R/model_WRMF.R:474-486)
  *
- * Arithmetic on the device is fp32 (the reference's precision="float" build); the *_double
- * entry points convert at the boundary.  Stated tolerance vs the reference CPU path: 1e-4
- * relative Frobenius on the factor matrices.
+ * Arithmetic: the *_float entry points and the device-resident layer (2) compute in fp32 (the
+ * reference's precision="float" build; stated tolerance vs the reference CPU path: 1e-4 relative
+ * Frobenius on the factor matrices).  The *_double entry points and the fp64 device layer (3)
+ * compute in double, as als_implicit<double> / als_explicit<double> do (src/wrmf_implicit.cpp:5-14,
+ * src/wrmf_explicit.cpp:5-14; precision = "double" is the R constructor's default, R/model_WRMF.R:82).
  */
 #ifndef RSPARSE_WRMF_HIP_H
 #define RSPARSE_WRMF_HIP_H
@@ -92,8 +94,8 @@ int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_pt
                                    double global_bias, float* global_bias_base, int global_bias_base_len,
                                    int initialize_bias_base, double* loss_out);
 
-/* replaces als_implicit_double (src/wrmf_implicit.cpp:5-14).  Buffers are f64 like the reference's;
- * converted to fp32 for the device and back. */
+/* replaces als_implicit_double (src/wrmf_implicit.cpp:5-14 -> als_implicit<double>).  Buffers are f64 like the
+ * reference's and the device computes in f64 (layer 3 below): every solver, biases and the global bias as for _float. */
 int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_ptrs,
                                     const int32_t* row_indices, const double* values,
                                     const double* X, double* Y, const double* XtX, int rank,
@@ -112,7 +114,7 @@ int rsparse_hip_als_explicit_float(int n_rows, int n_cols, const int32_t* col_pt
                                    unsigned cg_steps, int dynamic_lambda, int with_biases,
                                    int is_x_bias_last_row, double* loss_out);
 
-/* replaces als_explicit_double (src/wrmf_explicit.cpp:5-14) */
+/* replaces als_explicit_double (src/wrmf_explicit.cpp:5-14 -> als_explicit<double>); f64 arithmetic on the device */
 int rsparse_hip_als_explicit_double(int n_rows, int n_cols, const int32_t* col_ptrs,
                                     const int32_t* row_indices, const double* values,
                                     const double* X, double* Y, const double* cnt_X, int rank,
@@ -123,6 +125,8 @@ int rsparse_hip_als_explicit_double(int n_rows, int n_cols, const int32_t* col_p
 /* replaces the R-side Gramian  XtX = tcrossprod(X) + fl(diag(lambda))  (R/model_WRMF.R:474-486,
  * :347-353).  Host pointers; X is rank x n column-major; XtX_out rank x rank. */
 int rsparse_hip_gramian_float(const float* X, int rank, int64_t n, double lambda, float* XtX_out);
+/* the same in f64 (precision = "double": tcrossprod of a base matrix; the ridge still passes through fl()) */
+int rsparse_hip_gramian_double(const double* X, int rank, int64_t n, double lambda, double* XtX_out);
 
 /* replaces initialize_biases_float / initialize_biases_double (src/wrmf_init.cpp:5-34; .Call
  * _rsparse_initialize_biases_{float,double}, src/RcppExports.cpp:417-454): the 9 arguments of the reference with the
@@ -300,6 +304,55 @@ int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_use
                                    int k, const int32_t* d_not_recommend_p, const int32_t* d_not_recommend_j,
                                    const int32_t* d_exclude0, int n_exclude, double glob_mean,
                                    int32_t* d_res, float* d_scores, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (3) fp64 device layer: als_implicit<double> / als_explicit<double> with the data resident in HBM
+ * ---------------------------------------------------------------------------------------------- */
+
+/* What the `*_double` .Call targets compute (src/wrmf_implicit.cpp:5-14, src/wrmf_explicit.cpp:5-14), device-resident
+ * like layer (2): CSC with f64 values, X / Y / XtX column-major f64.  One kernel family covers every variant -- implicit
+ * and explicit feedback, Cholesky (general-solver fallback included) / conjugate gradient / NNLS, user/item biases, the
+ * implicit global bias -- by assembling each row's system in LDS (wrmf_f64.hip); it is the parity path of
+ * precision = "double", not the bench path. */
+typedef struct rsparse_hip_csc_f64 rsparse_hip_csc_f64;
+
+/* adopt arrays that live on the current device (not copied, not freed; they must outlive the handle); validated like
+ * rsparse_hip_csc_create_device */
+int rsparse_hip_csc_f64_create_device(int n_rows, int n_cols, const int32_t* d_col_ptrs, const int32_t* d_row_indices,
+                                      const double* d_values, rsparse_hip_csc_f64** out);
+int rsparse_hip_csc_f64_destroy(rsparse_hip_csc_f64* m);
+
+/* XtX = X X^T + fl(lambda) I in f64 (the ridge is rounded to fp32 in the double build too: float::fl(diag(lambda)),
+ * R/model_WRMF.R:476); d_sumsq_out (nullable) = sum(X^2) */
+int rsparse_hip_gramian_f64_device(const double* d_X, int rank, int64_t n, double lambda, double* d_XtX_out,
+                                   double* d_sumsq_out, void* stream);
+
+/* One half-iteration in f64: als_implicit<double> (implicit != 0; inst/include/wrmf_implicit.hpp:90-305) or
+ * als_explicit<double> (wrmf_explicit.hpp:33-174) over the columns of `conf`.  Arguments as in layer (2):
+ * with_biases / is_x_bias_last_row select the user/item-bias layout (rank counts the two extra coordinates; d_XtX is
+ * then (rank-1) x (rank-1)); global_bias (implicit feedback; below sqrt(DBL_EPSILON) = none, :108-109) is handled with
+ * every solver, global_bias_base = -global_bias * rowSums(X) computed on the device; dynamic_lambda: explicit feedback
+ * only.  implicit + with_biases + conjugate_gradient -> RSPARSE_HIP_ERR_UNSUPPORTED (:189,197).  d_loss_rows_out
+ * (nullable, device double[1]): the row part of the loss as for rsparse_hip_als_{implicit,explicit}_device.  A system
+ * that is not positive definite is re-solved by Gaussian elimination with partial pivoting inside the kernel and counted
+ * in rsparse_hip_take_numeric_failures. */
+int rsparse_hip_als_f64_device(const rsparse_hip_csc_f64* conf, int implicit, const double* d_X, double* d_Y,
+                               const double* d_XtX, int rank, double lambda, unsigned solver, unsigned cg_steps,
+                               int dynamic_lambda, int with_biases, int is_x_bias_last_row, double global_bias,
+                               double* d_loss_rows_out, void* stream);
+
+/* initialize_biases_double (src/wrmf_init.cpp:5-19 -> inst/include/wrmf_utils.hpp:32-165), device-resident: c_ui =
+ * users x items by item column, c_iu = its transpose.  With is_explicit_feedback and calculate_global_bias the mean of
+ * the values is removed from the resident values of BOTH handles in place. */
+int rsparse_hip_initialize_biases_f64_device(rsparse_hip_csc_f64* c_ui, rsparse_hip_csc_f64* c_iu, double* d_user_bias,
+                                             double* d_item_bias, double lambda, int dynamic_lambda, int non_negative,
+                                             int calculate_global_bias, int is_explicit_feedback,
+                                             double* global_bias_out, void* stream);
+
+/* f64 counterparts of rsparse_hip_values_subtract_mean_device / rsparse_hip_weighted_sumsq_device */
+int rsparse_hip_values_subtract_mean_f64_device(int64_t n, double* d_x, double* d_x_other, double* mean_out, void* stream);
+int rsparse_hip_weighted_sumsq_f64_device(const double* d_X, int rank, int64_t n, const double* d_w, double* d_out,
+                                          void* stream);
 
 /* Kernel timing for measurement harnesses (bench.py): when enabled, every device-layer call brackets
  * its kernels with HIP events on the caller's stream.  rsparse_hip_profile_last() waits for the last

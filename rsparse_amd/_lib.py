@@ -31,6 +31,7 @@ SIGNATURES = {
     "rsparse_hip_als_explicit_double": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint,
                                                  _c_uint, _c_uint, _c_int, _c_int, _c_int, _vp]),
     "rsparse_hip_gramian_float": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp]),
+    "rsparse_hip_gramian_double": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp]),
     "rsparse_hip_csc_create_host": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "rsparse_hip_csc_create_device": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "rsparse_hip_gramian_absmax_device": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp, _vp, _vp, _vp]),
@@ -58,6 +59,15 @@ SIGNATURES = {
     "rsparse_hip_weighted_sumsq_device": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp]),
     "rsparse_hip_top_product": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_uint, _c_uint, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp]),
     "rsparse_hip_top_product_device": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _vp]),
+    "rsparse_hip_csc_f64_create_device": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
+    "rsparse_hip_csc_f64_destroy": (_c_int, [_vp]),
+    "rsparse_hip_gramian_f64_device": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp, _vp, _vp]),
+    "rsparse_hip_als_f64_device": (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_uint, _c_int, _c_int,
+                                            _c_int, _c_dbl, _vp, _vp]),
+    "rsparse_hip_initialize_biases_f64_device": (_c_int, [_vp, _vp, _vp, _vp, _c_dbl, _c_int, _c_int, _c_int, _c_int,
+                                                          ctypes.POINTER(_c_dbl), _vp]),
+    "rsparse_hip_values_subtract_mean_f64_device": (_c_int, [_c_i64, _vp, _vp, ctypes.POINTER(_c_dbl), _vp]),
+    "rsparse_hip_weighted_sumsq_f64_device": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp]),
     "rsparse_hip_profile_enable": (_c_int, [_c_int]),
     "rsparse_hip_set_launch_mode": (_c_int, [_c_int]),
     "rsparse_hip_profile_last": (_c_int, [ctypes.POINTER(_c_dbl)]),

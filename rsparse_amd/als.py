@@ -46,10 +46,10 @@ def gramian(X, lambda_, precision):
     dt = np.float32 if precision == "float" else np.float64
     _f_contig(X, dt, "X")
     k, n = X.shape
-    X32 = X if dt == np.float32 else np.asfortranarray(X, dtype=np.float32)
-    out = np.zeros((k, k), dtype=np.float32, order="F")
-    _lib.check(lib.rsparse_hip_gramian_float(_vp(X32), k, n, float(lambda_), _vp(out)))
-    return out if dt == np.float32 else np.asfortranarray(out, dtype=np.float64)
+    out = np.zeros((k, k), dtype=dt, order="F")
+    fn = lib.rsparse_hip_gramian_float if dt == np.float32 else lib.rsparse_hip_gramian_double
+    _lib.check(fn(_vp(X), k, n, float(lambda_), _vp(out)))
+    return out
 
 
 def als_implicit(x, X, Y, lambda_, n_threads, solver_code, cg_steps, precision, with_user_item_bias,

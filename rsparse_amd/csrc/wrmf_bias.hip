@@ -11,6 +11,7 @@
 // both orientations, then five alternating sweeps  bias[c] = sum_{e in c}(v_e - other_bias[idx_e]) / (lambda_use + n_c),
 // one wave per column, sums in double.
 #include "wrmf_internal.h"
+#include "wrmf_f64.h"
 #include "wrmf_device.h"
 
 namespace rsparse_hip {
@@ -27,10 +28,12 @@ __global__ __launch_bounds__(256) void bias_shift_values_kernel(const float* __r
     out[e] = vals[e] - X[(size_t)row_idx[e] * k + bias_row];
 }
 
+// T = float (the device-resident fp32 layer) or double (wrmf_f64.h: the *_double entry points)
+template <class T>
 __global__ __launch_bounds__(256) void bias_sweep_kernel(const int32_t* __restrict__ p, const int32_t* __restrict__ i,
-                                                         const float* __restrict__ x, const float* __restrict__ other,
-                                                         int n_cols, float lambda, int dynamic_lambda, int non_negative,
-                                                         float* __restrict__ out) {
+                                                         const T* __restrict__ x, const T* __restrict__ other,
+                                                         int n_cols, T lambda, int dynamic_lambda, int non_negative,
+                                                         T* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
   const int n_waves = (int)((gridDim.x * (size_t)blockDim.x) >> 6);
@@ -41,16 +44,17 @@ __global__ __launch_bounds__(256) void bias_sweep_kernel(const int32_t* __restri
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
     if (lane == 0) {
-      const float cnt = (float)(p2 - p1);
-      const float lambda_use = lambda * (dynamic_lambda ? cnt : 1.f);
-      float b = (float)s / (lambda_use + cnt);   // an empty column with lambda = 0 gives 0/0 = NaN, as in the reference
-      if (non_negative) b = fmaxf(0.f, b);
+      const T cnt = (T)(p2 - p1);
+      const T lambda_use = lambda * (dynamic_lambda ? cnt : (T)1);
+      T b = (T)s / (lambda_use + cnt);   // an empty column with lambda = 0 gives 0/0 = NaN, as in the reference
+      if (non_negative) b = b > (T)0 ? b : (T)0;   // std::fmax(0, b) (NaN -> 0, as fmax defines it)
       out[c] = b;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void values_sum_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ partials) {
+template <class T>
+__global__ __launch_bounds__(256) void values_sum_kernel(const T* __restrict__ x, int64_t n, double* __restrict__ partials) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double s = 0.0;
@@ -60,9 +64,10 @@ __global__ __launch_bounds__(256) void values_sum_kernel(const float* __restrict
   if (lane == 0) partials[(size_t)blockIdx.x * 4 + wv] = s;
 }
 
-__global__ __launch_bounds__(256) void values_add_kernel(float* __restrict__ x, int64_t n, const double* __restrict__ sum,
+template <class T>
+__global__ __launch_bounds__(256) void values_add_kernel(T* __restrict__ x, int64_t n, const double* __restrict__ sum,
                                                          double inv_count) {
-  const float shift = (float)(sum[0] * inv_count);
+  const T shift = (T)(sum[0] * inv_count);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) x[e] -= shift;
 }
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(128) void bias_rhs_init_reduce_kernel(const float* 
 
 // initialize_biases_implicit (inst/include/wrmf_utils.hpp:86-165), one thread per column (the weighted running mean
 // over a column's entries is a serial recurrence).  Stage "prep": means[c], adj[c] (:101-124).
-__global__ __launch_bounds__(256) void bias_implicit_prep_kernel(const int32_t* __restrict__ p, const float* __restrict__ x,
+template <class T>
+__global__ __launch_bounds__(256) void bias_implicit_prep_kernel(const int32_t* __restrict__ p, const T* __restrict__ x,
                                                                  int n_cols, int n_other, double lambda,
                                                                  double* __restrict__ means, double* __restrict__ adj) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,13 +133,14 @@ __global__ __launch_bounds__(256) void bias_implicit_prep_kernel(const int32_t* 
   }
 }
 // one sweep (:136-143 / :152-159): bias[c] = (means[c] - running weighted mean of the other side's biases) * adj[c]
+template <class T>
 __global__ __launch_bounds__(256) void bias_implicit_sweep_kernel(const int32_t* __restrict__ p, const int32_t* __restrict__ i,
-                                                                  const float* __restrict__ x,
-                                                                  const float* __restrict__ other, int n_cols, int n_other,
+                                                                  const T* __restrict__ x,
+                                                                  const T* __restrict__ other, int n_cols, int n_other,
                                                                   const double* __restrict__ other_sum,
                                                                   const double* __restrict__ means,
                                                                   const double* __restrict__ adj, int non_negative,
-                                                                  double global_bias, float* __restrict__ out) {
+                                                                  double global_bias, T* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cols) return;
   double wsum = (double)n_other;
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(256) void bias_implicit_sweep_kernel(const int32_t*
     wsum += w;
     bias_this += (w * ((double)other[i[e]] - bias_this)) / wsum;
   }
-  float b = (float)((means[c] - bias_this - global_bias) * adj[c]);   // wrmf_utils.hpp:142,157
-  if (non_negative) b = fmaxf(0.f, b);
+  T b = (T)((means[c] - bias_this - global_bias) * adj[c]);   // wrmf_utils.hpp:142,157
+  if (non_negative) b = b > (T)0 ? b : (T)0;
   out[c] = b;
 }
 
@@ -170,20 +177,43 @@ hipError_t launch_bias_rhs_init(const float* X, int k, int off, int k1, int bias
 }
 size_t bias_rhs_init_scratch_floats() { return (size_t)kRhsInitBlocks * 128 + 128; }
 
-hipError_t launch_bias_implicit_prep(const int32_t* p, const float* x, int n_cols, int n_other, double lambda,
-                                     double* means, double* adj, hipStream_t s) {
+namespace {
+template <class T>
+hipError_t bias_implicit_prep_t(const int32_t* p, const T* x, int n_cols, int n_other, double lambda, double* means,
+                                double* adj, hipStream_t s) {
   if (n_cols <= 0) return hipSuccess;
-  hipLaunchKernelGGL(bias_implicit_prep_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, p, x, n_cols, n_other,
+  hipLaunchKernelGGL(bias_implicit_prep_kernel<T>, dim3((n_cols + 255) / 256), dim3(256), 0, s, p, x, n_cols, n_other,
                      lambda, means, adj);
   return hipGetLastError();
+}
+template <class T>
+hipError_t bias_implicit_sweep_t(const int32_t* p, const int32_t* i, const T* x, const T* other, int n_cols, int n_other,
+                                 const double* other_sum, const double* means, const double* adj, int non_negative,
+                                 double global_bias, T* out, hipStream_t s) {
+  if (n_cols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bias_implicit_sweep_kernel<T>, dim3((n_cols + 255) / 256), dim3(256), 0, s, p, i, x, other, n_cols,
+                     n_other, other_sum, means, adj, non_negative, global_bias, out);
+  return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_bias_implicit_prep(const int32_t* p, const float* x, int n_cols, int n_other, double lambda,
+                                     double* means, double* adj, hipStream_t s) {
+  return bias_implicit_prep_t<float>(p, x, n_cols, n_other, lambda, means, adj, s);
+}
+hipError_t launch_bias_implicit_prep(const int32_t* p, const double* x, int n_cols, int n_other, double lambda,
+                                     double* means, double* adj, hipStream_t s) {
+  return bias_implicit_prep_t<double>(p, x, n_cols, n_other, lambda, means, adj, s);
 }
 hipError_t launch_bias_implicit_sweep(const int32_t* p, const int32_t* i, const float* x, const float* other, int n_cols,
                                       int n_other, const double* other_sum, const double* means, const double* adj,
                                       int non_negative, double global_bias, float* out, hipStream_t s) {
-  if (n_cols <= 0) return hipSuccess;
-  hipLaunchKernelGGL(bias_implicit_sweep_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, p, i, x, other, n_cols,
-                     n_other, other_sum, means, adj, non_negative, global_bias, out);
-  return hipGetLastError();
+  return bias_implicit_sweep_t<float>(p, i, x, other, n_cols, n_other, other_sum, means, adj, non_negative, global_bias, out, s);
+}
+hipError_t launch_bias_implicit_sweep(const int32_t* p, const int32_t* i, const double* x, const double* other, int n_cols,
+                                      int n_other, const double* other_sum, const double* means, const double* adj,
+                                      int non_negative, double global_bias, double* out, hipStream_t s) {
+  return bias_implicit_sweep_t<double>(p, i, x, other, n_cols, n_other, other_sum, means, adj, non_negative, global_bias, out, s);
 }
 
 hipError_t launch_bias_shift_values(const float* vals, const int32_t* row_idx, const float* X, int k, int bias_row,
@@ -196,14 +226,27 @@ hipError_t launch_bias_shift_values(const float* vals, const int32_t* row_idx, c
 hipError_t launch_bias_sweep(const int32_t* p, const int32_t* i, const float* x, const float* other, int n_cols,
                              float lambda, int dynamic_lambda, int non_negative, float* out, hipStream_t s) {
   if (n_cols <= 0) return hipSuccess;
-  hipLaunchKernelGGL(bias_sweep_kernel, dim3(2048), dim3(256), 0, s, p, i, x, other, n_cols, lambda, dynamic_lambda,
+  hipLaunchKernelGGL(bias_sweep_kernel<float>, dim3(2048), dim3(256), 0, s, p, i, x, other, n_cols, lambda, dynamic_lambda,
+                     non_negative, out);
+  return hipGetLastError();
+}
+hipError_t launch_bias_sweep(const int32_t* p, const int32_t* i, const double* x, const double* other, int n_cols,
+                             double lambda, int dynamic_lambda, int non_negative, double* out, hipStream_t s) {
+  if (n_cols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bias_sweep_kernel<double>, dim3(2048), dim3(256), 0, s, p, i, x, other, n_cols, lambda, dynamic_lambda,
                      non_negative, out);
   return hipGetLastError();
 }
 
 // sum of x[0..n) in double -> out[0] (partials: >= 1024 doubles)
 hipError_t launch_values_sum(const float* x, int64_t n, double* partials, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(values_sum_kernel, dim3(256), dim3(256), 0, s, x, n, partials);
+  hipLaunchKernelGGL(values_sum_kernel<float>, dim3(256), dim3(256), 0, s, x, n, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return launch_sum_partials(partials, 1024, out, s);
+}
+hipError_t launch_values_sum(const double* x, int64_t n, double* partials, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(values_sum_kernel<double>, dim3(256), dim3(256), 0, s, x, n, partials);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_sum_partials(partials, 1024, out, s);
@@ -212,7 +255,12 @@ hipError_t launch_values_sum(const float* x, int64_t n, double* partials, double
 // x[e] -= sum[0] * inv_count
 hipError_t launch_values_subtract_mean(float* x, int64_t n, const double* sum, double inv_count, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(values_add_kernel, dim3(2048), dim3(256), 0, s, x, n, sum, inv_count);
+  hipLaunchKernelGGL(values_add_kernel<float>, dim3(2048), dim3(256), 0, s, x, n, sum, inv_count);
+  return hipGetLastError();
+}
+hipError_t launch_values_subtract_mean(double* x, int64_t n, const double* sum, double inv_count, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(values_add_kernel<double>, dim3(2048), dim3(256), 0, s, x, n, sum, inv_count);
   return hipGetLastError();
 }
 

@@ -845,6 +845,10 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
     HIP_TRY(upload(dW, cnt_X, (size_t)n_rows));
   }
   if ((rc = g_ws.ensure_device())) return rc;
+  {   // counters left behind by earlier device-resident calls are not this call's
+    int64_t stale = 0;
+    rsparse_hip_take_numeric_failures(&stale, nullptr);
+  }
   const bool gbias = implicit && has_global_bias(global_bias, sizeof(TX) == sizeof(double));
   DevBuf dBase;
   if (gbias && !with_biases) {
@@ -919,6 +923,9 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
 }  // namespace
 
 namespace rsparse_hip {
+int capi_fail(int code, const std::string& msg) { return fail(code, msg); }
+int capi_hip_fail(hipError_t e, const char* what) { return hip_fail(e, what); }
+int* capi_fail_counters() { return g_ws.ensure_device() ? nullptr : g_ws.fails; }
 void prof_note(hipEvent_t* ev_slot, const void* kernel_fn) {
   if (!ev_slot || !g_prof.on) return;
   const ptrdiff_t i = ev_slot - g_prof.ev;
@@ -929,7 +936,7 @@ void prof_note(hipEvent_t* ev_slot, const void* kernel_fn) {
 extern "C" {
 
 const char* rsparse_hip_last_error(void) { return g_err.c_str(); }
-int rsparse_hip_abi_version(void) { return 3; }
+int rsparse_hip_abi_version(void) { return 4; }
 
 int rsparse_hip_device_count(void) {
   int n = 0;
@@ -1466,21 +1473,6 @@ int rsparse_hip_als_implicit_float(int n_rows, int n_cols, const int32_t* col_pt
                           global_bias_base_len, initialize_bias_base);
 }
 
-int rsparse_hip_als_implicit_double(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
-                                    const double* values, const double* X, double* Y, const double* XtX, int rank,
-                                    double lambda, int n_threads, unsigned solver, unsigned cg_steps,
-                                    int with_biases, int is_x_bias_last_row, double global_bias,
-                                    double* global_bias_base, int global_bias_base_len, int initialize_bias_base,
-                                    double* loss_out) {
-  (void)n_threads;
-  int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
-  if (rc) return rc;
-  if ((rc = check_variant(solver, with_biases, global_bias))) return rc;
-  return stateless<double>(true, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, XtX, nullptr, rank, lambda,
-                           solver, cg_steps, 0, loss_out, with_biases, is_x_bias_last_row, global_bias, global_bias_base,
-                           global_bias_base_len, initialize_bias_base);
-}
-
 }  // extern "C"
 
 namespace {
@@ -1543,16 +1535,6 @@ int rsparse_hip_initialize_biases_float(int n_users, int n_items, const int32_t*
                                        lambda, dynamic_lambda, non_negative, calculate_global_bias, is_explicit_feedback,
                                        global_bias_out);
 }
-int rsparse_hip_initialize_biases_double(int n_users, int n_items, const int32_t* csc_p, const int32_t* csc_i,
-                                         double* csc_x, const int32_t* csr_p, const int32_t* csr_i, double* csr_x,
-                                         double* user_bias, double* item_bias, double lambda, int dynamic_lambda,
-                                         int non_negative, int calculate_global_bias, int is_explicit_feedback,
-                                         double* global_bias_out) {
-  return initialize_biases_host<double>(n_users, n_items, csc_p, csc_i, csc_x, csr_p, csr_i, csr_x, user_bias, item_bias,
-                                        lambda, dynamic_lambda, non_negative, calculate_global_bias, is_explicit_feedback,
-                                        global_bias_out);
-}
-
 }  // extern "C"
 
 namespace {
@@ -1570,18 +1552,6 @@ int rsparse_hip_als_explicit_float(int n_rows, int n_cols, const int32_t* col_pt
   if ((rc = check_variant(solver, with_biases, 0.0, false))) return rc;
   return stateless<float>(false, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, nullptr, cnt_X, rank, lambda,
                           solver, cg_steps, dynamic_lambda, loss_out, with_biases, is_x_bias_last_row);
-}
-
-int rsparse_hip_als_explicit_double(int n_rows, int n_cols, const int32_t* col_ptrs, const int32_t* row_indices,
-                                    const double* values, const double* X, double* Y, const double* cnt_X, int rank,
-                                    double lambda, unsigned n_threads, unsigned solver, unsigned cg_steps,
-                                    int dynamic_lambda, int with_biases, int is_x_bias_last_row, double* loss_out) {
-  (void)n_threads;
-  int rc = check_common(n_rows, n_cols, col_ptrs, row_indices, values, X, Y, rank);
-  if (rc) return rc;
-  if ((rc = check_variant(solver, with_biases, 0.0, false))) return rc;
-  return stateless<double>(false, n_rows, n_cols, col_ptrs, row_indices, values, X, Y, nullptr, cnt_X, rank, lambda,
-                           solver, cg_steps, dynamic_lambda, loss_out, with_biases, is_x_bias_last_row);
 }
 
 }  // extern "C"

@@ -1,0 +1,662 @@
+// fp64 device path (gfx950): als_implicit<double> / als_explicit<double> -- what the reference's `*_double` entry points
+// compute (src/wrmf_implicit.cpp:5-14, src/wrmf_explicit.cpp:5-14) and what `WRMF$new(precision = "double")`, the
+// constructor's default (R/model_WRMF.R:82), runs.  One kernel family for every variant of the path: implicit / explicit
+// feedback, Cholesky / conjugate gradient / NNLS, user/item biases, global bias.
+//
+// Per row (one workgroup, the row's k1 x k1 system in LDS):
+//     lhs = XtX + X_nnz diag(c - 1) X_nnz^T            (wrmf_implicit.hpp:207-208)     | X_nnz X_nnz^T + lambda_use I
+//     rhs = rhs_init + X_nnz (c - x_b % (c - 1))       (:226, :228-231)                | X_nnz (r - x_b)   (wrmf_explicit.hpp:89,103-106)
+// assembled from the gathered factor vectors in 4 x 4 register tiles of the lower triangle (chunks of the row staged in
+// LDS, every thread owns tiles), then
+//     Cholesky            right-looking LL^T in LDS, the forward substitution riding along, backward substitution by one
+//                         wave; a non-positive pivot sends the row to Gaussian elimination with partial pivoting in the same
+//                         workgroup -- what arma::solve(fast + likely_sympd) falls back to (:236, wrmf_explicit.hpp:108)
+//     conjugate gradient  cg_solver_implicit / _global_bias / cg_solver_explicit (wrmf_implicit.hpp:8-57,
+//                         wrmf_explicit.hpp:8-31) from the warm start, with A p evaluated from the assembled matrix: the same
+//                         operator as XtX p + X_nnz((c-1) % X_nnz^T p), rounded differently at the 1e-16 level; the first
+//                         residual of the global-bias variant is rhs - lhs x - g X_nnz (c - 1)
+//     NNLS                c_nnls / scd_ls_update (nnls.hpp:10-48): XtX = lhs^T lhs + 1e-16 I, mu = XtX init - lhs^T rhs, the
+//                         coordinate sweeps in order by one wave (lane = coordinate), stop at 1e-4 / 10000 sweeps
+// and the loss term from a second pass over the row's vectors (L2-resident by then).
+//
+// This is the parity path of the *_double entry points, built for correctness in double first: it moves k1^2 flops per
+// non-zero (the fp32 conjugate-gradient kernels move 8 k (cg_steps + 1)) and one row occupies a workgroup.  The bench line
+// (fp32, BASELINE.json) does not run through it.
+#include <algorithm>
+
+#include "wrmf_f64.h"
+#include "wrmf_internal.h"
+
+namespace rsparse_hip {
+namespace {
+
+constexpr double kCgTolD = 1e-10;        // CG_TOL, inst/include/wrmf.hpp:22
+constexpr unsigned kScdMaxIter = 10000;  // SCD_MAX_ITER, wrmf.hpp:20
+constexpr double kScdTol = 1e-4;         // SCD_TOL, wrmf.hpp:21
+constexpr double kNnlsEps = 1e-16;       // EPS, nnls.hpp:8
+
+__device__ __forceinline__ double wave_sum_d(double v) {   // butterfly: every lane ends with the same bits
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// sum over the workgroup, every thread gets it; all threads must call it.  red: NT / 64 doubles
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum_d(v);
+  __syncthreads();   // red may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w++) s += red[w];
+  return s;
+}
+
+// t-th 4 x 4 tile of the lower triangle, row-major over the tile rows: (ti, tj), tj <= ti
+__device__ __forceinline__ void tile_of(int t, int& ti, int& tj) {
+  ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+  while (ti * (ti + 1) / 2 > t) ti--;
+  tj = t - ti * (ti + 1) / 2;
+}
+
+// A[(4 ti + r) + (4 tj + c) lda] += sum_{j < cn} xs[j][4 ti + r] * w[j] * xs[j][4 tj + c] over the tiles of the lower triangle
+template <int NT>
+__device__ __forceinline__ void rank_update_tiles(double* A, int lda, const double* xs, int kp, const double* w, int cn,
+                                                  int ntiles) {
+  for (int t = threadIdx.x; t < ntiles; t += NT) {
+    int ti, tj;
+    tile_of(t, ti, tj);
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) acc[r][c] = 0.0;
+    const double* xa = xs + 4 * ti;
+    const double* xc = xs + 4 * tj;
+    for (int j = 0; j < cn; j++) {
+      const double wj = w ? w[j] : 1.0;
+      double av[4], bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) av[r] = xa[j * kp + r];
+#pragma unroll
+      for (int c = 0; c < 4; c++) bv[c] = wj * xc[j * kp + c];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) A[(4 * ti + r) + (size_t)(4 * tj + c) * lda] += acc[r][c];
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, int m2_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  constexpr int NW = NT / 64;
+  const int LDA = KP + 1;   // odd: rows and columns of the matrix are both conflict-free walks
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k = a.k, k1 = a.k1;
+  const bool nnls = a.solver == 2, cg = a.solver == 1;
+  double* A = sm;
+  double* M2 = A + (size_t)KP * LDA;
+  double* rhs = M2 + (m2_in_lds ? (size_t)KP * LDA : 0);
+  if (nnls && !m2_in_lds) M2 = a.m2_scratch + (size_t)blockIdx.x * KP * LDA;
+  double* x = rhs + KP;
+  double* r = x + KP;
+  double* p = r + KP;
+  double* ap = p + KP;
+  double* sv = ap + KP;     // X_nnz (c - 1): the global-bias term of the first CG residual
+  double* invd = sv + KP;   // Cholesky: 1 / L_jj
+  double* d0 = invd + KP;   // the diagonal and the right-hand side before the factorisation (general-solver fallback)
+  double* b0 = d0 + KP;
+  double* red = b0 + KP;    // 8
+  double* xs = red + 8;     // [CH][KP] staged factor vectors of the current chunk
+  double* cw = xs + (size_t)CH * KP;   // per staged non-zero: weight of x x^T
+  double* rw = cw + CH;                // ... of x in the right-hand side
+  double* lw = rw + CH;                // ... of the loss term
+  double* lt = lw + CH;                // target of the loss term
+  int* sidx = reinterpret_cast<int*>(lt + CH);
+  int* spiv = sidx + CH;               // general solver: pivot row / singular flag
+
+  const int T4 = KP / 4, ntiles = T4 * (T4 + 1) / 2;
+  // trailing update of the factorisation: RT rows per pass (a power of two >= min(NT, k1)), NT / RT column groups
+  int RT = 32;
+  while (RT < k1 && RT < NT) RT <<= 1;
+  const int CG = NT / RT, ri = tid & (RT - 1), cgi = tid / RT;
+
+  double wloss = 0.0;   // thread 0: loss terms of this workgroup's rows, in row order
+
+  auto stage = [&](const int p1, const int c0, const int cn) {
+    if (tid < cn) {
+      const int id = a.row_idx[p1 + c0 + tid];
+      const double c = a.vals[p1 + c0 + tid];
+      const double xbj = a.xb >= 0 ? a.X[(size_t)id * k + a.xb] : 0.0;
+      sidx[tid] = id;
+      if (a.implicit) {
+        cw[tid] = c - 1.0;
+        rw[tid] = c - xbj * (c - 1.0);                // wrmf_implicit.hpp:226 (x_b = 0: X_nnz c, :228-231)
+        lw[tid] = c;
+        lt[tid] = (1.0 - a.gbias) - xbj;              // :259-270
+      } else {
+        cw[tid] = 1.0;
+        rw[tid] = c - xbj;                            // wrmf_explicit.hpp:89
+        lw[tid] = 1.0;
+        lt[tid] = c - xbj;                            // :131
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < cn * KP; e += NT) {
+      const int j = e / KP, t = e - j * KP;
+      xs[e] = t < k1 ? a.X[(size_t)sidx[j] * k + a.xoff + t] : 0.0;
+    }
+    __syncthreads();
+  };
+  // s = (A v)[t], A the full symmetric matrix
+  auto matrow = [&](const double* M, const int t, const double* v) {
+    double s0 = 0.0, s1 = 0.0;
+    int c = 0;
+    for (; c + 1 < k1; c += 2) {
+      s0 = fma(M[t + (size_t)c * LDA], v[c], s0);
+      s1 = fma(M[t + (size_t)(c + 1) * LDA], v[c + 1], s1);
+    }
+    if (c < k1) s0 = fma(M[t + (size_t)c * LDA], v[c], s0);
+    return s0 + s1;
+  };
+
+  for (int row = blockIdx.x; row < a.n_cols; row += gridDim.x) {
+    const int p1 = a.col_ptrs[row], n = a.col_ptrs[row + 1] - p1;
+    double* yrow = a.Y + (size_t)row * k;
+    if (n <= 0 && !a.solve_empty) {   // empty column -> zeros (wrmf_implicit.hpp:272-283, wrmf_explicit.hpp:133-144)
+      for (int t = tid; t < k1; t += NT) yrow[a.ooff + t] = 0.0;
+      continue;
+    }
+    const double lam_use = a.implicit ? a.lambda : a.lambda * (a.dynamic_lambda ? (double)n : 1.0);   // wrmf_explicit.hpp:78
+    __syncthreads();   // the previous row's readers are done with the LDS
+    for (int e = tid; e < KP * LDA; e += NT) {
+      const int c = e / LDA, i = e - c * LDA;
+      A[e] = (a.implicit && i < k1 && c < k1) ? a.XtX[i + (size_t)c * k1] : 0.0;
+    }
+    for (int t = tid; t < KP; t += NT) {
+      rhs[t] = (a.rhs_init && t < k1) ? a.rhs_init[t] : 0.0;
+      sv[t] = 0.0;
+      x[t] = t < k1 ? yrow[a.ioff + t] : 0.0;   // warm start (CG, NNLS): Y.col(i), drop_row(init, !is_x_bias_last_row)
+    }
+    __syncthreads();
+    // ---- assembly ----
+    for (int c0 = 0; c0 < n; c0 += CH) {
+      const int cn = min(CH, n - c0);
+      stage(p1, c0, cn);
+      rank_update_tiles<NT>(A, LDA, xs, KP, cw, cn, ntiles);
+      for (int t = tid; t < k1; t += NT) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int j = 0; j < cn; j++) {
+          const double xv = xs[j * KP + t];
+          s1 = fma(rw[j], xv, s1);
+          s2 = fma(cw[j], xv, s2);
+        }
+        rhs[t] += s1;
+        sv[t] += s2;
+      }
+      __syncthreads();
+    }
+    if (!a.implicit)
+      for (int t = tid; t < k1; t += NT) A[t + (size_t)t * LDA] += lam_use;   // lhs.diag() += lambda_use
+    __syncthreads();
+    for (int e = tid; e < KP * KP; e += NT) {   // mirror the lower triangle
+      const int c = e / KP, i = e - c * KP;
+      if (i < c) A[i + (size_t)c * LDA] = A[c + (size_t)i * LDA];
+    }
+    for (int t = tid; t < KP; t += NT) {
+      d0[t] = A[t + (size_t)t * LDA];
+      b0[t] = rhs[t];
+    }
+    __syncthreads();
+
+    if (cg) {
+      // ---- conjugate gradient on the assembled system (wrmf_implicit.hpp:8-57, wrmf_explicit.hpp:8-31) ----
+      double part = 0.0;
+      for (int t = tid; t < k1; t += NT) {
+        const double rr = (rhs[t] - matrow(A, t, x)) - a.gbias * sv[t];
+        r[t] = rr;
+        p[t] = rr;
+        part += rr * rr;
+      }
+      double rsold = block_sum<NT>(part, red);
+      for (int it = 0; it < a.cg_steps; it++) {
+        __syncthreads();
+        part = 0.0;
+        for (int t = tid; t < k1; t += NT) {
+          const double s = matrow(A, t, p);
+          ap[t] = s;
+          part += p[t] * s;
+        }
+        const double alpha = rsold / block_sum<NT>(part, red);
+        part = 0.0;
+        for (int t = tid; t < k1; t += NT) {
+          x[t] += alpha * p[t];
+          const double rr = r[t] - alpha * ap[t];
+          r[t] = rr;
+          part += rr * rr;
+        }
+        const double rsnew = block_sum<NT>(part, red);
+        if (rsnew < kCgTolD) break;
+        const double beta = rsnew / rsold;
+        for (int t = tid; t < k1; t += NT) p[t] = r[t] + p[t] * beta;
+        rsold = rsnew;
+      }
+      __syncthreads();
+    } else if (nnls) {
+      // ---- c_nnls (nnls.hpp:36-48): XtX = lhs^T lhs + EPS I, mu = XtX init - lhs^T rhs ----
+      for (int t = tid; t < ntiles; t += NT) {
+        int ti, tj;
+        tile_of(t, ti, tj);
+        double acc[4][4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) acc[rr][c] = 0.0;
+        for (int m = 0; m < k1; m++) {
+          double av[4], bv[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) av[rr] = A[(4 * ti + rr) + (size_t)m * LDA];
+#pragma unroll
+          for (int c = 0; c < 4; c++) bv[c] = A[(4 * tj + c) + (size_t)m * LDA];
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[rr][c] = fma(av[rr], bv[c], acc[rr][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int gi = 4 * ti + rr, gc = 4 * tj + c;
+            const double v = acc[rr][c] + (gi == gc ? kNnlsEps : 0.0);
+            M2[gi + (size_t)gc * LDA] = v;
+            M2[gc + (size_t)gi * LDA] = v;
+          }
+      }
+      __syncthreads();
+      for (int t = tid; t < k1; t += NT) p[t] = matrow(M2, t, x) - matrow(A, t, rhs);   // mu
+      __syncthreads();
+      if (wv == 0) {
+        // scd_ls_update (nnls.hpp:10-34): lane l owns coordinates l and l + 64
+        const bool own0 = lane < k1, own1 = lane + 64 < k1;
+        double h0 = own0 ? x[lane] : 0.0, h1 = own1 ? x[lane + 64] : 0.0;
+        double mu0 = own0 ? p[lane] : 0.0, mu1 = own1 ? p[lane + 64] : 0.0;
+        const double dg0 = own0 ? M2[lane + (size_t)lane * LDA] : 1.0;
+        const double dg1 = own1 ? M2[(lane + 64) + (size_t)(lane + 64) * LDA] : 1.0;
+        for (unsigned it = 0; it < kScdMaxIter; it++) {
+          double rel = 0.0;
+          for (int c = 0; c < k1; c++) {
+            const int src = c & 63;
+            const bool hi = c >= 64;
+            const double old = __shfl(hi ? h1 : h0, src);
+            const double muc = __shfl(hi ? mu1 : mu0, src);
+            const double dg = __shfl(hi ? dg1 : dg0, src);
+            double nv = old - muc / dg;
+            if (nv < 0.0) nv = 0.0;
+            const double diff = nv - old;
+            if (diff != 0.0) {
+              if (lane == src) {
+                if (hi) h1 = nv; else h0 = nv;
+              }
+              const double* col = M2 + (size_t)c * LDA;
+              if (own0) mu0 += diff * col[lane];
+              if (own1) mu1 += diff * col[lane + 64];
+              const double se = fabs(diff) / (fabs(old) + kNnlsEps);
+              if (se > rel) rel = se;
+            }
+          }
+          if (rel <= kScdTol) break;
+        }
+        if (own0) x[lane] = h0;
+        if (own1) x[lane + 64] = h1;
+      }
+      __syncthreads();
+    } else {
+      // ---- Cholesky, right-looking; z = L^-1 rhs rides along in x ----
+      bool ok = true;
+      for (int j = 0; j < k1; j++) {
+        __syncthreads();
+        const double d = A[j + (size_t)j * LDA];
+        if (!(d > 0.0)) {
+          ok = false;
+          break;
+        }
+        const double dinv = 1.0 / sqrt(d);
+        for (int i = j + 1 + tid; i < k1; i += NT) A[i + (size_t)j * LDA] *= dinv;
+        if (tid == 0) {
+          invd[j] = dinv;
+          x[j] = rhs[j] * dinv;
+        }
+        __syncthreads();
+        const double zj = x[j];
+        const double* Lj = A + (size_t)j * LDA;
+        for (int i = j + 1 + ri; i < k1; i += RT) {
+          const double li = Lj[i];
+          for (int c = j + 1 + cgi; c <= i; c += CG) A[i + (size_t)c * LDA] = fma(-li, Lj[c], A[i + (size_t)c * LDA]);
+          if (cgi == 0) rhs[i] = fma(-li, zj, rhs[i]);
+        }
+      }
+      __syncthreads();
+      if (ok) {
+        if (wv == 0) {   // L^T y = z: lane l holds entries l and l + 64
+          double z0 = lane < k1 ? x[lane] : 0.0, z1 = lane + 64 < k1 ? x[lane + 64] : 0.0;
+          for (int m = k1 - 1; m >= 0; m--) {
+            const int src = m & 63;
+            const bool hi = m >= 64;
+            const double ym = __shfl(hi ? z1 : z0, src) * invd[m];
+            if (lane == src) {
+              if (hi) z1 = ym; else z0 = ym;
+            }
+            if (lane < m) z0 = fma(-A[m + (size_t)lane * LDA], ym, z0);
+            if (lane + 64 < m) z1 = fma(-A[m + (size_t)(lane + 64) * LDA], ym, z1);
+          }
+          if (lane < k1) x[lane] = z0;
+          if (lane + 64 < k1) x[lane + 64] = z1;
+        }
+        __syncthreads();
+      } else {
+        // ---- the general solver (gesv's order: partial pivoting, first largest entry) on the restored system ----
+        for (int e = tid; e < KP * KP; e += NT) {
+          const int c = e / KP, i = e - c * KP;
+          if (i > c) A[i + (size_t)c * LDA] = A[c + (size_t)i * LDA];
+          else if (i == c) A[i + (size_t)c * LDA] = d0[i];
+        }
+        for (int t = tid; t < KP; t += NT) rhs[t] = b0[t];
+        bool singular = false;
+        for (int c = 0; c < k1; c++) {
+          __syncthreads();
+          if (wv == 0) {
+            double best = -1.0;
+            int bi = c;
+            for (int i = c + lane; i < k1; i += 64) {
+              const double v = fabs(A[i + (size_t)c * LDA]);
+              if (v > best) { best = v; bi = i; }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+              const double ov = __shfl_xor(best, m);
+              const int oi = __shfl_xor(bi, m);
+              if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (lane == 0) {
+              spiv[0] = bi;
+              spiv[1] = best > 0.0 ? 0 : 1;
+            }
+          }
+          __syncthreads();
+          if (spiv[1]) {
+            singular = true;
+            break;
+          }
+          const int piv = spiv[0];
+          if (piv != c) {
+            for (int m = tid; m < k1; m += NT) {
+              const double t0 = A[c + (size_t)m * LDA];
+              A[c + (size_t)m * LDA] = A[piv + (size_t)m * LDA];
+              A[piv + (size_t)m * LDA] = t0;
+            }
+            if (tid == 0) {
+              const double t0 = rhs[c];
+              rhs[c] = rhs[piv];
+              rhs[piv] = t0;
+            }
+          }
+          __syncthreads();
+          const double pinv = 1.0 / A[c + (size_t)c * LDA];
+          const double bc = rhs[c];
+          for (int i = c + 1 + ri; i < k1; i += RT) {
+            const double f = A[i + (size_t)c * LDA] * pinv;
+            if (f != 0.0) {
+              for (int m = c + 1 + cgi; m < k1; m += CG) A[i + (size_t)m * LDA] = fma(-f, A[c + (size_t)m * LDA], A[i + (size_t)m * LDA]);
+              if (cgi == 0) rhs[i] = fma(-f, bc, rhs[i]);
+            }
+          }
+        }
+        __syncthreads();
+        if (!singular) {
+          if (wv == 0) {   // U y = b: lane l holds entries l and l + 64
+            double z0 = lane < k1 ? rhs[lane] : 0.0, z1 = lane + 64 < k1 ? rhs[lane + 64] : 0.0;
+            for (int m = k1 - 1; m >= 0; m--) {
+              const int src = m & 63;
+              const bool hi = m >= 64;
+              const double ym = __shfl(hi ? z1 : z0, src) / A[m + (size_t)m * LDA];
+              if (lane == src) {
+                if (hi) z1 = ym; else z0 = ym;
+              }
+              if (lane < m) z0 = fma(-A[lane + (size_t)m * LDA], ym, z0);
+              if (lane + 64 < m) z1 = fma(-A[(lane + 64) + (size_t)m * LDA], ym, z1);
+            }
+            if (lane < k1) x[lane] = z0;
+            if (lane + 64 < k1) x[lane + 64] = z1;
+          }
+        } else {
+          for (int t = tid; t < k1; t += NT) x[t] = 0.0;
+        }
+        if (tid == 0 && a.fail_counter) {
+          atomicAdd(a.fail_counter + 2, 1);
+          if (singular) atomicAdd(a.fail_counter + 3, 1);
+        }
+        __syncthreads();
+      }
+    }
+
+    // ---- write back, loss term (wrmf_implicit.hpp:254-270, wrmf_explicit.hpp:113-132) ----
+    for (int t = tid; t < k1; t += NT) yrow[a.ooff + t] = x[t];
+    double lpart = 0.0;
+    for (int c0 = 0; c0 < n; c0 += CH) {
+      const int cn = min(CH, n - c0);
+      stage(p1, c0, cn);
+      for (int j = wv; j < cn; j += NW) {
+        double s = 0.0;
+        for (int t = lane; t < k1; t += 64) s = fma(xs[j * KP + t], x[t], s);
+        s = wave_sum_d(s);
+        const double dlt = lt[j] - s;
+        lpart += lw[j] * dlt * dlt;
+      }
+      __syncthreads();
+    }
+    double yy = 0.0;
+    for (int t = tid; t < k1; t += NT) yy += x[t] * x[t];
+    const double tot = block_sum<NT>((lane == 0 ? lpart : 0.0) + lam_use * yy, red);
+    if (tid == 0) wloss += tot;
+  }
+  if (tid == 0) a.loss_partials[blockIdx.x] = wloss;
+}
+
+// ---- Gramian: partial[b] = sum over the block's columns of x x^T (lower-triangle tiles), then a fixed-order reduction ----
+__global__ __launch_bounds__(256) void f64_gramian_partial_kernel(const double* __restrict__ X, int k, int64_t n, int KP,
+                                                                  int CH, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* A = reinterpret_cast<double*>(smem_raw);
+  const int LDA = KP + 1, tid = threadIdx.x;
+  double* xs = A + (size_t)KP * LDA;
+  const int T4 = KP / 4, ntiles = T4 * (T4 + 1) / 2;
+  for (int e = tid; e < KP * LDA; e += 256) A[e] = 0.0;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t e0 = (int64_t)blockIdx.x * per, e1 = min(n, e0 + per);
+  __syncthreads();
+  for (int64_t c0 = e0; c0 < e1; c0 += CH) {
+    const int cn = (int)min((int64_t)CH, e1 - c0);
+    for (int e = tid; e < cn * KP; e += 256) {
+      const int j = e / KP, t = e - j * KP;
+      xs[e] = t < k ? X[(size_t)(c0 + j) * k + t] : 0.0;
+    }
+    __syncthreads();
+    rank_update_tiles<256>(A, LDA, xs, KP, nullptr, cn, ntiles);
+    __syncthreads();
+  }
+  double* out = partial + (size_t)blockIdx.x * KP * LDA;
+  for (int e = tid; e < KP * LDA; e += 256) out[e] = A[e];
+}
+
+__global__ __launch_bounds__(256) void f64_gramian_reduce_kernel(const double* __restrict__ partial, int blocks, int k, int KP,
+                                                                 double ridge, double* __restrict__ XtX,
+                                                                 double* __restrict__ sumsq) {
+  const int LDA = KP + 1;
+  const size_t mat = (size_t)KP * LDA;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < k * k) {
+    const int c = e / k, i = e - c * k;
+    const int lo = max(i, c), hi = min(i, c);   // the lower-triangle entry (lo, hi): the result is exactly symmetric
+    double s = 0.0;
+    for (int b = 0; b < blocks; b++) s += partial[(size_t)b * mat + lo + (size_t)hi * LDA];
+    XtX[e] = i == c ? s + ridge : s;
+  }
+  if (blockIdx.x == 0 && sumsq) {   // trace before the ridge = sum(X^2): the regulariser term of the loss for free
+    __shared__ double sdiag[128];
+    if (threadIdx.x < 128) {
+      double s = 0.0;
+      if ((int)threadIdx.x < k)
+        for (int b = 0; b < blocks; b++) s += partial[(size_t)b * mat + threadIdx.x + (size_t)threadIdx.x * LDA];
+      sdiag[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tr = 0.0;
+      for (int i = 0; i < k; i++) tr += sdiag[i];
+      sumsq[0] = tr;
+    }
+  }
+}
+
+constexpr int kRhsInitBlocksD = 256;
+__global__ __launch_bounds__(128) void f64_rhs_init_partial_kernel(const double* __restrict__ X, int k, int off, int k1,
+                                                                   int bias_row, double global_bias, int n,
+                                                                   double* __restrict__ partial) {
+  const int t = threadIdx.x;
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  const int e0 = blockIdx.x * per, e1 = min(n, e0 + per);
+  double s = 0.0;
+  if (t < k1)
+    for (int e = e0; e < e1; e++)   // rhs_init = -X' (x_b + global_bias)  (wrmf_implicit.hpp:146-153; :110-112 without biases)
+      s = fma(-X[(size_t)e * k + off + t], (bias_row >= 0 ? X[(size_t)e * k + bias_row] : 0.0) + global_bias, s);
+  partial[(size_t)blockIdx.x * 128 + t] = s;
+}
+__global__ __launch_bounds__(128) void f64_rhs_init_reduce_kernel(const double* __restrict__ partial, int blocks,
+                                                                  double* __restrict__ out) {
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int b = 0; b < blocks; b++) s += partial[(size_t)b * 128 + t];
+  out[t] = s;
+}
+
+__global__ __launch_bounds__(256) void f64_weighted_sumsq_kernel(const double* __restrict__ X, int k, int64_t n,
+                                                                 const double* __restrict__ w, double* __restrict__ partials) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
+  double s = 0.0;
+  for (int64_t j = wave; j < n; j += n_waves) {
+    double q = 0.0;
+    for (int t = lane; t < k; t += 64) {
+      const double v = X[(size_t)j * k + t];
+      q = fma(v, v, q);
+    }
+    s += (w ? w[j] : 1.0) * q;
+  }
+  s = wave_sum_d(s);
+  if (lane == 0) partials[wave] = s;
+}
+
+struct F64Geo {
+  int KP, NT, CH, m2_in_lds;
+  size_t lds;
+};
+constexpr size_t kF64LdsBudget = 156 * 1024;
+
+F64Geo f64_geometry(int k1, int solver) {
+  F64Geo g;
+  g.KP = std::max(4, (k1 + 3) / 4 * 4);
+  g.NT = g.KP <= 32 ? 64 : 256;
+  const size_t mat = (size_t)g.KP * (g.KP + 1);
+  const size_t vec = (size_t)9 * g.KP + 8;
+  auto bytes = [&](int mats, int ch) { return (mats * mat + vec + (size_t)ch * (g.KP + 4)) * 8 + (size_t)(ch + 4) * 4 + 16; };
+  g.m2_in_lds = (solver == 2 && bytes(2, 8) <= kF64LdsBudget) ? 1 : 0;
+  const int mats = 1 + g.m2_in_lds;
+  int ch = 64;
+  while (ch > 4 && bytes(mats, ch) > kF64LdsBudget) ch >>= 1;
+  // small systems: no need for the whole LDS (more workgroups per CU instead)
+  if (g.KP <= 32) ch = std::min(ch, 32);
+  g.CH = ch;
+  g.lds = bytes(mats, ch);
+  return g;
+}
+
+}  // namespace
+
+int f64_als_grid(int n_cols) { return std::max(1, std::min(n_cols, kF64MaxGrid)); }
+bool f64_needs_m2_scratch(int k1, int solver) { return solver == 2 && !f64_geometry(k1, solver).m2_in_lds; }
+size_t f64_m2_doubles_per_wg(int k1) {
+  const int KP = std::max(4, (k1 + 3) / 4 * 4);
+  return (size_t)KP * (KP + 1);
+}
+
+hipError_t launch_f64_als(const F64Args& a, hipStream_t s) {
+  if (a.n_cols <= 0) return hipSuccess;
+  const F64Geo g = f64_geometry(a.k1, a.solver);
+  const int grid = f64_als_grid(a.n_cols);
+  hipError_t err;
+  if (g.NT == 64) {
+    auto kern = f64_als_kernel<64>;
+    if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)) != hipSuccess)
+      return err;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), g.lds, s, a, g.KP, g.CH, g.m2_in_lds);
+  } else {
+    auto kern = f64_als_kernel<256>;
+    if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)) != hipSuccess)
+      return err;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), g.lds, s, a, g.KP, g.CH, g.m2_in_lds);
+  }
+  return hipGetLastError();
+}
+
+size_t f64_gramian_scratch_doubles(int k) {
+  const int KP = std::max(4, (k + 3) / 4 * 4);
+  return (size_t)kF64GramBlocks * KP * (KP + 1);
+}
+
+hipError_t launch_f64_gramian(const double* X, int k, int64_t n, double ridge, double* XtX, double* sumsq, double* scratch,
+                              hipStream_t s) {
+  const int KP = std::max(4, (k + 3) / 4 * 4);
+  int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kF64GramBlocks, (n + 63) / 64));
+  const size_t mat = (size_t)KP * (KP + 1);
+  int ch = 64;
+  while (ch > 4 && (mat + (size_t)ch * KP) * 8 > kF64LdsBudget) ch >>= 1;
+  const size_t lds = (mat + (size_t)ch * KP) * 8;
+  auto kern = f64_gramian_partial_kernel;
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, X, k, n, KP, ch, scratch);
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  hipLaunchKernelGGL(f64_gramian_reduce_kernel, dim3((k * k + 255) / 256), dim3(256), 0, s, scratch, blocks, k, KP, ridge, XtX, sumsq);
+  return hipGetLastError();
+}
+
+hipError_t launch_f64_rhs_init(const double* X, int k, int off, int k1, int bias_row, double global_bias, int n,
+                               double* scratch, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(f64_rhs_init_partial_kernel, dim3(kRhsInitBlocksD), dim3(128), 0, s, X, k, off, k1, bias_row,
+                     global_bias, n, scratch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(f64_rhs_init_reduce_kernel, dim3(1), dim3(128), 0, s, scratch, kRhsInitBlocksD, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_f64_weighted_sumsq(const double* X, int k, int64_t n, const double* w, double* out, double* partials,
+                                     hipStream_t s) {
+  hipLaunchKernelGGL(f64_weighted_sumsq_kernel, dim3(256), dim3(256), 0, s, X, k, n, w, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return launch_sum_partials(partials, 1024, out, s);
+}
+
+}  // namespace rsparse_hip

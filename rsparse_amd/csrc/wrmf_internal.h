@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <string>
 
 namespace rsparse_hip {
 
@@ -254,5 +255,12 @@ int padded_rank(int k);  // 32 / 64 / 128, or 0 if unsupported
 // says which kernel it is about to launch (host function pointer); rsparse_hip_profile_last_names resolves the pointers
 // to the names a profiler prints.  No-op when ev_slot is null.
 void prof_note(hipEvent_t* ev_slot, const void* kernel_fn);
+
+// Shared by the translation units of the C ABI (wrmf_capi.cpp, wrmf_f64_capi.cpp): the thread-local error text behind
+// rsparse_hip_last_error(), and the device block of the exact solvers' failure counters (see launch_fail_roll; nullptr if
+// the workspace could not be set up -- the error text then says why).
+int capi_fail(int code, const std::string& msg);
+int capi_hip_fail(hipError_t e, const char* what);
+int* capi_fail_counters();
 
 }  // namespace rsparse_hip

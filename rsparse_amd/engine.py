@@ -146,9 +146,14 @@ class HipBackend:
         return torch.as_tensor(a, dtype=dtype).to(self.device).contiguous()
 
     def make_csc(self, n_rows, n_cols, p, i, x):
-        """p/i/x: torch tensors already on the device (int32, int32, float32)."""
-        assert p.dtype == torch.int32 and i.dtype == torch.int32 and x.dtype == torch.float32
+        """p/i/x: torch tensors already on the device (int32, int32, float32 -- or float64: the handle then belongs to the
+        fp64 layer of the C ABI and every call that takes it computes in double)."""
+        assert p.dtype == torch.int32 and i.dtype == torch.int32 and x.dtype in (torch.float32, torch.float64)
         h = ctypes.c_void_p()
+        if x.dtype == torch.float64:
+            _lib.check(self.lib.rsparse_hip_csc_f64_create_device(int(n_rows), int(n_cols), p.data_ptr(), i.data_ptr(),
+                                                                  x.data_ptr(), ctypes.byref(h)))
+            return _CscHandle(self.lib, h, (p, i, x), n_rows, n_cols, f64=True)
         _lib.check(self.lib.rsparse_hip_csc_create_device(int(n_rows), int(n_cols), p.data_ptr(), i.data_ptr(),
                                                           x.data_ptr(), ctypes.byref(h)))
         return _CscHandle(self.lib, h, (p, i, x), n_rows, n_cols)
@@ -156,8 +161,14 @@ class HipBackend:
     def transpose_csc(self, n_rows, n_cols, p, i, x):
         """CSC (p, i, x) of an n_rows x n_cols matrix, on the device -> CSC of its transpose, row indices ascending
         inside every column (the second orientation of a fit, R/model_WRMF.R:190)."""
-        assert p.dtype == torch.int32 and i.dtype == torch.int32 and x.dtype == torch.float32
+        assert p.dtype == torch.int32 and i.dtype == torch.int32 and x.dtype in (torch.float32, torch.float64)
         nnz = int(i.numel())
+        if x.dtype == torch.float64:
+            # the ingest kernels move 32-bit payloads: send each entry's POSITION through them (bits are copied, never
+            # computed with) and gather the doubles by the permutation that comes back
+            pos = torch.arange(nnz, dtype=torch.int32, device=self.device).view(torch.float32)
+            pt, it, perm = self.transpose_csc(n_rows, n_cols, p, i, pos)
+            return pt, it, x[perm.view(torch.int32).to(torch.int64)].contiguous()
         pt = torch.empty(n_rows + 1, dtype=torch.int32, device=self.device)
         it = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.device)[:nnz]
         xt = torch.empty(max(nnz, 1), dtype=torch.float32, device=self.device)[:nnz]
@@ -177,6 +188,12 @@ class HipBackend:
     def gramian(self, F, lambda_, out, sumsq_out, absmax_inout=None):
         """absmax_inout (float32[1], optional): receives max(its content, max |F|) -- the Gramian reads F anyway."""
         n, k = F.shape
+        if F.dtype == torch.float64:
+            assert out.dtype == torch.float64
+            _lib.check(self.lib.rsparse_hip_gramian_f64_device(
+                F.data_ptr(), k, n, float(lambda_), out.data_ptr(), None if sumsq_out is None else sumsq_out.data_ptr(),
+                self._stream()))
+            return
         _lib.check(self.lib.rsparse_hip_gramian_absmax_device(
             F.data_ptr(), k, n, float(lambda_), out.data_ptr(), None if sumsq_out is None else sumsq_out.data_ptr(),
             None if absmax_inout is None else absmax_inout.data_ptr(), self._stream()))
@@ -187,6 +204,13 @@ class HipBackend:
         with_biases = TRUE.  absmax (float32[1] on the device, optional): max |F| if the caller knows it (implicit
         feedback; the Gramian pass yields it) -- F is then not scanned for the fp16 operand scales."""
         k = F.shape[1]
+        if csc.f64:   # the fp64 layer: one entry point for every variant
+            assert F.dtype == torch.float64 and S_block.dtype == torch.float64 and (G is None or G.dtype == torch.float64)
+            _lib.check(self.lib.rsparse_hip_als_f64_device(
+                csc.h, int(bool(implicit)), F.data_ptr(), S_block.data_ptr(), None if G is None else G.data_ptr(), k,
+                float(lambda_), int(solver), int(cg_steps), int(bool(dynamic_lambda)), int(bias_last_row is not None),
+                int(bool(bias_last_row)), float(global_bias) if implicit else 0.0, loss_out.data_ptr(), self._stream()))
+            return
         am = None if absmax is None else absmax.data_ptr()
         if implicit and global_bias:
             # implicit feedback with a global bias: every solver without user/item biases, Cholesky / NNLS with them
@@ -220,6 +244,11 @@ class HipBackend:
         """wrmf_utils.hpp:32-84 on the device; with calculate_global_bias the resident values of both handles
         lose their mean in place.  Returns the global bias."""
         gb = ctypes.c_double(0.0)
+        if csc_ui.f64:
+            _lib.check(self.lib.rsparse_hip_initialize_biases_f64_device(
+                csc_ui.h, csc_iu.h, user_bias.data_ptr(), item_bias.data_ptr(), float(lambda_), int(bool(dynamic_lambda)),
+                int(bool(non_negative)), int(bool(calculate_global_bias)), 1, ctypes.byref(gb), self._stream()))
+            return gb.value
         _lib.check(self.lib.rsparse_hip_initialize_biases_explicit_device(
             csc_ui.h, csc_iu.h, user_bias.data_ptr(), item_bias.data_ptr(), float(lambda_), int(bool(dynamic_lambda)),
             int(bool(non_negative)), int(bool(calculate_global_bias)), ctypes.byref(gb), self._stream()))
@@ -229,6 +258,11 @@ class HipBackend:
                                    calculate_global_bias=False):
         """wrmf_utils.hpp:86-165 on the device.  Returns the global bias (0 unless calculate_global_bias)."""
         gb = ctypes.c_double(0.0)
+        if csc_ui.f64:
+            _lib.check(self.lib.rsparse_hip_initialize_biases_f64_device(
+                csc_ui.h, csc_iu.h, user_bias.data_ptr(), item_bias.data_ptr(), float(lambda_), 0,
+                int(bool(non_negative)), int(bool(calculate_global_bias)), 0, ctypes.byref(gb), self._stream()))
+            return gb.value
         _lib.check(self.lib.rsparse_hip_initialize_biases_implicit_device(
             csc_ui.h, csc_iu.h, user_bias.data_ptr(), item_bias.data_ptr(), float(lambda_), int(bool(non_negative)),
             int(bool(calculate_global_bias)), ctypes.byref(gb), self._stream()))
@@ -237,16 +271,17 @@ class HipBackend:
     def subtract_mean(self, x, x_other=None):
         """global_bias = mean(x), removed in place from x (and from the other orientation's values) -- R/model_WRMF.R:278-282"""
         m = ctypes.c_double(0.0)
-        _lib.check(self.lib.rsparse_hip_values_subtract_mean_device(int(x.numel()), x.data_ptr(),
-                                                                    None if x_other is None else x_other.data_ptr(),
-                                                                    ctypes.byref(m), self._stream()))
+        fn = (self.lib.rsparse_hip_values_subtract_mean_f64_device if x.dtype == torch.float64
+              else self.lib.rsparse_hip_values_subtract_mean_device)
+        _lib.check(fn(int(x.numel()), x.data_ptr(),
+                      None if x_other is None else x_other.data_ptr(), ctypes.byref(m), self._stream()))
         return m.value
 
     def weighted_sumsq(self, F, w, out):
         n, k = F.shape
-        _lib.check(self.lib.rsparse_hip_weighted_sumsq_device(F.data_ptr(), k, n,
-                                                              None if w is None else w.data_ptr(),
-                                                              out.data_ptr(), self._stream()))
+        fn = self.lib.rsparse_hip_weighted_sumsq_f64_device if F.dtype == torch.float64 else self.lib.rsparse_hip_weighted_sumsq_device
+        assert w is None or w.dtype == F.dtype
+        _lib.check(fn(F.data_ptr(), k, n, None if w is None else w.data_ptr(), out.data_ptr(), self._stream()))
 
     def set_launch_mode(self, mode):
         """0 = the launches of a CG half-iteration back to back on one stream (profilers), 2 = the default overlap"""
@@ -282,11 +317,14 @@ class HipBackend:
 
 
 class _CscHandle:
-    def __init__(self, lib, h, keep, n_rows, n_cols):
+    def __init__(self, lib, h, keep, n_rows, n_cols, f64=False):
         self.lib, self.h, self.keep = lib, h, keep
         self.n_rows, self.n_cols = n_rows, n_cols
+        self.f64 = bool(f64)   # a handle of the fp64 layer (rsparse_hip_csc_f64): no launch schedule, no info()
 
     def info(self):
+        if self.f64:
+            raise RuntimeError("csc_info describes the fp32 launch schedule; an fp64 handle has none")
         buf = (ctypes.c_int64 * 40)()
         _lib.check(self.lib.rsparse_hip_csc_info(self.h, buf))
         return dict(n_rows=buf[0], n_cols=buf[1], nnz=buf[2], n_long=buf[3], max_len=buf[4], nnz_long=buf[5],
@@ -297,7 +335,7 @@ class _CscHandle:
     def __del__(self):
         try:
             if self.h:
-                self.lib.rsparse_hip_csc_destroy(self.h)
+                (self.lib.rsparse_hip_csc_f64_destroy if self.f64 else self.lib.rsparse_hip_csc_destroy)(self.h)
                 self.h = None
         except Exception:
             pass
@@ -329,12 +367,13 @@ class ShardedALS:
             lay_user, lay_item = self.layouts(n_user, n_item, self.ws)
         self.lay_user, self.lay_item = lay_user, lay_item
         dev = c_ui_block[0].device
+        self.dtype = c_ui_block[2].dtype   # float32, or float64: the fp64 layer (WRMF(precision="double"))
         # item half: fixed side = users, solved = my items; user half: fixed side = items, solved = my users
         self.csc_items, self.sub_items = self._make(c_ui_block, lay_user, lay_item)
         self.csc_users, self.sub_users = self._make(c_iu_block, lay_item, lay_user)
         self.scal_sub = torch.zeros(max(lay_user.n_sub, lay_item.n_sub), dtype=torch.float64, device=dev)
-        self.G = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
-        self.Gpart = torch.zeros((self.k, self.k), dtype=torch.float32, device=dev)
+        self.G = torch.zeros((self.k, self.k), dtype=self.dtype, device=dev)
+        self.Gpart = torch.zeros((self.k, self.k), dtype=self.dtype, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float64, device=dev)   # [0] sumsq, [1] loss rows, [2] spare
         # one collective per Gramian: every rank contributes [k x k partial, sum(F^2), max |F|] (doubles), all ranks get
         # all contributions and reduce them locally in rank order (sums and the maximum: deterministic, identical everywhere)
@@ -449,8 +488,8 @@ class ShardedALS:
         """(k-1) x (k-1) Gramian of F without its bias row + fl(lambda) I (R/model_WRMF.R:463-486, 345-351)."""
         k1 = self.k - 1
         if getattr(self, "Gb", None) is None:
-            self.Gb = torch.zeros((k1, k1), dtype=torch.float32, device=F.device)
-            self.Gbp = torch.zeros((k1, k1), dtype=torch.float32, device=F.device)
+            self.Gb = torch.zeros((k1, k1), dtype=self.dtype, device=F.device)
+            self.Gbp = torch.zeros((k1, k1), dtype=self.dtype, device=F.device)
         self.Gb.zero_()
         for a, b in self._my_pieces(lay):
             blk = (F[a:b, :k1] if bias_last_row else F[a:b, 1:]).contiguous()

@@ -39,6 +39,11 @@ class TopItems(np.ndarray):
 
 
 class WRMF:
+    # precision = "double" (the reference's default, R/model_WRMF.R:82) runs the fp64 layer of the library up to this rank
+    # (counting the two bias coordinates); above it the fp32 kernels are used and a RuntimeWarning says so.  The fp64 path
+    # is the parity path (one workgroup per row, k^2 flops per non-zero): set WRMF.f64_max_rank = 128 to take it always.
+    f64_max_rank = 63
+
     def __init__(self, rank=10, lambda_=0.0, dynamic_lambda=True, init=None, preprocess=_identity,
                  feedback="implicit", solver="conjugate_gradient", with_user_item_bias=False,
                  with_global_bias=False, cg_steps=3, precision="double", rng=None, device=None, group=None,
@@ -61,17 +66,19 @@ class WRMF:
         if with_user_item_bias and feedback != "explicit" and solver == "conjugate_gradient":
             raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "user/item biases + conjugate_gradient with implicit "
                                            "feedback: the reference cannot run this combination either")
-        if precision == "double":
-            import warnings
-            warnings.warn("rsparse_amd.WRMF(precision='double'): the device path computes in fp32 (the reference's "
-                          "precision='float' arithmetic); inputs and results are converted at the boundary.  Pass "
-                          "precision='float' to silence this.", RuntimeWarning, stacklevel=2)
         self._with_bias, self._with_global_bias = bool(with_user_item_bias), bool(with_global_bias)
         self._solver_code = SOLVER_CODES[solver]                                   # :99-100
         self._precision, self._feedback = precision, feedback
         self._lambda, self._dynamic_lambda = float(lambda_), bool(dynamic_lambda)
         self._cg_steps = int(cg_steps)
         self._rank = int(rank) + (2 if self._with_bias else 0)                     # :159-163
+        self._f64 = precision == "double" and self._rank <= self.f64_max_rank
+        if precision == "double" and not self._f64:
+            import warnings
+            warnings.warn("rsparse_amd.WRMF(precision='double') at rank %d > WRMF.f64_max_rank = %d: the device path computes "
+                          "in fp32 (the reference's precision='float' arithmetic); inputs and results are converted at the "
+                          "boundary.  Pass precision='float' to silence this, or raise WRMF.f64_max_rank (<= 128) to run "
+                          "the fp64 kernels." % (self._rank, self.f64_max_rank), RuntimeWarning, stacklevel=2)
         self._preprocess = preprocess
         self.components = init
         self.global_bias = 0.0
@@ -94,10 +101,17 @@ class WRMF:
     def _np_dtype(self):
         return np.float64 if self._precision == "double" else np.float32
 
+    def _dev_np(self):
+        """element type of the device arithmetic (numpy): float64 on the fp64 layer, else float32"""
+        return np.float64 if self._f64 else np.float32
+
+    def _dev_t(self):
+        return torch.float64 if self._f64 else torch.float32
+
     def _upload_csc(self, m):
         be = self._backend()
         return (be.to_device(m.indptr, torch.int32), be.to_device(m.indices, torch.int32),
-                be.to_device(m.data, torch.float32))
+                be.to_device(m.data, self._dev_t()))
 
     def _dist(self):
         """(world size, my rank) of the group this model shards over; (1, 0) without torch.distributed."""
@@ -127,21 +141,22 @@ class WRMF:
         n_user, n_item = c_ui.shape
         k = self._rank
         # large_rand_matrix(rank, n_user): N(0,1)/100, column-major rank x n_user  (:204-205)
+        ndt, tdt = self._dev_np(), self._dev_t()
         if self._init_user_factors is not None:
-            U0 = np.ascontiguousarray(self._init_user_factors, dtype=np.float32)
+            U0 = np.array(self._init_user_factors, dtype=ndt, order="C")
             if U0.shape != (n_user, k):
                 raise ValueError("initial user factors must be n_user x rank")
         else:
-            U0 = (self._rng.standard_normal((n_user, k)) * 0.01).astype(np.float32)
+            U0 = (self._rng.standard_normal((n_user, k)) * 0.01).astype(ndt)
         if self.components is None:
             if self._solver_code == 1:                                             # CG -> zeros (:219-231)
-                V0 = np.zeros((n_item, k), dtype=np.float32)
+                V0 = np.zeros((n_item, k), dtype=ndt)
             else:
-                V0 = (self._rng.standard_normal((n_item, k)) * 0.01).astype(np.float32)
+                V0 = (self._rng.standard_normal((n_item, k)) * 0.01).astype(ndt)
         else:
             if self.components.shape != (k, n_item):                               # :246-248
                 raise ValueError("init must be rank x n_item")
-            V0 = np.ascontiguousarray(self.components.T, dtype=np.float32)
+            V0 = np.array(self.components.T, dtype=ndt, order="C")
         if self._with_bias:                                                        # :208-245: the two rows of ones
             U0 = U0.copy()
             V0 = V0.copy()
@@ -151,20 +166,21 @@ class WRMF:
             U0, V0 = np.abs(U0), np.abs(V0)
         # one orientation crosses the boundary (f64 values as in dgCMatrix@x); the item-user orientation
         # c_iu = t_shallow(as.csr.matrix(c_ui)) (:190) and the f32 values are produced on the device
+        x64 = be.to_device(c_ui.data, torch.float64)
         d_ui = (be.to_device(c_ui.indptr, torch.int32), be.to_device(c_ui.indices, torch.int32),
-                be.values_to_float(be.to_device(c_ui.data, torch.float64)))
+                x64 if self._f64 else be.values_to_float(x64))
         d_iu = be.transpose_csc(n_user, n_item, *d_ui)
         als = ShardedALS(be, n_user, n_item, k, d_ui, d_iu, c_ui.nnz,
                          feedback=self._feedback, lambda_=self._lambda, dynamic_lambda=self._dynamic_lambda,
                          cg_steps=self._cg_steps, with_bias=self._with_bias)
-        als.cnt_user = torch.diff(d_iu[0]).to(torch.float32)                       # cnt_i in the reference (:312)
-        als.cnt_item = torch.diff(d_ui[0]).to(torch.float32)                       # cnt_u (:311)
-        U = be.to_device(U0, torch.float32)
-        V = be.to_device(V0, torch.float32)
+        als.cnt_user = torch.diff(d_iu[0]).to(tdt)                                 # cnt_i in the reference (:312)
+        als.cnt_item = torch.diff(d_ui[0]).to(tdt)                                 # cnt_u (:311)
+        U = be.to_device(U0, tdt)
+        V = be.to_device(V0, tdt)
         self.global_bias = 0.0
         if self._with_bias:                                                        # :259-277
-            user_bias = torch.zeros(n_user, dtype=torch.float32, device=U.device)
-            item_bias = torch.zeros(n_item, dtype=torch.float32, device=U.device)
+            user_bias = torch.zeros(n_user, dtype=tdt, device=U.device)
+            item_bias = torch.zeros(n_item, dtype=tdt, device=U.device)
             if self._feedback == "explicit":
                 gb = be.initialize_biases_explicit(als.csc_items, als.csc_users, user_bias, item_bias, self._lambda,
                                                    self._dynamic_lambda, self._non_negative, self._with_global_bias)
@@ -217,18 +233,22 @@ class WRMF:
             raise ValueError("all(c_ui@x >= 0) is not TRUE")
         n_user, n_item = c_ui.shape
         k = self._rank
-        # the SAME initial factors on every rank: drawn once from the model's generator ...
+        # the SAME initial factors on every rank: drawn once from the model's generator ...  (copies: the broadcast below
+        # writes into them, and the caller's arrays are not ours to change)
+        ndt, tdt = self._dev_np(), self._dev_t()
         if self._init_user_factors is not None:
-            U0 = np.ascontiguousarray(self._init_user_factors, dtype=np.float32)
+            U0 = np.array(self._init_user_factors, dtype=ndt, order="C")
+            if U0.shape != (n_user, k):
+                raise ValueError("initial user factors must be n_user x rank")
         else:
-            U0 = (self._rng.standard_normal((n_user, k)) * 0.01).astype(np.float32)
+            U0 = (self._rng.standard_normal((n_user, k)) * 0.01).astype(ndt)
         if self.components is None:
-            V0 = (np.zeros((n_item, k), dtype=np.float32) if self._solver_code == 1 else
-                  (self._rng.standard_normal((n_item, k)) * 0.01).astype(np.float32))
+            V0 = (np.zeros((n_item, k), dtype=ndt) if self._solver_code == 1 else
+                  (self._rng.standard_normal((n_item, k)) * 0.01).astype(ndt))
         else:
             if self.components.shape != (k, n_item):
                 raise ValueError("init must be rank x n_item")
-            V0 = np.ascontiguousarray(self.components.T, dtype=np.float32)
+            V0 = np.array(self.components.T, dtype=ndt, order="C")
         if self._non_negative:
             U0, V0 = np.abs(U0), np.abs(V0)
         dev0 = be.to_device(np.zeros(1, dtype=np.float32), torch.float32).device
@@ -253,15 +273,15 @@ class WRMF:
         def block(m, lo, hi):
             b = m[:, lo:hi]
             return (be.to_device(b.indptr, torch.int32), be.to_device(b.indices, torch.int32),
-                    be.to_device(b.data.astype(np.float32), torch.float32))
+                    be.to_device(b.data.astype(ndt), tdt))
         als = ShardedALS(be, n_user, n_item, k, block(c_ui, *lay_i.bounds[me]), block(c_iu, *lay_u.bounds[me]), c_ui.nnz,
                          feedback=self._feedback, lambda_=self._lambda, dynamic_lambda=self._dynamic_lambda,
                          cg_steps=self._cg_steps, group=self._group, world_size=ws, my_rank=me, lay_user=lay_u,
                          lay_item=lay_i)
-        als.cnt_user = be.to_device(cnt_user.numpy().astype(np.float32), torch.float32)
-        als.cnt_item = be.to_device(cnt_item.numpy().astype(np.float32), torch.float32)
-        U = lay_u.from_global(lay_u.alloc(k, dev0), be.to_device(U0, torch.float32))
-        V = lay_i.from_global(lay_i.alloc(k, dev0), be.to_device(V0, torch.float32))
+        als.cnt_user = be.to_device(cnt_user.numpy().astype(ndt), tdt)
+        als.cnt_item = be.to_device(cnt_item.numpy().astype(ndt), tdt)
+        U = lay_u.from_global(lay_u.alloc(k, dev0, tdt), be.to_device(U0, tdt))
+        V = lay_i.from_global(lay_i.alloc(k, dev0, tdt), be.to_device(V0, tdt))
         if self._feedback == "implicit":
             als.global_bias = self.global_bias
         loss_prev = float("inf")
@@ -277,7 +297,7 @@ class WRMF:
         # the returned embeddings: one more exact solve from zeros against the final item factors (:355-359), sharded like
         # a user half-iteration
         XtX = als.gramian(V, lay_i).clone() if self._feedback == "implicit" else None
-        res = lay_u.alloc(k, dev0)
+        res = lay_u.alloc(k, dev0, tdt)
         solver = 0 if self._solver_code == 1 else self._solver_code
         als.half_iteration("users", res, V, solver, G=XtX, want_loss=False)
         be.check_numeric()
@@ -333,7 +353,7 @@ class WRMF:
         """R/model_WRMF.R:412-452: one user half-iteration from zeros against the final item factors,
         Cholesky whenever the model's solver is CG (avoid_cg, :112).  Returns the device tensor."""
         be = self._backend()
-        res = torch.zeros((n_new, self._rank), dtype=torch.float32, device=self._V.device)   # :423-427
+        res = torch.zeros((n_new, self._rank), dtype=self._V.dtype, device=self._V.device)   # :423-427
         if self._with_bias:
             res[:, 0] = 1.0                                                                   # :427-429
         solver = 0 if self._solver_code == 1 else self._solver_code                          # :112
@@ -386,9 +406,11 @@ class WRMF:
         sc = torch.empty((n_mine, k), dtype=torch.float32, device=emb.device)
         lib = be.lib
         if n_mine > 0:
-            emb_mine = emb[a:b]
+            # scores are fp32 on the device whatever the model's precision (the reference multiplies in double; stated)
+            emb_mine = emb[a:b].to(torch.float32).contiguous()
+            V32 = self._V if self._V.dtype == torch.float32 else self._V.to(torch.float32)
             _lib.check(lib.rsparse_hip_top_product_device(
-                emb_mine.data_ptr(), self._V.data_ptr(), n_mine, n_item, self._rank, k,
+                emb_mine.data_ptr(), V32.data_ptr(), n_mine, n_item, self._rank, k,
                 None if nr_p is None else nr_p.data_ptr(), None if nr_j is None else nr_j.data_ptr(),
                 None if d_ex is None else d_ex.data_ptr(), int(excl.size), float(self.global_bias),
                 res.data_ptr(), sc.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)))

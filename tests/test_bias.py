@@ -376,8 +376,6 @@ def test_hip_implicit_global_bias_half_iteration(solver, with_biases, k, precisi
     """Stateless als_implicit_{float,double} with global_bias (R/model_WRMF.R:456-496): the base vector comes back when
     initialize_bias_base, is read when not, and both give the oracle's factors and loss."""
     from rsparse_amd import als
-    if k == 128 and precision == "double":
-        pytest.skip("same kernels as float; the 128 case is covered there")
     dt = np.float32 if precision == "float" else np.float64
     m, X, Y0 = _problem(300 + k, n_rows=300, n_cols=200, k=k, density=0.08)
     m.data[:] = np.abs(m.data) + 1.0
@@ -464,8 +462,6 @@ def test_hip_implicit_global_bias_cg_half_iteration(k, precision, cg_steps):
     its per-row term from launch_gb_row_terms (> 512 non-zeros, incl. rows split across workgroups) and empty columns,
     against the oracle in double; yardstick for the bound = the oracle in float (three CG steps from a warm start)."""
     from rsparse_amd import als
-    if precision == "double" and (k in (34, 64) or cg_steps == 0):
-        pytest.skip("same kernels as float")
     dt = np.float32 if precision == "float" else np.float64
     m, X32, Y32 = _long_row_problem(900 + k, k)
     p, i, x = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data

@@ -1,0 +1,280 @@
+"""The fp64 device layer (rsparse_amd/csrc/wrmf_f64.hip): what the reference's `*_double` entry points compute
+(src/wrmf_implicit.cpp:5-14 -> als_implicit<double>, src/wrmf_explicit.cpp:5-14 -> als_explicit<double>,
+src/wrmf_init.cpp:5-19 -> initialize_biases_double), against the fp64 oracle on the same inputs.
+
+Both sides compute in double, so the bound is far below the north star's 1e-4: 1e-9 per ROW for the exact solver and the
+conjugate gradient (the device evaluates A p from the assembled k x k system, the oracle as XtX p + X_nnz((c-1) % X_nnz^T p):
+the same operator, rounded differently at the 1e-16 level), 1e-6 for NNLS (its sweeps stop at a relative step of 1e-4; a
+coordinate that sits within an ulp of that threshold may take one sweep more on one side).  Every call goes through the C
+ABI (`rsparse_hip_als_{implicit,explicit}_double` -- the two drop-in symbols that had no test of their own arithmetic --
+and the device-resident `rsparse_hip_*_f64_device` entries through `WRMF(precision="double")`)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import rel_fro
+from oracle import wrmf_oracle as O
+from rsparse_amd import als, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n_user, n_item, k, seed, mean_deg=12, d_max=400, feedback="implicit", scale=0.1):
+    d = synth.make_dataset(n_user, n_item, seed=seed, mean_deg=mean_deg, d_max=d_max, feedback=feedback, device="cpu")
+    p, i, x = d["c_iu"]          # columns = users
+    p, i, x = p.numpy(), i.numpy(), x.numpy().astype(np.float64)
+    rng = np.random.default_rng(seed)
+    X = np.asfortranarray(rng.standard_normal((k, n_item)) * scale)
+    Y0 = np.asfortranarray(rng.standard_normal((k, n_user)) * scale)
+    return (n_item, n_user, p, i, x), X, Y0
+
+
+def _row_err(Y, Yref):
+    return np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-300)
+
+
+def _bound(solver):
+    return 1e-6 if solver == 2 else 1e-9
+
+
+@pytest.mark.parametrize("k,n", [(4, 1), (10, 7), (16, 1000), (33, 5000), (64, 20011), (128, 3000), (100, 333)])
+def test_gramian_double(k, n):
+    rng = np.random.default_rng(k * 1000 + n)
+    X = np.asfortranarray(rng.standard_normal((k, n)))
+    X[0, :] += 3.0
+    for lam in (0.0, 0.1):
+        G = als.gramian(X, lam, "double")
+        assert G.dtype == np.float64
+        ref = X @ X.T + float(np.float32(lam)) * np.eye(k)      # fl(diag(lambda)), R/model_WRMF.R:476
+        assert rel_fro(G, ref) < 1e-13
+        assert np.array_equal(G, G.T)
+        assert rel_fro(G, O.gramian(X, lam)) < 1e-13
+
+
+@pytest.mark.parametrize("k", [4, 10, 16, 33, 64, 100, 128])
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_implicit_double_half_iteration(k, solver):
+    """als_implicit_double, no biases: rows of 1..400 non-zeros, empty rows included."""
+    n_user = 700 if k > 64 else 1500
+    csc, X, Y0 = _problem(n_user, 400, k, seed=k + solver)
+    n_rows, n_cols, p, i, x = csc
+    if solver == 2:
+        X, Y0 = np.abs(X), np.abs(Y0)
+    lam = 0.1
+    G = O.gramian(X, lam)
+    Yref = Y0.copy(order="F")
+    lref = O.als_implicit(p, i, x, X, Yref, G, lam, solver, 3, n_threads=8)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, lam, 1, solver, 3, "double", False, False, XtX=G)
+    err = _row_err(Y, Yref)
+    assert err.max() < _bound(solver), (int(err.argmax()), float(err.max()))
+    assert abs(loss - lref) <= 1e-9 * abs(lref)
+    empty = np.diff(p) == 0
+    assert np.all(Y[:, empty] == 0)
+    # the Gramian computed by the wrapper on the device gives the same thing
+    Y2 = Y0.copy(order="F")
+    als.als_implicit(csc, X, Y2, lam, 1, solver, 3, "double", False, False)
+    assert _row_err(Y2, Yref).max() < 10 * _bound(solver)
+
+
+@pytest.mark.parametrize("cg_steps", [0, 1, 5])
+def test_implicit_double_cg_steps(cg_steps):
+    csc, X, Y0 = _problem(600, 200, 24, seed=11 + cg_steps)
+    n_rows, n_cols, p, i, x = csc
+    G = O.gramian(X, 0.05)
+    Yref = Y0.copy(order="F")
+    lref = O.als_implicit(p, i, x, X, Yref, G, 0.05, 1, cg_steps)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, 0.05, 1, 1, cg_steps, "double", False, False, XtX=G)
+    assert _row_err(Y, Yref).max() < 1e-9
+    assert abs(loss - lref) <= 1e-9 * abs(lref)
+    if cg_steps == 0:
+        live = np.diff(p) > 0
+        assert np.array_equal(Y[:, live], Y0[:, live])
+
+
+@pytest.mark.parametrize("k", [6, 16, 40, 64, 128])
+@pytest.mark.parametrize("solver", [0, 1, 2])
+@pytest.mark.parametrize("dynamic_lambda", [True, False])
+def test_explicit_double_half_iteration(k, solver, dynamic_lambda):
+    """als_explicit_double (the drop-in symbol without a GPU test until round 4): CG, Cholesky and NNLS, dynamic lambda on / off."""
+    csc, X, Y0 = _problem(500 if k > 64 else 1200, 300, k, seed=50 + k + solver, feedback="explicit", scale=0.3)
+    n_rows, n_cols, p, i, x = csc
+    if solver == 2:
+        X, Y0 = np.abs(X), np.abs(Y0)
+    lam = 0.1
+    cnt = np.diff(sp.csc_matrix((x, i, p), shape=(n_rows, n_cols)).tocsr().indptr).astype(np.float64)
+    Yref = Y0.copy(order="F")
+    lref = O.als_explicit(p, i, x, X, Yref, cnt, lam, solver, 3, dynamic_lambda, n_threads=8)
+    Y = Y0.copy(order="F")
+    loss = als.als_explicit(csc, X, Y, cnt, lam, 1, solver, 3, dynamic_lambda, "double", False, False)
+    err = _row_err(Y, Yref)
+    assert err.max() < _bound(solver), (int(err.argmax()), float(err.max()))
+    assert abs(loss - lref) <= 1e-9 * abs(lref)
+
+
+@pytest.mark.parametrize("k", [6, 9, 34, 128])
+@pytest.mark.parametrize("solver", [0, 1, 2])
+@pytest.mark.parametrize("bias_last", [True, False])
+def test_explicit_double_with_biases(k, solver, bias_last):
+    """wrmf_explicit.hpp:41-64,86-91,113-127 in double: X = [1, ..., x_bias] / Y = [y_bias, ..., 1] or the other way round."""
+    csc, X, Y0 = _problem(400, 150, k, seed=70 + k + solver, feedback="explicit", scale=0.3)
+    n_rows, n_cols, p, i, x = csc
+    if solver == 2:
+        X, Y0 = np.abs(X), np.abs(Y0)
+    X[0 if bias_last else k - 1, :] = 1.0
+    Y0[k - 1 if bias_last else 0, :] = 1.0
+    cnt = np.diff(sp.csc_matrix((x, i, p), shape=(n_rows, n_cols)).tocsr().indptr).astype(np.float64)
+    Yref = Y0.copy(order="F")
+    lref = O.als_explicit(p, i, x, X, Yref, cnt, 0.1, solver, 3, True, with_biases=True, is_x_bias_last_row=bias_last)
+    Y = Y0.copy(order="F")
+    loss = als.als_explicit(csc, X, Y, cnt, 0.1, 1, solver, 3, True, "double", True, bias_last)
+    err = _row_err(Y, Yref)
+    assert err.max() < _bound(solver), (int(err.argmax()), float(err.max()))
+    assert abs(loss - lref) <= 1e-9 * abs(lref)
+    keep = k - 1 if bias_last else 0
+    assert np.array_equal(Y[keep, :], Y0[keep, :])       # the placeholder entry is never written
+
+
+@pytest.mark.parametrize("k", [6, 34, 128])
+@pytest.mark.parametrize("solver", [0, 2])
+@pytest.mark.parametrize("bias_last", [True, False])
+@pytest.mark.parametrize("gbias", [0.0, 0.03])
+def test_implicit_double_with_biases(k, solver, bias_last, gbias):
+    """wrmf_implicit.hpp:114-154,186-252,256-270 in double (Cholesky / NNLS), with and without a global bias."""
+    csc, X, Y0 = _problem(300, 120, k, seed=90 + k + solver)
+    n_rows, n_cols, p, i, x = csc
+    if solver == 2:
+        X, Y0 = np.abs(X), np.abs(Y0)
+    X[0 if bias_last else k - 1, :] = 1.0
+    Y0[k - 1 if bias_last else 0, :] = 1.0
+    XX = np.asfortranarray(X[:-1, :] if bias_last else X[1:, :])
+    G = O.gramian(XX, 0.1)
+    Yref = Y0.copy(order="F")
+    lref = O.als_implicit(p, i, x, X, Yref, G, 0.1, solver, 3, with_biases=True, is_x_bias_last_row=bias_last,
+                          global_bias=gbias)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, 0.1, 1, solver, 3, "double", True, bias_last, global_bias=gbias, XtX=G)
+    err = _row_err(Y, Yref)
+    assert err.max() < _bound(solver), (int(err.argmax()), float(err.max()))
+    assert abs(loss - lref) <= 1e-9 * abs(lref)
+
+
+@pytest.mark.parametrize("k", [6, 34, 128])
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_implicit_double_global_bias(k, solver):
+    """A global bias without user/item biases, every solver (wrmf_implicit.hpp:35-57,108-112,155-157,203,228-229,262-264);
+    1e-7 is below the float threshold and above the double one (:108-109): the double entry point must keep it."""
+    csc, X, Y0 = _problem(300, 120, k, seed=120 + k + solver)
+    n_rows, n_cols, p, i, x = csc
+    if solver == 2:
+        X, Y0 = np.abs(X), np.abs(Y0)
+    G = O.gramian(X, 0.1)
+    for gbias in (0.02, 1e-7):
+        Yref = Y0.copy(order="F")
+        base_ref = np.zeros(k)
+        lref = O.als_implicit(p, i, x, X, Yref, G, 0.1, solver, 3, global_bias=gbias, base_out=base_ref)
+        Y = Y0.copy(order="F")
+        base = np.zeros(k)
+        loss = als.als_implicit(csc, X, Y, 0.1, 1, solver, 3, "double", False, False, global_bias=gbias, XtX=G,
+                                global_bias_base=base, initialize_bias_base=True)
+        err = _row_err(Y, Yref)
+        assert err.max() < _bound(solver), (gbias, int(err.argmax()), float(err.max()))
+        assert abs(loss - lref) <= 1e-9 * abs(lref)
+        assert rel_fro(base, base_ref) < 1e-12
+        empty = np.diff(p) == 0
+        if empty.any():
+            assert np.any(Y[:, empty] != 0)      # with a global bias empty columns are solved too (:178)
+
+
+def test_double_cholesky_falls_back_to_the_general_solver():
+    """Indefinite but regular systems (confidences below 1 against a weak Gramian): the kernel re-solves them by Gaussian
+    elimination with partial pivoting, as arma::solve(fast + likely_sympd) does (wrmf_implicit.hpp:236), and says how many."""
+    import torch
+    from rsparse_amd.engine import HipBackend
+    k = 24
+    csc, X, Y0 = _problem(400, 120, k, seed=4, scale=0.3)
+    n_rows, n_cols, p, i, x = csc
+    rng = np.random.default_rng(1)
+    x = np.where(rng.random(x.size) < 0.5, 0.25, 3.0)
+    G = np.asfortranarray(0.05 * (X @ X.T) + 0.1 * np.eye(k))
+    Yref = Y0.copy(order="F")
+    lref = O.als_implicit(p, i, x, X, Yref, G, 0.1, 0, 3)
+    n_bad, cond = 0, np.ones(n_cols)
+    for c in range(n_cols):
+        idx, val = i[p[c]:p[c + 1]], x[p[c]:p[c + 1]]
+        ev = np.linalg.eigvalsh(G + (X[:, idx] * (val - 1.0)) @ X[:, idx].T)
+        cond[c] = np.abs(ev).max() / np.abs(ev).min()
+        n_bad += ev.min() < -1e-9
+    assert n_bad >= 5
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit((n_rows, n_cols, p, i, x), X, Y, 0.1, 1, 0, 3, "double", False, False, XtX=G)
+    err = _row_err(Y, Yref)
+    bound = np.maximum(1e-9, 50.0 * cond * 2.3e-16)
+    assert np.all(err <= bound), (int(np.argmax(err / bound)), float(err.max()))
+    assert abs(loss - lref) <= 1e-7 * abs(lref)
+    be = HipBackend()
+    h = be.make_csc(n_rows, n_cols, be.to_device(p, torch.int32), be.to_device(i, torch.int32), be.to_device(x, torch.float64))
+    Xd, Yd = be.to_device(np.ascontiguousarray(X.T), torch.float64), be.to_device(np.ascontiguousarray(Y0.T), torch.float64)
+    lossd = torch.zeros(1, dtype=torch.float64, device=be.device)
+    be.half_iteration(h, True, Xd, Yd, be.to_device(np.ascontiguousarray(G), torch.float64), 0.1, 0, 3, True, lossd)
+    with pytest.warns(RuntimeWarning, match="general"):
+        be.check_numeric()
+    assert n_bad - 2 <= be.last_fallback_rows <= n_bad + 2
+    assert np.array_equal(Yd.cpu().numpy().T, Y)
+
+
+@pytest.mark.parametrize("explicit", [True, False])
+@pytest.mark.parametrize("global_bias", [False, True])
+def test_initialize_biases_double(ml_train, explicit, global_bias):
+    """initialize_biases_double (src/wrmf_init.cpp:5-19) against the oracle's double instantiation."""
+    n_user, n_item, p, i, x = ml_train
+    m = sp.csc_matrix((x, i, p), shape=(n_user, n_item))
+    mt = sp.csc_matrix(m.T)
+    mt.sort_indices()
+    ub_ref, ib_ref = np.zeros(n_user), np.zeros(n_item)
+    x1, x2 = m.data.copy(), mt.data.copy()
+    if explicit:
+        gb_ref = O.init_biases_explicit((m.indptr, m.indices, x1), (mt.indptr, mt.indices, x2), ub_ref, ib_ref, 0.1, True,
+                                        False, global_bias)
+    else:
+        gb_ref = O.init_biases_implicit((m.indptr, m.indices, x1), (mt.indptr, mt.indices, x2), ub_ref, ib_ref, 0.1, False,
+                                        calculate_global_bias=global_bias)
+    ub, ib = np.zeros(n_user), np.zeros(n_item)
+    y1, y2 = m.data.copy(), mt.data.copy()
+    gb = als.initialize_biases((n_user, n_item, m.indptr, m.indices, y1), (n_item, n_user, mt.indptr, mt.indices, y2),
+                               ub, ib, 0.1, True, False, global_bias, is_explicit_feedback=explicit)
+    assert abs(gb - gb_ref) <= 1e-12 * max(1.0, abs(gb_ref))
+    # (an empty column with dynamic lambda is 0 / 0 = NaN on both sides, as in the reference)
+    assert np.array_equal(np.isnan(ub), np.isnan(ub_ref)) and np.array_equal(np.isnan(ib), np.isnan(ib_ref))
+    assert rel_fro(np.nan_to_num(ub), np.nan_to_num(ub_ref)) < 1e-10 and rel_fro(np.nan_to_num(ib), np.nan_to_num(ib_ref)) < 1e-10
+    if explicit and global_bias:
+        assert rel_fro(y1, x1) < 1e-12 and rel_fro(y2, x2) < 1e-12     # the mean left BOTH value arrays in place
+        assert not np.array_equal(y1, m.data)
+
+
+def test_wrmf_double_runs_in_double(ml_train):
+    """WRMF(precision="double") -- the reference's default -- fits on the fp64 layer: no RuntimeWarning, results within
+    1e-9 of the fp64 oracle driver after three iterations (the fp32 layer sits at 1e-6 ... 1e-5 here)."""
+    import warnings
+    from rsparse_amd import WRMF
+    n_user, n_item, p, i, x = ml_train
+    train = sp.csc_matrix((x, i, p), shape=(n_user, n_item))
+    rng = np.random.default_rng(5)
+    U0 = rng.standard_normal((n_user, 12)) * 0.01
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model = WRMF(rank=12, lambda_=0.1, feedback="implicit", solver="conjugate_gradient", precision="double")
+    model._init_user_factors = U0
+    emb = model.fit_transform(train, n_iter=3, convergence_tol=-1)
+    ref = O.OracleWRMF(12, lam=0.1, feedback="implicit", solver="conjugate_gradient", dtype=np.float64, n_threads=8)
+    ref_emb = ref.fit_transform(n_user, n_item, p, i, x, U0.T.copy(), n_iter=3, convergence_tol=-1)
+    assert emb.dtype == np.float64 and rel_fro(emb, ref_emb) < 1e-9
+    assert rel_fro(model.components, ref.components) < 1e-9
+    assert np.allclose([l[1] for l in model.losses], [l[1] for l in ref.losses], rtol=1e-10)
+    assert np.array_equal(emb, model.transform(train))
+    top = model.predict(train[:50], 7)
+    assert top.shape == (50, 7)
+    # above WRMF.f64_max_rank the fp32 kernels run, and the constructor says so
+    with pytest.warns(RuntimeWarning, match="fp32"):
+        WRMF(rank=64, precision="double")

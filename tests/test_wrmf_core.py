@@ -99,6 +99,12 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
     # scaled by 1 +- 2^-22 (seeded signs).
     cell = "%s|%s|%g|%d|%s" % (feedback, solver, lam, bias, precision)
     errs = _fit_errors(model.components, user_emb, model.losses, ref, ref_emb)
+    if precision == "double":
+        # the reference computes these cells in double (R/model_WRMF.R:82) and so does the device (the fp64 layer of the
+        # library, rsparse_amd/csrc/wrmf_f64.hip): the north star's bound, flat, no yardstick
+        _record(cell, {"rank": rank0, "device": errs, "fp32_oracle": None, "fp32_fits": 0, "bound": 1e-4})
+        assert max(errs.values()) <= 1e-4, (cell, errs)
+        return
     yard, prng = None, np.random.default_rng(12345)
     for trial in range(5):
         Up = U0 if trial == 0 else (U0 * (1 + np.float32(2.0 ** -22) * prng.choice([-1, 1], size=U0.shape).astype(np.float32))).astype(np.float32)

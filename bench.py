@@ -75,6 +75,19 @@ def physical_cores():
         return len(allowed)
 
 
+def cpu_model():
+    """CPU model name of the host the baseline ran on (printed with the core count)."""
+    try:
+        names = {ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.lower().startswith("model name")}
+        sockets = {ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.lower().startswith("physical id")}
+        if names:
+            return "%s%s" % ("%d x " % len(sockets) if len(sockets) > 1 else "", " / ".join(sorted(names)))
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def _sample_rows(csc, n_take, seed):
     """CSC of `n_take` random columns (seeded), p re-based; returns numpy (p, i, x) and the picked ids."""
     p, i, x = csc
@@ -148,7 +161,7 @@ def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0, implicit=True, sol
                          user_rows_per_s=take_u / tu)
     main = res["f64"]
     return {
-        "value": main["value"], "unit": "iterations/s", "cores": threads, "kind": "port", "dtype": "f64",
+        "value": main["value"], "unit": "iterations/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port", "dtype": "f64",
         "sample": "%d random users + %d random items, extrapolated in nnz; Gramians incl. (user one from 1M rows)"
                   % (main["take_u"], main["take_i"]),
         "value_f32": res["f32"]["value"], "user_rows_per_s": main["user_rows_per_s"],

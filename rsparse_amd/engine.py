@@ -56,11 +56,9 @@ def equal_bounds(n, world_size):
 
 def default_subblocks(world_size):
     """Sub-blocks per rank and half-iteration: with several ranks the all-gather of a solved block (640 MB per rank on
-    the user side of config 3) costs about as much as the solve, so it is pipelined sub-block by sub-block."""
-    import os
-    if world_size <= 1:
-        return 1
-    return max(1, int(os.environ.get("RSPARSE_SUBBLOCKS", "4")))
+    the user side of config 3) costs about as much as the solve, so it is pipelined sub-block by sub-block.  A caller
+    that wants another granularity passes `n_sub` to ShardedALS.layouts / WRMF(n_sub=...); nothing reads the environment."""
+    return 1 if world_size <= 1 else 4
 
 
 class Layout:
@@ -302,18 +300,26 @@ class HipBackend:
         _lib.check(self.lib.rsparse_hip_profile_last_names(buf, 8192))
         return buf.value.decode().split("\n")
 
-    def check_numeric(self):
-        """Raises if per-row systems of the exact solver were singular for the general-solver fallback too; systems that
-        were merely not positive definite were re-solved on the device and are reported like the reference's warning."""
+    def numeric_counts(self):
+        """(rows whose general solve failed too, rows that went to the general solver) since the last call; resets."""
         bad, fell = ctypes.c_int64(0), ctypes.c_int64(0)
         _lib.check(self.lib.rsparse_hip_take_numeric_failures(ctypes.byref(bad), ctypes.byref(fell)))
-        self.last_fallback_rows = fell.value
-        if fell.value:
+        return int(bad.value), int(fell.value)
+
+    def report_numeric(self, bad, fell):
+        self.last_fallback_rows = fell
+        if fell:
             import warnings
             warnings.warn("rsparse_amd: %d per-row systems were not positive definite; solved by the general (LU) solver "
-                          "(the reference's arma::solve warns likewise)" % fell.value, RuntimeWarning, stacklevel=2)
-        if bad.value:
-            raise _lib.RsparseHipError(_lib.ERR_NUMERIC, "%d per-row systems were singular" % bad.value)
+                          "(the reference's arma::solve warns likewise)" % fell, RuntimeWarning, stacklevel=3)
+        if bad:
+            raise _lib.RsparseHipError(_lib.ERR_NUMERIC, "%d per-row systems were singular" % bad)
+
+    def check_numeric(self):
+        """Raises if per-row systems of the exact solver were singular for the general-solver fallback too; systems that
+        were merely not positive definite were re-solved on the device and are reported like the reference's warning.
+        (One rank's view: a sharded driver sums `numeric_counts()` over its ranks first -- WRMF._check_numeric.)"""
+        self.report_numeric(*self.numeric_counts())
 
 
 class _CscHandle:

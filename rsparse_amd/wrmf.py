@@ -47,7 +47,7 @@ class WRMF:
     def __init__(self, rank=10, lambda_=0.0, dynamic_lambda=True, init=None, preprocess=_identity,
                  feedback="implicit", solver="conjugate_gradient", with_user_item_bias=False,
                  with_global_bias=False, cg_steps=3, precision="double", rng=None, device=None, group=None,
-                 backend=None):
+                 backend=None, n_sub=None):
         if init is not None and not isinstance(init, np.ndarray):
             raise TypeError("init must be NULL or a matrix")                      # :84
         if solver not in SOLVER_CODES:
@@ -86,6 +86,7 @@ class WRMF:
         self._device = device
         self._be = backend   # None = HipBackend on first use; tests inject the CPU stand-in for the multi-rank control flow
         self._group = group  # torch.distributed process group to shard over (None = the default group if initialised)
+        self._n_sub = n_sub  # sub-blocks per rank and half-iteration of a sharded fit (None = engine.default_subblocks)
         self._V = None       # item factors on the device, (n_item, rank)
         self._XtX = None
         self._cnt_item = None
@@ -112,6 +113,22 @@ class WRMF:
         be = self._backend()
         return (be.to_device(m.indptr, torch.int32), be.to_device(m.indices, torch.int32),
                 be.to_device(m.data, self._dev_t()))
+
+    def _check_numeric(self):
+        """be.check_numeric() made collective: with several ranks the counts of the exact solver's failures are summed over
+        the group first, so that every rank raises (or warns) together -- a rank that raised alone would leave the others
+        waiting in the next collective."""
+        be = self._backend()
+        ws, _ = self._dist()
+        if ws <= 1 or not hasattr(be, "numeric_counts"):
+            be.check_numeric()
+            return
+        import torch.distributed as dist
+        bad, fell = be.numeric_counts()
+        on_dev = dist.get_backend(self._group) == "nccl"
+        t = torch.tensor([bad, fell], dtype=torch.int64, device=be.device if on_dev else "cpu")
+        dist.all_reduce(t, group=self._group)
+        be.report_numeric(int(t[0]), int(t[1]))
 
     def _dist(self):
         """(world size, my rank) of the group this model shards over; (1, 0) without torch.distributed."""
@@ -268,7 +285,7 @@ class WRMF:
         c_iu.sort_indices()
         cnt_item = torch.from_numpy(np.diff(c_ui.indptr).astype(np.int64))
         cnt_user = torch.from_numpy(np.diff(c_iu.indptr).astype(np.int64))
-        lay_u, lay_i = ShardedALS.layouts(n_user, n_item, ws, cnt_user, cnt_item)
+        lay_u, lay_i = ShardedALS.layouts(n_user, n_item, ws, cnt_user, cnt_item, n_sub=self._n_sub)
 
         def block(m, lo, hi):
             b = m[:, lo:hi]
@@ -293,14 +310,14 @@ class WRMF:
             if (loss_prev / lu if lu != 0 else float("inf")) - 1 < convergence_tol:   # every rank sees the same loss
                 break
             loss_prev = lu
-        be.check_numeric()
+        self._check_numeric()
         # the returned embeddings: one more exact solve from zeros against the final item factors (:355-359), sharded like
         # a user half-iteration
         XtX = als.gramian(V, lay_i).clone() if self._feedback == "implicit" else None
         res = lay_u.alloc(k, dev0, tdt)
         solver = 0 if self._solver_code == 1 else self._solver_code
         als.half_iteration("users", res, V, solver, G=XtX, want_loss=False)
-        be.check_numeric()
+        self._check_numeric()
         # what transform() / predict() need afterwards: a plain (n_item, rank) replica of the item factors on every rank
         self._V = lay_i.to_global(V).contiguous()
         self._XtX = XtX
@@ -362,7 +379,7 @@ class WRMF:
         be.half_iteration(csc_users, self._feedback == "implicit", self._V, res, self._XtX, self._lambda,
                           solver, self._cg_steps, self._dynamic_lambda, loss,
                           False if self._with_bias else None, **gb)                           # is_bias_last_row = FALSE
-        be.check_numeric()
+        self._check_numeric()   # (collective when the model shards: _transform_device runs it on every rank)
         return res
 
     def predict(self, x, k, not_recommend="x", items_exclude=()):

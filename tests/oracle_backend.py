@@ -69,7 +69,20 @@ class OracleBackend:
         out[0] = float((s * w.numpy().astype(np.float64)).sum() if w is not None else s.sum())
 
     def check_numeric(self):
-        pass
+        self.report_numeric(*self.numeric_counts())
+
+    # the two halves of check_numeric, as HipBackend has them: a sharded WRMF sums the counts over its ranks in between
+    fake_counts = (0, 0)
+
+    def numeric_counts(self):
+        c, self.fake_counts = self.fake_counts, (0, 0)
+        return c
+
+    def report_numeric(self, bad, fell):
+        self.last_fallback_rows = fell
+        if bad:
+            from rsparse_amd import _lib
+            raise _lib.RsparseHipError(_lib.ERR_NUMERIC, "%d per-row systems were singular" % bad)
 
 
 def _row_loss(csc, X, Y, implicit, lambda_, dynamic_lambda, target=1.0):

@@ -1,6 +1,8 @@
 """Full-size sampled parity: rows of every launch bucket of a full-size half-iteration re-solved
 by the fp64 oracle from the same inputs.  The CPU test checks the checker; the gpu tests run BASELINE configs 3, 4, 5
-at their full sizes on the device and compare ~64 rows per length class and side."""
+at their full sizes on the device and compare ~64 rows per length class and side -- config 2 (round 4) likewise, so that every
+BASELINE configuration that runs on the device meets the oracle inside the driver's own `pytest -m gpu` run (config 1 is the
+movielens protocol, tests/test_hip_parity.py::test_fit_transform_matches_goldens)."""
 import json
 import os
 from pathlib import Path
@@ -75,6 +77,13 @@ def _assert_reports(reports):
         # oracle run in float loses on the same rows, whichever is larger; everywhere else it is 1e-4 flat.
         tol = max(ROW_TOL, 3.0 * rep.get("max_row_err_f32_oracle", 0.0))
         assert rep["max_row_err"] <= tol, (rep["side"], rep["iteration"], rep["worst_row"], rep["worst_len"], rep["max_row_err"], rep["per_class"])
+
+
+@pytest.mark.gpu
+def test_config2_sampled_parity():
+    """BASELINE config 2: 1M x 100k, ~5e7 nnz, rank 64, implicit CG(3) on one GPU (the rank-64 launch table: 4-wave teams
+    for 257-512 non-zeros, the one-wave-per-step normal-equation kernel for the long rows).  Two iterations, as config 3."""
+    _assert_reports(_run_config(1_000_000, 100_000, 64, 1, "implicit", n_iter=2))
 
 
 @pytest.mark.gpu

@@ -235,11 +235,14 @@ int rsparse_hip_als_implicit_bias_device(const rsparse_hip_csc* conf, const floa
  * column is solved, empty ones too (:178).  The loss compares x_j.y with 1 - global_bias (- x_b).  solver =
  * conjugate_gradient (no biases): cg_solver_implicit_global_bias (:35-57, 203) from the warm start in d_Y, cg_steps
  * steps.  global_bias itself is the caller's: sum(x) / (sum(x) + n_user n_item - nnz), R/model_WRMF.R:286-287.
- * d_absmax: as for rsparse_hip_als_implicit_device. */
+ * double_threshold: which build's cut-off applies to a small global bias (:108-109) -- 0 = als_implicit<float>'s
+ * sqrt(FLT_EPSILON) = 3.45e-4, non-zero = als_implicit<double>'s 1.49e-8 (a model declared with precision = "double" whose
+ * arithmetic runs on this fp32 layer: on large sparse data sum / (sum + n_user n_item - nnz) is typically below 3.45e-4,
+ * and the double build keeps it).  d_absmax: as for rsparse_hip_als_implicit_device. */
 int rsparse_hip_als_implicit_global_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
                                                 const float* d_XtX, int rank, double lambda, unsigned solver,
                                                 unsigned cg_steps, int with_biases, int is_x_bias_last_row,
-                                                double global_bias, const float* d_absmax,
+                                                double global_bias, int double_threshold, const float* d_absmax,
                                                 double* d_loss_rows_out, void* stream);
 
 /* initialize_biases_implicit (inst/include/wrmf_utils.hpp:86-165; .Call _rsparse_initialize_biases_{double,float} with

@@ -1219,14 +1219,14 @@ int rsparse_hip_als_implicit_bias_device(const rsparse_hip_csc* conf, const floa
 int rsparse_hip_als_implicit_global_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y,
                                                 const float* d_XtX, int rank, double lambda, unsigned solver,
                                                 unsigned cg_steps, int with_biases, int is_x_bias_last_row,
-                                                double global_bias, const float* d_absmax, double* d_loss_rows_out,
-                                                void* stream) {
+                                                double global_bias, int double_threshold, const float* d_absmax,
+                                                double* d_loss_rows_out, void* stream) {
   int rc = check_variant(solver, with_biases, global_bias, true);
   if (rc) return rc;
   if (with_biases)
     return run_half_iteration_implicit_biased(conf, d_X, d_Y, d_XtX, rank, lambda, solver, is_x_bias_last_row,
-                                              d_loss_rows_out, (hipStream_t)stream, global_bias);
-  if (!has_global_bias(global_bias))
+                                              d_loss_rows_out, (hipStream_t)stream, global_bias, double_threshold != 0);
+  if (!has_global_bias(global_bias, double_threshold != 0))
     return run_half_iteration(conf, true, d_X, d_Y, d_XtX, rank, lambda, solver, cg_steps, 0, d_loss_rows_out,
                               (hipStream_t)stream, nullptr, d_absmax);
   return run_half_iteration_implicit_global(conf, d_X, d_Y, d_XtX, rank, lambda, solver, cg_steps, global_bias, nullptr,
@@ -1450,9 +1450,9 @@ int rsparse_hip_take_numeric_failures(int64_t* unresolved_out, int64_t* fallback
   int v[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpy(v, g_ws.fails, sizeof(v), hipMemcpyDeviceToHost));   // (synchronises with the device)
   if (v[0] | v[1] | v[2] | v[3]) HIP_TRY(hipMemset(g_ws.fails, 0, sizeof(v)));
-  const int64_t sent = (int64_t)v[0] + v[2];
-  // rows beyond the list's capacity could not be handed over: they count as unresolved
+  // rows beyond the list's capacity could not be handed over: they count as unresolved, not as re-solved
   const int64_t lost = v[0] > kFailCap ? (int64_t)v[0] - kFailCap : 0;
+  const int64_t sent = (int64_t)std::min(v[0], kFailCap) + v[2];
   *unresolved_out = (int64_t)v[1] + v[3] + lost;
   if (fallback_out) *fallback_out = sent;
   return RSPARSE_HIP_OK;

@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256, LONG ? 2 : RSP_CHOL_MINW) void als_chol2_kerne
       if (tid == 0) {
         const int pos = atomicAdd(a.fail_counter, 1);
         if (pos < a.fail_cap) a.fail_rows[pos] = row;
+        else for (int e = 0; e < k; e++) yrow[e] = 0.f;   // no room in the list: unresolved, zeroed like a singular row (no NaN is left behind)
         *sFlag = 0;
       }
       continue;   // (uniform; the assembly of the next row has barriers before the flag can be set again)

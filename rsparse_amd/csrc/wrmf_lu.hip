@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void als_lu_fallback_kernel(AlsArgs a, size_t 
 
 // start of a Cholesky half-iteration: the previous call's counts move to the running totals (words 2, 3), the list is empty again
 __global__ void fail_roll_kernel(int* fails) {
-  fails[2] += fails[0];
-  fails[3] += fails[1] + max(0, fails[0] - kFailCap);   // (rows beyond the list's capacity were never handed over)
+  fails[2] += min(fails[0], kFailCap);                   // rows the general solver took
+  fails[3] += fails[1] + max(0, fails[0] - kFailCap);   // rows beyond the list's capacity were never handed over: unresolved
   fails[0] = 0;
   fails[1] = 0;
 }

@@ -129,6 +129,9 @@ class HipBackend:
     """Numerics on the current HIP device through librsparse_wrmf_hip.so."""
 
     name = "hip"
+    # which build's cut-off applies to a small implicit global bias on the fp32 layer (wrmf_implicit.hpp:108-109): False =
+    # als_implicit<float>'s 3.45e-4, True = als_implicit<double>'s 1.49e-8 (WRMF sets it from its `precision`)
+    double_threshold = False
 
     def __init__(self, device=None):
         self.lib = _lib.load()
@@ -214,8 +217,8 @@ class HipBackend:
             # implicit feedback with a global bias: every solver without user/item biases, Cholesky / NNLS with them
             _lib.check(self.lib.rsparse_hip_als_implicit_global_bias_device(
                 csc.h, F.data_ptr(), S_block.data_ptr(), G.data_ptr(), k, float(lambda_), int(solver), int(cg_steps),
-                int(bias_last_row is not None), int(bool(bias_last_row)), float(global_bias), am, loss_out.data_ptr(),
-                self._stream()))
+                int(bias_last_row is not None), int(bool(bias_last_row)), float(global_bias), int(self.double_threshold), am,
+                loss_out.data_ptr(), self._stream()))
         elif bias_last_row is not None and implicit:
             # G: (k-1) x (k-1) Gramian of F without its bias row, ridge included (R/model_WRMF.R:463-486)
             _lib.check(self.lib.rsparse_hip_als_implicit_bias_device(csc.h, F.data_ptr(), S_block.data_ptr(), G.data_ptr(),

@@ -97,6 +97,8 @@ class WRMF:
     def _backend(self):
         if self._be is None:
             self._be = HipBackend(self._device)
+        if isinstance(self._be, HipBackend):
+            self._be.double_threshold = self._precision == "double"   # a small global bias: the double build keeps it
         return self._be
 
     def _np_dtype(self):

@@ -83,15 +83,17 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
                        with_user_item_bias=bias)
     ref_emb = ref.fit_transform(n_user, n_item, tp, ti, tx, U0.T.astype(np.float64), n_iter=5, convergence_tol=-1,
                                 init_components=None if solver == "conjugate_gradient" else V0.astype(np.float64))
-    # ONE rule for every cell of the grid, and every number in it comes from the oracle: five ALS iterations compound
+    # precision = "double" cells: the device computes in double like the reference -> 1e-4 flat (below; they sit at 1e-11).
+    # precision = "float" cells: ONE rule, and every number in it comes from the oracle: five ALS iterations compound
     # the per-solve fp32 differences, so the yardstick is the reference-shaped arithmetic in float -- the SAME fit on the
     # oracle in fp32 (the reference's precision = "float" build) against the oracle in fp64:
-    #     err(device vs fp64 oracle)  <=  max(1e-4, 3 x err(fp32 oracle vs fp64 oracle))
+    #     err(device vs fp64 oracle)  <=  max(1e-4, 2 x err(fp32 oracle vs fp64 oracle))      (precision = "float" cells)
     # (err = the largest of: relative Frobenius error of the item factors, of the user embeddings, relative error of the
     # user-side loss sequence).  1e-4 is the north star's tolerance; the cells whose yardstick exceeds it are the ones
     # where ANY fp32 arithmetic departs from fp64 (lambda = 1000: the factors shrink to ~1e-26, fp32 underflow; NNLS: the
     # solver squares the per-row system and stops at 1e-4 relative steps; explicit CG with biases: 3 CG steps from a warm
-    # start amplify the rounding of the previous iterate) -- profiles/r03/wrmf_core_parity_table.md lists both columns.
+    # start amplify the rounding of the previous iterate) -- profiles/r04/wrmf_core_parity_table.md lists both columns
+    # (device / fp32 oracle between 0.1 and 1.25 there, hence the factor 2: round 3's was 3).
     # In those cells the fp32 fit is a noisy trajectory: one-ulp changes of the initial factors move its distance from
     # the fp64 fit by a factor of two (implicit NNLS with biases: 1.4e-2 ... 4.7e-2 over six such fits), so a single
     # fp32 fit is a fragile yardstick.  Wherever the first one is above 3e-5 the yardstick is therefore the largest
@@ -116,7 +118,7 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
         yard = y if yard is None else {q: max(yard[q], y[q]) for q in y}
         if max(yard.values()) <= 3e-5:
             break
-    tol = max(1e-4, 3.0 * max(yard.values()))
+    tol = max(1e-4, 2.0 * max(yard.values()))
     _record(cell, {"rank": rank0, "device": errs, "fp32_oracle": yard, "fp32_fits": trial + 1, "bound": tol})
     assert max(errs.values()) <= tol, (cell, errs, yard, tol)
 

@@ -64,20 +64,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define RSP_STREAM_PREFIX_Q 4
 #endif
 
-// 8-wave resident teams (rows of 257..512 non-zeros): one workgroup owns the CU's whole register file, so its gather and
-// its sweeps cannot overlap with another workgroup's.  EXPERIMENT, OFF (0) in the shipped build: with RSP_LPF_QUADS = q the
-// first q quads (x 4 non-zeros) of every wave's share of the NEXT row are copied from HBM straight into LDS
-// (global_load_lds, no destination registers) while the current row is swept, and the gather at the row switch reads them
-// from there, so that this part of the gather traffic moves while HBM is otherwise idle for this CU.  Measured (round 3,
-// q = 4 = 36 % of the bucket's bytes staged, results bit-identical): 27.0 ms per launch against 21.6 -- the kernel sits at
-// 256 registers, hipcc answers the extra address arithmetic with spills and scatters s_waitcnt vmcnt(0) over the sweeps
-// (every such wait now also waits for the copies in flight), and moving the confidences to LDS to make room (CVL below)
-// did not get it spill-free.  It would take the normal-equation kernel's discipline (every VMEM instruction and every wait
-// written by hand) to collect the overlap; kept as a switch so that the measurement can be repeated.
-#ifndef RSP_LPF_QUADS
-#define RSP_LPF_QUADS 0
-#endif
-
 constexpr float kCgTolQ = 1e-10f;  // CG_TOL, inst/include/wrmf.hpp:22
 constexpr int kMaxSavedSweeps = 4;  // streamed rows keep the dot products of up to this many CG steps
 
@@ -96,17 +82,6 @@ template <>
 struct Piece<4> { using type = float4; };
 template <>
 struct Piece<2> { using type = float2; };
-
-// LDS-DMA (asm: the compiler neither sees these loads nor waits for them; lpf_wait() does).  One 16-byte / 4-byte piece
-// per lane: LDS destination = M0 + lane * 16 / 4 (wave-uniform base), source = each lane's own pointer.
-__device__ __forceinline__ unsigned q_lds_addr(const void* p) { return (unsigned)(reinterpret_cast<uintptr_t>(p)); }
-__device__ __forceinline__ void q_dma16(const void* g, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory", "m0");
-}
-__device__ __forceinline__ void q_dma4(const void* g, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory", "m0");
-}
-__device__ __forceinline__ void q_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // sum over the 16 lanes of a DPP row; every lane of the row gets the result (needs full EXEC)
 __device__ __forceinline__ float row16_sum(float v) {
@@ -184,11 +159,7 @@ struct QSmem {
   // the paddings shift consecutive rows by four banks, so the operand reads / result writes of four rows do not collide
   static constexpr int dmf_ps = KP + 8, dmf_os = KP + 4;
   static constexpr size_t dmf_floats = DMF ? (size_t)WAVES * dmf_ps + (size_t)WAVES * dmf_os : 0;
-  // staged prefix of the next row (8-wave resident teams): per wave LPF vectors + 64 indices + 64 values
-  static constexpr int lpfq = (STREAM == 0 && WPR == 8) ? RSP_LPF_QUADS : 0;
-  static constexpr size_t lpf_wave_floats = lpfq ? (size_t)lpfq * 4 * KP + 128 + CAPQ * 4 : 0;   // (+ the row's confidences)
-  static constexpr size_t lpf_floats = (size_t)WAVES * lpf_wave_floats;
-  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats + pre_floats + dmf_floats + lpf_floats) * 4 + 16;
+  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats + pre_floats + dmf_floats) * 4 + 16;
 };
 
 // GB: implicit feedback with a global bias (cg_solver_implicit_global_bias, wrmf_implicit.hpp:35-57,203): the first
@@ -216,8 +187,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   _Float16* sPh = reinterpret_cast<_Float16*>(sPre + SM::pre_floats);   // DMF: [WAVES][KP + 8] high fp16 terms
   _Float16* sPl = sPh + WAVES * SM::dmf_ps;                             //      [WAVES][KP + 8] low terms
   float* sOut = reinterpret_cast<float*>(sPl + WAVES * SM::dmf_ps);     //      [WAVES][KP + 4] G v (times the scales)
-  constexpr int LPFQ = SM::lpfq, LPF = LPFQ * 4;                         // staged prefix: quads / vectors per wave
-  float* sLpf = sPre + SM::pre_floats + SM::dmf_floats;                  // [WAVES][LPF vectors | 64 indices | 64 values]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
@@ -292,47 +261,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     if constexpr (DMF == 2) wave_sync();   // (each wave reads back only what it wrote)
   }
   float* vec = sVec + wv * KP;
-  // this wave's staging area as an LDS byte address in an SGPR; everything lane-dependent is re-derived at the point of use
-  // from a laundered lane id (hipcc otherwise hoists those address pieces out of the row loop and keeps them alive through
-  // the sweeps, where this kernel has no register to spare: a spill reload there waits on vmcnt, i.e. on the copies)
-  const unsigned lpf_base = (unsigned)rfl((int)q_lds_addr(sLpf + (size_t)wv * SM::lpf_wave_floats));
-  constexpr unsigned kLpfIdxOff = LPF * KP * 4, kLpfValOff = LPF * KP * 4 + 256;
-  auto lpf_ptr = [&](const unsigned byte_off) {   // generic pointer into the staging area (LDS aperture = low 32 bits)
-    return reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(smem) - q_lds_addr(smem) + lpf_base + byte_off);
-  };
-  // share of a row of `cnt_` non-zeros starting at `p1_` that wave tw of the team holds: (first non-zero, count)
-  auto lpf_share = [&](const int p1_, const int cnt_, int& base_, int& n_) {
-    const int per_ = min(CAP, (((cnt_ + WPR - 1) / WPR) + 15) & ~15);
-    n_ = max(0, min(per_, cnt_ - tw * per_));
-    base_ = p1_ + tw * per_;
-  };
-  // (1) indices and values of the first LPF non-zeros of the share -> LDS
-  auto lpf_issue_idx = [&](const int base_, const int n_) {
-    if constexpr (LPFQ > 0) {
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int j = n_ > 0 ? base_ + min(ln, n_ - 1) : 0;
-      q_dma4(a.row_idx + j, lpf_base + kLpfIdxOff);
-      q_dma4(a.vals + j, lpf_base + kLpfValOff);
-    }
-  };
-  // (2) their factor vectors -> LDS (slots beyond the share: the all-zero row); VPI vectors per copy instruction
-  auto lpf_issue_vec = [&](const int n_) {
-    if constexpr (LPFQ > 0) {
-      constexpr int LPV = KP / 4, VPI = 64 / LPV;   // lanes per vector, vectors per instruction
-      q_wait_vm0();                                  // the index chunk has landed
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int piece = min((ln % LPV) * 4, k - 4);
-      const int* ix = reinterpret_cast<const int*>(lpf_ptr(kLpfIdxOff)) + ln / LPV;
-#pragma unroll
-      for (int n = 0; n < LPF / VPI; n++) {
-        const int id = ix[n * VPI];
-        const float* src = n * VPI + ln / LPV < n_ ? a.X + (size_t)id * k + piece : a.zero_row + piece;
-        q_dma16(src, lpf_base + (unsigned)(n * 1024));
-      }
-    }
-  };
   float* tacc = sTsv + wv * 2 * CAP;  // resident rows only
   float* tcur = tacc + CAP;
   int buf = 0;
@@ -359,15 +287,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     p2_c = a.col_ptrs[row_c + 1];
   }
   if (rows_per_team > 1 && row_index(1) < n_rows) row_n = rows[row_index(1)];
-  if constexpr (LPFQ > 0) {   // the team's first row has no previous row to hide behind
-    if (rows_per_team > 0 && row_index(0) < n_rows) {
-      int fb, fn;
-      lpf_share(rfl(p1_c), rfl(p2_c) - rfl(p1_c), fb, fn);
-      lpf_issue_idx(fb, fn);
-      lpf_issue_vec(fn);
-    }
-  }
-
   for (int it = 0; it < rows_per_team; ++it) {
     const int ri = row_index(it);
     const bool have = ri < n_rows;
@@ -416,9 +335,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 
     float xt[CAPQ][RPN];  // gathered vectors: quad q, group g holds non-zero 4q+g of the chunk
     float cv[CAPQ];       // its confidence / rating (uniform inside the group)
-    // 8-wave teams with the staged prefix: the confidences live in LDS during the sweeps (slot 4q+g of the wave's area),
-    // 16 registers this kernel does not have next to the copy addresses
-    constexpr bool CVL = LPFQ > 0;
     constexpr int NSL = (CAP + 63) / 64;   // slots of the chunk per lane (2 only for the rank <= 64 geometry, CAP = 128)
     float cl[NSL];        // resident rows: confidence / rating of non-zero `lane` (+ 64) of the chunk (loss)
 #pragma unroll
@@ -456,37 +372,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         wave_sync();
       } else {
 #pragma unroll
-        for (int q = (NQG == CAPQ ? LPFQ : 0); q < NQG; q++) {
+        for (int q = 0; q < NQG; q++) {
           const int j = min(4 * q + g, n - 1);
           id[q] = a.row_idx[base + j];
           const float c = a.vals[base + j];
           cv[q] = (!ZPAD || 4 * q + g < n) ? c : 0.f;
         }
-        if constexpr (TSAVE && !(SM::lpfq > 0)) {   // (staged kernels: from LDS at the loss)
+        if constexpr (TSAVE) {
 #pragma unroll
           for (int s2 = 0; s2 < NSL; s2++) cl[s2] = lane + 64 * s2 < n ? a.vals[base + lane + 64 * s2] : 0.f;
         }
       }
-      if constexpr (LPFQ > 0 && NQG == CAPQ) {   // the staged quads: copied into LDS during the previous row's sweeps
-        int gi = g * KP + i * VW;   // one laundered lane offset; the (q, b) parts fit the DS instructions' immediate field
-        asm volatile("" : "+v"(gi));
-        const float* sv = reinterpret_cast<const float*>(lpf_ptr(0)) + gi;
-        const float* sc = reinterpret_cast<const float*>(lpf_ptr(kLpfValOff)) + (gi / KP);
 #pragma unroll
-        for (int q = 0; q < LPFQ; q++) {
-          cv[q] = 4 * q + g < n ? sc[4 * q] : 0.f;
-#pragma unroll
-          for (int b = 0; b < NV; b++) {
-            const int off = b * 16 * VW + i * VW;
-            const piece_t pc = *reinterpret_cast<const piece_t*>(sv + 4 * q * KP + b * 16 * VW);
-            const float* pf = reinterpret_cast<const float*>(&pc);
-#pragma unroll
-            for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
-          }
-        }
-      }
-#pragma unroll
-      for (int q = (NQG == CAPQ ? LPFQ : 0); q < NQG; q++) {
+      for (int q = 0; q < NQG; q++) {
         const float* src = (!ZPAD || 4 * q + g < n) ? a.X + (size_t)id[q] * k : a.zero_row;
 #pragma unroll
         for (int b = 0; b < NV; b++) {
@@ -543,17 +441,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       const int per = min(CAP, (((cnt + WPR - 1) / WPR) + 15) & ~15);
 #endif
       ccnt = max(0, min(per, cnt - tw * per));
-      if constexpr (LPFQ > 0) q_wait_vm0();   // the staged quads of this row (issued a row ago, or in the prologue)
       if (ccnt > 0) gather(p1 + tw * per, ccnt, pf_cnt == ccnt);
       pf_cnt = -1;
-      if constexpr (CVL) {   // park the confidences (slot 4q+g; the 16 lanes of a group hold the same value)
-        if (ccnt > 0 && i == 0) {
-          float* cs = reinterpret_cast<float*>(const_cast<char*>(lpf_ptr(kLpfValOff + 256))) + g;
-#pragma unroll
-          for (int q = 0; q < CAPQ; q++) cs[4 * q] = cv[q];
-        }
-        wave_sync();
-      }
     }
 
     CQ_T(0)   // row switch + gather
@@ -574,20 +463,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     auto quad_pass = [&](const float(&v)[RPN], const int mode, float(&acc)[RPN], float& lacc, float* tsave) {
       float* trec = (mode == 0 ? tacc : tcur) + g;  // resident rows: slot 4q+g <- t (same value from the 16 lanes)
       constexpr int QB = 4;  // quads per block: 4 independent dot/DPP chains interleave inside one basic block
-      const float* cbase = nullptr;   // CVL: the wave's confidences in LDS, lane offset laundered once per pass
-      if constexpr (CVL) {
-        int g4 = g * 4;
-        asm volatile("" : "+v"(g4));
-        cbase = reinterpret_cast<const float*>(lpf_ptr(kLpfValOff + 256) + g4);
-      }
 #pragma unroll
       for (int q0 = 0; q0 < CAPQ; q0 += QB) {
         if (4 * q0 < ccnt) {  // wave-uniform
-          float cq[QB];
-          if constexpr (CVL) {
-#pragma unroll
-            for (int u = 0; u < QB; u++) cq[u] = cbase[4 * (q0 + u)];   // requested ahead of the dot products
-          }
           float t[QB];
 #pragma unroll
           for (int u = 0; u < QB; u++) {
@@ -607,7 +485,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           for (int u = 0; u < QB; u++) {
             const int q = q0 + u;
             const bool valid = ZPAD || 4 * q + g < ccnt;
-            const float c = CVL ? cq[u] : cv[q];
+            const float c = cv[q];
             if constexpr (STREAM == 1) {  // keep t_j = x_j . v of this sweep: the loss is rebuilt from them
               if (tsave && valid && i == 0) tsave[4 * q + g] = t[u];
             } else if constexpr (TSAVE) {
@@ -760,12 +638,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
             for (int s2 = 0; s2 < NSL; s2++) {
               const int sl = NSL == 1 ? (lane & (CAP - 1)) : lane + 64 * s2;
               const float t = tacc[sl];
-              float clv = cl[s2];
-              if constexpr (SM::lpfq > 0) {   // the confidences were parked in LDS in exactly this order (slot = non-zero of the chunk)
-                int l4 = sl * 4;
-                asm volatile("" : "+v"(l4));
-                clv = *reinterpret_cast<const float*>(lpf_ptr(kLpfValOff + 256) + l4);
-              }
+              const float clv = cl[s2];
               const float d = IMPLICIT ? ltgt - t : clv - t;
               const float e = IMPLICIT ? clv * d * d : d * d;
               esum += lane + 64 * s2 < ccnt ? e : 0.f;
@@ -915,16 +788,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     CQ_T(1)   // warm start, setup
     sweep(x, 0, r, dummy, live);
     CQ_T(2)   // sweeps
-    int lpf_n = -1;   // >= 0: the next row's staged copy is under way (count of its share of this wave)
-    if constexpr (LPFQ > 0) {
-      // the next row's pointers were requested at the top of this iteration and have arrived by now
-      if (it + 1 < rows_per_team && row_index(it + 1) < n_rows) {
-        int nb;
-        lpf_share(rfl(p1_c), rfl(p2_c) - rfl(p1_c), nb, lpf_n);
-        lpf_issue_idx(nb, lpf_n);
-        if (a.cg_steps == 0) lpf_issue_vec(lpf_n);
-      }
-    }
     if constexpr (IDXPF && STREAM == 0) {
       // the next row's pointers were requested at the top of this iteration and have arrived by now
       if (it + 1 < rows_per_team && row_index(it + 1) < n_rows) {
@@ -949,9 +812,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       CQ_T(4)   // CG scalars and updates
       sweep(p, 1, ap, dummy, live && !conv, itc + 1);
       CQ_T(2)
-      if constexpr (LPFQ > 0) {
-        if (itc == 0 && lpf_n >= 0) lpf_issue_vec(lpf_n);   // lands during the remaining sweeps
-      }
       CQ_T(3)
       if (!conv) {
         const float pap = dot16(p, ap);

@@ -207,20 +207,29 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
         h[s2] = c < KP ? sH[c] : 0.f;
         dg[s2] = c < KP ? sB[c * KP + c] : 1.f;
       }
+      // A coordinate that sits at its bound (h = 0) with a non-negative gradient does not move: new = max(0, 0 - mu / d) = 0,
+      // diff = 0 (d > 0), and the reference's loop body does nothing for it (nnls.hpp:24).  Three quarters of the coordinate
+      // visits are of that kind (measured on the config-2 shape: 172 sweeps per row, 23 % of the visits move), so the sweep
+      // walks only the set bits of `act` = the lanes whose coordinate can move, re-evaluated after every move (a move changes
+      // every mu): exactly the reference's sequence of updates, without the division and the three lane reads per idle visit.
       for (int t = 0; t < kScdMaxIter; t++) {
         float rel = 0.f;
 #pragma unroll
         for (int s2 = 0; s2 < NSL; s2++) {
-          const int lim = min(64, KP - 64 * s2);
-          for (int l = 0; l < lim; l++) {
+          const int lim = min(64, min(KP, k) - 64 * s2);
+          if (lim <= 0) break;  // padded coordinates never move
+          const unsigned long long in_range = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+          unsigned long long act = __ballot(!(h[s2] == 0.f && mu[s2] >= 0.f)) & in_range;
+          while (act) {
+            const int l = __builtin_ctzll(act);
             const int kk = 64 * s2 + l;
-            if (kk >= k) break;  // padded coordinates never move
             const float old_v = readlane_f(h[s2], l);
             const float m_k = readlane_f(mu[s2], l);
             const float d_k = readlane_f(dg[s2], l);
             float new_v = old_v - m_k / d_k;
             if (new_v < 0.f) new_v = 0.f;
             const float diff = new_v - old_v;
+            const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
             if (diff != 0.f) {  // wave-uniform
               if (lane == l) h[s2] = new_v;
               const float* brow = sB + kk * KP;  // column kk = row kk (symmetric)
@@ -231,6 +240,9 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
               }
               const float step_err = fabsf(diff) / (fabsf(old_v) + kNnlsEps);
               rel = fmaxf(rel, step_err);
+              act = __ballot(!(h[s2] == 0.f && mu[s2] >= 0.f)) & in_range & above;
+            } else {
+              act &= above;
             }
           }
         }

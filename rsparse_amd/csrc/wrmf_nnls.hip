@@ -293,6 +293,281 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
   if (tid == 0) a.loss_partials[blockIdx.x] = (sLoss[0] + sLoss[1]) + (sLoss[2] + sLoss[3]);
 }
 
+// ---- rank <= 64: one WAVE per row, the squared system in the wave's registers (round 4) ----
+// What a row costs is the descent -- 172 sweeps per row on the config-2 shape, each a serial chain over the coordinates --
+// and in the 256-thread kernel above one wave walks it while three wait and the two k x k matrices in LDS allow three
+// workgroups per CU: three chains per CU.  Here every wave owns a row from the gather to the loss, nothing is shared and
+// there is no barrier: lane l holds column l of lhs while it is assembled (KP registers), then column l of XtX = lhs^T lhs
+// (KP registers: the update mu += diff XtX[:, c] of a coordinate c reads register c, the sweep is unrolled over c), mu_l, h_l
+// and XtX_ll; LDS (half of lhs at a time, 8.7 KB per wave) only carries the broadcasts of the assembly and of the square.
+// Twelve chains per CU (168 registers: three waves per SIMD).
+template <int KP>
+struct NnlsWaveSmem {
+  static constexpr int HR = KP / 2;          // columns of lhs staged at a time
+  static constexpr int LDH = KP + 4;         // their stride (16-byte aligned broadcast reads, 4-way conflicts on the writes)
+  static constexpr size_t wave_floats = (size_t)HR * LDH + 2 * KP;
+  static constexpr size_t bytes = 4 * wave_floats * 4 + 4 * sizeof(double) + 64;
+};
+
+template <int KP, bool IMPLICIT>
+__global__ __launch_bounds__(256, 3) void als_nnls_wave_kernel(AlsArgs a) {
+  using SM = NnlsWaveSmem<KP>;
+  constexpr int HR = SM::HR, LDH = SM::LDH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
+  float* sW = reinterpret_cast<float*>(smem) + (size_t)wv * SM::wave_floats;   // [HR][LDH] columns of lhs
+  float* sX = sW + (size_t)HR * LDH;                                           // [KP] a vector to broadcast
+  float* sR = sX + KP;                                                         // [KP] a second one
+  double* sLoss = reinterpret_cast<double*>(reinterpret_cast<float*>(smem) + 4 * SM::wave_floats);
+  const int k = a.k;
+  const bool on = lane < KP, lk = lane < k;
+  const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+  const unsigned long long in_range = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+  double wloss = 0.0;
+
+  for (int row = blockIdx.x * 4 + wv; row < a.n_cols; row += gridDim.x * 4) {
+    const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
+    const int cnt = p2 - p1;
+    float* yrow = a.Y + (size_t)row * k;
+    if (cnt <= 0 && !a.rhs_init) {  // empty column -> zeros (wrmf_implicit.hpp:281, wrmf_explicit.hpp:142)
+      if (lk) yrow[lane] = 0.f;
+      continue;
+    }
+    const float lam_use =
+        IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)cnt : 1.0));
+    // the lane id as this row sees it: hipcc otherwise hoists every lane-dependent address and compare of the unrolled
+    // loops below out of the row loop (KP 64-bit pointers, KP masks) and spills them
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+
+    // ---------------- assembly: lane l holds lhs(:, l) and rhs_l ----------------
+    float acol[KP];
+    {
+      const float* gcol = a.XtX + ln;
+#pragma unroll
+      for (int m = 0; m < KP; m++) {
+        float gv;
+        if (m >= k || !lk) gv = (m == ln) ? 1.f : 0.f;   // padded coordinates: identity, rhs 0 -> they stay 0
+        else if (IMPLICIT) gv = gcol[(size_t)m * k];
+        else gv = (m == ln) ? lam_use : 0.f;
+        acol[m] = gv;
+      }
+    }
+    float rhs = 0.f;
+    for (int base = p1; base < p2; base += 64) {
+      const int ccnt = min(64, p2 - base);
+      const int jl = min(lane, ccnt - 1);
+      const int idj = a.row_idx[base + jl];
+      const float cvj = a.vals[base + jl];
+      const float rcj = a.rhs_vals ? a.rhs_vals[base + jl] : cvj;   // coefficient in the right-hand side
+      constexpr int PF = 4;                                         // vectors in flight
+      float xq[PF];
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int id = __builtin_amdgcn_readlane(idj, min(u, ccnt - 1));
+        xq[u] = lk ? a.X[(size_t)id * k + ln] : 0.f;
+      }
+      for (int j0 = 0; j0 < ccnt; j0 += PF) {
+        float xn[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+          const int id = __builtin_amdgcn_readlane(idj, min(j0 + PF + u, ccnt - 1));
+          xn[u] = lk ? a.X[(size_t)id * k + ln] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+          if (j0 + u < ccnt) {   // wave-uniform
+            const float xv = xq[u];
+            const float cv = readlane_f(cvj, j0 + u);
+            const float f = (IMPLICIT ? cv - 1.f : 1.f) * xv;
+            rhs = fmaf(readlane_f(rcj, j0 + u), xv, rhs);
+            wave_sync();
+            if (on) sX[ln] = xv;
+            wave_sync();
+#pragma unroll
+            for (int m4 = 0; m4 < KP / 4; m4++) {
+              const float4 b = *reinterpret_cast<const float4*>(sX + 4 * m4);   // broadcast
+              acol[4 * m4 + 0] = fmaf(b.x, f, acol[4 * m4 + 0]);
+              acol[4 * m4 + 1] = fmaf(b.y, f, acol[4 * m4 + 1]);
+              acol[4 * m4 + 2] = fmaf(b.z, f, acol[4 * m4 + 2]);
+              acol[4 * m4 + 3] = fmaf(b.w, f, acol[4 * m4 + 3]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) xq[u] = xn[u];
+      }
+    }
+    if (a.rhs_init && lk) rhs += a.rhs_init[ln];
+    float h = lk ? yrow[ln] : 0.f;  // init = current Y.col(i)  (wrmf_implicit.hpp:185)
+
+    // ---------------- mu = XtX init - lhs^T rhs, first half: t_l = sum_m lhs(m, l) rhs_m ----------------
+    wave_sync();
+    if (on) {
+      sX[ln] = h;
+      sR[ln] = rhs;
+    }
+    wave_sync();
+    float mu = 0.f;
+#pragma unroll
+    for (int m4 = 0; m4 < KP / 4; m4++) {
+      const float4 b = *reinterpret_cast<const float4*>(sR + 4 * m4);
+      mu = fmaf(-acol[4 * m4 + 0], b.x, mu);
+      mu = fmaf(-acol[4 * m4 + 1], b.y, mu);
+      mu = fmaf(-acol[4 * m4 + 2], b.z, mu);
+      mu = fmaf(-acol[4 * m4 + 3], b.w, mu);
+    }
+
+    // ---------------- XtX(r, l) = sum_m lhs(m, r) lhs(m, l)  (nnls.hpp:41-44), HR columns r at a time ----------------
+    float m2[KP];
+    float dg;
+    {   // XtX(l, l): the lane's own column against itself, summed as the columns below are
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int m4 = 0; m4 < KP / 4; m4++) {
+        s0 = fmaf(acol[4 * m4 + 0], acol[4 * m4 + 0], s0);
+        s1 = fmaf(acol[4 * m4 + 1], acol[4 * m4 + 1], s1);
+        s0 = fmaf(acol[4 * m4 + 2], acol[4 * m4 + 2], s0);
+        s1 = fmaf(acol[4 * m4 + 3], acol[4 * m4 + 3], s1);
+      }
+      dg = (s0 + s1) + kNnlsEps;
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+      wave_sync();
+      if (ln >= hh * HR && ln < hh * HR + HR) {
+        float* dst = sW + (size_t)(ln - hh * HR) * LDH;
+#pragma unroll
+        for (int m4 = 0; m4 < KP / 4; m4++)
+          *reinterpret_cast<float4*>(dst + 4 * m4) = make_float4(acol[4 * m4], acol[4 * m4 + 1], acol[4 * m4 + 2], acol[4 * m4 + 3]);
+      }
+      wave_sync();
+      float chain = 0.f;
+#pragma unroll
+      for (int r = 0; r < HR; r++) {
+        // the column's address "depends" on the previous column's result: hipcc otherwise issues the broadcast reads of all
+        // HR columns first and spills what they return (8 KB of scratch per lane at rank 64)
+        int coff = r * LDH;   // (an integer offset, not the pointer: the loads stay LDS loads)
+        asm volatile("" : "+v"(coff) : "v"(chain));
+        const float* colr = sW + coff;
+        float s0 = 0.f, s1 = 0.f;
+        constexpr int MB = KP / 4 > 8 ? 8 : KP / 4;   // broadcast pieces in flight (32 registers: lhs and XtX hold 2 KP)
+#pragma unroll
+        for (int mb = 0; mb < KP / 4; mb += MB) {
+          if (mb > 0) {
+            asm volatile("" : "+v"(coff) : "v"(s0), "v"(s1));
+            colr = sW + coff;
+          }
+#pragma unroll
+          for (int m4 = mb; m4 < mb + MB; m4++) {
+            const float4 b = *reinterpret_cast<const float4*>(colr + 4 * m4);
+            s0 = fmaf(b.x, acol[4 * m4 + 0], s0);
+            s1 = fmaf(b.y, acol[4 * m4 + 1], s1);
+            s0 = fmaf(b.z, acol[4 * m4 + 2], s0);
+            s1 = fmaf(b.w, acol[4 * m4 + 3], s1);
+          }
+        }
+        const float s = s0 + s1;
+        m2[hh * HR + r] = s + (ln == hh * HR + r ? kNnlsEps : 0.f);   // XtX.diag() += EPS (nnls.hpp:44)
+        chain = s;
+      }
+    }
+    // ... second half: + sum_c XtX(l, c) init_c   (the clobber keeps hipcc from reading the 16 broadcast pieces of init
+    // before the square and carrying them -- 64 registers -- through it)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int m4 = 0; m4 < KP / 4; m4++) {
+      const float4 b = *reinterpret_cast<const float4*>(sX + 4 * m4);
+      mu = fmaf(m2[4 * m4 + 0], b.x, mu);
+      mu = fmaf(m2[4 * m4 + 1], b.y, mu);
+      mu = fmaf(m2[4 * m4 + 2], b.z, mu);
+      mu = fmaf(m2[4 * m4 + 3], b.w, mu);
+    }
+
+    // ---------------- scd_ls_update (nnls.hpp:10-34): only the coordinates that can move are visited ----------------
+    for (int t = 0; t < kScdMaxIter; t++) {
+      float rel = 0.f;
+      unsigned long long act = __ballot(!(h == 0.f && mu >= 0.f)) & in_range;
+#pragma unroll
+      for (int c = 0; c < KP; c++) {
+        if (act & (1ull << c)) {
+          const float old_v = readlane_f(h, c);
+          const float m_k = readlane_f(mu, c);
+          const float d_k = readlane_f(dg, c);
+          float new_v = old_v - m_k / d_k;
+          if (new_v < 0.f) new_v = 0.f;
+          const float diff = new_v - old_v;
+          if (diff != 0.f) {  // wave-uniform
+            if (ln == c) h = new_v;
+            mu = fmaf(diff, m2[c], mu);
+            const float step_err = fabsf(diff) / (fabsf(old_v) + kNnlsEps);
+            rel = fmaxf(rel, step_err);
+            act = __ballot(!(h == 0.f && mu >= 0.f)) & in_range;
+          }
+        }
+      }
+      if (rel <= kScdTol) break;
+    }
+    if (lk) yrow[ln] = h;
+
+    // ---------------- loss row term: lane j takes non-zero j of a chunk ----------------
+    wave_sync();
+    if (on) sX[ln] = h;
+    wave_sync();
+    float lacc = 0.f;
+    for (int base = p1; base < p2; base += 64) {
+      const int ccnt = min(64, p2 - base);
+      const int jl = min(lane, ccnt - 1);
+      const float* xr = a.X + (size_t)a.row_idx[base + jl] * k;
+      const float cvv = a.vals[base + jl];
+      const float tgt = a.loss_tgt ? a.loss_tgt[base + jl] : a.loss_tgt_const;
+      float t0 = 0.f, t1 = 0.f;
+      if (vec) {
+        for (int m4 = 0; m4 < k / 4; m4++) {
+          const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * m4);
+          const float4 b = *reinterpret_cast<const float4*>(sX + 4 * m4);
+          t0 = fmaf(xv.x, b.x, t0);
+          t1 = fmaf(xv.y, b.y, t1);
+          t0 = fmaf(xv.z, b.z, t0);
+          t1 = fmaf(xv.w, b.w, t1);
+        }
+      } else {
+        for (int m = 0; m < k; m++) t0 = fmaf(xr[m], sX[m], t0);
+      }
+      const float tt = t0 + t1;
+      const float d = IMPLICIT ? tgt - tt : cvv - tt;
+      lacc += lane < ccnt ? (IMPLICIT ? cvv * d * d : d * d) : 0.f;
+    }
+    const float lpart = wave_sum(lacc);
+    const float xxp = wave_sum(h * h);
+    wloss += IMPLICIT ? (double)lpart + a.lambda_loss * (double)xxp : (double)(lpart + lam_use * xxp);
+  }
+  if (lane == 0) sLoss[wv] = wloss;
+  __syncthreads();
+  if (tid == 0) a.loss_partials[blockIdx.x] = (sLoss[0] + sLoss[1]) + (sLoss[2] + sLoss[3]);
+}
+
+template <int KP, bool IMPLICIT>
+hipError_t launch_nnls_wave_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
+  using SM = NnlsWaveSmem<KP>;
+  hipError_t err;
+  const int grid = (int)chol_loss_slots(a.n_cols);
+  auto kc = als_nnls_wave_kernel<KP, IMPLICIT>;
+  if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)SM::bytes)) != hipSuccess)
+    return err;
+  if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
+  prof_note(ev, reinterpret_cast<const void*>(kc));
+  hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a);
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  if (ev) {
+    if ((err = hipEventRecord(ev[1], s)) != hipSuccess) return err;
+    if ((err = hipEventRecord(ev[2], s)) != hipSuccess) return err;
+  }
+  return hipSuccess;
+}
+
 template <int KP, bool IMPLICIT, bool VEC>
 hipError_t launch_nnls_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   using SM = NnlsSmem<KP>;
@@ -318,6 +593,9 @@ hipError_t launch_nnls_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev) {
   const int KP = padded_rank(a.k);
   const bool vec = (a.k % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+  // rank <= 64: one wave per row (see als_nnls_wave_kernel); rank 65..128: one workgroup per row, the squared system in LDS
+  if (KP == 32) return implicit ? launch_nnls_wave_t<32, true>(a, s, ev) : launch_nnls_wave_t<32, false>(a, s, ev);
+  if (KP == 64) return implicit ? launch_nnls_wave_t<64, true>(a, s, ev) : launch_nnls_wave_t<64, false>(a, s, ev);
 #define RSP_DISPATCH(KPV)                                                                                \
   if (KP == KPV) {                                                                                       \
     if (implicit) return vec ? launch_nnls_t<KPV, true, true>(a, s, ev) : launch_nnls_t<KPV, true, false>(a, s, ev); \

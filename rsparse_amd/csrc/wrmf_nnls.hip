@@ -485,29 +485,49 @@ __global__ __launch_bounds__(256, 3) void als_nnls_wave_kernel(AlsArgs a) {
       mu = fmaf(m2[4 * m4 + 3], b.w, mu);
     }
 
-    // ---------------- scd_ls_update (nnls.hpp:10-34): only the coordinates that can move are visited ----------------
+    // ---------------- scd_ls_update (nnls.hpp:10-34): only the coordinates that move are visited ----------------
+    // Every lane keeps the step its own coordinate would take against the CURRENT mu -- nv = max(0, h - mu / XtX_ll),
+    // df = nv - h: one vector division serves all coordinates, where a uniform one per visit would be the same instruction
+    // count for one of them -- and the sweep walks the set bits of ballot(df != 0): the reference's sequence of updates
+    // (an idle visit changes nothing, nnls.hpp:24).  After a move every mu has changed and the steps are recomputed.
+    // The quotient is the correctly rounded one (reciprocal refined once per row, residual correction per quotient: the
+    // sequence the compiler's own expansion uses, without its range scaling -- mu / XtX_ll is nowhere near the subnormals).
+    // The stopping rule needs only  max step_err <= tol: a step far from the threshold is decided by two products, the exact
+    // division fabs(diff) / (fabs(old) + EPS) runs only inside a +-0.1 % band around it.
+    float rdg;
+    {
+      const float r0 = __builtin_amdgcn_rcpf(dg);
+      rdg = fmaf(fmaf(-dg, r0, 1.f), r0, r0);
+    }
+    auto step_of = [&](float& nv_, float& df_) {
+      const float q0 = mu * rdg;
+      const float q = fmaf(fmaf(-q0, dg, mu), rdg, q0);   // mu / dg, correctly rounded
+      nv_ = (h - q) < 0.f ? 0.f : (h - q);                // the reference's `if (new_value < 0) new_value = 0`
+      df_ = nv_ - h;
+    };
+    constexpr float kTolHi = 1.001e-4f, kTolLo = 0.999e-4f;
     for (int t = 0; t < kScdMaxIter; t++) {
-      float rel = 0.f;
-      unsigned long long act = __ballot(!(h == 0.f && mu >= 0.f)) & in_range;
+      bool moved_far = false;   // some step of this sweep exceeded the tolerance
+      float nv, df;
+      step_of(nv, df);
+      unsigned long long act = __ballot(df != 0.f) & in_range;
 #pragma unroll
       for (int c = 0; c < KP; c++) {
-        if (act & (1ull << c)) {
-          const float old_v = readlane_f(h, c);
-          const float m_k = readlane_f(mu, c);
-          const float d_k = readlane_f(dg, c);
-          float new_v = old_v - m_k / d_k;
-          if (new_v < 0.f) new_v = 0.f;
-          const float diff = new_v - old_v;
-          if (diff != 0.f) {  // wave-uniform
-            if (ln == c) h = new_v;
-            mu = fmaf(diff, m2[c], mu);
-            const float step_err = fabsf(diff) / (fabsf(old_v) + kNnlsEps);
-            rel = fmaxf(rel, step_err);
-            act = __ballot(!(h == 0.f && mu >= 0.f)) & in_range;
+        if (__builtin_expect((act >> c) & 1ull, 0)) {
+          const float d_c = readlane_f(df, c);
+          if (!moved_far) {   // step_err of this move against the tolerance
+            const float den = fabsf(h) + kNnlsEps;
+            const unsigned long long far = __ballot(fabsf(df) > kTolHi * den), near = __ballot(fabsf(df) >= kTolLo * den);
+            if ((far >> c) & 1ull) moved_far = true;
+            else if ((near >> c) & 1ull) moved_far = fabsf(d_c) / (fabsf(readlane_f(h, c)) + kNnlsEps) > kScdTol;
           }
+          if (ln == c) h = nv;
+          mu = fmaf(d_c, m2[c], mu);
+          step_of(nv, df);
+          act = __ballot(df != 0.f) & in_range;
         }
       }
-      if (rel <= kScdTol) break;
+      if (!moved_far) break;
     }
     if (lk) yrow[ln] = h;
 

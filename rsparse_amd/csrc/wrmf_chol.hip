@@ -478,9 +478,13 @@ hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
       if ((err = hipStreamWaitEvent(s, g_long_stream.done, 0)) != hipSuccess) return err;
     }
   }
-  prof_note(ev ? ev + 1 : nullptr, reinterpret_cast<const void*>(kc));
-  hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a, 0);
-  if ((err = hipGetLastError()) != hipSuccess) return err;
+  if (chol_wave_supported(a.k) && !a.lr_flags) {   // rank <= 64: one wave per row, the system in its registers
+    if ((err = launch_als_chol_wave(a, IMPLICIT, grid, 0, s, ev ? ev + 1 : nullptr)) != hipSuccess) return err;
+  } else {
+    prof_note(ev ? ev + 1 : nullptr, reinterpret_cast<const void*>(kc));
+    hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a, 0);
+    if ((err = hipGetLastError()) != hipSuccess) return err;
+  }
   if (ev && (err = hipEventRecord(ev[2], s)) != hipSuccess) return err;
   return hipSuccess;
 }

@@ -204,6 +204,9 @@ bool chol_lr_supported(const AlsArgs& a, bool implicit);
 hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows, float* M, float* Mt, unsigned* flags,
                               int loss_slot0, hipStream_t s, hipEvent_t* ev_slot = nullptr);
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
+// rank <= 64: the main launch of the exact solve as one wave per row (wrmf_chol_wave.hip); same rows, same loss slots
+bool chol_wave_supported(int k);
+hipError_t launch_als_chol_wave(const AlsArgs& a, bool implicit, int grid, int loss_slot0, hipStream_t s, hipEvent_t* ev_slot);
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 constexpr int kLuGrid = 64;          // workgroups (and loss slots) of the general-solver fallback
 constexpr int kFailCap = 1 << 16;    // rows it can take per half-iteration call

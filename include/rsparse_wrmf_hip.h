@@ -287,7 +287,7 @@ int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, con
  * ---------------------------------------------------------------------------------------------- */
 
 #define RSPARSE_HIP_NA_INTEGER INT32_MIN /* R's NA_integer_: fewer than k admissible items */
-#define RSPARSE_HIP_MAX_TOPK 128
+#define RSPARSE_HIP_MAX_TOPK 256
 
 /* replaces top_product (src/matrix_top_product.cpp:20-102; .Call `_rsparse_top_product`,
  * R/RcppExports.R).  x: nr x rank and y: rank x nc, both column-major doubles as arma::mat holds them;
@@ -295,7 +295,7 @@ int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, con
  * item indices excluded for every row.  res: nr x k column-major 1-based indices (NA_integer_ where fewer
  * than k items are admissible), scores: nr x k column-major (+ glob_mean), best first; equal scores keep the
  * reference's order (larger index first).  Scores are computed in fp32 on the device (the reference
- * multiplies in double).  k > 128 -> ERR_UNSUPPORTED.  n_threads is accepted and ignored. */
+ * multiplies in double).  k > 256 -> ERR_UNSUPPORTED.  n_threads is accepted and ignored. */
 int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, int rank, unsigned k,
                             unsigned n_threads, const int32_t* not_recommend_p,
                             const int32_t* not_recommend_j, const int32_t* exclude, int n_exclude,

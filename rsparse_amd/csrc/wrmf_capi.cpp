@@ -1376,7 +1376,7 @@ int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_use
   if (!d_U || !d_V || !d_res || !d_scores) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or output");
   if (n_users < 0 || n_items < 0 || rank <= 0 || k < 1) return fail(RSPARSE_HIP_ERR_INVALID, "bad dimensions");
   if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
-  if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 128 is not on the device path");
+  if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 256 is not on the device path");
   if (n_exclude > 0 && !d_excl0) return fail(RSPARSE_HIP_ERR_INVALID, "exclude is NULL");
   hipError_t e = launch_top_product(d_U, d_V, n_users, n_items, rank, k, d_nr_p, d_nr_p ? d_nr_j : nullptr, d_excl0,
                                     n_exclude, (float)glob_mean, d_res, d_scores, (hipStream_t)stream);
@@ -1391,7 +1391,7 @@ int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, in
   if (!x || !y || !res || !scores) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or output");
   if (nr < 0 || nc < 0 || rank <= 0 || k < 1) return fail(RSPARSE_HIP_ERR_INVALID, "bad dimensions");
   if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
-  if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 128 is not on the device path");
+  if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 256 is not on the device path");
   if (n_exclude < 0 || (n_exclude > 0 && !exclude)) return fail(RSPARSE_HIP_ERR_INVALID, "bad exclude");
   // x is nr x rank column-major -> row-major fp32; y (rank x nc column-major) already has item vectors contiguous
   std::vector<float> U((size_t)nr * rank), V((size_t)nc * rank);

@@ -29,19 +29,30 @@ using namespace dev;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 constexpr int kTopBlock = 32;    // users per MFMA block
-constexpr int kTopMaxK = 128;    // RSPARSE_HIP_MAX_TOPK
-constexpr int kTopWaves = 4;
-// candidate buffer per user: the heap (k entries) + everything one round of 4 tiles can add (4 x 32 items)
-__host__ __device__ constexpr int top_cap(int topk) { return ((topk + 128 + 15) / 16) * 16; }
+constexpr int kTopMaxK = 256;    // RSPARSE_HIP_MAX_TOPK
+// candidate buffer per user: the heap (k entries) + everything one round can add (32 items per tile of the round)
+__host__ __device__ constexpr int top_cap(int topk, int tiles_per_round) { return ((topk + 32 * tiles_per_round + 3) / 4) * 4; }
 
-template <int KP, int UB>
+// the kernel in which every wave walks its own item tiles against the workgroup's 32 UB users (W waves = W tiles per round)
+template <int KP, int UB, int W>
 struct TopSmem {
   static constexpr int LDT = KP + 4;  // rows 16-byte aligned (ds_write_b128); fragment reads: 4-way conflict, hidden
   static constexpr int USERS = kTopBlock * UB;
-  static constexpr size_t tile_floats = (size_t)kTopWaves * 32 * LDT;
+  static constexpr size_t tile_floats = (size_t)W * 32 * LDT;
   static size_t bytes(int topk) {
-    const size_t cap = (size_t)top_cap(topk);
-    return (tile_floats + 2 * (size_t)USERS * cap + 8 * USERS) * 4 + 64 + (size_t)kTopWaves * cap * 8;   // + compaction scratch
+    const size_t cap = (size_t)top_cap(topk, W);
+    return (tile_floats + 2 * (size_t)USERS * cap + 8 * USERS) * 4 + 64 + (size_t)W * cap * 8;   // + compaction scratch
+  }
+};
+// the kernel in which the four waves share ONE item tile and own 32 UB users each (round 4)
+template <int KP, int UB>
+struct TopSharedSmem {
+  static constexpr int LDT = KP + 4;
+  static constexpr int USERS = 4 * kTopBlock * UB;
+  static constexpr size_t tile_floats = (size_t)32 * LDT;
+  static size_t bytes(int topk) {
+    const size_t cap = (size_t)top_cap(topk, 1);
+    return (tile_floats + 2 * (size_t)USERS * cap + 3 * USERS) * 4 + 64 + (size_t)4 * cap * 8;
   }
 };
 
@@ -62,17 +73,132 @@ __device__ __forceinline__ bool sel_before(float va, int ia, float vb, int ib) {
   return va > vb || (va == vb && ia < ib);
 }
 
-template <int KP, int UB, bool VEC>
-__global__ __launch_bounds__(256) void top_product_kernel(const float* __restrict__ U, const float* __restrict__ V,
+// Reduce one user's over-full candidate buffer (n > topk entries: bv / bi) to its top k by rank counting (tv / ti: scratch
+// of the calling wave), and return the new threshold (the k-th best score).  `old` = how many leading entries are the heap
+// as the previous reduction left it.  One wave; every lane gets the result.
+__device__ __forceinline__ float topk_reduce_user(float* bv, int* bi, float* tv, int* ti, const int n, const int topk,
+                                                  const int old, const int lane) {
+  // A full heap and a handful of arrivals (the steady state: after the first tiles a user sees a survivor every few hundred
+  // tiles): the arrivals go through the heap one by one -- the reference's own loop, src/matrix_top_product.cpp:61-86, and
+  // the code below for the tie case -- at O(k / 64) each, instead of the O(n^2 / 64) rank counting that pays for big batches.
+  const bool few = old == topk && n - old <= 8;
+  float kth = 0.f;
+  int ge = topk + 1;
+  if (!few) {
+  for (int c = lane; c < n; c += 64) {
+    const float v = bv[c];
+    const int ix = bi[c];
+    int rank = 0;
+    for (int c2 = 0; c2 < n; c2++) rank += sel_before(bv[c2], bi[c2], v, ix) ? 1 : 0;
+    if (rank < topk) {
+      tv[rank] = v;
+      ti[rank] = ix;
+    }
+  }
+  wave_sync();
+  // More candidates at the k-th score than places for them?  Then WHICH of them survive depends on the order in
+  // which the reference's heap met them (it evicts the smallest index among tied minima, but a tied newcomer
+  // never enters a full heap: scores [1,1,5], k = 2 -> {2,1}; [1,5,1] -> {1,0}), and the arrivals since the last
+  // reduction are replayed through that heap in index order.  Everything that arrived before was reduced the
+  // same way, so the buffer's first `old` entries ARE the reference's heap at that point.
+  kth = tv[topk - 1];
+  ge = 0;
+  for (int c = lane; c < n; c += 64) ge += bv[c] >= kth ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ge += __shfl_xor(ge, off);
+  }
+  if (ge > topk) {   // wave-uniform
+    wave_sync();
+    for (int c = lane; c < n; c += 64) {   // heap as it is, then the new arrivals sorted by item index
+      int dst = c;
+      if (c >= old) {
+        const int ix = bi[c];
+        int r = 0;
+        for (int c2 = old; c2 < n; c2++) r += bi[c2] < ix ? 1 : 0;
+        dst = old + r;
+      }
+      tv[dst] = bv[c];
+      ti[dst] = bi[c];
+    }
+    wave_sync();
+    int h = old;
+    for (int c = old; c < n; c++) {
+      const float v = tv[c];
+      const int ix = ti[c];
+      if (h < topk) {
+        if (lane == 0) {
+          bv[h] = v;
+          bi[h] = ix;
+        }
+        h++;
+      } else {
+        // smallest (score, index) of the heap: what std::priority_queue<pair, greater> has on top
+        float mv = INFINITY;
+        int mi = 0x7fffffff, mp = -1;
+        for (int e = lane; e < topk; e += 64) {
+          const float hv = bv[e];
+          const int hi = bi[e];
+          if (hv < mv || (hv == mv && hi < mi)) { mv = hv; mi = hi; mp = e; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const float ov = __shfl_xor(mv, off);
+          const int oi = __shfl_xor(mi, off), op = __shfl_xor(mp, off);
+          if (ov < mv || (ov == mv && oi < mi)) { mv = ov; mi = oi; mp = op; }
+        }
+        if (mv < v && lane == 0) {
+          bv[mp] = v;
+          bi[mp] = ix;
+        }
+      }
+      wave_sync();
+    }
+    float mn = INFINITY;
+    for (int e = lane; e < topk; e += 64) mn = fminf(mn, bv[e]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+    return mn;
+  }
+  for (int c = lane; c < topk; c += 64) {
+    bv[c] = tv[c];
+    bi[c] = ti[c];
+  }
+  wave_sync();
+  return kth;
+}
+
+// final output of one user: best first; equal scores with the larger index first (heap pop order of the reference)
+__device__ __forceinline__ void topk_emit_user(const float* bv, const int* bi, const int n, const int topk, const int lane,
+                                               const float glob_mean, int32_t* res_u, float* scores_u) {
+  for (int c = lane; c < topk; c += 64) {
+    if (c < n) {
+      const float v = bv[c];
+      const int ix = bi[c];
+      int rank = 0;
+      for (int c2 = 0; c2 < n; c2++) {
+        const float v2 = bv[c2];
+        rank += (v2 > v || (v2 == v && bi[c2] > ix)) ? 1 : 0;
+      }
+      res_u[rank] = ix + 1;               // 1-based, like R
+      scores_u[rank] = v + glob_mean;
+    } else {
+      res_u[c] = INT32_MIN;                // NA_integer_
+      scores_u[c] = __int_as_float(0x7fc00000);
+    }
+  }
+}
+
+template <int KP, int UB, bool VEC, int W>
+__global__ __launch_bounds__(W * 64) void top_product_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                           int n_users, int n_items, int k_rank, int topk,
                                                           const int32_t* __restrict__ nr_ptr,
                                                           const int32_t* __restrict__ nr_idx,
                                                           const int32_t* __restrict__ excl, int n_excl,
                                                           float glob_mean, int32_t* __restrict__ res,
                                                           float* __restrict__ scores_out) {
-  using SM = TopSmem<KP, UB>;
-  constexpr int LDT = SM::LDT, NK2 = KP / 2, kTopUsers = SM::USERS;
-  const int kTopCap = top_cap(topk);
+  using SM = TopSmem<KP, UB, W>;
+  constexpr int LDT = SM::LDT, NK2 = KP / 2, kTopUsers = SM::USERS, kTopWaves = W;
+  const int kTopCap = top_cap(topk, W);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sTile = reinterpret_cast<float*>(smem);
   float* sVal = sTile + SM::tile_floats;                            // [USERS][CAP]
@@ -80,8 +206,8 @@ __global__ __launch_bounds__(256) void top_product_kernel(const float* __restric
   int* sCnt = sIdx + (size_t)kTopUsers * kTopCap;                   // [USERS]
   float* sThr = reinterpret_cast<float*>(sCnt + kTopUsers);         // [USERS]
   int* sNeed = reinterpret_cast<int*>(sThr + kTopUsers);            // [USERS] spare / flags
-  float* sTmpV = reinterpret_cast<float*>(sNeed + 2 * kTopUsers + 4);  // [4][CAP]
-  int* sTmpI = reinterpret_cast<int*>(sTmpV + kTopWaves * kTopCap);    // [4][CAP]
+  float* sTmpV = reinterpret_cast<float*>(sNeed + 2 * kTopUsers + 4);  // [W][CAP]
+  int* sTmpI = reinterpret_cast<int*>(sTmpV + kTopWaves * kTopCap);    // [W][CAP]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int u0 = blockIdx.x * kTopUsers;
@@ -190,126 +316,179 @@ __global__ __launch_bounds__(256) void top_product_kernel(const float* __restric
     for (int ul = wv; ul < kTopUsers; ul += kTopWaves) {
       const int n = min(sCnt[ul], kTopCap);
       if (n > topk) {  // wave-uniform
-        float* bv = sVal + ul * kTopCap;
-        int* bi = sIdx + ul * kTopCap;
-        float* tv = sTmpV + wv * kTopCap;
-        int* ti = sTmpI + wv * kTopCap;
-        for (int c = lane; c < n; c += 64) {
-          const float v = bv[c];
-          const int ix = bi[c];
-          int rank = 0;
-          for (int c2 = 0; c2 < n; c2++) rank += sel_before(bv[c2], bi[c2], v, ix) ? 1 : 0;
-          if (rank < topk) {
-            tv[rank] = v;
-            ti[rank] = ix;
-          }
-        }
-        wave_sync();
-        // More candidates at the k-th score than places for them?  Then WHICH of them survive depends on the order in
-        // which the reference's heap met them (it evicts the smallest index among tied minima, but a tied newcomer
-        // never enters a full heap: scores [1,1,5], k = 2 -> {2,1}; [1,5,1] -> {1,0}), and the arrivals since the last
-        // reduction are replayed through that heap in index order.  Everything that arrived before was reduced the
-        // same way, so the buffer's first sNeed entries ARE the reference's heap at that point.
-        const float kth = tv[topk - 1];
-        int ge = 0;
-        for (int c = lane; c < n; c += 64) ge += bv[c] >= kth ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ge += __shfl_xor(ge, off);
-        if (ge > topk) {   // wave-uniform
-          const int old = sNeed[ul];
-          wave_sync();
-          for (int c = lane; c < n; c += 64) {   // heap as it is, then the new arrivals sorted by item index
-            int dst = c;
-            if (c >= old) {
-              const int ix = bi[c];
-              int r = 0;
-              for (int c2 = old; c2 < n; c2++) r += bi[c2] < ix ? 1 : 0;
-              dst = old + r;
-            }
-            tv[dst] = bv[c];
-            ti[dst] = bi[c];
-          }
-          wave_sync();
-          int h = old;
-          for (int c = old; c < n; c++) {
-            const float v = tv[c];
-            const int ix = ti[c];
-            if (h < topk) {
-              if (lane == 0) {
-                bv[h] = v;
-                bi[h] = ix;
-              }
-              h++;
-            } else {
-              // smallest (score, index) of the heap: what std::priority_queue<pair, greater> has on top
-              float mv = INFINITY;
-              int mi = 0x7fffffff, mp = -1;
-              for (int e = lane; e < topk; e += 64) {
-                const float hv = bv[e];
-                const int hi = bi[e];
-                if (hv < mv || (hv == mv && hi < mi)) { mv = hv; mi = hi; mp = e; }
-              }
-#pragma unroll
-              for (int off = 32; off > 0; off >>= 1) {
-                const float ov = __shfl_xor(mv, off);
-                const int oi = __shfl_xor(mi, off), op = __shfl_xor(mp, off);
-                if (ov < mv || (ov == mv && oi < mi)) { mv = ov; mi = oi; mp = op; }
-              }
-              if (mv < v && lane == 0) {
-                bv[mp] = v;
-                bi[mp] = ix;
-              }
-            }
-            wave_sync();
-          }
-          float mn = INFINITY;
-          for (int e = lane; e < topk; e += 64) mn = fminf(mn, bv[e]);
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
-          if (lane == 0) {
-            sCnt[ul] = topk;
-            sThr[ul] = mn;
-            sNeed[ul] = topk;
-          }
-        } else {
-          for (int c = lane; c < topk; c += 64) {
-            bv[c] = tv[c];
-            bi[c] = ti[c];
-          }
-          wave_sync();
-          if (lane == 0) {
-            sCnt[ul] = topk;
-            sThr[ul] = kth;
-            sNeed[ul] = topk;
-          }
+        const float thr = topk_reduce_user(sVal + ul * kTopCap, sIdx + ul * kTopCap, sTmpV + wv * kTopCap, sTmpI + wv * kTopCap, n,
+                                           topk, sNeed[ul], lane);
+        if (lane == 0) {
+          sCnt[ul] = topk;
+          sThr[ul] = thr;
+          sNeed[ul] = topk;
         }
       }
     }
     __syncthreads();
   }
-  // output: best first; equal scores with the larger index first (heap pop order of the reference)
   for (int ul = wv; ul < kTopUsers; ul += kTopWaves) {
     const int u = u0 + ul;
     if (u >= n_users) continue;
-    const int n = min(min(sCnt[ul], kTopCap), topk);
-    const float* bv = sVal + ul * kTopCap;
-    const int* bi = sIdx + ul * kTopCap;
-    for (int c = lane; c < topk; c += 64) {
-      if (c < n) {
-        const float v = bv[c];
-        const int ix = bi[c];
-        int rank = 0;
-        for (int c2 = 0; c2 < n; c2++) {
-          const float v2 = bv[c2];
-          rank += (v2 > v || (v2 == v && bi[c2] > ix)) ? 1 : 0;
-        }
-        res[(size_t)u * topk + rank] = ix + 1;               // 1-based, like R
-        scores_out[(size_t)u * topk + rank] = v + glob_mean;
-      } else {
-        res[(size_t)u * topk + c] = INT32_MIN;                // NA_integer_
-        scores_out[(size_t)u * topk + c] = __int_as_float(0x7fc00000);
+    topk_emit_user(sVal + ul * kTopCap, sIdx + ul * kTopCap, min(min(sCnt[ul], kTopCap), topk), topk, lane, glob_mean,
+                   res + (size_t)u * topk, scores_out + (size_t)u * topk);
+  }
+}
+
+
+// Round 4: the four waves SHARE one item tile and own 32 UB users each (128 / 256 users per workgroup).  The kernel above
+// reads every item vector once per 32 UB users -- at 1M x 1M, rank 128 that is 8 TB through the L2 for 64 users per
+// workgroup, and the matrix cores wait for it (52.7 TFLOP/s; one user block, as top-100 needs there, 9) --, this one once per
+// 128 UB: the tile is staged cooperatively (the next tile's 16-byte loads fly during this tile's MFMAs, as above), every
+// wave multiplies it with its own user blocks, and because a wave owns its users' candidate buffers outright the buffers
+// need room for ONE tile's survivors only (cap = k + 32) and are reduced by their wave without a workgroup barrier.
+template <int KP, int UB, bool VEC>
+__global__ __launch_bounds__(256) void top_product_shared_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                                 int n_users, int n_items, int k_rank, int topk,
+                                                                 const int32_t* __restrict__ nr_ptr,
+                                                                 const int32_t* __restrict__ nr_idx,
+                                                                 const int32_t* __restrict__ excl, int n_excl,
+                                                                 float glob_mean, int32_t* __restrict__ res,
+                                                                 float* __restrict__ scores_out) {
+  using SM = TopSharedSmem<KP, UB>;
+  constexpr int LDT = SM::LDT, NK2 = KP / 2, USERS = SM::USERS, UPW = 32 * UB;   // users per wave
+  const int cap = top_cap(topk, 1);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                     // [32][LDT]
+  float* sVal = tile + SM::tile_floats;                             // [USERS][cap]
+  int* sIdx = reinterpret_cast<int*>(sVal + (size_t)USERS * cap);   // [USERS][cap]
+  int* sCnt = sIdx + (size_t)USERS * cap;                           // [USERS]
+  float* sThr = reinterpret_cast<float*>(sCnt + USERS);             // [USERS]
+  int* sNeed = reinterpret_cast<int*>(sThr + USERS);                // [USERS]
+  float* sTmpV = reinterpret_cast<float*>(sNeed + USERS);           // [4][cap]
+  int* sTmpI = reinterpret_cast<int*>(sTmpV + 4 * cap);             // [4][cap]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
+  const int u0 = blockIdx.x * USERS, uw = wv * UPW;                 // this wave's users: [u0 + uw, u0 + uw + UPW)
+  const int col = lane & 31, half = lane >> 5;
+  for (int e = tid; e < USERS; e += 256) {
+    sCnt[e] = 0;
+    sThr[e] = -INFINITY;
+    sNeed[e] = 0;
+  }
+  float afrag[UB][NK2];
+#pragma unroll
+  for (int ub = 0; ub < UB; ub++) {
+    const int u = u0 + uw + 32 * ub + col;
+#pragma unroll
+    for (int t = 0; t < NK2; t++) {
+      const int kk = 2 * t + half;
+      afrag[ub][t] = (u < n_users && kk < k_rank) ? U[(size_t)u * k_rank + kk] : 0.f;
+    }
+  }
+  for (int e = tid; e < 32 * LDT; e += 256) tile[e] = 0.f;
+  __syncthreads();
+
+  const int n_tiles = (n_items + 31) / 32;
+  constexpr int NLD = KP / 32;   // 16-byte pieces per thread and tile
+  float4 pf[VEC ? NLD : 1];
+  auto load_tile = [&](const int tl) {
+    if constexpr (VEC) {
+      const int i0 = tl * 32;
+#pragma unroll
+      for (int j = 0; j < NLD; j++) {
+        const int e4 = j * 256 + tid, it = e4 / (KP / 4), c4 = e4 % (KP / 4);
+        pf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tl < n_tiles && i0 + it < n_items && 4 * c4 < k_rank)
+          pf[j] = *reinterpret_cast<const float4*>(V + (size_t)(i0 + it) * k_rank + 4 * c4);
       }
     }
+  };
+  auto store_tile = [&](const int tl) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < NLD; j++) {
+        const int e4 = j * 256 + tid, it = e4 / (KP / 4), c4 = e4 % (KP / 4);
+        *reinterpret_cast<float4*>(tile + it * LDT + 4 * c4) = pf[j];
+      }
+    } else {   // any rank / alignment: scalar staging (slow path)
+      const int i0 = tl * 32;
+      for (int it = wv; it < 32; it += 4)
+        for (int kk = lane; kk < k_rank; kk += 64)
+          tile[it * LDT + kk] = (tl < n_tiles && i0 + it < n_items) ? V[(size_t)(i0 + it) * k_rank + kk] : 0.f;
+    }
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int tl = 0; tl < n_tiles; tl++) {
+    load_tile(tl + 1);   // the next tile's loads fly during this tile's MFMAs
+    const int i0 = tl * 32;
+    f32x16_t acc[UB];
+#pragma unroll
+    for (int ub = 0; ub < UB; ub++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[ub][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NK2; t++) {
+      const float b = tile[col * LDT + 2 * t + half];  // B[kk = 2t + half][item = col]
+#pragma unroll
+      for (int ub = 0; ub < UB; ub++) acc[ub] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[ub][t], b, acc[ub], 0, 0, 0);
+    }
+    // lane holds item `col` for users row(e) = (e & 3) + 8 (e >> 2) + 4 half of each block
+    const int item = i0 + col;
+    const bool item_ok = item < n_items && !(n_excl > 0 && sorted_contains(excl, n_excl, item));
+    // the thresholds of this lane's users, four 16-byte reads per block in flight together (one read and one wait per
+    // accumulator entry left the matrix cores idle for a third of the tile)
+    float4 thr4[UB][4];
+#pragma unroll
+    for (int ub = 0; ub < UB; ub++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) thr4[ub][q] = *reinterpret_cast<const float4*>(sThr + uw + 32 * ub + 8 * q + 4 * half);
+#pragma unroll
+    for (int ub = 0; ub < UB; ub++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int ul = uw + 32 * ub + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int u = u0 + ul;
+        const float sc = acc[ub][e];
+        const float* tq = reinterpret_cast<const float*>(&thr4[ub][e >> 2]);
+        if (item_ok && u < n_users && sc > tq[e & 3]) {
+          bool skip = false;
+          if (nr_ptr) {
+            const int p1 = nr_ptr[u], p2 = nr_ptr[u + 1];
+            skip = sorted_contains(nr_idx + p1, p2 - p1, item);
+          }
+          if (!skip) {
+            const int pos = atomicAdd(&sCnt[ul], 1);   // (lanes of this wave only: at most 32 per user and tile)
+            sVal[ul * cap + pos] = sc;
+            sIdx[ul * cap + pos] = item;
+          }
+        }
+      }
+    wave_sync();
+    // this wave's over-full buffers -> their top k, threshold raised (after the first tiles almost nothing survives)
+    for (int b0 = 0; b0 < UPW; b0 += 64) {
+      const int ulq = uw + b0 + lane;
+      unsigned long long over = __ballot(b0 + lane < UPW && sCnt[ulq] > topk);
+      while (over) {
+        const int ul = uw + b0 + __builtin_ctzll(over);
+        over &= over - 1;
+        const float thr = topk_reduce_user(sVal + ul * cap, sIdx + ul * cap, sTmpV + wv * cap, sTmpI + wv * cap, sCnt[ul], topk,
+                                           sNeed[ul], lane);
+        wave_sync();
+        if (lane == 0) {
+          sCnt[ul] = topk;
+          sThr[ul] = thr;
+          sNeed[ul] = topk;
+        }
+        wave_sync();
+      }
+    }
+    __syncthreads();             // every wave has read the tile for the last time
+    store_tile(tl + 1);
+    __syncthreads();
+  }
+  for (int ul = uw; ul < uw + UPW; ul++) {
+    const int u = u0 + ul;
+    if (u >= n_users) break;
+    topk_emit_user(sVal + ul * cap, sIdx + ul * cap, min(sCnt[ul], topk), topk, lane, glob_mean, res + (size_t)u * topk,
+                   scores_out + (size_t)u * topk);
   }
 }
 
@@ -322,31 +501,50 @@ hipError_t launch_top_product(const float* U, const float* V, int n_users, int n
   if (!KP || topk < 1 || topk > kTopMaxK) return hipErrorInvalidValue;
   if (n_users <= 0) return hipSuccess;
   const bool vec = k_rank % 4 == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0;
+  constexpr size_t kLdsMax = 156 * 1024;
   hipError_t err;
-#define RSP_TOPK_L(KPV, UBV, VECV)                                                                           \
+#define RSP_TOPK_GO(KERN, LDS, USERS, THREADS)                                                               \
   {                                                                                                          \
-    auto kern = top_product_kernel<KPV, UBV, VECV>;                                                          \
-    const size_t lds = TopSmem<KPV, UBV>::bytes(topk);                                                       \
+    auto kern = KERN;                                                                                        \
+    const size_t lds = LDS;                                                                                  \
     if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)lds)) != hipSuccess)                                                 \
       return err;                                                                                            \
-    const int users = 32 * UBV, grid = (n_users + users - 1) / users;                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, U, V, n_users, n_items, k_rank, topk, nr_ptr, nr_idx, \
+    const int grid = (n_users + (USERS) - 1) / (USERS);                                                      \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, s, U, V, n_users, n_items, k_rank, topk, nr_ptr, nr_idx, \
                        excl, n_excl, glob_mean, res, scores);                                                \
     return hipGetLastError();                                                                                \
   }
-  // two user blocks per workgroup halve the passes over V; they need 64 candidate buffers in LDS next to the tiles
+  // Geometry, best first: the four waves share the item tile and own 64 / 32 users each (256 / 128 users per workgroup:
+  // every item vector is read once per that many users); then one tile per wave against 64 / 32 users; then the same on
+  // two waves (half the tiles and half the per-round candidates in LDS: top-k up to 256 at rank 128).  What decides is
+  // whether the users' candidate buffers fit the LDS next to the tiles, and that there are users enough for the block.
 #define RSP_TOPK(KPV)                                                                                        \
   if (KP == KPV) {                                                                                           \
-    const bool two = TopSmem<KPV, 2>::bytes(topk) <= 156 * 1024 && n_users > 32;                             \
-    if (two) { if (vec) RSP_TOPK_L(KPV, 2, true) else RSP_TOPK_L(KPV, 2, false) }                            \
-    if (vec) RSP_TOPK_L(KPV, 1, true) else RSP_TOPK_L(KPV, 1, false)                                         \
+    if (TopSharedSmem<KPV, 2>::bytes(topk) <= kLdsMax && n_users > 128) {                                    \
+      if (vec) RSP_TOPK_GO((top_product_shared_kernel<KPV, 2, true>), (TopSharedSmem<KPV, 2>::bytes(topk)), 256, 256) \
+      else RSP_TOPK_GO((top_product_shared_kernel<KPV, 2, false>), (TopSharedSmem<KPV, 2>::bytes(topk)), 256, 256)     \
+    }                                                                                                        \
+    if (TopSharedSmem<KPV, 1>::bytes(topk) <= kLdsMax && n_users > 64) {                                     \
+      if (vec) RSP_TOPK_GO((top_product_shared_kernel<KPV, 1, true>), (TopSharedSmem<KPV, 1>::bytes(topk)), 128, 256) \
+      else RSP_TOPK_GO((top_product_shared_kernel<KPV, 1, false>), (TopSharedSmem<KPV, 1>::bytes(topk)), 128, 256)     \
+    }                                                                                                        \
+    if (TopSmem<KPV, 2, 4>::bytes(topk) <= kLdsMax && n_users > 32) {                                        \
+      if (vec) RSP_TOPK_GO((top_product_kernel<KPV, 2, true, 4>), (TopSmem<KPV, 2, 4>::bytes(topk)), 64, 256) \
+      else RSP_TOPK_GO((top_product_kernel<KPV, 2, false, 4>), (TopSmem<KPV, 2, 4>::bytes(topk)), 64, 256)    \
+    }                                                                                                        \
+    if (TopSmem<KPV, 1, 4>::bytes(topk) <= kLdsMax) {                                                        \
+      if (vec) RSP_TOPK_GO((top_product_kernel<KPV, 1, true, 4>), (TopSmem<KPV, 1, 4>::bytes(topk)), 32, 256) \
+      else RSP_TOPK_GO((top_product_kernel<KPV, 1, false, 4>), (TopSmem<KPV, 1, 4>::bytes(topk)), 32, 256)    \
+    }                                                                                                        \
+    if (vec) RSP_TOPK_GO((top_product_kernel<KPV, 1, true, 2>), (TopSmem<KPV, 1, 2>::bytes(topk)), 32, 128)  \
+    else RSP_TOPK_GO((top_product_kernel<KPV, 1, false, 2>), (TopSmem<KPV, 1, 2>::bytes(topk)), 32, 128)     \
   }
   RSP_TOPK(32)
   RSP_TOPK(64)
   RSP_TOPK(128)
 #undef RSP_TOPK
-#undef RSP_TOPK_L
+#undef RSP_TOPK_GO
   return hipErrorInvalidValue;
 }
 

@@ -71,7 +71,12 @@ def _hip_top_product(x, y, k, nr=None, exclude=(), glob_mean=0.0):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rank,nr,nc,k", [(10, 100, 50, 10), (16, 70, 3001, 25), (64, 33, 777, 7), (128, 129, 5000, 100),
-                                          (20, 5, 40, 12)])
+                                          (20, 5, 40, 12),
+                                          # round 4: every launch geometry of wrmf_topk.hip -- four waves sharing the item tile
+                                          # with 256 / 128 users per workgroup, one tile per wave with 64 / 32, two waves with
+                                          # 32 (k up to 256 at rank 128) -- and the scalar staging path (rank % 4 != 0)
+                                          (128, 300, 5000, 10), (128, 100, 3000, 100), (128, 70, 4000, 200),
+                                          (64, 300, 2000, 256), (128, 33, 2000, 256), (30, 140, 900, 5), (128, 40, 1000, 120)])
 def test_hip_matches_oracle(rank, nr, nc, k):
     rng = np.random.default_rng(rank + nr)
     x = rng.standard_normal((nr, rank)).astype(np.float32).astype(np.float64)
@@ -118,15 +123,16 @@ def test_hip_tied_scores_follow_the_heap(k):
         got_i, got_s = _hip_top_product(one, np.array([sc]), kk)
         assert np.array_equal(got_i, ref_i) and np.array_equal(got_s, ref_s)
     rng = np.random.default_rng(100 + k)
-    x = rng.integers(0, 3, (70, 4)).astype(np.float64)
-    y = rng.integers(0, 3, (4, 1500)).astype(np.float64)          # scores are small integers: ties everywhere
-    nr = sp.random(70, 1500, density=0.02, format="csr", random_state=np.random.RandomState(k))
-    nr.sort_indices()
-    for kw in ({}, {"nr": nr, "exclude": [3, 77, 1400]}):
-        ref_i, ref_s = O.top_product(x, y, k, *((kw["nr"].indptr, kw["nr"].indices) if kw else (None, None)),
-                                     exclude=kw.get("exclude", ()))
-        got_i, got_s = _hip_top_product(x, y, k, **kw)
-        assert np.array_equal(got_i, ref_i) and np.array_equal(got_s, ref_s)
+    for n_users in (70, 300, 40):      # (the tile-sharing kernel with 128 / 256 users per workgroup, the tile-per-wave kernel)
+        x = rng.integers(0, 3, (n_users, 4)).astype(np.float64)
+        y = rng.integers(0, 3, (4, 1500)).astype(np.float64)          # scores are small integers: ties everywhere
+        nr = sp.random(n_users, 1500, density=0.02, format="csr", random_state=np.random.RandomState(k))
+        nr.sort_indices()
+        for kw in ({}, {"nr": nr, "exclude": [3, 77, 1400]}):
+            ref_i, ref_s = O.top_product(x, y, k, *((kw["nr"].indptr, kw["nr"].indices) if kw else (None, None)),
+                                         exclude=kw.get("exclude", ()))
+            got_i, got_s = _hip_top_product(x, y, k, **kw)
+            assert np.array_equal(got_i, ref_i) and np.array_equal(got_s, ref_s)
 
 
 @pytest.mark.gpu

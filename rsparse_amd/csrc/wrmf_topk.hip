@@ -167,6 +167,67 @@ __device__ __forceinline__ float topk_reduce_user(float* bv, int* bi, float* tv,
   return kth;
 }
 
+// The tile-sharing kernels append a score that beats its user's threshold WITHOUT looking at the exclusion lists (the
+// unrolled epilogue stays a compare and an append per accumulator entry: with two binary searches inlined 32 times the loop
+// outgrew the instruction cache); the lists are consulted here, one lane per arrival, before a buffer is reduced or emitted.
+// Drops the entries [from, n) of a user's buffer that `nr_row` (the user's not_recommend row) or `excl` rules out, closes
+// the gaps, returns the new count.  One wave.
+__device__ __forceinline__ int topk_verify_arrivals(float* bv, int* bi, const int from, const int n,
+                                                    const int32_t* __restrict__ nr_row, const int nr_len,
+                                                    const int32_t* __restrict__ excl, const int n_excl, const int lane) {
+  if (nr_len <= 0 && n_excl <= 0) return n;
+  int kept = from;
+  for (int c0 = from; c0 < n; c0 += 64) {
+    const int c = c0 + lane;
+    float v = 0.f;
+    int ix = 0;
+    bool ok = false;
+    if (c < n) {
+      v = bv[c];
+      ix = bi[c];
+      ok = !(nr_len > 0 && sorted_contains(nr_row, nr_len, ix)) && !(n_excl > 0 && sorted_contains(excl, n_excl, ix));
+    }
+    const unsigned long long m = __ballot(ok);
+    wave_sync();   // every lane has read its entry before any is overwritten
+    if (ok) {
+      const int dst = kept + __popcll(m & ((1ull << lane) - 1ull));
+      bv[dst] = v;
+      bi[dst] = ix;
+    }
+    kept += __popcll(m);
+    wave_sync();
+  }
+  return kept;
+}
+
+// arrivals verified, then the buffer reduced if it is over-full: what the tile-sharing kernels do for a user whose count
+// passed k.  Updates the user's count / threshold / verified length.  One wave.
+__device__ __forceinline__ void topk_settle_user(float* bv, int* bi, float* tv, int* ti, int* cnt, float* thr, int* need,
+                                                 const int topk, const int32_t* __restrict__ nr_ptr,
+                                                 const int32_t* __restrict__ nr_idx, const int u,
+                                                 const int32_t* __restrict__ excl, const int n_excl, const int lane) {
+  const int old = *need;
+  int p1 = 0, len = 0;
+  if (nr_ptr) {
+    p1 = nr_ptr[u];
+    len = nr_ptr[u + 1] - p1;
+  }
+  const int n = topk_verify_arrivals(bv, bi, old, *cnt, nr_idx + p1, len, excl, n_excl, lane);
+  float t = *thr;
+  int nn = n;
+  if (n > topk) {   // wave-uniform
+    t = topk_reduce_user(bv, bi, tv, ti, n, topk, old, lane);
+    nn = topk;
+  }
+  wave_sync();
+  if (lane == 0) {
+    *cnt = nn;
+    *thr = t;
+    *need = nn;
+  }
+  wave_sync();
+}
+
 // final output of one user: best first; equal scores with the larger index first (heap pop order of the reference)
 __device__ __forceinline__ void topk_emit_user(const float* bv, const int* bi, const int n, const int topk, const int lane,
                                                const float glob_mean, int32_t* res_u, float* scores_u) {
@@ -432,7 +493,7 @@ __global__ __launch_bounds__(256) void top_product_shared_kernel(const float* __
     }
     // lane holds item `col` for users row(e) = (e & 3) + 8 (e >> 2) + 4 half of each block
     const int item = i0 + col;
-    const bool item_ok = item < n_items && !(n_excl > 0 && sorted_contains(excl, n_excl, item));
+    const bool item_ok = item < n_items;
     // the thresholds of this lane's users, four 16-byte reads per block in flight together (one read and one wait per
     // accumulator entry left the matrix cores idle for a third of the tile)
     float4 thr4[UB][4];
@@ -445,39 +506,24 @@ __global__ __launch_bounds__(256) void top_product_shared_kernel(const float* __
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int ul = uw + 32 * ub + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const int u = u0 + ul;
         const float sc = acc[ub][e];
         const float* tq = reinterpret_cast<const float*>(&thr4[ub][e >> 2]);
-        if (item_ok && u < n_users && sc > tq[e & 3]) {
-          bool skip = false;
-          if (nr_ptr) {
-            const int p1 = nr_ptr[u], p2 = nr_ptr[u + 1];
-            skip = sorted_contains(nr_idx + p1, p2 - p1, item);
-          }
-          if (!skip) {
-            const int pos = atomicAdd(&sCnt[ul], 1);   // (lanes of this wave only: at most 32 per user and tile)
-            sVal[ul * cap + pos] = sc;
-            sIdx[ul * cap + pos] = item;
-          }
+        if (item_ok && u0 + ul < n_users && sc > tq[e & 3]) {   // appended unverified: topk_settle_user consults the lists
+          const int pos = atomicAdd(&sCnt[ul], 1);               // (lanes of this wave only: at most 32 per user and tile)
+          sVal[ul * cap + pos] = sc;
+          sIdx[ul * cap + pos] = item;
         }
       }
     wave_sync();
-    // this wave's over-full buffers -> their top k, threshold raised (after the first tiles almost nothing survives)
+    // this wave's over-full buffers: arrivals verified, top k kept, threshold raised (after the first tiles almost nothing survives)
     for (int b0 = 0; b0 < UPW; b0 += 64) {
       const int ulq = uw + b0 + lane;
       unsigned long long over = __ballot(b0 + lane < UPW && sCnt[ulq] > topk);
       while (over) {
         const int ul = uw + b0 + __builtin_ctzll(over);
         over &= over - 1;
-        const float thr = topk_reduce_user(sVal + ul * cap, sIdx + ul * cap, sTmpV + wv * cap, sTmpI + wv * cap, sCnt[ul], topk,
-                                           sNeed[ul], lane);
-        wave_sync();
-        if (lane == 0) {
-          sCnt[ul] = topk;
-          sThr[ul] = thr;
-          sNeed[ul] = topk;
-        }
-        wave_sync();
+        topk_settle_user(sVal + ul * cap, sIdx + ul * cap, sTmpV + wv * cap, sTmpI + wv * cap, sCnt + ul, sThr + ul, sNeed + ul,
+                         topk, nr_ptr, nr_idx, u0 + ul, excl, n_excl, lane);
       }
     }
     __syncthreads();             // every wave has read the tile for the last time
@@ -487,6 +533,193 @@ __global__ __launch_bounds__(256) void top_product_shared_kernel(const float* __
   for (int ul = uw; ul < uw + UPW; ul++) {
     const int u = u0 + ul;
     if (u >= n_users) break;
+    if (sCnt[ul] > sNeed[ul])   // arrivals that no reduction has looked at yet (the buffer never filled up again)
+      topk_settle_user(sVal + ul * cap, sIdx + ul * cap, sTmpV + wv * cap, sTmpI + wv * cap, sCnt + ul, sThr + ul, sNeed + ul, topk,
+                       nr_ptr, nr_idx, u, excl, n_excl, lane);
+    topk_emit_user(sVal + ul * cap, sIdx + ul * cap, min(sCnt[ul], topk), topk, lane, glob_mean, res + (size_t)u * topk,
+                   scores_out + (size_t)u * topk);
+  }
+}
+
+// The same with the epilogue hidden behind the NEXT tile's matrix instructions (round 4).  One wave per SIMD (the user blocks
+// take 128 registers, the accumulators 32): nothing else runs while a wave compares its 32 scores per lane with the users'
+// thresholds, so in the kernel above the matrix cores idle for that part of every tile.  Here two tiles are resident in LDS
+// and two accumulator sets alternate: the MFMAs of tile t + 1 are issued in chunks of KP / 32 k-steps between the
+// accumulator entries of tile t (a matrix instruction executes for 64 cycles after it has been issued; the compares, the rare
+// appends and the buffer reductions of tile t run meanwhile), and one barrier per tile is enough -- tile t + 2 lands in the
+// buffer whose last reader finished before the previous barrier.
+template <int KP, int UB>
+struct TopPipeSmem {
+  static constexpr int LDT = KP + 4;
+  static constexpr int USERS = 4 * kTopBlock * UB;
+  static constexpr size_t tile_floats = (size_t)2 * 32 * LDT;
+  static size_t bytes(int topk) {
+    const size_t cap = (size_t)top_cap(topk, 1);
+    return (tile_floats + 2 * (size_t)USERS * cap + 3 * USERS) * 4 + 64 + (size_t)4 * cap * 8;
+  }
+};
+
+template <int KP, int UB, bool VEC>
+__global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                               int n_users, int n_items, int k_rank, int topk,
+                                                               const int32_t* __restrict__ nr_ptr,
+                                                               const int32_t* __restrict__ nr_idx,
+                                                               const int32_t* __restrict__ excl, int n_excl,
+                                                               float glob_mean, int32_t* __restrict__ res,
+                                                               float* __restrict__ scores_out) {
+  using SM = TopPipeSmem<KP, UB>;
+  constexpr int LDT = SM::LDT, NK2 = KP / 2, USERS = SM::USERS, UPW = 32 * UB;
+  constexpr int CH = NK2 / 16;   // k-steps (x UB matrix instructions) issued per accumulator entry of the previous tile
+  const int cap = top_cap(topk, 1);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tiles = reinterpret_cast<float*>(smem);                    // [2][32][LDT]
+  float* sVal = tiles + SM::tile_floats;
+  int* sIdx = reinterpret_cast<int*>(sVal + (size_t)USERS * cap);
+  int* sCnt = sIdx + (size_t)USERS * cap;
+  float* sThr = reinterpret_cast<float*>(sCnt + USERS);
+  int* sNeed = reinterpret_cast<int*>(sThr + USERS);
+  float* sTmpV = reinterpret_cast<float*>(sNeed + USERS);
+  int* sTmpI = reinterpret_cast<int*>(sTmpV + 4 * cap);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
+  const int u0 = blockIdx.x * USERS, uw = wv * UPW;
+  const int col = lane & 31, half = lane >> 5;
+  for (int e = tid; e < USERS; e += 256) {
+    sCnt[e] = 0;
+    sThr[e] = -INFINITY;
+    sNeed[e] = 0;
+  }
+  float afrag[UB][NK2];
+#pragma unroll
+  for (int ub = 0; ub < UB; ub++) {
+    const int u = u0 + uw + 32 * ub + col;
+#pragma unroll
+    for (int t = 0; t < NK2; t++) {
+      const int kk = 2 * t + half;
+      afrag[ub][t] = (u < n_users && kk < k_rank) ? U[(size_t)u * k_rank + kk] : 0.f;
+    }
+  }
+  for (int e = tid; e < 2 * 32 * LDT; e += 256) tiles[e] = 0.f;
+  __syncthreads();
+
+  const int n_tiles = (n_items + 31) / 32;
+  constexpr int NLD = KP / 32;
+  float4 pf[VEC ? NLD : 1];
+  auto load_tile = [&](const int tl) {
+    if constexpr (VEC) {
+      const int i0 = tl * 32;
+#pragma unroll
+      for (int j = 0; j < NLD; j++) {
+        const int e4 = j * 256 + tid, it = e4 / (KP / 4), c4 = e4 % (KP / 4);
+        pf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tl < n_tiles && i0 + it < n_items && 4 * c4 < k_rank)
+          pf[j] = *reinterpret_cast<const float4*>(V + (size_t)(i0 + it) * k_rank + 4 * c4);
+      }
+    }
+  };
+  auto store_tile = [&](const int tl) {
+    float* tile = tiles + (tl & 1) * 32 * LDT;
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < NLD; j++) {
+        const int e4 = j * 256 + tid, it = e4 / (KP / 4), c4 = e4 % (KP / 4);
+        *reinterpret_cast<float4*>(tile + it * LDT + 4 * c4) = pf[j];
+      }
+    } else {
+      const int i0 = tl * 32;
+      for (int it = wv; it < 32; it += 4)
+        for (int kk = lane; kk < k_rank; kk += 64)
+          tile[it * LDT + kk] = (tl < n_tiles && i0 + it < n_items) ? V[(size_t)(i0 + it) * k_rank + kk] : 0.f;
+    }
+  };
+  // tile 0 -> LDS, its products (nothing to hide them behind), tile 1 -> LDS
+  load_tile(0);
+  store_tile(0);
+  load_tile(1);
+  __syncthreads();
+  f32x16_t acc[2][UB];   // [tile parity]
+#pragma unroll
+  for (int ub = 0; ub < UB; ub++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[0][ub][e] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NK2; t++) {
+    const float b = tiles[col * LDT + 2 * t + half];
+#pragma unroll
+    for (int ub = 0; ub < UB; ub++) acc[0][ub] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[ub][t], b, acc[0][ub], 0, 0, 0);
+  }
+  store_tile(1);
+  __syncthreads();
+
+  auto body = [&](const int tl, f32x16_t (&cur)[UB], f32x16_t (&nxt)[UB]) {
+    // cur: scores of tile tl; LDS buffer (tl + 1) & 1 holds tile tl + 1
+    load_tile(tl + 2);
+    const float* tn = tiles + ((tl + 1) & 1) * 32 * LDT + col * LDT + half;
+    const int item = tl * 32 + col;
+    const bool item_ok = item < n_items;
+    float4 thr4[UB][4];
+#pragma unroll
+    for (int ub = 0; ub < UB; ub++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) thr4[ub][q] = *reinterpret_cast<const float4*>(sThr + uw + 32 * ub + 8 * q + 4 * half);
+#pragma unroll
+    for (int ub = 0; ub < UB; ub++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) nxt[ub][e] = 0.f;
+    float bq[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) bq[c] = tn[2 * c];
+#pragma unroll
+    for (int el = 0; el < 16; el++) {
+      // the next tile's k-steps [el CH, el CH + CH) for every user block, then the operands of the chunk after it
+#pragma unroll
+      for (int c = 0; c < CH; c++)
+#pragma unroll
+        for (int ub = 0; ub < UB; ub++)
+          nxt[ub] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[ub][el * CH + c], bq[c], nxt[ub], 0, 0, 0);
+      if (el + 1 < 16) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) bq[c] = tn[2 * ((el + 1) * CH + c)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ... and entry el of every user block of the current tile (appended unverified: topk_settle_user consults the lists)
+#pragma unroll
+      for (int ub = 0; ub < UB; ub++) {
+        const int ul = uw + 32 * ub + (el & 3) + 8 * (el >> 2) + 4 * half;
+        const float sc = cur[ub][el];
+        const float* tq = reinterpret_cast<const float*>(&thr4[ub][el >> 2]);
+        if (item_ok && u0 + ul < n_users && sc > tq[el & 3]) {
+          const int pos = atomicAdd(&sCnt[ul], 1);
+          sVal[ul * cap + pos] = sc;
+          sIdx[ul * cap + pos] = item;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_sync();
+    for (int b0 = 0; b0 < UPW; b0 += 64) {
+      const int ulq = uw + b0 + lane;
+      unsigned long long over = __ballot(b0 + lane < UPW && sCnt[ulq] > topk);
+      while (over) {
+        const int ul = uw + b0 + __builtin_ctzll(over);
+        over &= over - 1;
+        topk_settle_user(sVal + ul * cap, sIdx + ul * cap, sTmpV + wv * cap, sTmpI + wv * cap, sCnt + ul, sThr + ul, sNeed + ul,
+                         topk, nr_ptr, nr_idx, u0 + ul, excl, n_excl, lane);
+      }
+    }
+    store_tile(tl + 2);   // into the buffer of tile tl: its last reader finished before the previous barrier
+    __syncthreads();
+  };
+  for (int tl = 0; tl < n_tiles; tl += 2) {
+    body(tl, acc[0], acc[1]);
+    if (tl + 1 < n_tiles) body(tl + 1, acc[1], acc[0]);
+  }
+  for (int ul = uw; ul < uw + UPW; ul++) {
+    const int u = u0 + ul;
+    if (u >= n_users) break;
+    if (sCnt[ul] > sNeed[ul])   // arrivals that no reduction has looked at yet (the buffer never filled up again)
+      topk_settle_user(sVal + ul * cap, sIdx + ul * cap, sTmpV + wv * cap, sTmpI + wv * cap, sCnt + ul, sThr + ul, sNeed + ul, topk,
+                       nr_ptr, nr_idx, u, excl, n_excl, lane);
     topk_emit_user(sVal + ul * cap, sIdx + ul * cap, min(sCnt[ul], topk), topk, lane, glob_mean, res + (size_t)u * topk,
                    scores_out + (size_t)u * topk);
   }
@@ -516,11 +749,20 @@ hipError_t launch_top_product(const float* U, const float* V, int n_users, int n
     return hipGetLastError();                                                                                \
   }
   // Geometry, best first: the four waves share the item tile and own 64 / 32 users each (256 / 128 users per workgroup:
-  // every item vector is read once per that many users); then one tile per wave against 64 / 32 users; then the same on
+  // every item vector is read once per that many users) -- with two tiles resident and the epilogue hidden behind the next
+  // tile's matrix instructions where the LDS allows it; then one tile per wave against 64 / 32 users; then the same on
   // two waves (half the tiles and half the per-round candidates in LDS: top-k up to 256 at rank 128).  What decides is
   // whether the users' candidate buffers fit the LDS next to the tiles, and that there are users enough for the block.
 #define RSP_TOPK(KPV)                                                                                        \
   if (KP == KPV) {                                                                                           \
+    if (TopPipeSmem<KPV, 2>::bytes(topk) <= kLdsMax && n_users > 128) {                                      \
+      if (vec) RSP_TOPK_GO((top_product_pipe_kernel<KPV, 2, true>), (TopPipeSmem<KPV, 2>::bytes(topk)), 256, 256) \
+      else RSP_TOPK_GO((top_product_pipe_kernel<KPV, 2, false>), (TopPipeSmem<KPV, 2>::bytes(topk)), 256, 256)     \
+    }                                                                                                        \
+    if (TopPipeSmem<KPV, 1>::bytes(topk) <= kLdsMax && n_users > 64) {                                       \
+      if (vec) RSP_TOPK_GO((top_product_pipe_kernel<KPV, 1, true>), (TopPipeSmem<KPV, 1>::bytes(topk)), 128, 256) \
+      else RSP_TOPK_GO((top_product_pipe_kernel<KPV, 1, false>), (TopPipeSmem<KPV, 1>::bytes(topk)), 128, 256)     \
+    }                                                                                                        \
     if (TopSharedSmem<KPV, 2>::bytes(topk) <= kLdsMax && n_users > 128) {                                    \
       if (vec) RSP_TOPK_GO((top_product_shared_kernel<KPV, 2, true>), (TopSharedSmem<KPV, 2>::bytes(topk)), 256, 256) \
       else RSP_TOPK_GO((top_product_shared_kernel<KPV, 2, false>), (TopSharedSmem<KPV, 2>::bytes(topk)), 256, 256)     \

@@ -24,7 +24,9 @@ ap.add_argument("--items", type=int, default=1_000_000)
 ap.add_argument("--rank", type=int, default=128)
 ap.add_argument("--topk", type=int, default=10)
 ap.add_argument("--exclude-deg", type=int, default=50, help="not_recommend entries per user (0 = no exclusion list)")
-ap.add_argument("--batch", type=int, default=100_000, help="users per call")
+ap.add_argument("--batch", type=int, default=0, help="users per call (0 = all in one call: a call's last wave of workgroups is "
+                "partly empty -- 100k users are 391 workgroups of 256 users on 256 CUs, 1.5 rounds that cost 2 --, which is what the "
+                "100k batches of round 3 measured)")
 ap.add_argument("--reps", type=int, default=1)
 a = ap.parse_args()
 lib = _lib.load()
@@ -32,7 +34,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
 U = torch.randn(a.users, a.rank, generator=g, device=dev) * 0.1
 V = torch.randn(a.items, a.rank, generator=g, device=dev) * 0.1
-nb = min(a.batch, a.users)
+nb = min(a.batch, a.users) if a.batch > 0 else a.users
 nr_p = nr_j = None
 if a.exclude_deg > 0:
     d = a.exclude_deg

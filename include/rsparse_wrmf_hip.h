@@ -277,6 +277,22 @@ int rsparse_hip_initialize_biases_explicit_device(rsparse_hip_csc* c_ui, rsparse
                                                   int non_negative, int calculate_global_bias,
                                                   double* global_bias_out, void* stream);
 
+/* The bias initialisation one sweep at a time, over ONE block of columns: for drivers that shard the matrix (every rank
+ * owns a block of items and a block of users and holds both bias vectors in full, exchanging the swept block after each
+ * sweep).  initialize_biases_explicit (inst/include/wrmf_utils.hpp:54-82) is five times
+ *     item sweep: item_bias[c] = sum_{e in c} (x_e - user_bias[idx_e]) / (lambda_use + n_c)     then the same for the users;
+ * initialize_biases_implicit (:86-165) is, once, means / adjustments per column (prep; n_other = the TRUE size of the other
+ * side), then five times an item sweep and a user sweep of the weighted running mean (:136-143, 152-159), each given the
+ * SUM of the other side's current biases (d_other_sum, device double[1]; NULL = 0: the first item sweep, :131-135).
+ * d_other_bias is indexed by conf's row indices; d_out / d_means / d_adj by conf's columns. */
+int rsparse_hip_bias_sweep_explicit_device(const rsparse_hip_csc* conf, const float* d_other_bias, double lambda,
+                                           int dynamic_lambda, int non_negative, float* d_out, void* stream);
+int rsparse_hip_bias_prep_implicit_device(const rsparse_hip_csc* conf, int n_other, double lambda, double* d_means,
+                                          double* d_adj, void* stream);
+int rsparse_hip_bias_sweep_implicit_device(const rsparse_hip_csc* conf, const float* d_other_bias, int n_other,
+                                           const double* d_other_sum, const double* d_means, const double* d_adj,
+                                           int non_negative, double global_bias, float* d_out, void* stream);
+
 /* sum_j w_j |X[:,j]|^2 on the device (w = NULL -> 1): the regulariser terms
  * lambda*accu(X%X) and lambda*accu((X%X)*cnt_X) (wrmf_explicit.hpp:160-170). */
 int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, const float* d_w,
@@ -351,6 +367,15 @@ int rsparse_hip_initialize_biases_f64_device(rsparse_hip_csc_f64* c_ui, rsparse_
                                              double* d_item_bias, double lambda, int dynamic_lambda, int non_negative,
                                              int calculate_global_bias, int is_explicit_feedback,
                                              double* global_bias_out, void* stream);
+
+/* f64 counterparts of the single bias sweeps (rsparse_hip_bias_*_device above) */
+int rsparse_hip_bias_sweep_explicit_f64_device(const rsparse_hip_csc_f64* conf, const double* d_other_bias, double lambda,
+                                               int dynamic_lambda, int non_negative, double* d_out, void* stream);
+int rsparse_hip_bias_prep_implicit_f64_device(const rsparse_hip_csc_f64* conf, int n_other, double lambda, double* d_means,
+                                              double* d_adj, void* stream);
+int rsparse_hip_bias_sweep_implicit_f64_device(const rsparse_hip_csc_f64* conf, const double* d_other_bias, int n_other,
+                                               const double* d_other_sum, const double* d_means, const double* d_adj,
+                                               int non_negative, double global_bias, double* d_out, void* stream);
 
 /* f64 counterparts of rsparse_hip_values_subtract_mean_device / rsparse_hip_weighted_sumsq_device */
 int rsparse_hip_values_subtract_mean_f64_device(int64_t n, double* d_x, double* d_x_other, double* mean_out, void* stream);

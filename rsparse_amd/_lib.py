@@ -51,6 +51,12 @@ SIGNATURES = {
     "rsparse_hip_initialize_biases_explicit_device": (_c_int, [_vp, _vp, _vp, _vp, _c_dbl, _c_int, _c_int, _c_int,
                                                                ctypes.POINTER(_c_dbl), _vp]),
     "rsparse_hip_values_subtract_mean_device": (_c_int, [_c_i64, _vp, _vp, ctypes.POINTER(_c_dbl), _vp]),
+    "rsparse_hip_bias_sweep_explicit_device": (_c_int, [_vp, _vp, _c_dbl, _c_int, _c_int, _vp, _vp]),
+    "rsparse_hip_bias_prep_implicit_device": (_c_int, [_vp, _c_int, _c_dbl, _vp, _vp, _vp]),
+    "rsparse_hip_bias_sweep_implicit_device": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp]),
+    "rsparse_hip_bias_sweep_explicit_f64_device": (_c_int, [_vp, _vp, _c_dbl, _c_int, _c_int, _vp, _vp]),
+    "rsparse_hip_bias_prep_implicit_f64_device": (_c_int, [_vp, _c_int, _c_dbl, _vp, _vp, _vp]),
+    "rsparse_hip_bias_sweep_implicit_f64_device": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp]),
     "rsparse_hip_csc_transpose_device": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rsparse_hip_values_to_float_device": (_c_int, [_c_i64, _vp, _vp, _vp]),
     "rsparse_hip_gramian_device": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp, _vp, _vp]),

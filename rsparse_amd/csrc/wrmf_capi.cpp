@@ -1288,6 +1288,37 @@ int rsparse_hip_initialize_biases_implicit_device(const rsparse_hip_csc* c_ui, c
   return RSPARSE_HIP_OK;
 }
 
+// ---- single sweeps of the bias initialisation over ONE column block (sharded drivers; see the header) ----
+int rsparse_hip_bias_sweep_explicit_device(const rsparse_hip_csc* conf, const float* d_other_bias, double lambda,
+                                           int dynamic_lambda, int non_negative, float* d_out, void* stream) {
+  if (!conf || !d_other_bias || !d_out) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or bias vector");
+  const DevCSC& a = conf->d;
+  hipError_t e = launch_bias_sweep(a.col_ptrs, a.row_idx, a.vals, d_other_bias, a.n_cols, (float)lambda, dynamic_lambda,
+                                   non_negative, d_out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "launch_bias_sweep");
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_bias_prep_implicit_device(const rsparse_hip_csc* conf, int n_other, double lambda, double* d_means,
+                                          double* d_adj, void* stream) {
+  if (!conf || !d_means || !d_adj) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or output");
+  const DevCSC& a = conf->d;
+  hipError_t e = launch_bias_implicit_prep(a.col_ptrs, a.vals, a.n_cols, n_other, lambda, d_means, d_adj, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "launch_bias_implicit_prep");
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_bias_sweep_implicit_device(const rsparse_hip_csc* conf, const float* d_other_bias, int n_other,
+                                           const double* d_other_sum, const double* d_means, const double* d_adj,
+                                           int non_negative, double global_bias, float* d_out, void* stream) {
+  if (!conf || !d_other_bias || !d_means || !d_adj || !d_out) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or vector");
+  const DevCSC& a = conf->d;
+  hipError_t e = launch_bias_implicit_sweep(a.col_ptrs, a.row_idx, a.vals, d_other_bias, a.n_cols, n_other, d_other_sum, d_means,
+                                            d_adj, non_negative, global_bias, d_out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "launch_bias_implicit_sweep");
+  return RSPARSE_HIP_OK;
+}
+
 int rsparse_hip_als_explicit_bias_device(const rsparse_hip_csc* conf, const float* d_X, float* d_Y, int rank,
                                          double lambda, unsigned solver, unsigned cg_steps, int dynamic_lambda,
                                          int is_x_bias_last_row, double* d_loss_rows_out, void* stream) {

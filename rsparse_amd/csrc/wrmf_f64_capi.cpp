@@ -379,6 +379,34 @@ int rsparse_hip_values_subtract_mean_f64_device(int64_t n, double* d_x, double* 
   return RSPARSE_HIP_OK;
 }
 
+int rsparse_hip_bias_sweep_explicit_f64_device(const rsparse_hip_csc_f64* conf, const double* d_other_bias, double lambda,
+                                               int dynamic_lambda, int non_negative, double* d_out, void* stream) {
+  if (!conf || !d_other_bias || !d_out) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or bias vector");
+  hipError_t e = launch_bias_sweep(conf->col_ptrs, conf->row_idx, conf->vals, d_other_bias, conf->n_cols, lambda, dynamic_lambda,
+                                   non_negative, d_out, (hipStream_t)stream);
+  if (e != hipSuccess) return capi_hip_fail(e, "launch_bias_sweep");
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_bias_prep_implicit_f64_device(const rsparse_hip_csc_f64* conf, int n_other, double lambda, double* d_means,
+                                              double* d_adj, void* stream) {
+  if (!conf || !d_means || !d_adj) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or output");
+  hipError_t e = launch_bias_implicit_prep(conf->col_ptrs, conf->vals, conf->n_cols, n_other, lambda, d_means, d_adj,
+                                           (hipStream_t)stream);
+  if (e != hipSuccess) return capi_hip_fail(e, "launch_bias_implicit_prep");
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_bias_sweep_implicit_f64_device(const rsparse_hip_csc_f64* conf, const double* d_other_bias, int n_other,
+                                               const double* d_other_sum, const double* d_means, const double* d_adj,
+                                               int non_negative, double global_bias, double* d_out, void* stream) {
+  if (!conf || !d_other_bias || !d_means || !d_adj || !d_out) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or vector");
+  hipError_t e = launch_bias_implicit_sweep(conf->col_ptrs, conf->row_idx, conf->vals, d_other_bias, conf->n_cols, n_other,
+                                            d_other_sum, d_means, d_adj, non_negative, global_bias, d_out, (hipStream_t)stream);
+  if (e != hipSuccess) return capi_hip_fail(e, "launch_bias_implicit_sweep");
+  return RSPARSE_HIP_OK;
+}
+
 int rsparse_hip_initialize_biases_f64_device(rsparse_hip_csc_f64* c_ui, rsparse_hip_csc_f64* c_iu, double* d_user_bias,
                                              double* d_item_bias, double lambda, int dynamic_lambda, int non_negative,
                                              int calculate_global_bias, int is_explicit_feedback,

@@ -269,6 +269,26 @@ class HipBackend:
             int(bool(calculate_global_bias)), ctypes.byref(gb), self._stream()))
         return gb.value
 
+    def bias_sweep_explicit(self, csc, other_bias, lambda_, dynamic_lambda, non_negative, out):
+        """one sweep of initialize_biases_explicit over the columns of `csc` (a block): out[c] = sum (x - other_bias[idx]) /
+        (lambda_use + n_c)  (wrmf_utils.hpp:56-81)"""
+        fn = self.lib.rsparse_hip_bias_sweep_explicit_f64_device if csc.f64 else self.lib.rsparse_hip_bias_sweep_explicit_device
+        _lib.check(fn(csc.h, other_bias.data_ptr(), float(lambda_), int(bool(dynamic_lambda)), int(bool(non_negative)),
+                      out.data_ptr(), self._stream()))
+
+    def bias_prep_implicit(self, csc, n_other, lambda_, means, adj):
+        """means / adjustments of the columns of `csc` (wrmf_utils.hpp:97-124); n_other = the true size of the other side"""
+        fn = self.lib.rsparse_hip_bias_prep_implicit_f64_device if csc.f64 else self.lib.rsparse_hip_bias_prep_implicit_device
+        _lib.check(fn(csc.h, int(n_other), float(lambda_), means.data_ptr(), adj.data_ptr(), self._stream()))
+
+    def bias_sweep_implicit(self, csc, other_bias, n_other, other_sum, means, adj, non_negative, global_bias, out):
+        """one sweep of initialize_biases_implicit over the columns of `csc` (wrmf_utils.hpp:136-143, 152-159); other_sum:
+        float64[1] on the device = sum of the other side's biases (None: 0)"""
+        fn = self.lib.rsparse_hip_bias_sweep_implicit_f64_device if csc.f64 else self.lib.rsparse_hip_bias_sweep_implicit_device
+        _lib.check(fn(csc.h, other_bias.data_ptr(), int(n_other), None if other_sum is None else other_sum.data_ptr(),
+                      means.data_ptr(), adj.data_ptr(), int(bool(non_negative)), float(global_bias), out.data_ptr(),
+                      self._stream()))
+
     def subtract_mean(self, x, x_other=None):
         """global_bias = mean(x), removed in place from x (and from the other orientation's values) -- R/model_WRMF.R:278-282"""
         m = ctypes.c_double(0.0)
@@ -380,6 +400,7 @@ class ShardedALS:
         # item half: fixed side = users, solved = my items; user half: fixed side = items, solved = my users
         self.csc_items, self.sub_items = self._make(c_ui_block, lay_user, lay_item)
         self.csc_users, self.sub_users = self._make(c_iu_block, lay_item, lay_user)
+        self.x_items, self.x_users = c_ui_block[2], c_iu_block[2]   # the resident values (the sub-block handles view them)
         self.scal_sub = torch.zeros(max(lay_user.n_sub, lay_item.n_sub), dtype=torch.float64, device=dev)
         self.G = torch.zeros((self.k, self.k), dtype=self.dtype, device=dev)
         self.Gpart = torch.zeros((self.k, self.k), dtype=self.dtype, device=dev)
@@ -507,6 +528,69 @@ class ShardedALS:
         self._all_reduce(self.Gb)
         self.Gb.diagonal().add_(float(np.float32(self.lambda_)))
         return self.Gb
+
+    def _gather_vec(self, v, lay):
+        """all sub-blocks of a storage-order vector (a bias vector) -> every rank"""
+        for j in range(lay.n_sub):
+            w = self._gather_slab(v, lay, j)
+            if w is not None:
+                w.wait()
+
+    def initialize_biases(self, user_bias, item_bias, non_negative, calculate_global_bias):
+        """initialize_biases_explicit / _implicit (inst/include/wrmf_utils.hpp:32-165) over the sharded matrix: user_bias
+        (lay_user.rows,) and item_bias (lay_item.rows,) are storage-order vectors, complete on every rank on return.  Every
+        sweep runs over the rank's own block against the full vector of the other side (the rule of a sweep is per column),
+        then the swept block is all-gathered; sums that span the matrix (the global mean, the mean of a bias vector) are
+        all-reduced or taken from the full vector.  With explicit feedback and calculate_global_bias the mean leaves the
+        resident values of both orientations in place, as in the reference (:41-52).  Returns the global bias."""
+        be, lu, li = self.be, self.lay_user, self.lay_item
+        dev = user_bias.device
+        gb = 0.0
+
+        def total(t):   # sum over all ranks of a local float64 scalar tensor
+            self._all_reduce(t)
+            return float(t)
+
+        def sweep(subs, lay, fn):
+            for j, (c0, c1, sub) in enumerate(subs):
+                if c1 > c0:
+                    a = lay.sub_start(self.me, j)
+                    fn(sub, c0, c1, a)
+
+        if not self.implicit:
+            if calculate_global_bias and self.total_nnz > 0:   # :41-52 (the mean is global; each rank shifts its own values)
+                gb = total(self.x_items.double().sum().reshape(1)) / float(self.total_nnz)
+                self.x_items.sub_(gb)
+                self.x_users.sub_(gb)
+            for _ in range(5):                                 # :54-82
+                sweep(self.sub_items, li, lambda sub, c0, c1, a: be.bias_sweep_explicit(
+                    sub, user_bias, self.lambda_, self.dynamic_lambda, non_negative, item_bias[a:a + (c1 - c0)]))
+                self._gather_vec(item_bias, li)
+                sweep(self.sub_users, lu, lambda sub, c0, c1, a: be.bias_sweep_explicit(
+                    sub, item_bias, self.lambda_, self.dynamic_lambda, non_negative, user_bias[a:a + (c1 - c0)]))
+                self._gather_vec(user_bias, lu)
+            return gb
+        n_it = li.bounds[self.me][1] - li.bounds[self.me][0]
+        n_us = lu.bounds[self.me][1] - lu.bounds[self.me][0]
+        im, ia = (torch.zeros(max(n_it, 1), dtype=torch.float64, device=dev) for _ in range(2))
+        um, ua = (torch.zeros(max(n_us, 1), dtype=torch.float64, device=dev) for _ in range(2))
+        sweep(self.sub_items, li, lambda sub, c0, c1, a: be.bias_prep_implicit(sub, self.n_user, self.lambda_, im[c0:c1], ia[c0:c1]))
+        sweep(self.sub_users, lu, lambda sub, c0, c1, a: be.bias_prep_implicit(sub, self.n_item, self.lambda_, um[c0:c1], ua[c0:c1]))
+        if calculate_global_bias:                              # :90-93
+            sm = total(self.x_items.double().sum().reshape(1))
+            gb = sm / (sm + float(self.n_user) * float(self.n_item) - float(self.total_nnz))
+        if non_negative:
+            gb = max(0.0, gb)
+        for it in range(5):                                    # :130-162 (padding rows of a bias vector are zero: the sums are the real ones)
+            usum = user_bias.double().sum().reshape(1) if it > 0 else None
+            sweep(self.sub_items, li, lambda sub, c0, c1, a: be.bias_sweep_implicit(
+                sub, user_bias, self.n_user, usum, im[c0:c1], ia[c0:c1], non_negative, gb, item_bias[a:a + (c1 - c0)]))
+            self._gather_vec(item_bias, li)
+            isum = item_bias.double().sum().reshape(1)
+            sweep(self.sub_users, lu, lambda sub, c0, c1, a: be.bias_sweep_implicit(
+                sub, item_bias, self.n_item, isum, um[c0:c1], ua[c0:c1], non_negative, gb, user_bias[a:a + (c1 - c0)]))
+            self._gather_vec(user_bias, lu)
+        return gb
 
     def half_iteration(self, side, U, V, solver, G=None, want_loss=True):
         """side 'items': solve V (item factors) given U; side 'users': solve U given V (both in storage order).

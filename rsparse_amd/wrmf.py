@@ -242,9 +242,6 @@ class WRMF:
         stopping rule as the one-rank path; the factors of a row do not depend on the number of ranks (only the order of
         the Gramian / loss sums does)."""
         import torch.distributed as dist
-        if self._with_bias:
-            raise _lib.UnsupportedOnDevice(_lib.ERR_UNSUPPORTED, "with_user_item_bias is single-rank only: its initialisation "
-                                           "sweeps (initialize_biases_*) alternate over the WHOLE matrix")
         be = self._backend()
         c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))
         c_ui.sort_indices()
@@ -268,6 +265,9 @@ class WRMF:
             if self.components.shape != (k, n_item):
                 raise ValueError("init must be rank x n_item")
             V0 = np.array(self.components.T, dtype=ndt, order="C")
+        if self._with_bias:                                                        # :208-245: the two rows of ones
+            U0[:, 0] = 1.0
+            V0[:, k - 1] = 1.0
         if self._non_negative:
             U0, V0 = np.abs(U0), np.abs(V0)
         dev0 = be.to_device(np.zeros(1, dtype=np.float32), torch.float32).device
@@ -276,7 +276,9 @@ class WRMF:
             dist.broadcast(t, src=dist.get_global_rank(self._group, 0) if self._group is not None else 0, group=self._group)
             buf[...] = t.cpu().numpy()
         self.global_bias = 0.0
-        if self._with_global_bias and self._feedback == "explicit":                # :278-282, on the host: the mean is global
+        if self._with_bias:
+            pass                                                                   # :259-277: initialize_biases below owns the global bias
+        elif self._with_global_bias and self._feedback == "explicit":              # :278-282, on the host: the mean is global
             self.global_bias = float(np.mean(c_ui.data)) if c_ui.nnz else 0.0
             c_ui = c_ui.copy()
             c_ui.data -= self.global_bias
@@ -296,11 +298,19 @@ class WRMF:
         als = ShardedALS(be, n_user, n_item, k, block(c_ui, *lay_i.bounds[me]), block(c_iu, *lay_u.bounds[me]), c_ui.nnz,
                          feedback=self._feedback, lambda_=self._lambda, dynamic_lambda=self._dynamic_lambda,
                          cg_steps=self._cg_steps, group=self._group, world_size=ws, my_rank=me, lay_user=lay_u,
-                         lay_item=lay_i)
+                         lay_item=lay_i, with_bias=self._with_bias)
         als.cnt_user = be.to_device(cnt_user.numpy().astype(ndt), tdt)
         als.cnt_item = be.to_device(cnt_item.numpy().astype(ndt), tdt)
         U = lay_u.from_global(lay_u.alloc(k, dev0, tdt), be.to_device(U0, tdt))
         V = lay_i.from_global(lay_i.alloc(k, dev0, tdt), be.to_device(V0, tdt))
+        if self._with_bias:                                                        # :259-277, sweep by sweep over the shards
+            user_bias = torch.zeros(lay_u.rows, dtype=tdt, device=dev0)
+            item_bias = torch.zeros(lay_i.rows, dtype=tdt, device=dev0)
+            gb = als.initialize_biases(user_bias, item_bias, self._non_negative, self._with_global_bias)
+            V[:, 0] = item_bias
+            U[:, k - 1] = user_bias
+            if self._with_global_bias:
+                self.global_bias = gb
         if self._feedback == "implicit":
             als.global_bias = self.global_bias
         loss_prev = float("inf")
@@ -315,8 +325,12 @@ class WRMF:
         self._check_numeric()
         # the returned embeddings: one more exact solve from zeros against the final item factors (:355-359), sharded like
         # a user half-iteration
-        XtX = als.gramian(V, lay_i).clone() if self._feedback == "implicit" else None
+        XtX = None
+        if self._feedback == "implicit":                                           # :345-353 (with biases: components[-1, ] out)
+            XtX = (als.gramian_bias(V, lay_i, False) if self._with_bias else als.gramian(V, lay_i)).clone()
         res = lay_u.alloc(k, dev0, tdt)
+        if self._with_bias:
+            res[:, 0] = 1.0                                                         # :427-429
         solver = 0 if self._solver_code == 1 else self._solver_code
         als.half_iteration("users", res, V, solver, G=XtX, want_loss=False)
         self._check_numeric()

@@ -12,7 +12,11 @@ class _Csc:
         self.n_rows, self.n_cols = n_rows, n_cols
         self.p = p.numpy().astype(np.int32)
         self.i = i.numpy().astype(np.int32)
-        self.x = x.numpy().astype(np.float64)
+        self._x = x   # a VIEW of the caller's values, like the device handle: in-place changes (the global mean) are seen
+
+    @property
+    def x(self):
+        return self._x.numpy().astype(np.float64)
 
     def info(self):
         return dict(n_rows=self.n_rows, n_cols=self.n_cols, nnz=int(self.p[-1]), n_long=0, max_len=0)
@@ -47,11 +51,22 @@ class OracleBackend:
         if absmax is not None:
             self.absmax_seen = getattr(self, "absmax_seen", 0) + 1
             assert abs(float(absmax[0]) - float(F.abs().max())) <= 1e-6 * max(1.0, float(absmax[0])), "stale or local absmax"
-        assert bias_last_row is None, "the CPU stand-in backend covers the no-bias control flow only"
         X = np.asfortranarray(self._f(F))
         Y = np.asfortranarray(self._f(S_block)).copy(order="F")
         if csc.n_cols == 0:
             loss_out[0] = 0.0
+            return
+        if bias_last_row is not None:   # user/item biases (wrmf_explicit.hpp:41-64,86-91,113-127; wrmf_implicit.hpp:114-154,186-252)
+            blr = bool(bias_last_row)
+            if implicit:
+                O.als_implicit(csc.p, csc.i, csc.x, X, Y, np.asfortranarray(G.numpy().T), lambda_, solver, cg_steps,
+                               with_biases=True, is_x_bias_last_row=blr, global_bias=global_bias)
+            else:
+                cnt = np.zeros(X.shape[1], dtype=X.dtype)
+                O.als_explicit(csc.p, csc.i, csc.x, X, Y, cnt, lambda_, solver, cg_steps, dynamic_lambda, with_biases=True,
+                               is_x_bias_last_row=blr)
+            S_block.copy_(torch.from_numpy(np.ascontiguousarray(Y.T)))
+            loss_out[0] = _row_loss_bias(csc, X, Y, implicit, lambda_, dynamic_lambda, blr, global_bias if implicit else 0.0)
             return
         if implicit:
             Gn = np.asfortranarray(G.numpy().T)
@@ -68,6 +83,43 @@ class OracleBackend:
         s = (Ff ** 2).sum(axis=0)
         out[0] = float((s * w.numpy().astype(np.float64)).sum() if w is not None else s.sum())
 
+    # the bias initialisation, one sweep over one column block (wrmf_utils.hpp:32-165; HipBackend has the same three)
+    def bias_sweep_explicit(self, csc, other_bias, lambda_, dynamic_lambda, non_negative, out):
+        o = other_bias.numpy()
+        dt = o.dtype.type
+        for c in range(csc.n_cols):
+            p1, p2 = csc.p[c], csc.p[c + 1]
+            cnt = dt(p2 - p1)
+            lam_use = dt(lambda_) * (cnt if dynamic_lambda else dt(1))
+            with np.errstate(invalid="ignore", divide="ignore"):
+                b = dt(np.sum(csc.x[p1:p2] - o[csc.i[p1:p2]].astype(np.float64))) / (lam_use + cnt)
+            out[c] = float(max(b, 0) if non_negative else b)
+
+    def bias_prep_implicit(self, csc, n_other, lambda_, means, adj):
+        for c in range(csc.n_cols):
+            p1, p2 = csc.p[c], csc.p[c + 1]
+            cnt = p2 - p1
+            if cnt > 0:
+                a = float(csc.x[p1:p2].sum())
+                means[c] = a / (a + (n_other - cnt))
+                a += n_other - cnt
+                adj[c] = a / (a + lambda_)
+            else:
+                means[c] = 0.0
+                adj[c] = n_other / (n_other + lambda_)
+
+    def bias_sweep_implicit(self, csc, other_bias, n_other, other_sum, means, adj, non_negative, global_bias, out):
+        o = other_bias.numpy().astype(np.float64)
+        mean0 = 0.0 if other_sum is None else float(other_sum[0]) / n_other
+        for c in range(csc.n_cols):
+            wsum, bias_this = float(n_other), mean0
+            for e in range(csc.p[c], csc.p[c + 1]):
+                w = csc.x[e] - 1.0
+                wsum += w
+                bias_this += (w * (o[csc.i[e]] - bias_this)) / wsum
+            b = (float(means[c]) - bias_this - global_bias) * float(adj[c])
+            out[c] = float(max(b, 0.0) if non_negative else b)
+
     def check_numeric(self):
         self.report_numeric(*self.numeric_counts())
 
@@ -83,6 +135,31 @@ class OracleBackend:
         if bad:
             from rsparse_amd import _lib
             raise _lib.RsparseHipError(_lib.ERR_NUMERIC, "%d per-row systems were singular" % bad)
+
+
+def _row_loss_bias(csc, X, Y, implicit, lambda_, dynamic_lambda, blr, global_bias):
+    """the same with user/item biases: X = [1, ..., x_bias] / Y = [y_bias, ..., 1] when blr, the other way round otherwise;
+    every column is solved with implicit feedback (wrmf_implicit.hpp:178,256-270; wrmf_explicit.hpp:131-132)"""
+    X = X.astype(np.float64)
+    Y = Y.astype(np.float64)
+    k = X.shape[0]
+    xs, xb, ys = (slice(0, k - 1), k - 1, slice(0, k - 1)) if blr else (slice(1, k), 0, slice(1, k))
+    tot = 0.0
+    for c in range(csc.n_cols):
+        p1, p2 = csc.p[c], csc.p[c + 1]
+        y = Y[ys, c]
+        yy = float(y @ y)
+        if p1 == p2:
+            if implicit:
+                tot += lambda_ * yy
+            continue
+        idx, v = csc.i[p1:p2], csc.x[p1:p2]
+        t = y @ X[xs][:, idx]
+        if implicit:
+            tot += float((((1.0 - global_bias) - t - X[xb, idx]) ** 2) @ v) + lambda_ * yy
+        else:
+            tot += float(((v - X[xb, idx] - t) ** 2).sum()) + lambda_ * ((p2 - p1) if dynamic_lambda else 1.0) * yy
+    return tot
 
 
 def _row_loss(csc, X, Y, implicit, lambda_, dynamic_lambda, target=1.0):

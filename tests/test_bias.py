@@ -570,3 +570,46 @@ def test_hip_wrmf_implicit_global_bias(ml_train, solver, bias):
     assert rel_fro(emb, ref_emb) < tol and rel_fro(model.components, ref.components) < tol
     assert np.allclose([l[1] for l in model.losses], [l[1] for l in ref.losses], rtol=max(tol, 1e-4))
     assert np.array_equal(emb, model.transform(train))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("explicit", [True, False])
+@pytest.mark.parametrize("precision", ["float", "double"])
+def test_hip_sweepwise_bias_initialisation_equals_the_fused_one(ml_train, explicit, precision):
+    """What a sharded fit runs (ShardedALS.initialize_biases: one C-ABI call per sweep and sub-block,
+    rsparse_hip_bias_{sweep_explicit,prep_implicit,sweep_implicit}[_f64]_device) against the one-call initialisation of the
+    single-rank fit (rsparse_hip_initialize_biases_*_device) on the same resident matrix: the same sweeps, so the same bits up
+    to the order of the two global sums (the mean of the values, the mean of a bias vector)."""
+    import torch
+    from rsparse_amd.engine import HipBackend, Layout, ShardedALS
+    n_user, n_item, p, i, x = ml_train
+    be = HipBackend()
+    tdt = torch.float64 if precision == "double" else torch.float32
+    c_ui = sp.csc_matrix((x, i, p), shape=(n_user, n_item))
+    c_iu = sp.csc_matrix(c_ui.T)
+    c_iu.sort_indices()
+
+    def blocks():
+        return tuple((be.to_device(m.indptr, torch.int32), be.to_device(m.indices, torch.int32), be.to_device(m.data, tdt))
+                     for m in (c_ui, c_iu))
+    out = {}
+    for mode, n_sub in (("fused", 1), ("sweeps", 3)):
+        b_ui, b_iu = blocks()
+        lay_u, lay_i = Layout(n_user, [(0, n_user)], n_sub), Layout(n_item, [(0, n_item)], n_sub)
+        als = ShardedALS(be, n_user, n_item, 8, b_ui, b_iu, c_ui.nnz, feedback="explicit" if explicit else "implicit",
+                         lambda_=0.1, with_bias=True, lay_user=lay_u, lay_item=lay_i)
+        ub = torch.zeros(lay_u.rows, dtype=tdt, device=be.device)
+        ib = torch.zeros(lay_i.rows, dtype=tdt, device=be.device)
+        if mode == "fused":
+            gb = (be.initialize_biases_explicit(als.csc_items, als.csc_users, ub, ib, 0.1, True, False, True) if explicit else
+                  be.initialize_biases_implicit(als.csc_items, als.csc_users, ub, ib, 0.1, False, True))
+        else:
+            gb = als.initialize_biases(ub, ib, False, True)
+        out[mode] = (gb, lay_u.to_global(ub.reshape(-1, 1)).cpu().numpy().ravel(), lay_i.to_global(ib.reshape(-1, 1)).cpu().numpy().ravel(),
+                     als.x_items.cpu().numpy())
+    eps = 1e-12 if precision == "double" else 2e-6
+    (g0, u0, i0, x0), (g1, u1, i1, x1) = out["fused"], out["sweeps"]
+    assert abs(g0 - g1) <= eps * max(1.0, abs(g0))
+    assert np.array_equal(np.isnan(u0), np.isnan(u1)) and np.array_equal(np.isnan(i0), np.isnan(i1))
+    assert rel_fro(np.nan_to_num(u1), np.nan_to_num(u0)) < 10 * eps and rel_fro(np.nan_to_num(i1), np.nan_to_num(i0)) < 10 * eps
+    assert rel_fro(x1, x0) < 10 * eps      # explicit: the mean left the resident values both ways

@@ -133,12 +133,61 @@ def test_one_ranks_numeric_failure_raises_on_every_rank(tmp_path):
         assert (tmp_path / ("f%d.txt" % r)).read_text() == "raised:%d:True" % _lib.ERR_NUMERIC
 
 
-def test_wrmf_sharded_rejects_user_item_biases(tmp_path):
-    """(the bias initialisation alternates over the whole matrix: single-rank only, stated in the error)"""
-    from rsparse_amd import WRMF, _lib
+def _worker_bias(rank, ws, port, feedback, solver, gb, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
     from oracle_backend import OracleBackend
-    m, _ = _problem()
-    model = WRMF(rank=4, feedback="explicit", solver="cholesky", with_user_item_bias=True, precision="float",
-                 backend=OracleBackend())
-    with pytest.raises(_lib.UnsupportedOnDevice):
-        model._fit_transform_sharded(m, 1, -1, 2, 0)
+    from rsparse_amd import WRMF
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        m, new = _problem()
+        rng = np.random.default_rng(5)
+        k = 6
+        model = WRMF(rank=k, lambda_=0.1, feedback=feedback, solver=solver, with_user_item_bias=True, with_global_bias=gb,
+                     precision="float", backend=OracleBackend(), rng=123, n_sub=3)
+        model._init_user_factors = (rng.standard_normal((m.shape[0], k + 2)) * 0.01).astype(np.float32)
+        if solver != "conjugate_gradient":
+            model.components = (rng.standard_normal((k + 2, m.shape[1])) * 0.01).astype(np.float32)
+        emb = model.fit_transform(m, n_iter=3, convergence_tol=-1)
+        torch.save({"emb": emb, "new": model.transform(new), "components": model.components, "losses": model.losses,
+                    "global_bias": model.global_bias}, os.path.join(out_dir, "b%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("feedback,solver,gb", [("explicit", "cholesky", True), ("explicit", "conjugate_gradient", False),
+                                                ("implicit", "cholesky", False), ("implicit", "cholesky", True),
+                                                ("explicit", "nnls", False)])
+def test_wrmf_two_ranks_with_user_item_biases(tmp_path, feedback, solver, gb):
+    """with_user_item_bias under sharding (round 4): the bias initialisation runs sweep by sweep over the ranks' blocks
+    (ShardedALS.initialize_biases: every sweep against the full vector of the other side, the swept block all-gathered, the
+    means all-reduced), then the half-iterations carry the two extra coordinates -- against the one-process oracle driver."""
+    import torch.multiprocessing as mp
+    from oracle import wrmf_oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_bias, args=(2, port, feedback, solver, gb, str(tmp_path)), nprocs=2, join=True)
+    rs = [torch.load(tmp_path / ("b%d.pt" % r), weights_only=False) for r in range(2)]
+    for key in ("emb", "new", "components"):
+        assert np.array_equal(rs[0][key], rs[1][key]), key
+    # (users without ratings get 0 / 0 = NaN as their initial bias under dynamic lambda, in the reference too: the first
+    # item-half loss carries it through the regulariser; the user half then solves those users and the NaN is gone)
+    assert np.array_equal(np.array(rs[0]["losses"]), np.array(rs[1]["losses"]), equal_nan=True)
+    m, new = _problem()
+    rng = np.random.default_rng(5)
+    k = 6
+    U0 = (rng.standard_normal((m.shape[0], k + 2)) * 0.01).astype(np.float32)
+    V0 = None if solver == "conjugate_gradient" else (rng.standard_normal((k + 2, m.shape[1])) * 0.01).astype(np.float32)
+    c = sp.csc_matrix(m); c.sort_indices()
+    ref = O.OracleWRMF(k, lam=0.1, feedback=feedback, solver=solver, dtype=np.float32, n_threads=4, with_user_item_bias=True,
+                       with_global_bias=gb)
+    ref_emb = ref.fit_transform(m.shape[0], m.shape[1], c.indptr.astype(np.int32), c.indices.astype(np.int32),
+                                c.data.astype(np.float64), U0.T.copy(), n_iter=3, convergence_tol=-1, init_components=V0)
+    tol = 2e-3 if solver == "nnls" else 1e-4
+    assert abs(rs[0]["global_bias"] - ref.global_bias) <= 1e-6 * max(1.0, abs(ref.global_bias))
+    assert rel_fro(rs[0]["components"], ref.components) < tol
+    assert rel_fro(rs[0]["emb"], ref_emb) < tol
+    assert np.allclose([l[1] for l in rs[0]["losses"]], [l[1] for l in ref.losses], rtol=tol)
+    nt = sp.csc_matrix(new.T); nt.sort_indices()
+    ref_new = ref.transform(nt.indptr.astype(np.int32), nt.indices.astype(np.int32), nt.data.astype(np.float64))
+    assert rel_fro(rs[0]["new"], ref_new) < tol

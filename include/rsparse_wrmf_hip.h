@@ -57,7 +57,8 @@ extern "C" {
 #define RSPARSE_SOLVER_CONJUGATE_GRADIENT 1
 #define RSPARSE_SOLVER_NNLS 2 /* sequential coordinate descent, inst/include/nnls.hpp:10-48 */
 
-#define RSPARSE_HIP_MAX_RANK 128
+#define RSPARSE_HIP_MAX_RANK 256     /* fp32 entry points and layer (2); ranks 129..256 run on one generic kernel family */
+#define RSPARSE_HIP_MAX_RANK_F64 128 /* the *_double entry points and layer (3) */
 
 const char* rsparse_hip_last_error(void);
 int rsparse_hip_abi_version(void);

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void bias_implicit_terms_kernel(const float* _
 // rhs_init = -drop_row(X) * x_biases (wrmf_implicit.hpp:142-147): partial[b][t] = -sum over the block's entities of
 // X[e][off + t] * X[e][bias_row]; fixed-order second stage -> deterministic
 constexpr int kRhsInitBlocks = 256;
-__global__ __launch_bounds__(128) void bias_rhs_init_partial_kernel(const float* __restrict__ X, int k, int off, int k1,
+constexpr int kRhsInitW = 256;   // >= the largest system order (RSPARSE_HIP_MAX_RANK)
+__global__ __launch_bounds__(kRhsInitW) void bias_rhs_init_partial_kernel(const float* __restrict__ X, int k, int off, int k1,
                                                                     int bias_row, float global_bias, int n,
                                                                     float* __restrict__ partial) {
   const int t = threadIdx.x;
@@ -101,13 +102,13 @@ __global__ __launch_bounds__(128) void bias_rhs_init_partial_kernel(const float*
   if (t < k1)
     for (int e = e0; e < e1; e++)   // rhs_init = -X' (x_b + global_bias)  (wrmf_implicit.hpp:146-153; :110-112 without biases)
       s = fmaf(-X[(size_t)e * k + off + t], (bias_row >= 0 ? X[(size_t)e * k + bias_row] : 0.f) + global_bias, s);
-  partial[(size_t)blockIdx.x * 128 + t] = s;
+  partial[(size_t)blockIdx.x * kRhsInitW + t] = s;
 }
-__global__ __launch_bounds__(128) void bias_rhs_init_reduce_kernel(const float* __restrict__ partial, int blocks,
+__global__ __launch_bounds__(kRhsInitW) void bias_rhs_init_reduce_kernel(const float* __restrict__ partial, int blocks,
                                                                    float* __restrict__ out) {
   const int t = threadIdx.x;
   float s = 0.f;
-  for (int b = 0; b < blocks; b++) s += partial[(size_t)b * 128 + t];
+  for (int b = 0; b < blocks; b++) s += partial[(size_t)b * kRhsInitW + t];
   out[t] = s;
 }
 
@@ -165,17 +166,17 @@ hipError_t launch_bias_implicit_terms(const float* vals, const int32_t* row_idx,
   return hipGetLastError();
 }
 
-// out[0..128): rhs_init (entries >= k1 are zero); scratch: kRhsInitBlocks * 128 floats
+// out[0..256): rhs_init (entries >= k1 are zero); scratch: kRhsInitBlocks * 256 floats
 hipError_t launch_bias_rhs_init(const float* X, int k, int off, int k1, int bias_row, float global_bias, int n,
                                 float* scratch, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(bias_rhs_init_partial_kernel, dim3(kRhsInitBlocks), dim3(128), 0, s, X, k, off, k1, bias_row,
+  hipLaunchKernelGGL(bias_rhs_init_partial_kernel, dim3(kRhsInitBlocks), dim3(kRhsInitW), 0, s, X, k, off, k1, bias_row,
                      global_bias, n, scratch);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bias_rhs_init_reduce_kernel, dim3(1), dim3(128), 0, s, scratch, kRhsInitBlocks, out);
+  hipLaunchKernelGGL(bias_rhs_init_reduce_kernel, dim3(1), dim3(kRhsInitW), 0, s, scratch, kRhsInitBlocks, out);
   return hipGetLastError();
 }
-size_t bias_rhs_init_scratch_floats() { return (size_t)kRhsInitBlocks * 128 + 128; }
+size_t bias_rhs_init_scratch_floats() { return (size_t)kRhsInitBlocks * kRhsInitW + kRhsInitW; }
 
 namespace {
 template <class T>

@@ -68,6 +68,10 @@ struct Workspace {
   size_t gb_r0_floats = 0;
   int32_t* gb_slot = nullptr;  // ... and the slot of every row in it
   size_t gb_slot_ints = 0;
+  float* wide_m2 = nullptr;    // ranks 129..256 (wrmf_wide.hip): NNLS squared systems / the general solver's matrices
+  size_t wide_m2_floats = 0;
+  float* wide_lu = nullptr;
+  size_t wide_lu_floats = 0;
   int device = -1;
 
   int ensure_device() {
@@ -156,6 +160,21 @@ struct Workspace {
     }
     return RSPARSE_HIP_OK;
   }
+  int ensure_wide(size_t m2, size_t lu) {
+    if (m2 > wide_m2_floats) {
+      if (wide_m2) (void)hipFree(wide_m2);
+      wide_m2 = nullptr; wide_m2_floats = 0;
+      HIP_TRY(hipMalloc(&wide_m2, m2 * sizeof(float)));
+      wide_m2_floats = m2;
+    }
+    if (lu > wide_lu_floats) {
+      if (wide_lu) (void)hipFree(wide_lu);
+      wide_lu = nullptr; wide_lu_floats = 0;
+      HIP_TRY(hipMalloc(&wide_lu, lu * sizeof(float)));
+      wide_lu_floats = lu;
+    }
+    return RSPARSE_HIP_OK;
+  }
   int ensure_tscr(size_t floats) {
     if (floats > tscr_floats) {
       if (tscr) (void)hipFree(tscr);
@@ -167,6 +186,9 @@ struct Workspace {
     return RSPARSE_HIP_OK;
   }
   void release() {
+    if (wide_m2) (void)hipFree(wide_m2);
+    if (wide_lu) (void)hipFree(wide_lu);
+    wide_m2 = wide_lu = nullptr; wide_m2_floats = wide_lu_floats = 0;
     if (gb_r0) (void)hipFree(gb_r0);
     if (gb_slot) (void)hipFree(gb_slot);
     gb_r0 = nullptr; gb_slot = nullptr; gb_r0_floats = 0; gb_slot_ints = 0;
@@ -461,7 +483,7 @@ int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_i
   if (!X || !Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
   if (rank <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive");
   if (rank > RSPARSE_HIP_MAX_RANK)
-    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+    return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
   (void)row_indices; (void)values;
   return RSPARSE_HIP_OK;
 }
@@ -500,11 +522,40 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (!d_X || !d_Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
   if (implicit && !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "XtX is NULL");
   if (rank <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
   int rc = check_variant(solver, 0, 0.0);
   if (rc) return rc;
   if ((rc = g_ws.ensure_device())) return rc;
   const DevCSC& d = conf->d;
+  if (wide_supported(rank)) {
+    // ranks 129..256: one kernel family for every solver and operand set (wrmf_wide.hip), no launch schedule
+    double* outw = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
+    if (d.n_cols == 0) {
+      HIP_TRY(hipMemsetAsync(outw, 0, sizeof(double), s));
+      return RSPARSE_HIP_OK;
+    }
+    const int grid = wide_als_grid(d.n_cols);
+    if ((rc = g_ws.ensure_partials((size_t)grid))) return rc;
+    if ((rc = g_ws.ensure_wide(solver == RSPARSE_SOLVER_NNLS ? (size_t)grid * wide_m2_floats_per_wg(rank) : 0,
+                               solver == RSPARSE_SOLVER_CHOLESKY ? (size_t)grid * rank * rank : 0)))
+      return rc;
+    AlsArgs a{};
+    a.col_ptrs = d.col_ptrs; a.row_idx = d.row_idx; a.vals = d.vals;
+    a.X = d_X; a.Y = d_Y; a.XtX = implicit ? d_XtX : nullptr;
+    a.n_cols = d.n_cols; a.k = rank; a.cg_steps = (int)cg_steps;
+    a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
+    a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails;
+    a.rhs_vals = bias ? bias->rhs_vals : nullptr;
+    a.loss_tgt = bias ? bias->loss_tgt : nullptr;
+    a.rhs_init = bias ? bias->rhs_init : nullptr;
+    a.loss_tgt_const = bias ? bias->tgt_const : 1.f;
+    a.gbias = (solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT && implicit && bias) ? bias->gbias : 0.f;
+    hipError_t we = launch_als_wide(a, implicit, solver, g_ws.wide_m2, g_ws.wide_lu, s);
+    if (we != hipSuccess) return hip_fail(we, "launch_als_wide");
+    if ((we = launch_sum_partials(g_ws.partials, (size_t)grid, outw, s, g_ws.partials + g_ws.partial_slots)) != hipSuccess)
+      return hip_fail(we, "launch_sum_partials");
+    return RSPARSE_HIP_OK;
+  }
   const bool cg = solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT;
   const bool cgq = cg && use_cgq(rank, d_X, d_Y);
   QSchedule qs;
@@ -695,7 +746,7 @@ int run_half_iteration_explicit_biased(const rsparse_hip_csc* conf, const float*
   if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
   if (!d_X || !d_Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
   if (rank < 2) return fail(RSPARSE_HIP_ERR_INVALID, "with_biases needs rank >= 2 (a row of ones and a bias row)");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
   int rc = g_ws.ensure_device();
   if (rc) return rc;
   const DevCSC& d = conf->d;
@@ -739,7 +790,7 @@ int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float*
   if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
   if (!d_X || !d_Y || !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "X, Y or XtX is NULL");
   if (rank < 2) return fail(RSPARSE_HIP_ERR_INVALID, "with_biases needs rank >= 2 (a row of ones and a bias row)");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
   int rc = g_ws.ensure_device();
   if (rc) return rc;
   const DevCSC& d = conf->d;
@@ -754,7 +805,7 @@ int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float*
   float* rcoef = Yp + ny;
   float* tgt = rcoef + nv;
   float* scratch = tgt + nv;
-  float* rinit = scratch + (nscr - 128);
+  float* rinit = scratch + (nscr - 256);
   if (d.n_rows > 0)
     HIP_TRY(hipMemcpy2DAsync(Xp, (size_t)k1 * 4, d_X + xoff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_rows,
                              hipMemcpyDeviceToDevice, s));
@@ -786,14 +837,14 @@ int run_half_iteration_implicit_global(const rsparse_hip_csc* conf, const float*
   if (!conf) return fail(RSPARSE_HIP_ERR_INVALID, "conf is NULL");
   if (!d_X || !d_Y || !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "X, Y or XtX is NULL");
   if (rank <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
   int rc = g_ws.ensure_device();
   if (rc) return rc;
   const DevCSC& d = conf->d;
   const size_t nscr = bias_rhs_init_scratch_floats();
   if ((rc = g_ws.ensure_bias(nscr + 16))) return rc;
   float* scratch = g_ws.bias_buf;
-  float* rinit = scratch + (nscr - 128);
+  float* rinit = scratch + (nscr - 256);
   if (d_base_in) {
     HIP_TRY(hipMemcpyAsync(rinit, d_base_in, (size_t)rank * 4, hipMemcpyDeviceToDevice, s));
   } else {
@@ -1163,9 +1214,15 @@ int rsparse_hip_gramian_absmax_device(const float* d_X, int rank, int64_t n, dou
                                       double* d_sumsq_out, float* d_absmax_inout, void* stream) {
   if (!d_X || !d_XtX_out) return fail(RSPARSE_HIP_ERR_INVALID, "X or XtX_out is NULL");
   if (rank <= 0 || n < 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive and n non-negative");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
   int rc = g_ws.ensure_device();
   if (rc) return rc;
+  if (wide_supported(rank)) {   // ranks 129..256 (d_absmax_inout is left as it is: only the rank <= 128 long-row kernel reads it)
+    if ((rc = g_ws.ensure_gram(wide_gramian_scratch_floats(rank)))) return rc;
+    hipError_t we = launch_gramian_wide(d_X, rank, n, (float)lambda, d_XtX_out, d_sumsq_out, g_ws.gram, (hipStream_t)stream);
+    if (we != hipSuccess) return hip_fail(we, "launch_gramian_wide");
+    return RSPARSE_HIP_OK;
+  }
   if ((rc = g_ws.ensure_gram(gramian_scratch_floats(rank, n)))) return rc;
   const float ridge = (float)lambda;  // float::fl(diag(lambda)), R/model_WRMF.R:476
   hipEvent_t* ev = g_prof.begin();
@@ -1406,7 +1463,7 @@ int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_use
                                    int n_exclude, double glob_mean, int32_t* d_res, float* d_scores, void* stream) {
   if (!d_U || !d_V || !d_res || !d_scores) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or output");
   if (n_users < 0 || n_items < 0 || rank <= 0 || k < 1) return fail(RSPARSE_HIP_ERR_INVALID, "bad dimensions");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
   if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 256 is not on the device path");
   if (n_exclude > 0 && !d_excl0) return fail(RSPARSE_HIP_ERR_INVALID, "exclude is NULL");
   hipError_t e = launch_top_product(d_U, d_V, n_users, n_items, rank, k, d_nr_p, d_nr_p ? d_nr_j : nullptr, d_excl0,
@@ -1421,7 +1478,7 @@ int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, in
   (void)n_threads;
   if (!x || !y || !res || !scores) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or output");
   if (nr < 0 || nc < 0 || rank <= 0 || k < 1) return fail(RSPARSE_HIP_ERR_INVALID, "bad dimensions");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
   if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 256 is not on the device path");
   if (n_exclude < 0 || (n_exclude > 0 && !exclude)) return fail(RSPARSE_HIP_ERR_INVALID, "bad exclude");
   // x is nr x rank column-major -> row-major fp32; y (rank x nc column-major) already has item vectors contiguous

@@ -103,7 +103,7 @@ int f64_half_iteration(const rsparse_hip_csc_f64* conf, bool implicit, const dou
   if (!d_X || !d_Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
   if (implicit && !d_XtX) return fail(RSPARSE_HIP_ERR_INVALID, "XtX is NULL");
   if (rank <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK_F64) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the fp64 device path");
   if (solver > RSPARSE_SOLVER_NNLS) return fail(RSPARSE_HIP_ERR_INVALID, "unknown solver code");
   if (with_biases && rank < 2) return fail(RSPARSE_HIP_ERR_INVALID, "with_biases needs rank >= 2 (a row of ones and a bias row)");
   if (with_biases && implicit && solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT)
@@ -171,7 +171,7 @@ int stateless_double(bool implicit, int n_rows, int n_cols, const int32_t* col_p
   if (!col_ptrs) return fail(RSPARSE_HIP_ERR_INVALID, "col_ptrs is NULL");
   if (!X || !Y) return fail(RSPARSE_HIP_ERR_INVALID, "X or Y is NULL");
   if (rank <= 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK_F64) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the fp64 device path");
   if (solver > RSPARSE_SOLVER_NNLS) return fail(RSPARSE_HIP_ERR_INVALID, "unknown solver code");
   if (with_biases && implicit && solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT)
     return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "with_user_item_bias + conjugate_gradient with implicit feedback is not on the device path");
@@ -313,7 +313,7 @@ int rsparse_hip_gramian_f64_device(const double* d_X, int rank, int64_t n, doubl
                                    double* d_sumsq_out, void* stream) {
   if (!d_X || !d_XtX_out) return fail(RSPARSE_HIP_ERR_INVALID, "X or XtX_out is NULL");
   if (rank <= 0 || n < 0) return fail(RSPARSE_HIP_ERR_INVALID, "rank must be positive and n non-negative");
-  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the device path");
+  if (rank > RSPARSE_HIP_MAX_RANK_F64) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 128 is not on the fp64 device path");
   int rc = g_w64.ensure();
   if (rc) return rc;
   if ((rc = g_w64.ensure_gram(f64_gramian_scratch_doubles(rank)))) return rc;

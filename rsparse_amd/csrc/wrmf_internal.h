@@ -254,6 +254,18 @@ hipError_t launch_top_product(const float* U, const float* V, int n_users, int n
 
 int padded_rank(int k);  // 32 / 64 / 128, or 0 if unsupported
 
+// ranks 129..256 (wrmf_wide.hip): every variant of the half-iteration on one kernel family, the row's system a packed lower
+// triangle in LDS; the Gramian likewise.  launch_als_wide reads the operands of `a` that the rank <= 128 kernels read
+// (col_ptrs, row_idx, vals, X, Y, XtX, k, cg_steps, lambda_loss, dynamic_lambda, rhs_vals, loss_tgt, loss_tgt_const, rhs_init,
+// gbias, loss_partials [wide_als_grid(n_cols) slots], fail_counter).
+bool wide_supported(int k);
+int wide_als_grid(int n_cols);
+size_t wide_m2_floats_per_wg(int k);            // NNLS scratch per workgroup
+size_t wide_gramian_scratch_floats(int k);
+hipError_t launch_als_wide(const AlsArgs& a, bool implicit, unsigned solver, float* m2_scratch, float* lu_scratch, hipStream_t s);
+hipError_t launch_gramian_wide(const float* X, int k, int64_t n, float ridge, float* XtX, double* sumsq, float* scratch,
+                               hipStream_t s);
+
 // Measurement harness (rsparse_hip_profile_*): the launcher that records the event `ev_slot` in front of a kernel also
 // says which kernel it is about to launch (host function pointer); rsparse_hip_profile_last_names resolves the pointers
 // to the names a profiler prints.  No-op when ev_slot is null.

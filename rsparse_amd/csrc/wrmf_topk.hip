@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
 hipError_t launch_top_product(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
                               const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
                               float glob_mean, int32_t* res, float* scores, hipStream_t s) {
-  const int KP = padded_rank(k_rank);
+  const int KP = (k_rank > 128 && k_rank <= 256) ? 256 : padded_rank(k_rank);   // (ranks 129..256: one user block per wave)
   if (!KP || topk < 1 || topk > kTopMaxK) return hipErrorInvalidValue;
   if (n_users <= 0) return hipSuccess;
   const bool vec = k_rank % 4 == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0;
@@ -785,6 +785,22 @@ hipError_t launch_top_product(const float* U, const float* V, int n_users, int n
   RSP_TOPK(32)
   RSP_TOPK(64)
   RSP_TOPK(128)
+  if (KP == 256) {   // the user block of a wave is 128 registers at this rank: one block per wave in every geometry
+    if (TopPipeSmem<256, 1>::bytes(topk) <= kLdsMax && n_users > 64) {
+      if (vec) RSP_TOPK_GO((top_product_pipe_kernel<256, 1, true>), (TopPipeSmem<256, 1>::bytes(topk)), 128, 256)
+      else RSP_TOPK_GO((top_product_pipe_kernel<256, 1, false>), (TopPipeSmem<256, 1>::bytes(topk)), 128, 256)
+    }
+    if (TopSharedSmem<256, 1>::bytes(topk) <= kLdsMax && n_users > 64) {
+      if (vec) RSP_TOPK_GO((top_product_shared_kernel<256, 1, true>), (TopSharedSmem<256, 1>::bytes(topk)), 128, 256)
+      else RSP_TOPK_GO((top_product_shared_kernel<256, 1, false>), (TopSharedSmem<256, 1>::bytes(topk)), 128, 256)
+    }
+    if (TopSmem<256, 1, 4>::bytes(topk) <= kLdsMax) {
+      if (vec) RSP_TOPK_GO((top_product_kernel<256, 1, true, 4>), (TopSmem<256, 1, 4>::bytes(topk)), 32, 256)
+      else RSP_TOPK_GO((top_product_kernel<256, 1, false, 4>), (TopSmem<256, 1, 4>::bytes(topk)), 32, 256)
+    }
+    if (vec) RSP_TOPK_GO((top_product_kernel<256, 1, true, 2>), (TopSmem<256, 1, 2>::bytes(topk)), 32, 128)
+    else RSP_TOPK_GO((top_product_kernel<256, 1, false, 2>), (TopSmem<256, 1, 2>::bytes(topk)), 32, 128)
+  }
 #undef RSP_TOPK
 #undef RSP_TOPK_GO
   return hipErrorInvalidValue;

@@ -59,7 +59,7 @@ def test_status_codes_without_device():
     assert rc == _lib.ERR_INVALID and "rank" in msg
     rc, msg = _call_implicit(lib, p, i, x, None, Y, G)
     assert rc == _lib.ERR_INVALID
-    rc, msg = _call_implicit(lib, p, i, x, X, Y, G, rank=129)
+    rc, msg = _call_implicit(lib, p, i, x, X, Y, G, rank=257)     # ranks up to RSPARSE_HIP_MAX_RANK = 256 are on the device
     assert rc == _lib.ERR_UNSUPPORTED
     rc, msg = _call_implicit(lib, p, i, x, X, Y, G, solver=2)          # nnls is a device solver: past the argument
     assert rc not in (_lib.ERR_UNSUPPORTED, _lib.ERR_INVALID)         # checks (no device here -> runtime error)

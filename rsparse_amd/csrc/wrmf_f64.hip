@@ -293,26 +293,40 @@ __global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, 
         double mu0 = own0 ? p[lane] : 0.0, mu1 = own1 ? p[lane + 64] : 0.0;
         const double dg0 = own0 ? M2[lane + (size_t)lane * LDA] : 1.0;
         const double dg1 = own1 ? M2[(lane + 64) + (size_t)(lane + 64) * LDA] : 1.0;
+        // (a coordinate at its bound with a non-negative gradient does not move -- new = max(0, 0 - mu / d) = 0 -- and the
+        // reference's loop body does nothing for it, nnls.hpp:24: the sweep visits only the lanes whose coordinate can move,
+        // re-evaluated after every move; the same sequence of updates without the idle visits, three quarters of all visits)
         for (unsigned it = 0; it < kScdMaxIter; it++) {
           double rel = 0.0;
-          for (int c = 0; c < k1; c++) {
-            const int src = c & 63;
-            const bool hi = c >= 64;
-            const double old = __shfl(hi ? h1 : h0, src);
-            const double muc = __shfl(hi ? mu1 : mu0, src);
-            const double dg = __shfl(hi ? dg1 : dg0, src);
-            double nv = old - muc / dg;
-            if (nv < 0.0) nv = 0.0;
-            const double diff = nv - old;
-            if (diff != 0.0) {
-              if (lane == src) {
-                if (hi) h1 = nv; else h0 = nv;
+          for (int half = 0; half < 2; half++) {
+            const bool hi = half == 1;
+            const int lim = min(64, k1 - 64 * half);
+            if (lim <= 0) break;
+            const unsigned long long in_range = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+            unsigned long long act = __ballot(!((hi ? h1 : h0) == 0.0 && (hi ? mu1 : mu0) >= 0.0)) & in_range;
+            while (act) {
+              const int src = __builtin_ctzll(act);
+              const int c = 64 * half + src;
+              const double old = __shfl(hi ? h1 : h0, src);
+              const double muc = __shfl(hi ? mu1 : mu0, src);
+              const double dg = __shfl(hi ? dg1 : dg0, src);
+              double nv = old - muc / dg;
+              if (nv < 0.0) nv = 0.0;
+              const double diff = nv - old;
+              const unsigned long long above = src >= 63 ? 0ull : (~0ull << (src + 1));
+              if (diff != 0.0) {
+                if (lane == src) {
+                  if (hi) h1 = nv; else h0 = nv;
+                }
+                const double* col = M2 + (size_t)c * LDA;
+                if (own0) mu0 += diff * col[lane];
+                if (own1) mu1 += diff * col[lane + 64];
+                const double se = fabs(diff) / (fabs(old) + kNnlsEps);
+                if (se > rel) rel = se;
+                act = __ballot(!((hi ? h1 : h0) == 0.0 && (hi ? mu1 : mu0) >= 0.0)) & in_range & above;
+              } else {
+                act &= above;
               }
-              const double* col = M2 + (size_t)c * LDA;
-              if (own0) mu0 += diff * col[lane];
-              if (own1) mu1 += diff * col[lane + 64];
-              const double se = fabs(diff) / (fabs(old) + kNnlsEps);
-              if (se > rel) rel = se;
             }
           }
           if (rel <= kScdTol) break;

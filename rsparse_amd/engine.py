@@ -420,9 +420,10 @@ class ShardedALS:
         """Layouts of the two factor matrices: nnz-balanced blocks when the per-row counts are given, equal row counts
         otherwise; callers cut their CSC blocks at exactly `lay.bounds`."""
         n_sub = default_subblocks(world_size) if n_sub is None else n_sub
+        nsu, nsi = (n_sub if isinstance(n_sub, (tuple, list)) else (n_sub, n_sub))   # (users, items): the user side moves 10x the bytes
         bu = balanced_bounds(cnt_user, world_size) if cnt_user is not None else equal_bounds(n_user, world_size)
         bi = balanced_bounds(cnt_item, world_size) if cnt_item is not None else equal_bounds(n_item, world_size)
-        return Layout(n_user, bu, n_sub), Layout(n_item, bi, n_sub)
+        return Layout(n_user, bu, int(nsu)), Layout(n_item, bi, int(nsi))
 
     def _make(self, block, lay_fixed, lay_solved):
         """CSC handle of my whole block (single-rank path, info, parity sampling) and one handle per sub-block, with the

@@ -100,7 +100,7 @@ struct Workspace {
     return RSPARSE_HIP_OK;
   }
   int ensure_lr() {   // M = L^-T and its transpose of the low-rank Cholesky path
-    if (!lr_M) HIP_TRY(hipMalloc(&lr_M, (size_t)2 * 128 * 128 * sizeof(float)));
+    if (!lr_M) HIP_TRY(hipMalloc(&lr_M, (size_t)3 * 128 * 128 * sizeof(float)));
     return RSPARSE_HIP_OK;
   }
   int ensure_ne_seg(size_t slots) {   // split rows of the normal-equation kernel: partial accumulators + ready flags
@@ -398,7 +398,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
   d.q_nec_rows = nullptr; d.q_nec_ptr = nullptr; d.q_nec_wg = 0; d.q_nec_segs = nullptr; d.q_nec_nseg = 0; d.q_nec_entries = 0;
   d.q_nec_split_rows = nullptr; d.q_nec_split_ptr = nullptr; d.q_nec_nsplit = 0; d.q_nec_own = false; d.q_nec_min = kNeCholMinLen;
   d.q_n_chol_long = 0;
-  d.q_lr_first = 0; d.q_n_lr = 0; d.q_gt32 = 0;
+  d.q_lr_first = 0; d.q_n_lr = 0; d.q_gt32 = 0; d.q_gt48 = 0;
   d.q_pair_first = 0;
   d.q_cfg = cgq_default_cfg();
   if (n <= 0) return RSPARSE_HIP_OK;
@@ -412,6 +412,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     if (len > kCholLongLen) d.q_n_chol_long++;
     if (len > 16) d.q_pair_first++;                // the order is longest first: the rows of <= 16 non-zeros are a suffix
     if (len > 32) d.q_gt32++;
+    if (len > 48) d.q_gt48++;
     if (len > kCholLrMax) d.q_lr_first++;          // the order is longest first: the short rows are a suffix
     else if (len >= 1) d.q_n_lr++;
     cnt_b[b]++;
@@ -597,7 +598,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.long_rows = d.long_rows; a.n_long = d.n_long; a.n_cols = d.n_cols;
   a.chol_long_rows = d.q_order; a.n_chol_long = d.q_order ? d.q_n_chol_long : 0;
   a.chol_list = nullptr; a.chol_first = 0; a.chol_n_main = 0; a.chol_empty_first = 0;
-  a.lr_rows = nullptr; a.n_lr = 0; a.lr_flags = nullptr; a.lr_M = nullptr; a.lr_n_gt32 = a.lr_n_gt16 = -1;
+  a.lr_rows = nullptr; a.n_lr = 0; a.lr_flags = nullptr; a.lr_M = nullptr; a.lr_n_gt32 = a.lr_n_gt16 = a.lr_n_gt48 = -1;
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails; a.zero_row = g_ws.zero_row;
@@ -663,6 +664,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     }
     a.lr_rows = d.q_order + d.q_lr_first; a.n_lr = d.q_n_lr; a.lr_flags = g_ws.ne_stats + 2; a.lr_M = g_ws.lr_M;
     a.lr_n_gt32 = d.q_gt32 - d.q_lr_first; a.lr_n_gt16 = d.q_pair_first - d.q_lr_first;
+    a.lr_n_gt48 = d.q_gt48 - d.q_lr_first;
   }
   const bool chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY;
   if (chol) {

@@ -22,6 +22,8 @@
 //
 // Needs every confidence >= 1 (D^1/2) and XtX positive definite: both are decided on the device (flags[0] != 0 ->
 // this kernel returns at once and wrmf_chol.hip's kernel, which otherwise skips the short rows, takes them).
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -35,6 +37,7 @@ using namespace dev;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -66,6 +69,9 @@ __device__ __forceinline__ void lr_sfor(F&& f) {
 #ifndef RSP_LR_ABL
 #define RSP_LR_ABL 0   // dev builds: timing-only ablations (1 no V' GEMM, 2 no S GEMM, 4 no LDL^T, 8 no substitution, 16 no y = M q, 32 no gather)
 #endif
+#ifndef RSP_LRW_ABL
+#define RSP_LRW_ABL 0   // dev builds of the wave-per-pass kernel, timing only: 1 no V' GEMM, 2 no T GEMM, 4 no n x n solve, 8 no P GEMM
+#endif
 constexpr int kLrLd = 130;   // LDS row stride (floats) of V' (fp32)
 constexpr int kLrLh = 136;   // ... (halves) of the fp16 terms of X_nnz and of W: 16-byte aligned rows for the operand reads
 constexpr int kLrLs = 65;    // ... of the n x n system
@@ -74,9 +80,13 @@ constexpr int kLrLs = 65;    // ... of the n x n system
 // M and Mt are written KP x KP, zero padded.  flags[0] |= 1 when XtX is not positive definite.
 // Also written: the two fp16 terms of Mt * 2^e (the B operand of V' = X_nnz M: M[kk][col] = Mt[col][kk], 8 consecutive kk
 // per lane) into M16 = [2][KP][KP] halves, and e (biased exponent) into flags[1].
+// MT16 (nullable; the wave-per-pass kernel's B operand of P = V' M^T) = [2][KP][KP] halves: MT16[c][16 chunk + q] = the terms
+// of Mt[16 chunk + o][c] * 2^e with q = 8 h + e', o = 8 (e' / 4) + 4 h + (e' % 4): the 16 factor dimensions of a chunk in
+// the order in which the two lane halves of an accumulator tile hold them (see als_chol_lrw_kernel).
 template <int KP>
 __global__ __launch_bounds__(256) void chol_lr_prep_kernel(const float* __restrict__ G, int k, _Float16* __restrict__ M16,
-                                                           float* __restrict__ Mt, unsigned* __restrict__ flags) {
+                                                           float* __restrict__ Mt, unsigned* __restrict__ flags,
+                                                           _Float16* __restrict__ MT16) {
   constexpr int LD = KP + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sL = reinterpret_cast<float*>(smem);   // [KP][LD]
@@ -145,6 +155,12 @@ __global__ __launch_bounds__(256) void chol_lr_prep_kernel(const float* __restri
     const _Float16 h = (_Float16)(v * sM);
     M16[e] = h;
     M16[KP * KP + e] = (_Float16)(v * sM - (float)h);
+    if (MT16) {   // entry (kk = r, column c) of Mt -> row c, position of kk
+      const int o = r & 15, q = 8 * ((o >> 2) & 1) + (o & 3) + 4 * (o >> 3);
+      const int d = c * KP + (r & ~15) + q;
+      MT16[d] = h;
+      MT16[KP * KP + d] = (_Float16)(v * sM - (float)h);
+    }
   }
 }
 
@@ -644,7 +660,567 @@ __global__ __launch_bounds__(256, 2) void als_chol_lr_kernel(AlsArgs a, const in
   if (tid == 0) a.loss_partials[loss_slot0 + blockIdx.x] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
 }
 
+
+// ---- one WAVE per pass (round 4) ---------------------------------------------------------------------------------------
+// The workgroup kernel above keeps four waves in step through a dozen barriers per pass and solves the n x n system on ONE of
+// them (SQ counters on config 4: waves issuing 24 % of their cycles, waiting 69 %).  Here a pass -- the same 64 slots -- belongs
+// to one wave from the gather to the loss, nothing is shared between waves but a read-only copy of the terms of M^T in LDS,
+// and there is no barrier: eight passes are in flight per CU, each in a different phase.  The algebra is regrouped so that
+// nothing has to be reduced over the lanes that hold the slots:
+//     V'^T = M^T X_nnz^T            matrix cores; accumulator layout = lane: slot, registers: factor dimensions
+//     T    = V' V'^T  (n x n)       matrix cores, both operands are the SAME registers (the fp16 terms of the tiles of V'^T)
+//     S    = I + D^1/2 T D^1/2,  h = D^1/2 T c,  z = S^-1 h          lane i = slot i: T is symmetric, so the accumulator tiles
+//                                   (lane: column, registers: rows) ARE rows spread over the lane pair (n, n + 32): one
+//                                   v_permlane32_swap per register pair completes them -- T never touches LDS either
+//     e    = c - D^1/2 z,   x_j . y = (T e)_j = (T c)_j - (h_j - z_j) / sqrt(c_j - 1)  (loss),   y = M V'^T e = P^T e
+//     P    = V' M^T                 matrix cores again (A = the terms of V'^T, B = MT16); accumulator layout = lane: factor
+//                                   dimension, registers: slots -> y is a sum over REGISTERS with coefficients e, no reduction
+// g, h, q of the formulation above never exist as k-vectors.  A lane (n, hf) = (lane % 32, lane / 32) gathers ITS slots'
+// vectors straight into the B-operand layout (slot n and slot 32 + n, the factor dimensions 16 ch + 8 hf ... + 7 of chunk
+// ch: two 16-byte loads per slot and chunk), so X_nnz never touches LDS.
+struct LrwSmem {
+  static constexpr int LH = kLrLh;                              // halves per row of the copies of M16 and MT16
+  static constexpr size_t m16_bytes = (size_t)2 * 128 * LH * 2;
+  static constexpr int wave_floats = 64;                        // e
+  static constexpr size_t bytes = 2 * m16_bytes + (size_t)8 * wave_floats * 4;
+};
+
+// r *= u(lane E of this lane's row of 16 lanes)
+template <int E>
+__device__ __forceinline__ void mul_row_bcast(float& r, const float u) {
+  asm("v_mul_f32_dpp %0, %1, %0 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(u), "n"(E));
+}
+// copies of the value held one per lane such that lane t of a GROUP of SL lanes is lane t % 16 of rep[t / 16] in every lane
+// of the group (SL = 64: the wave; 32; 16: a row of 16 lanes)
+template <int SL>
+__device__ __forceinline__ void lrw_group(const float v, float (&rep)[4]) {
+  if constexpr (SL == 64) {
+    rows_to_all<4>(v, rep);
+  } else if constexpr (SL == 32) {
+    const unsigned uu = __float_as_uint(v);
+    const auto sw = __builtin_amdgcn_permlane16_swap(uu, uu, false, false);   // rows (0, 0, 2, 2) and (1, 1, 3, 3)
+    rep[0] = __uint_as_float(sw[0]);
+    rep[1] = __uint_as_float(sw[1]);
+    rep[2] = rep[3] = 0.f;
+  } else {
+    rep[0] = v;
+    rep[1] = rep[2] = rep[3] = 0.f;
+  }
+}
+// 16 bytes at p + OFF, not waited for (the caller counts)
+template <int OFF>
+__device__ __forceinline__ void lrw_ld16(f32x4& d, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(d) : "v"(p), "n"(OFF));
+}
+__device__ __forceinline__ void lrw_wait_all(f32x4 (&x)[8][2]) {   // (tied to the registers: nothing reads them before the wait)
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]), "+v"(x[3][1]),
+                 "+v"(x[4][0]), "+v"(x[4][1]), "+v"(x[5][0]), "+v"(x[5][1]), "+v"(x[6][0]), "+v"(x[6][1]), "+v"(x[7][0]), "+v"(x[7][1])
+               :: "memory");
+}
+__device__ __forceinline__ f16x8 lrw_pack(const unsigned a, const unsigned b, const unsigned c, const unsigned d) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = {a, b, c, d};
+  return __builtin_bit_cast(f16x8, v);
+}
+
+#ifdef RSP_LRW_PROF
+// dev builds: s_memtime ticks per phase, summed over the waves of a class (read by rsparse_hip_dev_lrw_prof)
+__device__ unsigned long long g_lrw_prof[4][8];
+#define LRW_TICK(k, dep)                                  \
+  {                                                       \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    asm volatile("s_nop 0" ::"v"(dep) : "memory");        \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    prof_t[k] += now_ - prof_last;                        \
+    prof_last = now_;                                     \
+  }
+#else
+#define LRW_TICK(k, dep)
+#endif
+
+// One instantiation per class of passes -- SL = slots per row (64, 32, 16), NS = columns of the system held (48 for the rows
+// of 33..48 non-zeros: the list is longest first, so they are a range of passes too) -- and one launch per class over its
+// passes [pass_lo, pass_hi): every launch's code fits the instruction cache (all four unrolled solves in one kernel were
+// 100 KB of code for eight waves in different phases) and has the register allocation of its own solve.
+template <int KP, int SL, int NS>
+__global__ __launch_bounds__(512) void als_chol_lrw_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows, int n64,
+                                                           int n32, int pass_lo, int pass_hi,
+                                                           const _Float16* __restrict__ M16,
+                                                           const _Float16* __restrict__ MT16,
+                                                           const unsigned* __restrict__ flags, int loss_slot0) {
+  static_assert(KP == 128, "written for rank 128");
+  constexpr int lsh = SL == 64 ? 6 : (SL == 32 ? 5 : 4);
+  constexpr int LH = LrwSmem::LH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  _Float16* sM = reinterpret_cast<_Float16*>(smem);   // [2][KP][LH]: the two fp16 terms of Mt * 2^eM (A operand of V'^T)
+  __shared__ double sRed[8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
+  _Float16* sMT = sM + (size_t)2 * KP * LH;           // [2][KP][LH]: MT16 (B operand of P = V' M^T)
+  float* sE = reinterpret_cast<float*>(smem + 2 * LrwSmem::m16_bytes) + wv * LrwSmem::wave_floats;
+  if (flags[0] != 0) return;   // some confidence < 1 or XtX not positive definite: wrmf_chol.hip takes these rows
+  for (int e = tid; e < 2 * KP * 16; e += 512) {   // 16-byte pieces
+    const int t = e >> 11, r = (e >> 4) & (KP - 1), p = e & 15;
+    *reinterpret_cast<uint4*>(sM + (size_t)(t * KP + r) * LH + 8 * p) =
+        *reinterpret_cast<const uint4*>(M16 + (size_t)t * KP * KP + (size_t)r * KP + 8 * p);
+    *reinterpret_cast<uint4*>(sMT + (size_t)(t * KP + r) * LH + 8 * p) =
+        *reinterpret_cast<const uint4*>(MT16 + (size_t)t * KP * KP + (size_t)r * KP + 8 * p);
+  }
+  __syncthreads();
+  const int ex = lr_scale_exp(fmaxf(__uint_as_float(flags[-2]), 1e-30f)), eM = (int)flags[1];
+  const float sx = lr_pow2(ex), cs = lr_pow2(254 - ex) * lr_pow2(254 - eM), cm = lr_pow2(254 - eM);
+
+  const int P64 = n64, P32 = (n32 + 1) >> 1;
+  struct PassGeo { int lsh, li, lim; };
+  auto geo = [&](const int pp) {   // (all passes of a launch are of its class)
+    PassGeo g;
+    g.lsh = lsh;
+    if constexpr (SL == 64) { g.li = pp; g.lim = n64; }
+    else if constexpr (SL == 32) { g.li = n64 + 2 * (pp - P64) + (lane >> 5); g.lim = n64 + n32; }
+    else { g.li = n64 + n32 + 4 * (pp - P64 - P32) + (lane >> 4); g.lim = n_rows; }
+    if (pp >= pass_hi) g.lim = 0;
+    return g;
+  };
+
+  double wloss = 0.0;
+  // row metadata ahead of the passes, as in the workgroup kernel (all per lane: lane j works for the row of slot j)
+  const int G = gridDim.x * 8;
+  int it = pass_lo + blockIdx.x * 8 + wv;
+  int rid_c = -1, n_c = 0, rid_n = -1, p1_n = 0, n_n = 0, rid_nn = -1;
+  int id_c = 0;
+  float c_c = 1.f;
+  {
+    const PassGeo g0 = geo(it), g1 = geo(it + G), g2 = geo(it + 2 * G);
+    int p1_c = 0;
+    if (g0.li < g0.lim) {
+      rid_c = rows[g0.li];
+      p1_c = a.col_ptrs[rid_c];
+      n_c = a.col_ptrs[rid_c + 1] - p1_c;
+    }
+    if (g1.li < g1.lim) {
+      rid_n = rows[g1.li];
+      p1_n = a.col_ptrs[rid_n];
+      n_n = a.col_ptrs[rid_n + 1] - p1_n;
+    }
+    if (g2.li < g2.lim) rid_nn = rows[g2.li];
+    const int nz = lane & ((1 << g0.lsh) - 1);
+    if (nz < n_c) {
+      id_c = a.row_idx[p1_c + nz];
+      c_c = a.vals[p1_c + nz];
+    }
+  }
+#ifdef RSP_LRW_PROF
+  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_last = __builtin_readcyclecounter();
+#endif
+  for (; it < pass_hi; it += G) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // the lane id as this pass sees it (keeps lane-dependent addresses inside the pass)
+    const int nz_c = ln & ((1 << lsh) - 1);
+    const bool valid = nz_c < n_c;
+    const unsigned long long vmask = __ballot(valid);
+    int id_nx = 0, p1_nn = 0, n_nn = 0, rid_n3 = -1;
+    float c_nx = 1.f;
+    {
+      const PassGeo g1 = geo(it + G), g3 = geo(it + 3 * G);
+      const int nz1 = ln & ((1 << g1.lsh) - 1);
+      if (nz1 < n_n) {
+        id_nx = a.row_idx[p1_n + nz1];
+        c_nx = a.vals[p1_n + nz1];
+      }
+      if (rid_nn >= 0) {
+        p1_nn = a.col_ptrs[rid_nn];
+        n_nn = a.col_ptrs[rid_nn + 1] - p1_nn;
+      }
+      if (g3.li < g3.lim) rid_n3 = rows[g3.li];
+    }
+    const float cval = valid ? c_c : 0.f;
+    const float sq = valid ? sqrtf(fmaxf(c_c - 1.f, 0.f)) : 0.f;
+    const int n = ln & 31, hf = ln >> 5;
+
+    // ---- 1. gather + V'^T = Mt X_nnz^T: acc[ob][st] = dims 32 ob.. x slots 32 st.. ----
+    // Every load of the pass is issued at once (32 per lane); the chunks are then taken in DESCENDING order: Mt is lower
+    // triangular, so chunk ch only feeds the block rows ob >= ch / 2 -- the accumulators come to life (32 registers per block
+    // row) as the gathered registers are consumed, and the two never exceed 160 registers together.
+    f32x16 acc[4][2];
+    {
+      // (a slot beyond its row has index 0 and scale 0: its loads hit row 0 of X, its vector is zero)
+      const auto idsw = __builtin_amdgcn_permlane32_swap((unsigned)id_c, (unsigned)id_c, false, false);
+      const float sx0 = ((vmask >> n) & 1) ? sx : 0.f, sx1 = ((vmask >> (32 + n)) & 1) ? sx : 0.f;
+      const float* x0 = a.X + (size_t)idsw[0] * KP + 8 * hf;
+      const float* x1 = a.X + (size_t)idsw[1] * KP + 8 * hf;
+      // (from inline asm: hipcc sinks plain loads to their uses -- six in flight, a round trip per chunk -- whatever
+      //  scheduling barrier follows them; the one wait below covers everything this wave has in flight)
+      f32x4 xr[2][8][2];   // [slot tile][chunk][two 16-byte pieces]
+      lr_sfor<8>([&](auto ct) {
+        constexpr int c8 = 7 - decltype(ct)::value;
+        lrw_ld16<64 * c8>(xr[0][c8][0], x0);
+        lrw_ld16<64 * c8 + 16>(xr[0][c8][1], x0);
+        lrw_ld16<64 * c8>(xr[1][c8][0], x1);
+        lrw_ld16<64 * c8 + 16>(xr[1][c8][1], x1);
+      });
+      LRW_TICK(0, ln);
+      lrw_wait_all(xr[0]);
+      lrw_wait_all(xr[1]);
+      LRW_TICK(1, xr[0][0][0].x);
+      const _Float16* ap0 = sM + (size_t)n * LH + 8 * hf;
+      lr_sfor<8>([&](auto cht) {
+        constexpr int ch = 7 - decltype(cht)::value;
+        if constexpr (ch % 2 == 1) {   // first use of block row ch / 2
+#pragma unroll
+          for (int e = 0; e < 16; e++) acc[ch / 2][0][e] = acc[ch / 2][1][e] = 0.f;
+        }
+        f16x8 bh[2], bl[2];
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+          const f32x4 p0 = xr[st][ch][0], p1 = xr[st][ch][1];
+          const float sxs = st ? sx1 : sx0;
+          unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+          lr_split(p0.x * sxs, p0.y * sxs, h0, l0);
+          lr_split(p0.z * sxs, p0.w * sxs, h1, l1);
+          lr_split(p1.x * sxs, p1.y * sxs, h2, l2);
+          lr_split(p1.z * sxs, p1.w * sxs, h3, l3);
+          bh[st] = lrw_pack(h0, h1, h2, h3);
+          bl[st] = lrw_pack(l0, l1, l2, l3);
+        }
+        lr_sfor<4 - ch / 2>([&](auto obt) {
+          constexpr int ob = ch / 2 + decltype(obt)::value;   // Mt is lower triangular: block row ob ends at chunk 2 ob + 1
+          const _Float16* ap = ap0 + (size_t)(32 * ob) * LH + 16 * ch;
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(ap);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(ap + (size_t)KP * LH);
+          if constexpr (!(RSP_LRW_ABL & 1)) {
+            acc[ob][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], acc[ob][0], 0, 0, 0);
+            acc[ob][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], acc[ob][1], 0, 0, 0);
+            acc[ob][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], acc[ob][0], 0, 0, 0);
+            acc[ob][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], acc[ob][1], 0, 0, 0);
+            acc[ob][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], acc[ob][0], 0, 0, 0);
+            acc[ob][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], acc[ob][1], 0, 0, 0);
+          } else {   // (timing only)
+            acc[ob][0][0] += (float)ah[0] * (float)bh[0][0] + (float)al[1] * (float)bl[0][1];
+            acc[ob][1][0] += (float)ah[0] * (float)bh[1][0] + (float)al[1] * (float)bl[1][1];
+          }
+        });
+      });
+    }
+    LRW_TICK(2, acc[0][0][0] + acc[3][1][0]);
+    // ---- 2. the fp16 terms of V'^T * 2^ew (th / tl[ob][st][g]: the 16 factor dimensions of chunk 2 ob + g, in the order the
+    // accumulator holds them) ----
+    float wm = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+      for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) wm = fmaxf(wm, fabsf(acc[ob][st][e]));
+    for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+    const int ew = lr_scale_exp(fmaxf(wm, 1e-30f));
+    const float fw = lr_pow2(ew), c2 = cs * lr_pow2(254 - ew);   // terms = V' / c2
+    f16x8 th[4][2][2], tl[4][2][2];
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+      for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          unsigned hh[4], ll[4];
+#pragma unroll
+          for (int p = 0; p < 4; p++)
+            lr_split(acc[ob][st][8 * g + 2 * p] * fw, acc[ob][st][8 * g + 2 * p + 1] * fw, hh[p], ll[p]);
+          th[ob][st][g] = lrw_pack(hh[0], hh[1], hh[2], hh[3]);
+          tl[ob][st][g] = lrw_pack(ll[0], ll[1], ll[2], ll[3]);
+        }
+    // ---- 3. T = V' V'^T / c2^2, all four tiles; tile (a, b) at lane (n, hf), register v = T[32 a + rho(v, hf)][32 b + n] with
+    // rho(v, hf) = 8 (v / 4) + 4 hf + v % 4 -- by symmetry ROW 32 b + n at the columns 32 a + rho(v, hf).  Lane (n, 0) is slot n
+    // and keeps its tiles (a, 0), lane (n, 1) is slot 32 + n and keeps its tiles (a, 1); the other two go to the partner lane:
+    // afterwards ra[a][v] = column 32 a + rho(v, 0) and rb[a][v] = column 32 a + rho(v, 1) of the lane's own row, in every lane ----
+    float rl[NS];   // rl[t] = T[slot][base + t] / c2^2
+    {
+      f32x16 t[2][2];
+#pragma unroll
+      for (int e = 0; e < 16; e++) t[0][0][e] = t[0][1][e] = t[1][0][e] = t[1][1][e] = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          const f16x8 a0h = th[ob][0][g], a0l = tl[ob][0][g], a1h = th[ob][1][g], a1l = tl[ob][1][g];
+          if constexpr (!(RSP_LRW_ABL & 2)) {
+            t[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a0h, t[0][0], 0, 0, 0);
+            t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a0h, t[1][0], 0, 0, 0);
+            t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a1h, t[0][1], 0, 0, 0);
+            t[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a1h, t[1][1], 0, 0, 0);
+            t[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a0l, t[0][0], 0, 0, 0);
+            t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a0l, t[1][0], 0, 0, 0);
+            t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a1l, t[0][1], 0, 0, 0);
+            t[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a1l, t[1][1], 0, 0, 0);
+            t[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, a0h, t[0][0], 0, 0, 0);
+            t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, a0h, t[1][0], 0, 0, 0);
+            t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, a1h, t[0][1], 0, 0, 0);
+            t[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, a1h, t[1][1], 0, 0, 0);
+          } else {
+            t[0][0][0] += (float)a0h[0]; t[1][0][0] += (float)a0l[0]; t[0][1][0] += (float)a1h[0]; t[1][1][0] += (float)a1l[0];
+          }
+        }
+      // (the columns of the lane's own group only: rl[t] = T[slot][base + t], base = slot - slot % SL)
+      auto swp = [&](const int ta, const int v, float& c_lo, float& c_hi) {   // columns 32 ta + rho(v, 0) and + rho(v, 1)
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[ta][0][v]), __float_as_uint(t[ta][1][v]), false, false);
+        c_lo = __uint_as_float(sw[0]);
+        c_hi = __uint_as_float(sw[1]);
+      };
+      if constexpr (SL == 64) {
+#pragma unroll
+        for (int ta = 0; ta < 2; ta++)
+#pragma unroll
+          for (int v = 0; v < 16; v++) {
+            const int c0 = 32 * ta + 8 * (v >> 2) + (v & 3);
+            float x0, x1;
+            swp(ta, v, x0, x1);
+            if (c0 < NS) rl[c0] = x0;
+            if (c0 + 4 < NS) rl[c0 + 4] = x1;
+          }
+      } else if constexpr (SL == 32) {
+#pragma unroll
+        for (int v = 0; v < 16; v++) {   // slots 0..31: the tiles ta = 0, slots 32..63: ta = 1
+          const int c0 = 8 * (v >> 2) + (v & 3);
+          float a0, a1, b0, b1;
+          swp(0, v, a0, a1);
+          swp(1, v, b0, b1);
+          rl[c0] = hf ? b0 : a0;
+          rl[c0 + 4] = hf ? b1 : a1;
+        }
+      } else {
+        const int gq = (ln >> 4) & 1;
+#pragma unroll
+        for (int v = 0; v < 8; v++) {   // group (2 ta + gq): the rows v and v + 8 of the tiles ta
+          const int c0 = 8 * (v >> 2) + (v & 3);
+          float a0, a1, b0, b1, c0v, c1v, d0, d1;
+          swp(0, v, a0, a1);
+          swp(0, v + 8, b0, b1);
+          swp(1, v, c0v, c1v);
+          swp(1, v + 8, d0, d1);
+          const float lo0 = gq ? b0 : a0, lo1 = gq ? b1 : a1, hi0 = gq ? d0 : c0v, hi1 = gq ? d1 : c1v;
+          rl[c0] = hf ? hi0 : lo0;
+          rl[c0 + 4] = hf ? hi1 : lo1;
+        }
+      }
+    }
+    LRW_TICK(3, rl[0] + rl[NS - 1]);
+    // ---- 4. lane i = slot i: S z = h in registers, e, the loss terms ----
+    const float sqs = sq * c2;   // (D^1/2 T D^1/2)_ic = r[c] sqs_i sqs_c
+    float e_i = 0.f, p_i = 0.f;   // p = x_j . y
+    {
+      const int i = ln, il = i & (SL - 1);
+      // A slot of confidence exactly 1 (d = 0) has no row in W: row and column of S are those of the identity.  Its lane keeps
+      // its row of T instead, scaled like a right-hand side (T_ic sqrt(d_c)), and lets EVERY pivot eliminate it: what the
+      // forward pass leaves in its u is (T c)_i - T_i D^1/2 S^-1 h = (T e)_i = x_i . y, the slot's loss term, for free.  (The
+      // bench matrix has half of its confidences at 1.)  The broadcast copies of a pivot column are masked at such lanes, so
+      // the other rows never see them: the system stays the symmetric one.
+      const bool unit = valid && !(sq > 0.f);
+      const int ie = unit ? 1024 : il;   // "row index" for the elimination: a unit lane is below every pivot
+      float repc[4], repq[4];
+      lrw_group<SL>(cval, repc);
+      lrw_group<SL>(sqs, repq);
+      dpp_ready(repc[0], repc[1], repc[2], repc[3]);
+      dpp_ready(repq[0], repq[1], repq[2], repq[3]);
+      const float rowf = unit ? c2 : sqs;
+      float tc = 0.f;   // -(T c)_i / c2^2
+      lr_sfor<NS>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        fnma_row_bcast<t % 16>(tc, repc[t / 16], rl[t]);
+        rl[t] *= rowf;
+        mul_row_bcast<t % 16>(rl[t], repq[t / 16]);   // (D^1/2 T D^1/2)_{i, base + t}; the identity is added at the pivots
+      });
+      tc = -(tc * c2) * c2;   // (T c)_i
+      float u = unit ? tc : tc * sq;   // h_i
+      float dinv = 1.f, z = 0.f;
+      if constexpr (RSP_LRW_ABL & 4) {
+        z = u + rl[0] + rl[NS - 1];
+      } else if constexpr (SL == 64) {
+        // one system on the whole wave (the register solve of the workgroup kernel; diagonal entries are only ever read as
+        // pivots, which is where S = I + ... gets its identity)
+        float pj = readlane_f(rl[0], 0) + 1.f;
+        lr_sfor<NS>([&](auto jt) {
+          constexpr int j = decltype(jt)::value;
+          const float inv = __builtin_amdgcn_rcpf(pj);
+          const float uj = readlane_f(u, j);
+          if (i == j) dinv = inv;
+          const float lij = ie > j ? rl[j] * inv : 0.f;
+          u = fmaf(-lij, uj, u);
+          if constexpr (j + 1 < NS) {
+            float cj = unit ? 0.f : rl[j];   // column j as the symmetric system has it
+            rl[j + 1] = fmaf(-lij, readlane_f(cj, j + 1), rl[j + 1]);
+            pj = readlane_f(rl[j + 1], j + 1) + 1.f;
+            if constexpr (j + 2 < NS) {
+              float rep[4];
+              dpp_ready(cj);
+              rows_to_all<4>(cj, rep);
+              dpp_ready(rep[0], rep[1], rep[2], rep[3]);
+              lr_sfor<NS - j - 2>([&](auto ct) {
+                constexpr int c = j + 2 + decltype(ct)::value;
+                fnma_row_bcast<c % 16>(rl[c], rep[c / 16], lij);
+              });
+            }
+          }
+        });
+        p_i = u;   // (unit lanes)
+        if (unit) dinv = 0.f;
+        float bacc = 0.f;
+#pragma unroll
+        for (int c = NS - 1; c >= 0; c--) {
+          if (i == c) z = (u - bacc) * dinv;
+          const float zc = readlane_f(z, c);
+          bacc = fmaf(i < c ? rl[c] : 0.f, zc, bacc);
+        }
+      } else {
+        // 64 / SL independent systems, one per group of SL lanes; register t = column t of the group
+        lr_sfor<SL>([&](auto tt) {
+          constexpr int t = decltype(tt)::value;
+          float rep[4], ur[4];
+          float ct = unit ? 0.f : rl[t];   // column t as the symmetric system has it
+          dpp_ready(ct, u);
+          lrw_group<SL>(ct, rep);
+          lrw_group<SL>(u, ur);
+          dpp_ready(rep[0], rep[1], ur[0], ur[1]);
+          const float pv = lr_row_bcast<t % 16>(rep[t / 16]) + 1.f;
+          const float inv = __builtin_amdgcn_rcpf(pv);
+          if (il == t) dinv = inv;
+          const float lij = ie > t ? rl[t] * inv : 0.f;
+          fnma_row_bcast<t % 16>(u, ur[t / 16], lij);
+          lr_sfor<SL - t - 1>([&](auto ct) {
+            constexpr int c = t + 1 + decltype(ct)::value;
+            fnma_row_bcast<c % 16>(rl[c], rep[c / 16], lij);
+          });
+        });
+        p_i = u;   // (unit lanes)
+        if (unit) dinv = 0.f;
+        float bacc = 0.f;
+        lr_sfor<SL>([&](auto tt) {
+          constexpr int c = SL - 1 - decltype(tt)::value;
+          if (il == c) z = (u - bacc) * dinv;
+          float zr[4];
+          lrw_group<SL>(z, zr);
+          dpp_ready(zr[0], zr[1]);
+          const float m = il < c ? -rl[c] : 0.f;
+          fnma_row_bcast<c % 16>(bacc, zr[c / 16], m);
+        });
+      }
+      e_i = cval - sq * z;   // (slots beyond the row: c = 0, sq = 0; unit slots: z = 0)
+      // x_i . y = (T e)_i, and D^1/2 T e = D^1/2 T c - D^1/2 T D^1/2 z = h - (S - I) z = z
+      if (!unit) p_i = z * __builtin_amdgcn_rcpf(fmaxf(sq, 1e-30f));
+    }
+    LRW_TICK(4, e_i + p_i);
+    wave_sync();   // (the previous pass has read its e)
+    sE[ln] = e_i;
+    wave_sync();
+    // ---- 5. y = P^T e, P = V' M^T one block of 32 columns at a time ----
+    float yy = 0.f;
+    {
+      float4 ec[2][4];
+#pragma unroll
+      for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) ec[st][q] = *reinterpret_cast<const float4*>(sE + 32 * st + 8 * q + 4 * hf);
+      const _Float16* bp0 = sMT + (size_t)n * LH + 8 * hf;
+      const float pscale = c2;
+      lr_sfor<4>([&](auto cbt) {
+        constexpr int cb = decltype(cbt)::value;
+        f32x16 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 16; e++) p0[e] = p1[e] = 0.f;
+        lr_sfor<8 - 2 * cb>([&](auto cht) {
+          constexpr int chunk = 2 * cb + decltype(cht)::value;   // Mt[kk][c] = 0 for kk < c
+          constexpr int ob = chunk / 2, g = chunk % 2;
+          const _Float16* bp = bp0 + (size_t)(32 * cb) * LH + 16 * chunk;
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(bp);
+          const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + (size_t)KP * LH);
+          if constexpr (!(RSP_LRW_ABL & 8)) {
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[ob][0][g], bh, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[ob][1][g], bh, p1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[ob][0][g], bl, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[ob][1][g], bl, p1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[ob][0][g], bh, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[ob][1][g], bh, p1, 0, 0, 0);
+          } else {
+            p0[0] += (float)th[ob][0][g][0] * (float)bh[0] + (float)tl[ob][0][g][0] * (float)bl[0];
+            p1[0] += (float)th[ob][1][g][0] * (float)bh[1] + (float)tl[ob][1][g][0] * (float)bl[1];
+          }
+        });
+        // sums over the slots of this lane half, by 16-slot group: q[2 st + (a >> 1)], a = 8-row block of the tile
+        float q[4];
+#pragma unroll
+        for (int a2 = 0; a2 < 4; a2++) {
+          const float4 e0 = ec[0][a2], e1 = ec[1][a2];
+          const float s0 = fmaf(e0.x, p0[4 * a2], fmaf(e0.y, p0[4 * a2 + 1], fmaf(e0.z, p0[4 * a2 + 2], e0.w * p0[4 * a2 + 3])));
+          const float s1 = fmaf(e1.x, p1[4 * a2], fmaf(e1.y, p1[4 * a2 + 1], fmaf(e1.z, p1[4 * a2 + 2], e1.w * p1[4 * a2 + 3])));
+          if (a2 & 1) { q[a2 >> 1] += s0; q[2 + (a2 >> 1)] += s1; }
+          else { q[a2 >> 1] = s0; q[2 + (a2 >> 1)] = s1; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const unsigned uq = __float_as_uint(q[r]);
+          const auto sw = __builtin_amdgcn_permlane32_swap(uq, uq, false, false);
+          q[r] = ((__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * pscale) * cm;
+        }
+        // rows of the pass: one (all four groups), two (groups 0 + 1, 2 + 3) or four
+        float yr[4];
+        if constexpr (SL == 64) { yr[0] = (q[0] + q[1]) + (q[2] + q[3]); yr[1] = yr[2] = yr[3] = 0.f; }
+        else if constexpr (SL == 32) { yr[0] = q[0] + q[1]; yr[1] = q[2] + q[3]; yr[2] = yr[3] = 0.f; }
+        else { yr[0] = q[0]; yr[1] = q[1]; yr[2] = q[2]; yr[3] = q[3]; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (r < (64 >> lsh)) {   // wave-uniform
+            const int rid = __builtin_amdgcn_readlane(rid_c, r << lsh);
+            if (rid >= 0 && hf == 0) {
+              a.Y[(size_t)rid * KP + 32 * cb + n] = yr[r];
+              yy = fmaf(yr[r], yr[r], yy);
+            }
+          }
+        }
+      });
+    }
+    LRW_TICK(5, yy);
+    const float dlt = 1.f - p_i;
+    const float loss_i = cval * dlt * dlt;
+    const float lsum = wave_sum(loss_i), ysum = wave_sum(yy);
+    wloss += (double)lsum + a.lambda_loss * (double)ysum;
+    rid_c = rid_n; n_c = n_n;
+    rid_n = rid_nn; p1_n = p1_nn; n_n = n_nn;
+    rid_nn = rid_n3;
+    id_c = id_nx; c_c = c_nx;
+    LRW_TICK(6, (float)(id_c + rid_c) + c_c);
+#ifdef RSP_LRW_PROF
+    prof_t[7] += 1;
+#endif
+  }
+#ifdef RSP_LRW_PROF
+  if (lane == 0) {
+    constexpr int cls = SL == 64 ? (NS == 64 ? 0 : 1) : (SL == 32 ? 2 : 3);
+    for (int q = 0; q < 8; q++) atomicAdd(&g_lrw_prof[cls][q], prof_t[q]);
+  }
+#endif
+  if (lane == 0) sRed[wv] = wloss;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 8; w++) s += sRed[w];
+    a.loss_partials[loss_slot0 + blockIdx.x] = s;
+  }
+}
+
 }  // namespace
+
+// dev builds (-DRSP_AB): RSPARSE_HIP_LR_WAVE=0 keeps rank 128 on the workgroup kernel, for same-box comparisons
+static bool lr_wave_on() {
+#ifdef RSP_AB
+  static const bool on = [] {
+    const char* e = std::getenv("RSPARSE_HIP_LR_WAVE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+#else
+  return true;
+#endif
+}
 
 bool chol_lr_supported(const AlsArgs& a, bool implicit) {
   return implicit && a.k > 96 && a.k <= 128 && a.k % 2 == 0 && !a.rhs_vals && !a.loss_tgt && !a.rhs_init &&
@@ -674,8 +1250,36 @@ hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows,
   if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(prep), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  prep_lds)) != hipSuccess)
     return err;
-  hipLaunchKernelGGL(prep, dim3(1), dim3(256), prep_lds, s, a.XtX, a.k, reinterpret_cast<_Float16*>(M), Mt, flags);
+  _Float16* MT16 = reinterpret_cast<_Float16*>(Mt + 128 * 128);   // (the scratch is 3 x 128 x 128 floats)
+  const bool wave_form = lr_wave_on() && a.k == KP;
+  hipLaunchKernelGGL(prep, dim3(1), dim3(256), prep_lds, s, a.XtX, a.k, reinterpret_cast<_Float16*>(M), Mt, flags,
+                     wave_form ? MT16 : nullptr);
   if ((err = hipGetLastError()) != hipSuccess) return err;
+  if (wave_form) {   // rank 128: one wave per pass, one launch per class of passes
+    int n48 = n64;   // rows of more than 48 non-zeros (a prefix of the n64 rows of 33..64)
+    if (a.lr_n_gt48 >= 0 && a.lr_n_gt48 <= n64) n48 = a.lr_n_gt48;
+    const int P64 = n64, P32 = (n32 + 1) / 2, P16 = (n_rows - n64 - n32 + 3) / 4;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = std::min(cus, kCholLrGrid / 4);
+    auto go = [&](auto kw, const int lo, const int hi, const int slot, const bool note) -> hipError_t {
+      if (hi <= lo) return hipSuccess;
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)LrwSmem::bytes);
+      if (e2 != hipSuccess) return e2;
+      const int gridw = std::min((hi - lo + 7) / 8, cus);   // one resident workgroup of 8 waves per CU
+      if (note) prof_note(ev_slot, reinterpret_cast<const void*>(kw));
+      hipLaunchKernelGGL(kw, dim3(gridw), dim3(512), LrwSmem::bytes, s, a, rows, n_rows, n64, n32, lo, hi,
+                         reinterpret_cast<const _Float16*>(M), reinterpret_cast<const _Float16*>(MT16), flags,
+                         loss_slot0 + slot * cus);
+      return hipGetLastError();
+    };
+    // (the event segment is named after the class with the most passes on the bench matrix)
+    if ((err = go(als_chol_lrw_kernel<KP, 64, 64>, 0, n48, 0, false)) != hipSuccess) return err;
+    if ((err = go(als_chol_lrw_kernel<KP, 64, 48>, n48, P64, 1, true)) != hipSuccess) return err;
+    if ((err = go(als_chol_lrw_kernel<KP, 32, 32>, P64, P64 + P32, 2, false)) != hipSuccess) return err;
+    return go(als_chol_lrw_kernel<KP, 16, 16>, P64 + P32, P64 + P32 + P16, 3, false);
+  }
   auto kern = als_chol_lr_kernel<KP>;
   if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)LrSmem<KP>::bytes)) != hipSuccess)
@@ -689,3 +1293,16 @@ hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows,
 }
 
 }  // namespace rsparse_hip
+
+#ifdef RSP_LRW_PROF
+// dev builds: out[4][8] = per class (49..64, 33..48, 17..32, <= 16 non-zeros) the s_memtime ticks of the phases (issue of the
+// gather, wait for it, split + V' GEMM, terms + T GEMM + lane swaps, n x n solve, P GEMM + y, bookkeeping) and the passes
+extern "C" int rsparse_hip_dev_lrw_prof(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rsparse_hip::g_lrw_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rsparse_hip::g_lrw_prof), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

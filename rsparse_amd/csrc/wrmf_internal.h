@@ -32,6 +32,7 @@ struct DevCSC {
   // time first; workgroup b owns q_ne_rows[q_ne_ptr[b], q_ne_ptr[b+1])
   int q_n_chol_long = 0;   // rows of more than kCholLongLen non-zeros (a prefix of q_order)
   int q_gt32 = 0;                   // rows of more than 32 non-zeros
+  int q_gt48 = 0;                   // ... of more than 48
   int q_lr_first = 0, q_n_lr = 0;   // rows of 1..kCholLrMax non-zeros: q_order[q_lr_first, q_lr_first + q_n_lr)
   int32_t* q_ne_rows = nullptr;
   int32_t* q_ne_ptr = nullptr;
@@ -114,10 +115,11 @@ struct AlsArgs {
   const int32_t* chol_list;
   int chol_first, chol_n_main, chol_empty_first;
   // Cholesky, short rows: lr_rows = the n_lr rows of 1..kCholLrMax non-zeros; lr_flags (device word, nullable): 0 = the
-  // low-rank kernel solves them and wrmf_chol.hip's skips them, else the other way round; lr_M = 2 x 128 x 128 floats
+  // low-rank kernel solves them and wrmf_chol.hip's skips them, else the other way round; lr_M = 3 x 128 x 128 floats
   const int32_t* lr_rows;
   int n_lr;
   int lr_n_gt32, lr_n_gt16;   // how many of them (a prefix: the list is longest first) have more than 32 / 16 non-zeros; -1 = unknown
+  int lr_n_gt48;              // ... more than 48
   unsigned* lr_flags;
   float* lr_M;
   // rows split across workgroups: segment table, per-segment partial accumulators (kNeSegFloats floats each) and flags

@@ -20,5 +20,21 @@ for rep in range(2):
     als.half_iteration("users", U, V, 0, G=G, want_loss=False)
     torch.cuda.synchronize(); t = time.perf_counter() - t0
 print("lib [$n] users half %.1f ms" % (1e3 * t))
+be.profile(True)
+als.half_iteration("users", U, V, 0, G=G, want_loss=False)
+torch.cuda.synchronize()
+ms = be.profile_last(); names = be.profile_last_names()
+print("lib [$n] per launch:", "; ".join("%s %.1f" % (nm[:44], t) for nm, t in zip(names, ms) if t > 0.05))
+be.profile(False)
+if hasattr(be.lib, "rsparse_hip_dev_lrw_prof"):   # -DRSP_LRW_PROF builds: ticks per phase and class of the wave-per-pass kernel
+    import ctypes
+    buf = (ctypes.c_ulonglong * 32)()
+    be.lib.rsparse_hip_dev_lrw_prof(buf, 1)
+    als.half_iteration("users", U, V, 0, G=G, want_loss=False)
+    torch.cuda.synchronize()
+    be.lib.rsparse_hip_dev_lrw_prof(buf, 1)
+    for c, nm in enumerate(("49..64", "33..48", "17..32", "<=16")):
+        v = list(buf[8 * c: 8 * c + 8]); n = max(v[7], 1)
+        print("lrw prof %-7s passes %8d  ticks/pass: issue %.0f  gather-wait %.0f  split+V' %.0f  terms+T %.0f  solve %.0f  P+y %.0f  rest %.0f  | total %.0f" % (nm, v[7], *[x / n for x in v[:7]], sum(v[:7]) / n))
 PY
 done

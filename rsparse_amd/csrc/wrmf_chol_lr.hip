@@ -19,6 +19,10 @@
 //
 // Round 3: the n x n systems are solved by one wave in registers with the pivot-row multipliers as DPP row broadcasts inside
 // the FMAs, and rows of <= 16 / <= 32 non-zeros share a pass four / two at a time (see "the rows" below).
+// Round 4: at rank 128 a pass belongs to ONE wave from the gather to the loss (als_chol_lrw_kernel, second half of this
+// file): the same algebra regrouped so that nothing is reduced over the lanes that hold the slots, no barrier, no operand
+// in LDS but a read-only copy of the terms of M^T -- 185 -> 55 ms on the user half of the bench matrix.  The workgroup kernel
+// below keeps the ranks 98..126.
 //
 // Needs every confidence >= 1 (D^1/2) and XtX positive definite: both are decided on the device (flags[0] != 0 ->
 // this kernel returns at once and wrmf_chol.hip's kernel, which otherwise skips the short rows, takes them).
@@ -930,7 +934,7 @@ __global__ __launch_bounds__(512) void als_chol_lrw_kernel(AlsArgs a, const int3
           th[ob][st][g] = lrw_pack(hh[0], hh[1], hh[2], hh[3]);
           tl[ob][st][g] = lrw_pack(ll[0], ll[1], ll[2], ll[3]);
         }
-    // ---- 3. T = V' V'^T / c2^2, all four tiles; tile (a, b) at lane (n, hf), register v = T[32 a + rho(v, hf)][32 b + n] with
+    // ---- 3. T = V' V'^T / c2^2, all four tiles (packed rows: the two diagonal ones, the others only feed lanes that do not read them); tile (a, b) at lane (n, hf), register v = T[32 a + rho(v, hf)][32 b + n] with
     // rho(v, hf) = 8 (v / 4) + 4 hf + v % 4 -- by symmetry ROW 32 b + n at the columns 32 a + rho(v, hf).  Lane (n, 0) is slot n
     // and keeps its tiles (a, 0), lane (n, 1) is slot 32 + n and keeps its tiles (a, 1); the other two go to the partner lane:
     // afterwards ra[a][v] = column 32 a + rho(v, 0) and rb[a][v] = column 32 a + rho(v, 1) of the lane's own row, in every lane ----
@@ -946,16 +950,16 @@ __global__ __launch_bounds__(512) void als_chol_lrw_kernel(AlsArgs a, const int3
           const f16x8 a0h = th[ob][0][g], a0l = tl[ob][0][g], a1h = th[ob][1][g], a1l = tl[ob][1][g];
           if constexpr (!(RSP_LRW_ABL & 2)) {
             t[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a0h, t[0][0], 0, 0, 0);
-            t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a0h, t[1][0], 0, 0, 0);
-            t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a1h, t[0][1], 0, 0, 0);
+            if constexpr (SL == 64) t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a0h, t[1][0], 0, 0, 0);
+            if constexpr (SL == 64) t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a1h, t[0][1], 0, 0, 0);
             t[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a1h, t[1][1], 0, 0, 0);
             t[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a0l, t[0][0], 0, 0, 0);
-            t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a0l, t[1][0], 0, 0, 0);
-            t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a1l, t[0][1], 0, 0, 0);
+            if constexpr (SL == 64) t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a0l, t[1][0], 0, 0, 0);
+            if constexpr (SL == 64) t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a1l, t[0][1], 0, 0, 0);
             t[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a1l, t[1][1], 0, 0, 0);
             t[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, a0h, t[0][0], 0, 0, 0);
-            t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, a0h, t[1][0], 0, 0, 0);
-            t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, a1h, t[0][1], 0, 0, 0);
+            if constexpr (SL == 64) t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, a0h, t[1][0], 0, 0, 0);
+            if constexpr (SL == 64) t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, a1h, t[0][1], 0, 0, 0);
             t[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, a1h, t[1][1], 0, 0, 0);
           } else {
             t[0][0][0] += (float)a0h[0]; t[1][0][0] += (float)a0l[0]; t[0][1][0] += (float)a1h[0]; t[1][1][0] += (float)a1l[0];
@@ -1108,6 +1112,10 @@ __global__ __launch_bounds__(512) void als_chol_lrw_kernel(AlsArgs a, const int3
       // x_i . y = (T e)_i, and D^1/2 T e = D^1/2 T c - D^1/2 T D^1/2 z = h - (S - I) z = z
       if (!unit) p_i = z * __builtin_amdgcn_rcpf(fmaxf(sq, 1e-30f));
     }
+    // (the look-ahead requested at the top has long arrived: waited for HERE, before this pass's stores are in the queue --
+    //  hipcc waits for loop-carried loads with vmcnt(0) at their first use, which at the top of the next pass would be a wait for
+    //  those stores)
+    asm volatile("" : "+v"(id_nx), "+v"(c_nx), "+v"(p1_nn), "+v"(n_nn), "+v"(rid_n3));
     LRW_TICK(4, e_i + p_i);
     wave_sync();   // (the previous pass has read its e)
     sE[ln] = e_i;

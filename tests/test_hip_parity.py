@@ -131,6 +131,37 @@ def test_cholesky_short_rows_share_a_pass(k, classes):
     assert abs(loss - lref) <= TOL * abs(lref)
 
 
+@pytest.mark.parametrize("k", [128, 112])
+@pytest.mark.parametrize("conf", ["half_unit", "all_unit", "barely_above_one", "one_normal"])
+def test_cholesky_short_rows_with_confidence_exactly_one(k, conf):
+    """wrmf_chol_lr.hip, wave-per-pass kernel (rank 128; the workgroup kernel at 112): a slot of confidence exactly 1 has no row in
+    W = D^1/2 V' -- its lane rides through the elimination as a right-hand-side row and the forward pass leaves its loss term.
+    Rows of every class (49..64, 33..48, 17..32, <= 16 non-zeros) with half of the confidences at 1 (what the bench matrix has),
+    all of them at 1 (S = I), confidences 1 + 1e-6 (x_j . y = z_j / sqrt(c_j - 1) with a tiny divisor) and a single one above 1."""
+    rng = np.random.default_rng(3)
+    lens = np.asarray(list(rng.integers(1, 65, size=150)) + [64, 49, 48, 33, 32, 17, 16, 1, 64, 50, 40, 20, 10], dtype=np.int64)
+    (n_item, n_rows, p_, idx, x), X, Y0 = _rows_of_lengths(lens, 400, k, seed=5 + k)
+    x = x.copy()
+    if conf == "half_unit":
+        x[rng.random(x.size) < 0.5] = 1.0
+    elif conf == "all_unit":
+        x[:] = 1.0
+    elif conf == "barely_above_one":
+        m = rng.random(x.size) < 0.5
+        x[m] = np.float32(1.0 + 1e-6)
+        x[~m & (rng.random(x.size) < 0.5)] = 1.0
+    else:
+        x[:] = 1.0
+        x[p_[:-1][lens > 0]] = 3.0          # the first non-zero of every row
+    csc = (n_item, n_rows, p_, idx, x)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 0, 3, True)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, 0.1, 1, 0, 3, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, (conf, int(np.argmax(err)), int(lens[int(np.argmax(err))]), float(err.max()))
+    assert abs(loss - lref) <= TOL * abs(lref), (loss, lref)
+
+
 @pytest.mark.parametrize("k", [128, 96, 64, 20])
 @pytest.mark.parametrize("implicit", [True, False])
 def test_cg_long_rows_all_buckets(k, implicit):

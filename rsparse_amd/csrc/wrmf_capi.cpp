@@ -612,7 +612,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.ne_r0 = nullptr; a.ne_r0_slot = nullptr;
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
   a.ne_prof = nullptr;
-  a.ne_stats = nullptr;
+  a.ne_stats = nullptr; a.wave_stats = nullptr;
   a.ne_segs = nullptr; a.ne_seg_scratch = nullptr; a.ne_seg_flags = nullptr;
   a.ne_chol = ne_chol ? 1 : 0;
   a.ne_chol_min = nec_lists ? d.q_nec_min : kNeMinLen;
@@ -667,6 +667,14 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     a.lr_n_gt48 = d.q_gt48 - d.q_lr_first;
   }
   const bool chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY;
+  if (chol && chol_wave_supported(rank) && padded_rank(rank) == 64) {
+    // rank 33..64, one wave per row: the assembly runs on the matrix cores from fp16 operand terms scaled by max |X| (and max c)
+    if (!a.ne_stats) {
+      hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax);
+      if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
+    }
+    a.wave_stats = g_ws.ne_stats;
+  }
   if (chol) {
     hipError_t fe = launch_fail_roll(g_ws.fails, s);
     if (fe != hipSuccess) return hip_fail(fe, "launch_fail_roll");

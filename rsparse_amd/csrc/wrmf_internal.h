@@ -129,6 +129,7 @@ struct AlsArgs {
   int ne_chol;                   // long rows through wrmf_ne.hip with the exact solve instead of CG (solver == CHOLESKY)
   int ne_chol_min;               // ... the rows of more than this many non-zeros (wrmf_chol.hip skips them)
   const unsigned* ne_stats;      // implicit NE launches: {bits of max |x|, bits of max c, any c < 1} (launch_ne_stats), or nullptr
+  const unsigned* wave_stats;    // the same block for the wave-per-row kernels at rank 33..64 (operand scales of their matrix-core assembly), or nullptr
   unsigned long long* ne_prof;   // RSP_NE_PROF builds: [workgroup][wave][8] cycle counters of wrmf_ne.hip (else nullptr)
 };
 

@@ -60,11 +60,11 @@ __device__ __forceinline__ int cw_scale_exp(float vmax) {
 __device__ __forceinline__ float cw_pow2(int biased) { return __uint_as_float((unsigned)biased << 23); }
 
 template <int KP, bool IMPLICIT>
-__global__ __launch_bounds__(256, 3) void als_chol_wave_kernel(AlsArgs a, int loss_slot0) {
-  __shared__ __attribute__((aligned(16))) float sXv[4][KP];   // per wave: the vector being broadcast
-  __shared__ double sLoss[4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
-  float* sX = sXv[wv];
+__global__ __launch_bounds__(64, 3) void als_chol_wave_kernel(AlsArgs a, int loss_slot0) {
+  // (one wave per WORKGROUP: with four, a workgroup held its slot until the longest of its four rows was done)
+  __shared__ __attribute__((aligned(16))) float sXv[KP];   // the vector being broadcast
+  const int lane = threadIdx.x & 63;
+  float* sX = sXv;
   const int k = a.k;
   const bool on = lane < KP, lk = lane < k;
   const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 3) void als_chol_wave_kernel(AlsArgs a, int lo
     return (int)a.chol_list[it2 < a.chol_n_main ? a.chol_first + it2 : tail0 + (it2 - a.chol_n_main)];
   };
 
-  for (int it = blockIdx.x * 4 + wv; it < n_iter; it += gridDim.x * 4) {
+  for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
     const int row = rfl(row_at(it));
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     const int cnt = p2 - p1;
@@ -367,23 +367,21 @@ __global__ __launch_bounds__(256, 3) void als_chol_wave_kernel(AlsArgs a, int lo
     const float xxp = wave_sum(z * z);
     wloss += IMPLICIT ? (double)lpart + a.lambda_loss * (double)xxp : (double)(lpart + lam_use * xxp);
   }
-  if (lane == 0) sLoss[wv] = wloss;
-  __syncthreads();
-  if (tid == 0) a.loss_partials[loss_slot0 + blockIdx.x] = (sLoss[0] + sLoss[1]) + (sLoss[2] + sLoss[3]);
+  if (lane == 0) a.loss_partials[loss_slot0 + blockIdx.x] = wloss;
 }
 
 }  // namespace
 
 bool chol_wave_supported(int k) { return padded_rank(k) == 32 || padded_rank(k) == 64; }
 
-// grid workgroups (4 rows each at a time); loss partials [loss_slot0, loss_slot0 + grid)
+// grid workgroups of one wave (a row each at a time); loss partials [loss_slot0, loss_slot0 + grid)
 hipError_t launch_als_chol_wave(const AlsArgs& a, bool implicit, int grid, int loss_slot0, hipStream_t s, hipEvent_t* ev_slot) {
   const int KP = padded_rank(a.k);
 #define RSP_CW(KPV, IMP)                                                                  \
   {                                                                                       \
     auto kern = als_chol_wave_kernel<KPV, IMP>;                                           \
     prof_note(ev_slot, reinterpret_cast<const void*>(kern));                              \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, a, loss_slot0);                 \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, a, loss_slot0);                  \
     return hipGetLastError();                                                             \
   }
   if (KP == 32) {

@@ -306,26 +306,27 @@ struct NnlsWaveSmem {
   static constexpr int HR = KP / 2;          // columns of lhs staged at a time
   static constexpr int LDH = KP + 4;         // their stride (16-byte aligned broadcast reads, 4-way conflicts on the writes)
   static constexpr size_t wave_floats = (size_t)HR * LDH + 2 * KP;
-  static constexpr size_t bytes = 4 * wave_floats * 4 + 4 * sizeof(double) + 64;
+  static constexpr size_t bytes = wave_floats * 4 + 64;   // (one wave per workgroup)
 };
 
 template <int KP, bool IMPLICIT>
-__global__ __launch_bounds__(256, 3) void als_nnls_wave_kernel(AlsArgs a) {
+__global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
+  // One wave per WORKGROUP: a row's cost is its sweep count (median 114, a tenth of the rows above 390, the cap 10000), and a
+  // workgroup of four waves held its slot until the slowest of its four rows was done.
   using SM = NnlsWaveSmem<KP>;
   constexpr int HR = SM::HR, LDH = SM::LDH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
-  float* sW = reinterpret_cast<float*>(smem) + (size_t)wv * SM::wave_floats;   // [HR][LDH] columns of lhs
+  const int lane = threadIdx.x & 63;
+  float* sW = reinterpret_cast<float*>(smem);                                  // [HR][LDH] columns of lhs
   float* sX = sW + (size_t)HR * LDH;                                           // [KP] a vector to broadcast
   float* sR = sX + KP;                                                         // [KP] a second one
-  double* sLoss = reinterpret_cast<double*>(reinterpret_cast<float*>(smem) + 4 * SM::wave_floats);
   const int k = a.k;
   const bool on = lane < KP, lk = lane < k;
   const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
   const unsigned long long in_range = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
   double wloss = 0.0;
 
-  for (int row = blockIdx.x * 4 + wv; row < a.n_cols; row += gridDim.x * 4) {
+  for (int row = blockIdx.x; row < a.n_cols; row += gridDim.x) {
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     const int cnt = p2 - p1;
     float* yrow = a.Y + (size_t)row * k;
@@ -563,9 +564,7 @@ __global__ __launch_bounds__(256, 3) void als_nnls_wave_kernel(AlsArgs a) {
     const float xxp = wave_sum(h * h);
     wloss += IMPLICIT ? (double)lpart + a.lambda_loss * (double)xxp : (double)(lpart + lam_use * xxp);
   }
-  if (lane == 0) sLoss[wv] = wloss;
-  __syncthreads();
-  if (tid == 0) a.loss_partials[blockIdx.x] = (sLoss[0] + sLoss[1]) + (sLoss[2] + sLoss[3]);
+  if (lane == 0) a.loss_partials[blockIdx.x] = wloss;
 }
 
 template <int KP, bool IMPLICIT>
@@ -579,7 +578,7 @@ hipError_t launch_nnls_wave_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
     return err;
   if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
   prof_note(ev, reinterpret_cast<const void*>(kc));
-  hipLaunchKernelGGL(kc, dim3(grid), dim3(256), SM::bytes, s, a);
+  hipLaunchKernelGGL(kc, dim3(grid), dim3(64), SM::bytes, s, a);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   if (ev) {
     if ((err = hipEventRecord(ev[1], s)) != hipSuccess) return err;

@@ -598,7 +598,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.long_rows = d.long_rows; a.n_long = d.n_long; a.n_cols = d.n_cols;
   a.chol_long_rows = d.q_order; a.n_chol_long = d.q_order ? d.q_n_chol_long : 0;
   a.chol_list = nullptr; a.chol_first = 0; a.chol_n_main = 0; a.chol_empty_first = 0;
-  a.lr_rows = nullptr; a.n_lr = 0; a.lr_flags = nullptr; a.lr_M = nullptr; a.lr_n_gt32 = a.lr_n_gt16 = a.lr_n_gt48 = -1;
+  a.lr_rows = nullptr; a.n_lr = 0; a.lr_flags = nullptr; a.lr_M = nullptr; a.lr_n_gt32 = a.lr_n_gt16 = a.lr_n_gt48 = -1; a.lrx = 0;
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails; a.zero_row = g_ws.zero_row;
@@ -667,9 +667,20 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     a.lr_n_gt48 = d.q_gt48 - d.q_lr_first;
   }
   const bool chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY;
+  if (chol && d.q_order && d.q_n_lr > 0 && chol_lrx_supported(a, implicit)) {
+    // explicit feedback, ranks 64 / 128: the rows of 1..64 ratings in push-through form, one wave per pass
+    if (!a.ne_stats && !a.wave_stats) {
+      hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax);
+      if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
+    }
+    a.wave_stats = g_ws.ne_stats;
+    a.lr_rows = d.q_order + d.q_lr_first; a.n_lr = d.q_n_lr; a.lrx = 1;
+    a.lr_n_gt32 = d.q_gt32 - d.q_lr_first; a.lr_n_gt16 = d.q_pair_first - d.q_lr_first;
+    a.lr_n_gt48 = d.q_gt48 - d.q_lr_first;
+  }
   if (chol && chol_wave_supported(rank) && padded_rank(rank) == 64) {
     // rank 33..64, one wave per row: the assembly runs on the matrix cores from fp16 operand terms scaled by max |X| (and max c)
-    if (!a.ne_stats) {
+    if (!a.ne_stats && !a.wave_stats) {
       hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax);
       if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
     }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, LONG ? 2 : RSP_CHOL_MINW) void als_chol2_kerne
   double wloss = 0.0;
 
   // short rows belong to the low-rank kernel (wrmf_chol_lr.hip) unless it stood down (flag set on the device)
-  const bool lr_on = !LONG && IMPLICIT && a.lr_flags && rfl((int)a.lr_flags[0]) == 0;
+  const bool lr_on = !LONG && ((IMPLICIT && a.lr_flags && rfl((int)a.lr_flags[0]) == 0) || a.lrx);
   // the main launch walks its own ranges of the length-sorted order (a.chol_list; see AlsArgs) instead of every column:
   // on the bench matrix it owns 1.5 of the 10 million user rows, and every skipped column was a dependent load
   const bool listed = !LONG && a.chol_list != nullptr;
@@ -451,7 +451,9 @@ hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
     return err;
   // per-kernel timing: ev[0] | low-rank kernel for the short rows (+ its one-workgroup prep) | ev[1] | k x k kernel(s) | ev[2]
   if (ev && (err = hipEventRecord(ev[0], s)) != hipSuccess) return err;
-  if (a.lr_flags) {   // the short rows first (its prep kernel also settles lr_flags before the launches below read it)
+  if (a.lrx) {   // explicit feedback: the short rows in push-through form
+    if ((err = launch_als_chol_lrx(a, a.lr_rows, a.n_lr, a.wave_stats, grid + kCholLongGrid, s, ev)) != hipSuccess) return err;
+  } else if (a.lr_flags) {   // the short rows first (its prep kernel also settles lr_flags before the launches below read it)
     if ((err = launch_als_chol_lr(a, a.lr_rows, a.n_lr, a.lr_M, a.lr_M + 128 * 128, a.lr_flags, grid + kCholLongGrid, s,
                                   ev)) != hipSuccess)
       return err;

@@ -22,7 +22,8 @@
 // Round 4: at rank 128 a pass belongs to ONE wave from the gather to the loss (als_chol_lrw_kernel, second half of this
 // file): the same algebra regrouped so that nothing is reduced over the lanes that hold the slots, no barrier, no operand
 // in LDS but a read-only copy of the terms of M^T -- 185 -> 55 ms on the user half of the bench matrix.  The workgroup kernel
-// below keeps the ranks 98..126.
+// below keeps the ranks 98..126.  Explicit feedback (als_explicit<T>'s exact branch, wrmf_explicit.hpp:103-108) has the same
+// form without a Gramian: als_chol_lrx_kernel, third part of this file, ranks 64 and 128.
 //
 // Needs every confidence >= 1 (D^1/2) and XtX positive definite: both are decided on the device (flags[0] != 0 ->
 // this kernel returns at once and wrmf_chol.hip's kernel, which otherwise skips the short rows, takes them).
@@ -728,6 +729,90 @@ __device__ __forceinline__ f16x8 lrw_pack(const unsigned a, const unsigned b, co
   return __builtin_bit_cast(f16x8, v);
 }
 
+// (S + padd I) z = u in registers, S symmetric, lane i = row i of its system: rl[t] = S[i][base + t] (diagonal entries are only
+// ever read as pivots, which is where padd is added: the identity of S = I + D^1/2 T D^1/2, or lambda).  SL = 64: one system on
+// the whole wave, NS <= 64 columns held (the register solve of the workgroup kernel: the pivot column's rows of 16 lanes are
+// copied into every row once per pivot, the multipliers are DPP row broadcasts inside the FMAs, the next pivot column is served
+// first and by v_readlane).  SL = 32 / 16: 64 / SL independent systems, one per group of SL lanes, register t = column t of the
+// group, every broadcast local to the group.  A `unit` lane is not a row of the system: it holds a row of right-hand-side kind,
+// every pivot eliminates it, its column is masked out of the broadcasts, and what the forward pass leaves in its u is returned
+// in u_fwd (its z is 0).  rl is destroyed.
+template <int SL, int NS>
+__device__ __forceinline__ void lrw_solve(float (&rl)[NS], float u, const int i, const bool unit, const float padd, float& z,
+                                          float& u_fwd) {
+  const int il = i & (SL - 1);
+  const int ie = unit ? 1024 : il;   // "row index" for the elimination: a unit lane is below every pivot
+  float dinv = 1.f;
+  z = 0.f;
+  if constexpr (SL == 64) {
+    float pj = readlane_f(rl[0], 0) + readlane_f(padd, 0);
+    lr_sfor<NS>([&](auto jt) {
+      constexpr int j = decltype(jt)::value;
+      const float inv = __builtin_amdgcn_rcpf(pj);
+      const float uj = readlane_f(u, j);
+      if (i == j) dinv = inv;
+      const float lij = ie > j ? rl[j] * inv : 0.f;
+      u = fmaf(-lij, uj, u);
+      if constexpr (j + 1 < NS) {
+        float cj = unit ? 0.f : rl[j];   // column j as the symmetric system has it
+        rl[j + 1] = fmaf(-lij, readlane_f(cj, j + 1), rl[j + 1]);
+        pj = readlane_f(rl[j + 1], j + 1) + readlane_f(padd, j + 1);
+        if constexpr (j + 2 < NS) {
+          float rep[4];
+          dpp_ready(cj);
+          rows_to_all<4>(cj, rep);
+          dpp_ready(rep[0], rep[1], rep[2], rep[3]);
+          lr_sfor<NS - j - 2>([&](auto ct) {
+            constexpr int c = j + 2 + decltype(ct)::value;
+            fnma_row_bcast<c % 16>(rl[c], rep[c / 16], lij);
+          });
+        }
+      }
+    });
+    u_fwd = u;
+    if (unit) dinv = 0.f;
+    float bacc = 0.f;
+#pragma unroll
+    for (int c = NS - 1; c >= 0; c--) {
+      if (i == c) z = (u - bacc) * dinv;
+      const float zc = readlane_f(z, c);
+      bacc = fmaf(i < c ? rl[c] : 0.f, zc, bacc);
+    }
+  } else {
+    static_assert(NS == SL || SL == 64, "packed systems hold all their columns");
+    lr_sfor<SL>([&](auto tt) {
+      constexpr int t = decltype(tt)::value;
+      float rep[4], ur[4];
+      float ct = unit ? 0.f : rl[t];   // column t as the symmetric system has it
+      dpp_ready(ct, u);
+      lrw_group<SL>(ct, rep);
+      lrw_group<SL>(u, ur);
+      dpp_ready(rep[0], rep[1], ur[0], ur[1]);
+      const float pv = lr_row_bcast<t % 16>(rep[t / 16]) + padd;   // (padd is uniform inside a group)
+      const float inv = __builtin_amdgcn_rcpf(pv);
+      if (il == t) dinv = inv;
+      const float lij = ie > t ? rl[t] * inv : 0.f;
+      fnma_row_bcast<t % 16>(u, ur[t / 16], lij);
+      lr_sfor<SL - t - 1>([&](auto ct2) {
+        constexpr int c = t + 1 + decltype(ct2)::value;
+        fnma_row_bcast<c % 16>(rl[c], rep[c / 16], lij);
+      });
+    });
+    u_fwd = u;
+    if (unit) dinv = 0.f;
+    float bacc = 0.f;
+    lr_sfor<SL>([&](auto tt) {
+      constexpr int c = SL - 1 - decltype(tt)::value;
+      if (il == c) z = (u - bacc) * dinv;
+      float zr[4];
+      lrw_group<SL>(z, zr);
+      dpp_ready(zr[0], zr[1]);
+      const float m = il < c ? -rl[c] : 0.f;
+      fnma_row_bcast<c % 16>(bacc, zr[c / 16], m);
+    });
+  }
+}
+
 #ifdef RSP_LRW_PROF
 // dev builds: s_memtime ticks per phase, summed over the waves of a class (read by rsparse_hip_dev_lrw_prof)
 __device__ unsigned long long g_lrw_prof[4][8];
@@ -1020,7 +1105,6 @@ __global__ __launch_bounds__(512) void als_chol_lrw_kernel(AlsArgs a, const int3
       // bench matrix has half of its confidences at 1.)  The broadcast copies of a pivot column are masked at such lanes, so
       // the other rows never see them: the system stays the symmetric one.
       const bool unit = valid && !(sq > 0.f);
-      const int ie = unit ? 1024 : il;   // "row index" for the elimination: a unit lane is below every pivot
       float repc[4], repq[4];
       lrw_group<SL>(cval, repc);
       lrw_group<SL>(sqs, repq);
@@ -1036,77 +1120,11 @@ __global__ __launch_bounds__(512) void als_chol_lrw_kernel(AlsArgs a, const int3
       });
       tc = -(tc * c2) * c2;   // (T c)_i
       float u = unit ? tc : tc * sq;   // h_i
-      float dinv = 1.f, z = 0.f;
+      float z = 0.f;
       if constexpr (RSP_LRW_ABL & 4) {
         z = u + rl[0] + rl[NS - 1];
-      } else if constexpr (SL == 64) {
-        // one system on the whole wave (the register solve of the workgroup kernel; diagonal entries are only ever read as
-        // pivots, which is where S = I + ... gets its identity)
-        float pj = readlane_f(rl[0], 0) + 1.f;
-        lr_sfor<NS>([&](auto jt) {
-          constexpr int j = decltype(jt)::value;
-          const float inv = __builtin_amdgcn_rcpf(pj);
-          const float uj = readlane_f(u, j);
-          if (i == j) dinv = inv;
-          const float lij = ie > j ? rl[j] * inv : 0.f;
-          u = fmaf(-lij, uj, u);
-          if constexpr (j + 1 < NS) {
-            float cj = unit ? 0.f : rl[j];   // column j as the symmetric system has it
-            rl[j + 1] = fmaf(-lij, readlane_f(cj, j + 1), rl[j + 1]);
-            pj = readlane_f(rl[j + 1], j + 1) + 1.f;
-            if constexpr (j + 2 < NS) {
-              float rep[4];
-              dpp_ready(cj);
-              rows_to_all<4>(cj, rep);
-              dpp_ready(rep[0], rep[1], rep[2], rep[3]);
-              lr_sfor<NS - j - 2>([&](auto ct) {
-                constexpr int c = j + 2 + decltype(ct)::value;
-                fnma_row_bcast<c % 16>(rl[c], rep[c / 16], lij);
-              });
-            }
-          }
-        });
-        p_i = u;   // (unit lanes)
-        if (unit) dinv = 0.f;
-        float bacc = 0.f;
-#pragma unroll
-        for (int c = NS - 1; c >= 0; c--) {
-          if (i == c) z = (u - bacc) * dinv;
-          const float zc = readlane_f(z, c);
-          bacc = fmaf(i < c ? rl[c] : 0.f, zc, bacc);
-        }
       } else {
-        // 64 / SL independent systems, one per group of SL lanes; register t = column t of the group
-        lr_sfor<SL>([&](auto tt) {
-          constexpr int t = decltype(tt)::value;
-          float rep[4], ur[4];
-          float ct = unit ? 0.f : rl[t];   // column t as the symmetric system has it
-          dpp_ready(ct, u);
-          lrw_group<SL>(ct, rep);
-          lrw_group<SL>(u, ur);
-          dpp_ready(rep[0], rep[1], ur[0], ur[1]);
-          const float pv = lr_row_bcast<t % 16>(rep[t / 16]) + 1.f;
-          const float inv = __builtin_amdgcn_rcpf(pv);
-          if (il == t) dinv = inv;
-          const float lij = ie > t ? rl[t] * inv : 0.f;
-          fnma_row_bcast<t % 16>(u, ur[t / 16], lij);
-          lr_sfor<SL - t - 1>([&](auto ct) {
-            constexpr int c = t + 1 + decltype(ct)::value;
-            fnma_row_bcast<c % 16>(rl[c], rep[c / 16], lij);
-          });
-        });
-        p_i = u;   // (unit lanes)
-        if (unit) dinv = 0.f;
-        float bacc = 0.f;
-        lr_sfor<SL>([&](auto tt) {
-          constexpr int c = SL - 1 - decltype(tt)::value;
-          if (il == c) z = (u - bacc) * dinv;
-          float zr[4];
-          lrw_group<SL>(z, zr);
-          dpp_ready(zr[0], zr[1]);
-          const float m = il < c ? -rl[c] : 0.f;
-          fnma_row_bcast<c % 16>(bacc, zr[c / 16], m);
-        });
+        lrw_solve<SL, NS>(rl, u, i, unit, 1.f, z, p_i);
       }
       e_i = cval - sq * z;   // (slots beyond the row: c = 0, sq = 0; unit slots: z = 0)
       // x_i . y = (T e)_i, and D^1/2 T e = D^1/2 T c - D^1/2 T D^1/2 z = h - (S - I) z = z
@@ -1215,6 +1233,293 @@ __global__ __launch_bounds__(512) void als_chol_lrw_kernel(AlsArgs a, const int3
   }
 }
 
+
+// ---- explicit feedback, one wave per pass (round 4) ---------------------------------------------------------------------
+// als_explicit<T>'s exact branch (inst/include/wrmf_explicit.hpp:103-108): lhs = X_nnz X_nnz^T + lambda_use I, rhs = X_nnz r.  For a
+// row of n <= 64 ratings the k x k factorisation is wasted on a rank-n matrix plus a multiple of the identity; push the inverse
+// through (no Gramian, so no M either):
+//     y = X_nnz (lambda I_n + T)^-1 r,   T = X_nnz^T X_nnz (n x n),     r_j - x_j . y = lambda z_j  with z = (lambda I + T)^-1 r
+// -- the loss terms are lambda z.  A pass is the 64 slots of the implicit kernel above (one row, two of <= 32 ratings, four of
+// <= 16), a wave owns it from the gather to the loss: the gathered vectors (lane = slot) ARE both operands of T on the matrix
+// cores, T reaches lane = row by lane swaps, (T + lambda I) z = r is lrw_solve, and y = sum_j z_j x_j is a sum over REGISTERS once
+// the vectors have been turned to lane = coordinate -- by multiplying them with the identity on the matrix cores.  Ranks 64 and 128.
+template <int NCH>
+__device__ __forceinline__ void lrx_wait_all(f32x4 (&x)[NCH][2]) {
+  if constexpr (NCH == 8) {
+    lrw_wait_all(x);
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]), "+v"(x[3][1])
+                 :: "memory");
+  }
+}
+
+template <int KP, int SL, int NS>
+__global__ __launch_bounds__(512) void als_chol_lrx_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows, int n64,
+                                                           int n32, int pass_lo, int pass_hi,
+                                                           const unsigned* __restrict__ stats, int loss_slot0) {
+  static_assert(KP == 64 || KP == 128, "ranks 64 and 128");
+  constexpr int lsh = SL == 64 ? 6 : (SL == 32 ? 5 : 4);
+  constexpr int NCH = KP / 16, NB = KP / 32;
+  __shared__ float sEall[8][64];
+  __shared__ double sRed[8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
+  float* sE = sEall[wv];
+  const int ex = lr_scale_exp(fmaxf(__uint_as_float(stats[0]), 1e-30f));
+  const float sx = lr_pow2(ex), ux = lr_pow2(254 - ex);   // scale of the fp16 terms and its inverse
+
+  const int P64 = n64, P32 = (n32 + 1) >> 1;
+  struct PassGeo { int lsh, li, lim; };
+  auto geo = [&](const int pp) {   // (all passes of a launch are of its class)
+    PassGeo g;
+    g.lsh = lsh;
+    if constexpr (SL == 64) { g.li = pp; g.lim = n64; }
+    else if constexpr (SL == 32) { g.li = n64 + 2 * (pp - P64) + (lane >> 5); g.lim = n64 + n32; }
+    else { g.li = n64 + n32 + 4 * (pp - P64 - P32) + (lane >> 4); g.lim = n_rows; }
+    if (pp >= pass_hi) g.lim = 0;
+    return g;
+  };
+
+  double wloss = 0.0;
+  const int G = gridDim.x * 8;
+  int it = pass_lo + blockIdx.x * 8 + wv;
+  int rid_c = -1, n_c = 0, rid_n = -1, p1_n = 0, n_n = 0, rid_nn = -1;
+  int id_c = 0;
+  float c_c = 0.f;
+  {
+    const PassGeo g0 = geo(it), g1 = geo(it + G), g2 = geo(it + 2 * G);
+    int p1_c = 0;
+    if (g0.li < g0.lim) {
+      rid_c = rows[g0.li];
+      p1_c = a.col_ptrs[rid_c];
+      n_c = a.col_ptrs[rid_c + 1] - p1_c;
+    }
+    if (g1.li < g1.lim) {
+      rid_n = rows[g1.li];
+      p1_n = a.col_ptrs[rid_n];
+      n_n = a.col_ptrs[rid_n + 1] - p1_n;
+    }
+    if (g2.li < g2.lim) rid_nn = rows[g2.li];
+    const int nz = lane & ((1 << g0.lsh) - 1);
+    if (nz < n_c) {
+      id_c = a.row_idx[p1_c + nz];
+      c_c = a.vals[p1_c + nz];
+    }
+  }
+  // the identity as B fragments: chunk cc of a block of 32 columns, element e of lane (n, hf) = (16 cc + 8 hf + e == n)
+  f16x8 idf[2];
+  {
+    const int n0 = lane & 31, hf0 = lane >> 5;
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+      const bool mine = (n0 >> 4) == cc && ((n0 >> 3) & 1) == hf0;
+      const int e1 = n0 & 7;   // 1.0 as fp16 = 0x3c00
+      unsigned w[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) w[q] = (mine && (e1 >> 1) == q) ? ((e1 & 1) ? 0x3c000000u : 0x00003c00u) : 0u;
+      idf[cc] = lrw_pack(w[0], w[1], w[2], w[3]);
+    }
+  }
+  for (; it < pass_hi; it += G) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // the lane id as this pass sees it (keeps lane-dependent addresses inside the pass)
+    const int nz_c = ln & ((1 << lsh) - 1);
+    const bool valid = nz_c < n_c;
+    const unsigned long long vmask = __ballot(valid);
+    int id_nx = 0, p1_nn = 0, n_nn = 0, rid_n3 = -1;
+    float c_nx = 0.f;
+    {
+      const PassGeo g1 = geo(it + G), g3 = geo(it + 3 * G);
+      const int nz1 = ln & ((1 << g1.lsh) - 1);
+      if (nz1 < n_n) {
+        id_nx = a.row_idx[p1_n + nz1];
+        c_nx = a.vals[p1_n + nz1];
+      }
+      if (rid_nn >= 0) {
+        p1_nn = a.col_ptrs[rid_nn];
+        n_nn = a.col_ptrs[rid_nn + 1] - p1_nn;
+      }
+      if (g3.li < g3.lim) rid_n3 = rows[g3.li];
+    }
+    const float rating = valid ? c_c : 0.f;
+    // lambda_use of the lane's row (a group without a row: 1, its lanes are inert)
+    const float lam_i = n_c > 0 ? (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)n_c : 1.0)) : 1.f;
+    const int n = ln & 31, hf = ln >> 5;
+
+    // ---- 1. gather (lane (n, hf): slots n and 32 + n, the coordinates 16 ch + 8 hf .. + 7 of chunk ch) -> fp16 terms ----
+    f16x8 th[NCH][2], tl[NCH][2];   // [chunk][slot tile]
+    {
+      const auto idsw = __builtin_amdgcn_permlane32_swap((unsigned)id_c, (unsigned)id_c, false, false);
+      const float sx0 = ((vmask >> n) & 1) ? sx : 0.f, sx1 = ((vmask >> (32 + n)) & 1) ? sx : 0.f;
+      const float* x0 = a.X + (size_t)idsw[0] * KP + 8 * hf;
+      const float* x1 = a.X + (size_t)idsw[1] * KP + 8 * hf;
+      f32x4 xr[2][NCH][2];
+      lr_sfor<NCH>([&](auto ct) {
+        constexpr int c8 = decltype(ct)::value;
+        lrw_ld16<64 * c8>(xr[0][c8][0], x0);
+        lrw_ld16<64 * c8 + 16>(xr[0][c8][1], x0);
+        lrw_ld16<64 * c8>(xr[1][c8][0], x1);
+        lrw_ld16<64 * c8 + 16>(xr[1][c8][1], x1);
+      });
+      lrx_wait_all<NCH>(xr[0]);
+      lrx_wait_all<NCH>(xr[1]);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+          const f32x4 p0 = xr[st][ch][0], p1 = xr[st][ch][1];
+          const float sxs = st ? sx1 : sx0;
+          unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+          lr_split(p0.x * sxs, p0.y * sxs, h0, l0);
+          lr_split(p0.z * sxs, p0.w * sxs, h1, l1);
+          lr_split(p1.x * sxs, p1.y * sxs, h2, l2);
+          lr_split(p1.z * sxs, p1.w * sxs, h3, l3);
+          th[ch][st] = lrw_pack(h0, h1, h2, h3);
+          tl[ch][st] = lrw_pack(l0, l1, l2, l3);
+        }
+    }
+    // ---- 2. T sx^2 = X_nnz^T X_nnz on the matrix cores, rows by lane swaps (see the implicit kernel) ----
+    float rl[NS];
+    {
+      f32x16 t[2][2];
+#pragma unroll
+      for (int e = 0; e < 16; e++) t[0][0][e] = t[0][1][e] = t[1][0][e] = t[1][1][e] = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ch++) {
+        const f16x8 a0h = th[ch][0], a0l = tl[ch][0], a1h = th[ch][1], a1l = tl[ch][1];
+        t[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a0h, t[0][0], 0, 0, 0);
+        if constexpr (SL == 64) t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a0h, t[1][0], 0, 0, 0);
+        if constexpr (SL == 64) t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a1h, t[0][1], 0, 0, 0);
+        t[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a1h, t[1][1], 0, 0, 0);
+        t[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a0l, t[0][0], 0, 0, 0);
+        if constexpr (SL == 64) t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a0l, t[1][0], 0, 0, 0);
+        if constexpr (SL == 64) t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, a1l, t[0][1], 0, 0, 0);
+        t[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, a1l, t[1][1], 0, 0, 0);
+        t[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, a0h, t[0][0], 0, 0, 0);
+        if constexpr (SL == 64) t[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, a0h, t[1][0], 0, 0, 0);
+        if constexpr (SL == 64) t[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, a1h, t[0][1], 0, 0, 0);
+        t[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, a1h, t[1][1], 0, 0, 0);
+      }
+      auto swp = [&](const int ta, const int v, float& c_lo, float& c_hi) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[ta][0][v]), __float_as_uint(t[ta][1][v]), false, false);
+        c_lo = __uint_as_float(sw[0]);
+        c_hi = __uint_as_float(sw[1]);
+      };
+      if constexpr (SL == 64) {
+#pragma unroll
+        for (int ta = 0; ta < 2; ta++)
+#pragma unroll
+          for (int v = 0; v < 16; v++) {
+            const int c0 = 32 * ta + 8 * (v >> 2) + (v & 3);
+            float y0, y1;
+            swp(ta, v, y0, y1);
+            if (c0 < NS) rl[c0] = y0;
+            if (c0 + 4 < NS) rl[c0 + 4] = y1;
+          }
+      } else if constexpr (SL == 32) {
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+          const int c0 = 8 * (v >> 2) + (v & 3);
+          float a0, a1, b0, b1;
+          swp(0, v, a0, a1);
+          swp(1, v, b0, b1);
+          rl[c0] = hf ? b0 : a0;
+          rl[c0 + 4] = hf ? b1 : a1;
+        }
+      } else {
+        const int gq = (ln >> 4) & 1;
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+          const int c0 = 8 * (v >> 2) + (v & 3);
+          float a0, a1, b0, b1, c0v, c1v, d0, d1;
+          swp(0, v, a0, a1);
+          swp(0, v + 8, b0, b1);
+          swp(1, v, c0v, c1v);
+          swp(1, v + 8, d0, d1);
+          const float lo0 = gq ? b0 : a0, lo1 = gq ? b1 : a1, hi0 = gq ? d0 : c0v, hi1 = gq ? d1 : c1v;
+          rl[c0] = hf ? hi0 : lo0;
+          rl[c0 + 4] = hf ? hi1 : lo1;
+        }
+      }
+    }
+    // ---- 3. (T + lambda I) z = r, in the scaled system: (T sx^2 + lambda sx^2 I) z' = r, z = z' sx^2 ----
+    float z = 0.f, dummy = 0.f;
+    lrw_solve<SL, NS>(rl, rating, ln, false, (lam_i * sx) * sx, z, dummy);
+    const float e_i = valid ? (z * sx) * sx : 0.f;
+    const float res = lam_i * e_i;   // r_j - x_j . y
+    const float loss_i = valid ? res * res : 0.f;
+    asm volatile("" : "+v"(id_nx), "+v"(c_nx), "+v"(p1_nn), "+v"(n_nn), "+v"(rid_n3));   // (see the implicit kernel)
+    wave_sync();
+    sE[ln] = e_i;
+    wave_sync();
+    // ---- 4. y = sum_j z_j x_j: the terms times the identity turn the vectors to lane = coordinate ----
+    float yreg = 0.f;   // sum over the pass's rows of lambda_use |y|^2
+    {
+      float4 ec[2][4];
+#pragma unroll
+      for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) ec[st][q] = *reinterpret_cast<const float4*>(sE + 32 * st + 8 * q + 4 * hf);
+      lr_sfor<NB>([&](auto cbt) {
+        constexpr int cb = decltype(cbt)::value;
+        f32x16 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 16; e++) p0[e] = p1[e] = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+          p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[2 * cb + cc][0], idf[cc], p0, 0, 0, 0);
+          p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[2 * cb + cc][1], idf[cc], p1, 0, 0, 0);
+          p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[2 * cb + cc][0], idf[cc], p0, 0, 0, 0);
+          p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[2 * cb + cc][1], idf[cc], p1, 0, 0, 0);
+        }
+        float q[4];
+#pragma unroll
+        for (int a2 = 0; a2 < 4; a2++) {
+          const float4 e0 = ec[0][a2], e1 = ec[1][a2];
+          const float s0 = fmaf(e0.x, p0[4 * a2], fmaf(e0.y, p0[4 * a2 + 1], fmaf(e0.z, p0[4 * a2 + 2], e0.w * p0[4 * a2 + 3])));
+          const float s1 = fmaf(e1.x, p1[4 * a2], fmaf(e1.y, p1[4 * a2 + 1], fmaf(e1.z, p1[4 * a2 + 2], e1.w * p1[4 * a2 + 3])));
+          if (a2 & 1) { q[a2 >> 1] += s0; q[2 + (a2 >> 1)] += s1; }
+          else { q[a2 >> 1] = s0; q[2 + (a2 >> 1)] = s1; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const unsigned uq = __float_as_uint(q[r]);
+          const auto sw = __builtin_amdgcn_permlane32_swap(uq, uq, false, false);
+          q[r] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * ux;
+        }
+        float yr[4];
+        if constexpr (SL == 64) { yr[0] = (q[0] + q[1]) + (q[2] + q[3]); yr[1] = yr[2] = yr[3] = 0.f; }
+        else if constexpr (SL == 32) { yr[0] = q[0] + q[1]; yr[1] = q[2] + q[3]; yr[2] = yr[3] = 0.f; }
+        else { yr[0] = q[0]; yr[1] = q[1]; yr[2] = q[2]; yr[3] = q[3]; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (r < (64 >> lsh)) {   // wave-uniform
+            const int rid = __builtin_amdgcn_readlane(rid_c, r << lsh);
+            const float lam_r = readlane_f(lam_i, r << lsh);
+            if (rid >= 0 && hf == 0) {
+              a.Y[(size_t)rid * KP + 32 * cb + n] = yr[r];
+              yreg = fmaf(lam_r * yr[r], yr[r], yreg);
+            }
+          }
+        }
+      });
+    }
+    const float lsum = wave_sum(loss_i), ysum = wave_sum(yreg);
+    wloss += (double)(lsum + ysum);
+    rid_c = rid_n; n_c = n_n;
+    rid_n = rid_nn; p1_n = p1_nn; n_n = n_nn;
+    rid_nn = rid_n3;
+    id_c = id_nx; c_c = c_nx;
+  }
+  if (lane == 0) sRed[wv] = wloss;
+  __syncthreads();
+  if (tid == 0) {
+    double s2 = 0.0;
+    for (int w = 0; w < 8; w++) s2 += sRed[w];
+    a.loss_partials[loss_slot0 + blockIdx.x] = s2;
+  }
+}
+
 }  // namespace
 
 // dev builds (-DRSP_AB): RSPARSE_HIP_LR_WAVE=0 keeps rank 128 on the workgroup kernel, for same-box comparisons
@@ -1298,6 +1603,52 @@ hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows,
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LrSmem<KP>::bytes, s, a, rows, n_rows, n64, n32,
                      reinterpret_cast<const _Float16*>(M), Mt, flags, loss_slot0);
   return hipGetLastError();
+}
+
+
+// explicit feedback, ranks 64 and 128, no bias operands: the rows of 1..kCholLrMax ratings in push-through form
+bool chol_lrx_supported(const AlsArgs& a, bool implicit) {
+  return !implicit && (a.k == 64 || a.k == 128) && !a.rhs_vals && !a.loss_tgt && !a.rhs_init &&
+         (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
+}
+
+// rows / counts as launch_als_chol_lr; stats: word 0 = bits of max |X| (launch_ne_stats).  Loss partials from loss_slot0 on
+// (kCholLrGrid slots, zeroed here).
+hipError_t launch_als_chol_lrx(const AlsArgs& a, const int32_t* rows, int n_rows, const unsigned* stats, int loss_slot0,
+                               hipStream_t s, hipEvent_t* ev_slot) {
+  int n64 = n_rows, n32 = 0;
+  if (a.lr_n_gt32 >= 0 && a.lr_n_gt16 >= a.lr_n_gt32 && a.lr_n_gt16 <= n_rows) {
+    n64 = a.lr_n_gt32;
+    n32 = a.lr_n_gt16 - a.lr_n_gt32;
+  }
+  hipError_t err;
+  if ((err = hipMemsetAsync(a.loss_partials + loss_slot0, 0, (size_t)kCholLrGrid * sizeof(double), s)) != hipSuccess)
+    return err;
+  if (n_rows <= 0) return hipSuccess;
+  int n48 = n64;
+  if (a.lr_n_gt48 >= 0 && a.lr_n_gt48 <= n64) n48 = a.lr_n_gt48;
+  const int P64 = n64, P32 = (n32 + 1) / 2, P16 = (n_rows - n64 - n32 + 3) / 4;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  cus = std::min(cus, kCholLrGrid / 4);
+  auto go = [&](auto kw, const int lo, const int hi, const int slot, const bool note) -> hipError_t {
+    if (hi <= lo) return hipSuccess;
+    const int gridw = std::min((hi - lo + 7) / 8, cus);
+    if (note) prof_note(ev_slot, reinterpret_cast<const void*>(kw));
+    hipLaunchKernelGGL(kw, dim3(gridw), dim3(512), 0, s, a, rows, n_rows, n64, n32, lo, hi, stats, loss_slot0 + slot * cus);
+    return hipGetLastError();
+  };
+#define RSP_LRX(KPV)                                                                                        \
+  {                                                                                                         \
+    if ((err = go(als_chol_lrx_kernel<KPV, 64, 64>, 0, n48, 0, false)) != hipSuccess) return err;           \
+    if ((err = go(als_chol_lrx_kernel<KPV, 64, 48>, n48, P64, 1, true)) != hipSuccess) return err;          \
+    if ((err = go(als_chol_lrx_kernel<KPV, 32, 32>, P64, P64 + P32, 2, false)) != hipSuccess) return err;   \
+    return go(als_chol_lrx_kernel<KPV, 16, 16>, P64 + P32, P64 + P32 + P16, 3, false);                      \
+  }
+  if (a.k == 64) RSP_LRX(64)
+  if (a.k == 128) RSP_LRX(128)
+#undef RSP_LRX
+  return hipErrorInvalidValue;
 }
 
 }  // namespace rsparse_hip

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(64, 3) void als_chol_wave_kernel(AlsArgs a, int los
 
   // the rows of the main launch as ranges of the length-sorted order (see als_chol2_kernel)
   const bool listed = a.chol_list != nullptr;
-  const int tail0 = listed ? a.chol_first + a.chol_n_main : 0;
+  // (explicit feedback with the push-through kernel of wrmf_chol_lr.hip: the rows of 1..64 ratings are its, the tail is the empty rows)
+  const int tail0 = listed ? (a.lrx ? a.chol_empty_first : a.chol_first + a.chol_n_main) : 0;
   const int n_tail = listed ? a.n_cols - tail0 : 0;
   const int n_iter = listed ? a.chol_n_main + n_tail : a.n_cols;
   auto row_at = [&](const int it2) {

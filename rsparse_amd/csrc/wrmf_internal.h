@@ -120,6 +120,7 @@ struct AlsArgs {
   int n_lr;
   int lr_n_gt32, lr_n_gt16;   // how many of them (a prefix: the list is longest first) have more than 32 / 16 non-zeros; -1 = unknown
   int lr_n_gt48;              // ... more than 48
+  int lrx;                    // explicit feedback: lr_rows are solved by the push-through wave kernel (wrmf_chol_lr.hip) and the k x k kernels skip them
   unsigned* lr_flags;
   float* lr_M;
   // rows split across workgroups: segment table, per-segment partial accumulators (kNeSegFloats floats each) and flags
@@ -204,6 +205,9 @@ constexpr int kCholLrMax = 64;
 constexpr int kCholLrGrid = 65536;   // (many more than workgroup slots: the hardware deals them as slots free up, see build_ne_lists)
 size_t chol2_loss_slots(int n_cols);
 bool chol_lr_supported(const AlsArgs& a, bool implicit);
+bool chol_lrx_supported(const AlsArgs& a, bool implicit);
+hipError_t launch_als_chol_lrx(const AlsArgs& a, const int32_t* rows, int n_rows, const unsigned* stats, int loss_slot0,
+                               hipStream_t s, hipEvent_t* ev_slot);
 hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows, float* M, float* Mt, unsigned* flags,
                               int loss_slot0, hipStream_t s, hipEvent_t* ev_slot = nullptr);
 hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);

@@ -131,6 +131,28 @@ def test_cholesky_short_rows_share_a_pass(k, classes):
     assert abs(loss - lref) <= TOL * abs(lref)
 
 
+@pytest.mark.parametrize("k", [64, 128, 60])
+@pytest.mark.parametrize("dynamic_lambda", [True, False])
+def test_cholesky_short_rows_explicit_push_through(k, dynamic_lambda):
+    """Explicit feedback, exact solver, rows of <= 64 ratings at rank 64 / 128 (wrmf_chol_lr.hip, als_chol_lrx_kernel):
+    y = X_nnz (lambda I + X_nnz^T X_nnz)^-1 r on one wave per pass, rows of <= 16 / <= 32 ratings sharing a pass -- every class
+    (49..64, 33..48, 17..32, <= 16), class sizes that are not multiples of the packing, empty rows and longer rows (the k x k /
+    wave-per-row kernels' share) in between, lambda_use = lambda * n and plain lambda; rank 60 keeps the k x k path."""
+    rng = np.random.default_rng(17)
+    lens = np.asarray(list(rng.integers(0, 70, size=260)) + [64, 49, 48, 33, 32, 17, 16, 1, 0, 65, 130, 64, 50, 40, 20, 10, 3],
+                      dtype=np.int64)
+    (n_item, n_rows, p_, idx, x), X, Y0 = _rows_of_lengths(lens, 400, k, seed=23 + k)
+    x = np.round(1.0 + 4.0 * rng.random(x.size))                 # ratings 1..5
+    csc = (n_item, n_rows, p_, idx, x)
+    cnt = np.bincount(idx, minlength=n_item).astype(np.float64)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 0, 3, False, dynamic_lambda, cnt)
+    Y = Y0.copy(order="F")
+    loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), 0.1, 1, 0, 3, dynamic_lambda, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, (int(np.argmax(err)), int(lens[int(np.argmax(err))]), float(err.max()))
+    assert abs(loss - lref) <= TOL * abs(lref), (loss, lref)
+
+
 @pytest.mark.parametrize("k", [128, 112])
 @pytest.mark.parametrize("conf", ["half_unit", "all_unit", "barely_above_one", "one_normal"])
 def test_cholesky_short_rows_with_confidence_exactly_one(k, conf):

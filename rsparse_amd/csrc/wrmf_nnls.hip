@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
   __syncthreads();
   double wloss = 0.0;
 
-  for (int row = blockIdx.x; row < a.n_cols; row += gridDim.x) {
+  for (int it = blockIdx.x; it < a.n_cols; it += gridDim.x) {
+    const int row = a.nnls_order ? rfl(a.nnls_order[it]) : it;   // (longest first: see AlsArgs)
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     const int cnt = p2 - p1;
     float* yrow = a.Y + (size_t)row * k;
@@ -326,7 +327,8 @@ __global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
   const unsigned long long in_range = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
   double wloss = 0.0;
 
-  for (int row = blockIdx.x; row < a.n_cols; row += gridDim.x) {
+  for (int it = blockIdx.x; it < a.n_cols; it += gridDim.x) {
+    const int row = a.nnls_order ? rfl(a.nnls_order[it]) : it;
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     const int cnt = p2 - p1;
     float* yrow = a.Y + (size_t)row * k;

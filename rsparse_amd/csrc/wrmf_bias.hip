@@ -10,6 +10,8 @@
 // initialize_biases_explicit (inst/include/wrmf_utils.hpp:32-84): optional global mean removed from the values of
 // both orientations, then five alternating sweeps  bias[c] = sum_{e in c}(v_e - other_bias[idx_e]) / (lambda_use + n_c),
 // one wave per column, sums in double.
+#include <algorithm>
+
 #include "wrmf_internal.h"
 #include "wrmf_f64.h"
 #include "wrmf_device.h"
@@ -177,6 +179,42 @@ hipError_t launch_bias_rhs_init(const float* X, int k, int off, int k1, int bias
   return hipGetLastError();
 }
 size_t bias_rhs_init_scratch_floats() { return (size_t)kRhsInitBlocks * kRhsInitW + kRhsInitW; }
+
+// ---- the re-packed operands at a rank that is a multiple of 4 ----
+// The solves of a biased half-iteration run at rank - 1 (the x-bias row dropped): 65 for the reference's rank = 64 + 2, an odd
+// number for every even user rank -- which the register-resident kernels do not take (their vectors are 16-byte pieces; the
+// LDS-tile fallback is an order of magnitude slower).  Coordinates of zeros change nothing: X' has no component there, the
+// warm start is 0 there, the system gets lambda (explicit) or 1 (the padded Gramian's diagonal) there against a right-hand side
+// of 0, so y stays 0 there under every solver, and the loss sums see zeros.  So the copies are padded to the next multiple of 4.
+namespace {
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, int src_stride, int src_off, int k1,
+                                                       int k1p, int64_t n, float* __restrict__ dst) {
+  const int64_t total = n * k1p;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / k1p;
+    const int c = (int)(e - r * k1p);
+    dst[e] = c < k1 ? src[r * src_stride + src_off + c] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void pad_gramian_kernel(const float* __restrict__ G, int k1, int k1p, float* __restrict__ Gp) {
+  for (int e = threadIdx.x; e < k1p * k1p; e += 256) {
+    const int r = e / k1p, c = e % k1p;
+    Gp[e] = (r < k1 && c < k1) ? G[r * k1 + c] : (r == c ? 1.f : 0.f);
+  }
+}
+}  // namespace
+
+hipError_t launch_pad_rows(const float* src, int src_stride, int src_off, int k1, int k1p, int64_t n, float* dst, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int64_t total = n * k1p;
+  const int grid = (int)std::min<int64_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, s, src, src_stride, src_off, k1, k1p, n, dst);
+  return hipGetLastError();
+}
+hipError_t launch_pad_gramian(const float* G, int k1, int k1p, float* Gp, hipStream_t s) {
+  hipLaunchKernelGGL(pad_gramian_kernel, dim3(1), dim3(256), 0, s, G, k1, k1p, Gp);
+  return hipGetLastError();
+}
 
 namespace {
 template <class T>

@@ -135,6 +135,18 @@ struct Workspace {
     }
     return RSPARSE_HIP_OK;
   }
+  float* pad_buf = nullptr;   // ranks that are not a multiple of 4: the padded copies of X, Y, XtX, rhs_init (run_half_iteration)
+  size_t pad_floats = 0;
+  int ensure_pad(size_t floats) {
+    if (floats > pad_floats) {
+      if (pad_buf) (void)hipFree(pad_buf);
+      pad_buf = nullptr;
+      pad_floats = 0;
+      HIP_TRY(hipMalloc(&pad_buf, floats * sizeof(float)));
+      pad_floats = floats;
+    }
+    return RSPARSE_HIP_OK;
+  }
   int ensure_bias(size_t floats) {
     if (floats > bias_floats) {
       if (bias_buf) (void)hipFree(bias_buf);
@@ -209,6 +221,8 @@ struct Workspace {
     ne_seg_scratch = nullptr; ne_seg_flags = nullptr; ne_seg_slots = 0;
     if (lr_M) (void)hipFree(lr_M);
     lr_M = nullptr;
+    if (pad_buf) (void)hipFree(pad_buf);
+    pad_buf = nullptr; pad_floats = 0;
     if (zero_row) (void)hipFree(zero_row);
     gram = nullptr; partials = nullptr; scalars = nullptr; fails = nullptr; zero_row = nullptr;
     gram_floats = 0; partial_slots = 0;
@@ -528,6 +542,38 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (rc) return rc;
   if ((rc = g_ws.ensure_device())) return rc;
   const DevCSC& d = conf->d;
+  if (rank % 4 != 0 && rank < 128) {
+    // A rank that is not a multiple of 4 (the reference's default is 10): the register-resident kernels take their vectors in
+    // 16-byte pieces, and the LDS-tile fallback that took these ranks through round 3 is several times slower.  Coordinates of
+    // zeros change nothing (wrmf_bias.hip, launch_pad_rows: the same argument as for the biased half-iterations), so the
+    // half-iteration runs on copies padded to the next multiple of 4 and the solved rows are copied back.
+    const int kp = (rank + 3) & ~3;
+    const size_t nx = (size_t)d.n_rows * kp, ny = (size_t)d.n_cols * kp, ng = (size_t)kp * kp;
+    if ((rc = g_ws.ensure_pad(nx + ny + ng + 256 + 16))) return rc;
+    float* Xp = g_ws.pad_buf;
+    float* Yp = Xp + nx;
+    float* Gp = Yp + ny;
+    float* rp = Gp + ng;
+    hipError_t e;
+    if ((e = launch_pad_rows(d_X, rank, 0, rank, kp, d.n_rows, Xp, s)) != hipSuccess) return hip_fail(e, "launch_pad_rows");
+    if ((e = launch_pad_rows(d_Y, rank, 0, rank, kp, d.n_cols, Yp, s)) != hipSuccess) return hip_fail(e, "launch_pad_rows");
+    if (implicit && (e = launch_pad_gramian(d_XtX, rank, kp, Gp, s)) != hipSuccess) return hip_fail(e, "launch_pad_gramian");
+    BiasTerms bp;
+    if (bias) {
+      bp = *bias;
+      if (bias->rhs_init) {   // (rank entries at the caller's: one row of kp, zeros beyond)
+        if ((e = launch_pad_rows(bias->rhs_init, rank, 0, rank, kp, 1, rp, s)) != hipSuccess) return hip_fail(e, "launch_pad_rows");
+        bp.rhs_init = rp;
+      }
+    }
+    rc = run_half_iteration(conf, implicit, Xp, Yp, implicit ? Gp : nullptr, kp, lambda, solver, cg_steps, dynamic_lambda,
+                            d_loss_rows_out, s, bias ? &bp : nullptr, d_absmax);
+    if (rc) return rc;
+    if (d.n_cols > 0)
+      HIP_TRY(hipMemcpy2DAsync(d_Y, (size_t)rank * 4, Yp, (size_t)kp * 4, (size_t)rank * 4, (size_t)d.n_cols,
+                               hipMemcpyDeviceToDevice, s));
+    return RSPARSE_HIP_OK;
+  }
   if (wide_supported(rank)) {
     // ranks 129..256: one kernel family for every solver and operand set (wrmf_wide.hip), no launch schedule
     double* outw = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
@@ -777,27 +823,25 @@ int run_half_iteration_explicit_biased(const rsparse_hip_csc* conf, const float*
   const int xb = is_x_bias_last_row ? rank - 1 : 0;  // row of X holding the x biases       (:59-64)
   const int ioff = is_x_bias_last_row ? 1 : 0;       // first kept entry of the warm start  (:90)
   const int ooff = is_x_bias_last_row ? 0 : 1;       // head / tail of Y.col(i)             (:115-127)
-  const size_t nx = (size_t)d.n_rows * k1, ny = (size_t)d.n_cols * k1, nv = (size_t)std::max<int64_t>(d.nnz, 1);
+  const int k1p = std::min((k1 + 3) & ~3, RSPARSE_HIP_MAX_RANK);   // the copies are padded to a multiple of 4 (wrmf_bias.hip: why)
+  const size_t nx = (size_t)d.n_rows * k1p, ny = (size_t)d.n_cols * k1p, nv = (size_t)std::max<int64_t>(d.nnz, 1);
   if ((rc = g_ws.ensure_bias(nx + ny + nv + 16))) return rc;
   float* Xp = g_ws.bias_buf;
   float* Yp = Xp + nx;
   float* vp = Yp + ny;
-  if (d.n_rows > 0)
-    HIP_TRY(hipMemcpy2DAsync(Xp, (size_t)k1 * 4, d_X + xoff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_rows,
-                             hipMemcpyDeviceToDevice, s));
-  if (d.n_cols > 0)
-    HIP_TRY(hipMemcpy2DAsync(Yp, (size_t)k1 * 4, d_Y + ioff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_cols,
-                             hipMemcpyDeviceToDevice, s));
-  hipError_t e = launch_bias_shift_values(d.vals, d.row_idx, d_X, rank, xb, d.nnz, vp, s);
+  hipError_t e;
+  if ((e = launch_pad_rows(d_X, rank, xoff, k1, k1p, d.n_rows, Xp, s)) != hipSuccess) return hip_fail(e, "launch_pad_rows");
+  if ((e = launch_pad_rows(d_Y, rank, ioff, k1, k1p, d.n_cols, Yp, s)) != hipSuccess) return hip_fail(e, "launch_pad_rows");
+  e = launch_bias_shift_values(d.vals, d.row_idx, d_X, rank, xb, d.nnz, vp, s);
   if (e != hipSuccess) return hip_fail(e, "launch_bias_shift_values");
   rsparse_hip_csc shifted = *conf;   // same sparsity and schedule, shifted ratings (a view: never destroyed)
   shifted.d.vals = vp;
   shifted.d.owns_matrix = false;
-  rc = run_half_iteration(&shifted, false, Xp, Yp, nullptr, k1, lambda, solver, cg_steps, dynamic_lambda,
+  rc = run_half_iteration(&shifted, false, Xp, Yp, nullptr, k1p, lambda, solver, cg_steps, dynamic_lambda,
                           d_loss_rows_out, s);
   if (rc) return rc;
   if (d.n_cols > 0)
-    HIP_TRY(hipMemcpy2DAsync(d_Y + ooff, (size_t)rank * 4, Yp, (size_t)k1 * 4, (size_t)k1 * 4, (size_t)d.n_cols,
+    HIP_TRY(hipMemcpy2DAsync(d_Y + ooff, (size_t)rank * 4, Yp, (size_t)k1p * 4, (size_t)k1 * 4, (size_t)d.n_cols,
                              hipMemcpyDeviceToDevice, s));
   return RSPARSE_HIP_OK;
 }
@@ -819,31 +863,35 @@ int run_half_iteration_implicit_biased(const rsparse_hip_csc* conf, const float*
   const int k1 = rank - 1;
   const int xoff = is_x_bias_last_row ? 0 : 1, xb = is_x_bias_last_row ? rank - 1 : 0;
   const int ioff = is_x_bias_last_row ? 1 : 0, ooff = is_x_bias_last_row ? 0 : 1;
-  const size_t nx = (size_t)d.n_rows * k1, ny = (size_t)d.n_cols * k1, nv = (size_t)std::max<int64_t>(d.nnz, 1);
-  const size_t nscr = bias_rhs_init_scratch_floats();
-  if ((rc = g_ws.ensure_bias(nx + ny + 2 * nv + nscr + 16))) return rc;
+  const int k1p = std::min((k1 + 3) & ~3, RSPARSE_HIP_MAX_RANK);   // the copies are padded to a multiple of 4 (wrmf_bias.hip: why)
+  const size_t nx = (size_t)d.n_rows * k1p, ny = (size_t)d.n_cols * k1p, nv = (size_t)std::max<int64_t>(d.nnz, 1);
+  const size_t nscr = bias_rhs_init_scratch_floats(), ng = (size_t)k1p * k1p;
+  if ((rc = g_ws.ensure_bias(nx + ny + 2 * nv + nscr + ng + 16))) return rc;
   float* Xp = g_ws.bias_buf;
   float* Yp = Xp + nx;
   float* rcoef = Yp + ny;
   float* tgt = rcoef + nv;
   float* scratch = tgt + nv;
-  float* rinit = scratch + (nscr - 256);
-  if (d.n_rows > 0)
-    HIP_TRY(hipMemcpy2DAsync(Xp, (size_t)k1 * 4, d_X + xoff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_rows,
-                             hipMemcpyDeviceToDevice, s));
-  if (d.n_cols > 0)
-    HIP_TRY(hipMemcpy2DAsync(Yp, (size_t)k1 * 4, d_Y + ioff, (size_t)rank * 4, (size_t)k1 * 4, (size_t)d.n_cols,
-                             hipMemcpyDeviceToDevice, s));
+  float* rinit = scratch + (nscr - 256);   // (256 entries, zeros beyond k1)
+  float* Gp = scratch + nscr;
+  hipError_t e;
+  if ((e = launch_pad_rows(d_X, rank, xoff, k1, k1p, d.n_rows, Xp, s)) != hipSuccess) return hip_fail(e, "launch_pad_rows");
+  if ((e = launch_pad_rows(d_Y, rank, ioff, k1, k1p, d.n_cols, Yp, s)) != hipSuccess) return hip_fail(e, "launch_pad_rows");
+  const float* G_use = d_XtX;
+  if (k1p != k1) {
+    if ((e = launch_pad_gramian(d_XtX, k1, k1p, Gp, s)) != hipSuccess) return hip_fail(e, "launch_pad_gramian");
+    G_use = Gp;
+  }
   const float gb = has_global_bias(global_bias, dbl_threshold) ? (float)global_bias : 0.f;
-  hipError_t e = launch_bias_implicit_terms(d.vals, d.row_idx, d_X, rank, xb, d.nnz, gb, rcoef, tgt, s);
+  e = launch_bias_implicit_terms(d.vals, d.row_idx, d_X, rank, xb, d.nnz, gb, rcoef, tgt, s);
   if (e != hipSuccess) return hip_fail(e, "launch_bias_implicit_terms");
   if ((e = launch_bias_rhs_init(d_X, rank, xoff, k1, xb, gb, d.n_rows, scratch, rinit, s)) != hipSuccess)
     return hip_fail(e, "launch_bias_rhs_init");
   BiasTerms bt{rcoef, tgt, rinit};
-  rc = run_half_iteration(conf, true, Xp, Yp, d_XtX, k1, lambda, solver, 0, 0, d_loss_rows_out, s, &bt);
+  rc = run_half_iteration(conf, true, Xp, Yp, G_use, k1p, lambda, solver, 0, 0, d_loss_rows_out, s, &bt);
   if (rc) return rc;
   if (d.n_cols > 0)
-    HIP_TRY(hipMemcpy2DAsync(d_Y + ooff, (size_t)rank * 4, Yp, (size_t)k1 * 4, (size_t)k1 * 4, (size_t)d.n_cols,
+    HIP_TRY(hipMemcpy2DAsync(d_Y + ooff, (size_t)rank * 4, Yp, (size_t)k1p * 4, (size_t)k1 * 4, (size_t)d.n_cols,
                              hipMemcpyDeviceToDevice, s));
   return RSPARSE_HIP_OK;
 }

@@ -236,6 +236,10 @@ hipError_t launch_bias_implicit_terms(const float* vals, const int32_t* row_idx,
 hipError_t launch_bias_rhs_init(const float* X, int k, int off, int k1, int bias_row, float global_bias, int n,
                                 float* scratch, float* out, hipStream_t s);
 size_t bias_rhs_init_scratch_floats();
+// dst (n x k1p, k1p = k1 rounded up to a multiple of 4) = columns [src_off, src_off + k1) of src (n rows of src_stride floats),
+// zeros beyond; Gp (k1p x k1p) = G (k1 x k1) with an identity on the padded diagonal (wrmf_bias.hip: why)
+hipError_t launch_pad_rows(const float* src, int src_stride, int src_off, int k1, int k1p, int64_t n, float* dst, hipStream_t s);
+hipError_t launch_pad_gramian(const float* G, int k1, int k1p, float* Gp, hipStream_t s);
 hipError_t launch_bias_implicit_prep(const int32_t* p, const float* x, int n_cols, int n_other, double lambda,
                                      double* means, double* adj, hipStream_t s);
 hipError_t launch_bias_implicit_sweep(const int32_t* p, const int32_t* i, const float* x, const float* other, int n_cols,

@@ -33,7 +33,7 @@ struct F64Args {
   double* m2_scratch;   // NNLS when two matrices do not fit the LDS: per workgroup KP * (KP + 1) doubles
 };
 
-constexpr int kF64MaxGrid = 256 * 8;       // workgroups of the per-row kernel (grid-stride over the rows)
+constexpr int kF64MaxGrid = 256 * 48;      // workgroups of the per-row kernel (grid-stride over the rows; the small-rank kernel is one wave and little LDS: up to 32 per CU are resident)
 constexpr int kF64GramBlocks = 256;        // partial Gramians
 size_t f64_gramian_scratch_doubles(int k);
 // XtX = X X^T + ridge I (k x k column-major), sumsq (nullable) = trace before the ridge

@@ -24,6 +24,9 @@
 // (fp32, BASELINE.json) does not run through it.
 #include <algorithm>
 
+#include <type_traits>
+#include <utility>
+
 #include "wrmf_f64.h"
 #include "wrmf_internal.h"
 
@@ -31,6 +34,15 @@ namespace rsparse_hip {
 namespace {
 
 constexpr double kCgTolD = 1e-10;        // CG_TOL, inst/include/wrmf.hpp:22
+template <class F, int... I>
+__device__ __forceinline__ void static_for_f64_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for_f64(F&& f) {
+  static_for_f64_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 constexpr unsigned kScdMaxIter = 10000;  // SCD_MAX_ITER, wrmf.hpp:20
 constexpr double kScdTol = 1e-4;         // SCD_TOL, wrmf.hpp:21
 constexpr double kNnlsEps = 1e-16;       // EPS, nnls.hpp:8
@@ -487,6 +499,232 @@ __global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, 
   if (tid == 0) a.loss_partials[blockIdx.x] = wloss;
 }
 
+// ---- the plain conjugate-gradient half-iteration, one WAVE per row (end of round 4) -------------------------------------------
+// cg_solver_implicit / cg_solver_explicit (wrmf_implicit.hpp:8-32, wrmf_explicit.hpp:8-31) with the operator evaluated as the
+// reference evaluates it -- A v = XtX v + X_nnz ((c - 1) o (X_nnz^T v)) (explicit: X_nnz X_nnz^T v + lambda_use v) -- instead of on
+// an assembled k x k system: the reference's DEFAULT configuration (rank 10, implicit, conjugate gradient, precision "double") ran
+// at 6 of 64 lanes in the generic kernel above (its 4 x 4 assembly tiles: six of them at rank 10..12) -- 53 ms per half-iteration
+// at 1M x 100k where the fp32 path takes 4.  No bias operands, no global bias; everything else stays with the generic kernel.
+// Layout: a group of W lanes (16 / 32 / 64: the rank rounded up) holds one gathered vector, lane l of the group = coordinate l, so a
+// step takes 64 / W non-zeros; x, r, p, A p live one coordinate per lane, replicated in every group.
+// lane-crossing helpers on doubles (two 32-bit halves through the DPP / lane-swap paths: no LDS round trips)
+template <int CTRL>
+__device__ __forceinline__ double f64_dpp(const double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int W>
+__device__ __forceinline__ double f64_group_sum(double v) {   // every lane of a group of W (16 / 32 / 64) ends with the group's sum
+  v += f64_dpp<0xB1>(v);    // quad_perm:[1,0,3,2]
+  v += f64_dpp<0x4E>(v);    // quad_perm:[2,3,0,1]
+  v += f64_dpp<0x141>(v);   // row_half_mirror
+  v += f64_dpp<0x140>(v);   // row_mirror: every lane of a row of 16 holds the row's sum
+  if constexpr (W >= 32) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // rows (0, 0, 2, 2) and (1, 1, 3, 3)
+    const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)sh[0], (int)sl[0]) + __hiloint2double((int)sh[1], (int)sl[1]);
+  }
+  if constexpr (W == 64) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto sl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);   // halves (0, 0) and (1, 1)
+    const auto sh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __hiloint2double((int)sh[0], (int)sl[0]) + __hiloint2double((int)sh[1], (int)sl[1]);
+  }
+  return v;
+}
+// the sum over the groups of a value held per lane (same coordinate in every group)
+template <int W>
+__device__ __forceinline__ double f64_across_groups(double v) {
+  if constexpr (W == 16) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)sh[0], (int)sl[0]) + __hiloint2double((int)sh[1], (int)sl[1]);
+  }
+  if constexpr (W <= 32) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto sl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto sh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __hiloint2double((int)sh[0], (int)sl[0]) + __hiloint2double((int)sh[1], (int)sl[1]);
+  }
+  return v;
+}
+// the value lane (group g, position ST) of the wave holds, in every lane of group g
+template <int W, int ST>
+__device__ __forceinline__ int f64_from_step_lane(const int v, const int g) {
+  if constexpr (W == 16) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + ST, 0xf, 0xf, true);   // row_newbcast:ST
+  } else if constexpr (W == 32) {
+    const int a0 = __builtin_amdgcn_readlane(v, ST), a1 = __builtin_amdgcn_readlane(v, 32 + ST);
+    return g ? a1 : a0;
+  } else {
+    return __builtin_amdgcn_readlane(v, ST);
+  }
+}
+
+template <int W, bool IMPLICIT>
+__global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, int n_hi, int slot0) {   // rows of n_lo < n <= n_hi non-zeros
+  constexpr int NPS = 64 / W;   // non-zeros per step
+  constexpr int BS = 16;        // steps per batch: their vectors are requested together, the next batch's before this one is used
+  constexpr int NBATCH = W / BS;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sG = reinterpret_cast<double*>(smem_raw);   // XtX (implicit), k x k
+  __shared__ double sLoss[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k = a.k;
+  const int l = lane & (W - 1), g = lane / W;
+  const bool lk = l < k;
+  const int lc = min(l, k - 1);
+  if (IMPLICIT) {
+    for (int e = tid; e < k * k; e += 256) sG[e] = a.XtX[e];
+    __syncthreads();
+  }
+  // (G v)_l, v one coordinate per lane (replicated in the groups): v_m from lane m of the wave
+  auto gmv = [&](const double v) {
+    double s0 = 0.0;
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    for (int m = 0; m < k; m++) {
+      const double vm = __hiloint2double(__builtin_amdgcn_readlane(hi, m), __builtin_amdgcn_readlane(lo, m));
+      s0 = fma(sG[lc + (size_t)m * k], vm, s0);
+    }
+    return lk ? s0 : 0.0;
+  };
+  double wloss = 0.0;
+  for (int row = blockIdx.x * 4 + wv; row < a.n_cols; row += gridDim.x * 4) {
+    const int p1 = a.col_ptrs[row], n = a.col_ptrs[row + 1] - p1;
+    double* yrow = a.Y + (size_t)row * k;
+    if (!(n > n_lo && n <= n_hi)) continue;   // another launch's row
+    if (n <= 0) {   // empty column -> zeros (wrmf_implicit.hpp:272-283, wrmf_explicit.hpp:133-144)
+      if (lane < k) yrow[lane] = 0.0;
+      continue;
+    }
+    const double lam_use = IMPLICIT ? a.lambda : a.lambda * (a.dynamic_lambda ? (double)n : 1.0);
+    // One pass over the row's vectors: out_l = sum_j coef(c_j, x_j . v) x_j[l], or (MODE 2) sum_j lw_j (lt_j - x_j . v)^2 in every lane.
+    // A chunk is 64 non-zeros: lane (g, st) holds the index and the value of the non-zero st * NPS + g, the one group g gathers in step st.
+    auto pass = [&](const double v, auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;   // 0: first residual, 1: operator, 2: loss
+      double acc = 0.0;
+      // (index, value) of the lane's non-zero of the chunk at c0, requested two chunks ahead of its use; the vectors of a batch of
+      // 16 steps one batch ahead, across chunk boundaries: a row of 500 non-zeros is 8 chunks x 5 passes, and every chunk used to
+      // cost two exposed round trips (its indices, then its vectors)
+      auto meta = [&](const int c0, int& idj, int& cjl, int& cjh) {
+        if (c0 < n) {   // wave-uniform
+          const int mine = min(l * NPS + g, n - c0 - 1);
+          idj = a.row_idx[p1 + c0 + mine];
+          const double cj = a.vals[p1 + c0 + mine];
+          cjl = __double2loint(cj);
+          cjh = __double2hiint(cj);
+        }
+      };
+      auto fetch = [&](auto bt, const int idj, const int nst, double (&dst)[BS]) {
+        constexpr int B = decltype(bt)::value;
+        if (B * BS < nst) {   // wave-uniform
+          static_for_f64<BS>([&](auto ut) {
+            constexpr int U = decltype(ut)::value, ST = B * BS + U;
+            const int id = f64_from_step_lane<W, ST>(idj, g);   // (steps beyond the chunk repeat its last non-zero: weight 0)
+            dst[U] = a.X[(size_t)id * k + lc];
+          });
+        }
+      };
+      int id0 = 0, c0l = 0, c0h = 0, id1 = 0, c1l = 0, c1h = 0, id2 = 0, c2l = 0, c2h = 0;
+      meta(0, id0, c0l, c0h);
+      meta(64, id1, c1l, c1h);
+      double cur[BS], nxt[BS];
+      fetch(std::integral_constant<int, 0>{}, id0, (min(64, n) + NPS - 1) / NPS, cur);
+      for (int c0 = 0; c0 < n; c0 += 64) {
+        const int cn = min(64, n - c0);
+        const int nst = (cn + NPS - 1) / NPS;                                       // steps of this chunk (<= W)
+        const int nst1 = c0 + 64 < n ? (min(64, n - c0 - 64) + NPS - 1) / NPS : 0;   // ... of the next one
+        meta(c0 + 128, id2, c2l, c2h);
+        static_for_f64<NBATCH>([&](auto bt) {
+          constexpr int B = decltype(bt)::value;
+          if (B * BS < nst) {   // wave-uniform
+            // the batch after this one: of this chunk, or the first of the next chunk
+            if ((B + 1) * BS < nst) {
+              if constexpr (B + 1 < NBATCH) fetch(std::integral_constant<int, (B + 1 < NBATCH ? B + 1 : 0)>{}, id0, nst, nxt);
+            } else if (nst1 > 0) {
+              fetch(std::integral_constant<int, 0>{}, id1, nst1, nxt);
+            }
+            static_for_f64<BS>([&](auto ut) {
+              constexpr int U = decltype(ut)::value, ST = B * BS + U;
+              if (ST < nst) {   // wave-uniform
+                const double yv = lk ? cur[U] : 0.0;
+                const bool in = ST * NPS + g < cn;
+                const double c = __hiloint2double(f64_from_step_lane<W, ST>(c0h, g), f64_from_step_lane<W, ST>(c0l, g));
+                const double t = f64_group_sum<W>(yv * v);
+                if constexpr (MODE == 2) {
+                  const double dlt = (IMPLICIT ? 1.0 : c) - t;
+                  acc += in ? (IMPLICIT ? c : 1.0) * dlt * dlt : 0.0;
+                } else {
+                  double coef;
+                  if constexpr (MODE == 0) coef = IMPLICIT ? c - (c - 1.0) * t : c - t;
+                  else coef = IMPLICIT ? (c - 1.0) * t : t;
+                  acc = fma(in ? coef : 0.0, yv, acc);
+                }
+              }
+            });
+#pragma unroll
+            for (int u = 0; u < BS; u++) cur[u] = nxt[u];
+          }
+        });
+        id0 = id1; c0l = c1l; c0h = c1h;
+        id1 = id2; c1l = c2l; c1h = c2h;
+      }
+      // the groups' shares (loss: every lane of a group holds the group's term)
+      return f64_across_groups<W>(acc);
+    };
+    // sums over the coordinates (one group's lanes; the groups hold copies)
+    auto dot = [&](const double u, const double v) { return f64_group_sum<W>(lk ? u * v : 0.0); };
+
+    double x = lk ? yrow[l] : 0.0;   // warm start
+    double r = pass(x, std::integral_constant<int, 0>{}) - (IMPLICIT ? gmv(x) : lam_use * x);
+    double pv = r;
+    double rsold = dot(r, r);
+    for (int it = 0; it < a.cg_steps; it++) {
+      const double ap = pass(pv, std::integral_constant<int, 1>{}) + (IMPLICIT ? gmv(pv) : lam_use * pv);
+      const double alpha = rsold / dot(pv, ap);
+      x = fma(alpha, pv, x);
+      r = fma(-alpha, ap, r);
+      const double rsnew = dot(r, r);
+      if (rsnew < kCgTolD) break;
+      pv = fma(pv, rsnew / rsold, r);
+      rsold = rsnew;
+    }
+    if (lane < k) yrow[lane] = x;   // (group 0)
+    const double lrow = pass(x, std::integral_constant<int, 2>{});
+    wloss += lrow + lam_use * dot(x, x);
+  }
+  if (lane == 0) sLoss[wv] = wloss;
+  __syncthreads();
+  if (tid == 0) a.loss_partials[slot0 + blockIdx.x] = (sLoss[0] + sLoss[1]) + (sLoss[2] + sLoss[3]);
+}
+
+bool f64_cg_wave_supported(const F64Args& a) {
+  return a.solver == 1 && a.xb < 0 && !a.rhs_init && a.gbias == 0.0 && a.k1 == a.k && a.xoff == 0 && a.ioff == 0 && a.ooff == 0 &&
+         !a.solve_empty && a.k >= 1 && a.k <= 64;
+}
+
+// slots: the loss partials a.loss_partials[0 .. slots) are this call's (all written or zeroed)
+// (Measured and not kept: the row's vectors resident in registers across the five passes -- one wave per row up to 256 non-zeros,
+//  the four waves of a workgroup sharing a row up to 1024 -- lost to the streaming kernel on both sides of the 1M x 100k matrix:
+//  200..256 registers and 64 unrolled steps per pass against 140 registers here; users 6.4 -> 12.5 ms, items 19 -> 23 ms.)
+template <int W>
+hipError_t launch_f64_cg_wave_w(const F64Args& a, int slots, hipStream_t s) {
+  const size_t lds = a.implicit ? (size_t)a.k * a.k * sizeof(double) : 0;
+  hipError_t err;
+  const int grid = std::max(1, std::min((a.n_cols + 3) / 4, slots));
+  if (grid < slots && (err = hipMemsetAsync(a.loss_partials + grid, 0, (size_t)(slots - grid) * sizeof(double), s)) != hipSuccess)
+    return err;
+  if (a.implicit) {
+    hipLaunchKernelGGL((f64_cg_wave_kernel<W, true>), dim3(grid), dim3(256), lds, s, a, -1, 0x7fffffff, 0);
+  } else {
+    hipLaunchKernelGGL((f64_cg_wave_kernel<W, false>), dim3(grid), dim3(256), lds, s, a, -1, 0x7fffffff, 0);
+  }
+  return hipGetLastError();
+}
+
 // ---- Gramian: partial[b] = sum over the block's columns of x x^T (lower-triangle tiles), then a fixed-order reduction ----
 __global__ __launch_bounds__(256) void f64_gramian_partial_kernel(const double* __restrict__ X, int k, int64_t n, int KP,
                                                                   int CH, double* __restrict__ partial) {
@@ -619,6 +857,11 @@ hipError_t launch_f64_als(const F64Args& a, hipStream_t s) {
   const F64Geo g = f64_geometry(a.k1, a.solver);
   const int grid = f64_als_grid(a.n_cols);
   hipError_t err;
+  if (f64_cg_wave_supported(a)) {   // the plain conjugate-gradient half-iteration: one wave per row, four rows per workgroup
+    if (a.k <= 16) return launch_f64_cg_wave_w<16>(a, grid, s);
+    if (a.k <= 32) return launch_f64_cg_wave_w<32>(a, grid, s);
+    return launch_f64_cg_wave_w<64>(a, grid, s);
+  }
   if (g.NT == 64) {
     auto kern = f64_als_kernel<64>;
     if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)) != hipSuccess)

@@ -1536,8 +1536,16 @@ int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_use
   if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
   if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 256 is not on the device path");
   if (n_exclude > 0 && !d_excl0) return fail(RSPARSE_HIP_ERR_INVALID, "exclude is NULL");
+  // (few users over many items: the items are split over the workgroups, the slices' lists land in this scratch)
+  float* scratch = nullptr;
+  const size_t ent = top_product_scratch_entries(n_users, n_items, k);
+  if (ent > 0) {
+    int rc = g_ws.ensure_pad(2 * ent + (size_t)n_users + 16);
+    if (rc) return rc;
+    scratch = g_ws.pad_buf;
+  }
   hipError_t e = launch_top_product(d_U, d_V, n_users, n_items, rank, k, d_nr_p, d_nr_p ? d_nr_j : nullptr, d_excl0,
-                                    n_exclude, (float)glob_mean, d_res, d_scores, (hipStream_t)stream);
+                                    n_exclude, (float)glob_mean, d_res, d_scores, (hipStream_t)stream, scratch);
   if (e != hipSuccess) return hip_fail(e, "launch_top_product");
   return RSPARSE_HIP_OK;
 }

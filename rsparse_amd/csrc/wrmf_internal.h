@@ -263,7 +263,10 @@ hipError_t launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t
 // both row-major; res / scores: n_users x topk row-major, indices 1-based, INT32_MIN / NaN when fewer than topk
 hipError_t launch_top_product(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
                               const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
-                              float glob_mean, int32_t* res, float* scores, hipStream_t s);
+                              float glob_mean, int32_t* res, float* scores, hipStream_t s, float* scratch = nullptr);
+// a call for few users over many items is split over the items (wrmf_topk.hip): floats of scratch it wants
+// (2 x entries + n_users), 0 = not split
+size_t top_product_scratch_entries(int n_users, int n_items, int topk);
 
 int padded_rank(int k);  // 32 / 64 / 128, or 0 if unsupported
 

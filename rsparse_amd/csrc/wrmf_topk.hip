@@ -18,6 +18,8 @@
 // reduced to their top k by rank counting and the threshold is raised.  After the first few tiles almost nothing
 // survives.  (Round 3: the staging loop used to be 4-byte loads with a run-time division per element and no load in
 // flight during the MFMAs -- 8.6 TFLOP/s at 1M x 1M, rank 128; see profiles/r03.)
+#include <algorithm>
+
 #include "wrmf_internal.h"
 #include "wrmf_device.h"
 
@@ -249,6 +251,25 @@ __device__ __forceinline__ void topk_emit_user(const float* bv, const int* bi, c
   }
 }
 
+// A split launch (few users, many items: blockIdx.y = item slice): the workgroup sees its slice as the matrix -- item ids are
+// item_base + local -- and writes to the slice's block of the scratch; the fall-back launch of the unsplit kernel (user_flags
+// given) runs only the workgroups that hold a flagged user.  See launch_top_product.
+#define RSP_TOPK_SLICE(USERS_, THREADS_)                                                                 \
+  int item_base = 0;                                                                                     \
+  if (slice_items > 0) {                                                                                 \
+    item_base = (int)blockIdx.y * slice_items;                                                           \
+    V += (size_t)item_base * k_rank;                                                                     \
+    n_items = max(0, min(n_items - item_base, slice_items));                                             \
+    res += (size_t)blockIdx.y * n_users * topk;                                                          \
+    scores_out += (size_t)blockIdx.y * n_users * topk;                                                   \
+  }                                                                                                      \
+  if (user_flags) {                                                                                      \
+    int f_ = 0;                                                                                          \
+    for (int e_ = threadIdx.x; e_ < (USERS_); e_ += (THREADS_))                                          \
+      if (u0 + e_ < n_users) f_ |= user_flags[u0 + e_];                                                  \
+    if (!__syncthreads_or(f_)) return;                                                                   \
+  }
+
 template <int KP, int UB, bool VEC, int W>
 __global__ __launch_bounds__(W * 64) void top_product_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                           int n_users, int n_items, int k_rank, int topk,
@@ -256,7 +277,8 @@ __global__ __launch_bounds__(W * 64) void top_product_kernel(const float* __rest
                                                           const int32_t* __restrict__ nr_idx,
                                                           const int32_t* __restrict__ excl, int n_excl,
                                                           float glob_mean, int32_t* __restrict__ res,
-                                                          float* __restrict__ scores_out) {
+                                                          float* __restrict__ scores_out, int slice_items,
+                                                          const int* __restrict__ user_flags) {
   using SM = TopSmem<KP, UB, W>;
   constexpr int LDT = SM::LDT, NK2 = KP / 2, kTopUsers = SM::USERS, kTopWaves = W;
   const int kTopCap = top_cap(topk, W);
@@ -272,6 +294,7 @@ __global__ __launch_bounds__(W * 64) void top_product_kernel(const float* __rest
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int u0 = blockIdx.x * kTopUsers;
+  RSP_TOPK_SLICE(kTopUsers, W * 64)
   const int col = lane & 31, half = lane >> 5;
   if (tid < kTopUsers) {
     sCnt[tid] = 0;
@@ -345,8 +368,8 @@ __global__ __launch_bounds__(W * 64) void top_product_kernel(const float* __rest
         for (int ub = 0; ub < UB; ub++) acc[ub] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[ub][t], b, acc[ub], 0, 0, 0);
       }
       // lane holds item `col` for users row(e) = (e & 3) + 8 (e >> 2) + 4 half of each block
-      const int item = i0 + col;
-      const bool item_ok = item < n_items && !(n_excl > 0 && sorted_contains(excl, n_excl, item));
+      const int item = i0 + col, gitem = item + item_base;
+      const bool item_ok = item < n_items && !(n_excl > 0 && sorted_contains(excl, n_excl, gitem));
 #pragma unroll
       for (int ub = 0; ub < UB; ub++)
 #pragma unroll
@@ -358,13 +381,13 @@ __global__ __launch_bounds__(W * 64) void top_product_kernel(const float* __rest
             bool skip = false;
             if (nr_ptr) {
               const int p1 = nr_ptr[u], p2 = nr_ptr[u + 1];
-              skip = sorted_contains(nr_idx + p1, p2 - p1, item);
+              skip = sorted_contains(nr_idx + p1, p2 - p1, gitem);
             }
             if (!skip) {
               const int pos = atomicAdd(&sCnt[ul], 1);
               if (pos < kTopCap) {
                 sVal[ul * kTopCap + pos] = s;
-                sIdx[ul * kTopCap + pos] = item;
+                sIdx[ul * kTopCap + pos] = gitem;
               }
             }
           }
@@ -410,7 +433,8 @@ __global__ __launch_bounds__(256) void top_product_shared_kernel(const float* __
                                                                  const int32_t* __restrict__ nr_idx,
                                                                  const int32_t* __restrict__ excl, int n_excl,
                                                                  float glob_mean, int32_t* __restrict__ res,
-                                                                 float* __restrict__ scores_out) {
+                                                                 float* __restrict__ scores_out, int slice_items,
+                                                                 const int* __restrict__ user_flags) {
   using SM = TopSharedSmem<KP, UB>;
   constexpr int LDT = SM::LDT, NK2 = KP / 2, USERS = SM::USERS, UPW = 32 * UB;   // users per wave
   const int cap = top_cap(topk, 1);
@@ -426,6 +450,7 @@ __global__ __launch_bounds__(256) void top_product_shared_kernel(const float* __
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int u0 = blockIdx.x * USERS, uw = wv * UPW;                 // this wave's users: [u0 + uw, u0 + uw + UPW)
+  RSP_TOPK_SLICE(USERS, 256)
   const int col = lane & 31, half = lane >> 5;
   for (int e = tid; e < USERS; e += 256) {
     sCnt[e] = 0;
@@ -511,7 +536,7 @@ __global__ __launch_bounds__(256) void top_product_shared_kernel(const float* __
         if (item_ok && u0 + ul < n_users && sc > tq[e & 3]) {   // appended unverified: topk_settle_user consults the lists
           const int pos = atomicAdd(&sCnt[ul], 1);               // (lanes of this wave only: at most 32 per user and tile)
           sVal[ul * cap + pos] = sc;
-          sIdx[ul * cap + pos] = item;
+          sIdx[ul * cap + pos] = item + item_base;
         }
       }
     wave_sync();
@@ -566,7 +591,8 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
                                                                const int32_t* __restrict__ nr_idx,
                                                                const int32_t* __restrict__ excl, int n_excl,
                                                                float glob_mean, int32_t* __restrict__ res,
-                                                               float* __restrict__ scores_out) {
+                                                               float* __restrict__ scores_out, int slice_items,
+                                                               const int* __restrict__ user_flags) {
   using SM = TopPipeSmem<KP, UB>;
   constexpr int LDT = SM::LDT, NK2 = KP / 2, USERS = SM::USERS, UPW = 32 * UB;
   constexpr int CH = NK2 / 16;   // k-steps (x UB matrix instructions) issued per accumulator entry of the previous tile
@@ -583,6 +609,7 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int u0 = blockIdx.x * USERS, uw = wv * UPW;
+  RSP_TOPK_SLICE(USERS, 256)
   const int col = lane & 31, half = lane >> 5;
   for (int e = tid; e < USERS; e += 256) {
     sCnt[e] = 0;
@@ -691,7 +718,7 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
         if (item_ok && u0 + ul < n_users && sc > tq[el & 3]) {
           const int pos = atomicAdd(&sCnt[ul], 1);
           sVal[ul * cap + pos] = sc;
-          sIdx[ul * cap + pos] = item;
+          sIdx[ul * cap + pos] = item + item_base;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -725,11 +752,134 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
   }
 }
 
+
+// ---- few users, many items: the items split over the workgroups, the slices' lists merged (end of round 4) --------------------
+// A call for a handful of users (the serving case) used to be ONE workgroup walking every item: 4.4 ms for one user over 100 k
+// items, 33 ms for 1000 users, on 1..4 of 256 CUs.  Split launch: grid = (user blocks, item slices), every slice produces its own
+// top k (exclusion lists applied, global item ids); one wave per user merges the S sorted lists.  The reference's result depends
+// on the order of arrival only through candidates AT the k-th score (its heap replaces on strict >): the merged list is the
+// sequential one whenever membership at that score is unambiguous -- no candidate left over at the k-th score, and no slice whose
+// own k-th entry sits at it (that slice may have dropped equals).  Otherwise the user is flagged and the unsplit kernel, launched
+// behind the merge with the flags, recomputes the workgroups that hold a flagged user (exact ties are degenerate inputs:
+// tests/test_top_product.py has them).
+__global__ __launch_bounds__(64) void top_merge_kernel(const float* __restrict__ sl_scores, const int32_t* __restrict__ sl_idx,
+                                                       int n_slices, int n_users, int topk, float glob_mean,
+                                                       int32_t* __restrict__ res, float* __restrict__ scores_out,
+                                                       int* __restrict__ user_flags) {
+  const int u = blockIdx.x, lane = threadIdx.x;
+  const size_t ustride = (size_t)n_users * topk;
+  const float* ls = sl_scores + (size_t)lane * ustride + (size_t)u * topk;
+  const int32_t* li = sl_idx + (size_t)lane * ustride + (size_t)u * topk;
+  const bool mine = lane < n_slices;
+  int pos = 0;
+  auto head = [&](float& hv, int& hi) {   // this slice's best unused entry (-inf: none)
+    hv = -INFINITY;
+    hi = INT32_MIN;
+    if (mine && pos < topk) {
+      const int ix = li[pos];
+      if (ix != INT32_MIN) {
+        hv = ls[pos];
+        hi = ix;
+      }
+    }
+  };
+  float tau = -INFINITY;
+  for (int out = 0; out < topk; out++) {
+    float hv;
+    int hi;
+    head(hv, hi);
+    float best = hv;
+    for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+    int bi = (hv == best && hi != INT32_MIN) ? hi : INT32_MIN;   // equal scores: the larger index first
+    for (int o = 32; o > 0; o >>= 1) bi = max(bi, __shfl_xor(bi, o));
+    if (bi == INT32_MIN) {   // fewer admissible items than k
+      if (lane == 0) {
+        res[(size_t)u * topk + out] = INT32_MIN;
+        scores_out[(size_t)u * topk + out] = __int_as_float(0x7fc00000);
+      }
+      tau = -INFINITY;
+    } else {
+      if (lane == 0) {
+        res[(size_t)u * topk + out] = bi;
+        scores_out[(size_t)u * topk + out] = best + glob_mean;
+      }
+      if (hi == bi && hv == best) pos++;
+      tau = best;
+    }
+  }
+  // ambiguity at the k-th score
+  float hv;
+  int hi;
+  head(hv, hi);
+  bool amb = false;
+  if (tau > -INFINITY) {
+    amb = hv == tau;                                                      // a candidate left over at tau
+    if (mine && li[topk - 1] != INT32_MIN && ls[topk - 1] == tau) amb = true;   // a full slice list that ends at tau
+  }
+  if (__any(amb) && lane == 0) user_flags[u] = 1;
+}
+
 }  // namespace
 
+namespace {
+hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
+                                  const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
+                                  float glob_mean, int32_t* res, float* scores, hipStream_t s, int n_slices, int slice_items,
+                                  const int* user_flags);
+}
+
+// how a call is split: slices of `slice_items` items (a multiple of 32), 1 = not at all
+int top_product_slices(int n_users, int n_items, int topk, int* slice_items) {
+  *slice_items = 0;
+  // (users per workgroup of the geometry launch_top_product_geo picks for this many users; a smaller one -- when the candidate
+  //  buffers of a large k do not fit -- only means more workgroups than planned)
+  const int upw = n_users > 128 ? 256 : (n_users > 64 ? 128 : (n_users > 32 ? 64 : 32));
+  const int ublocks = (n_users + upw - 1) / upw;
+  const int n_tiles = (n_items + 31) / 32;
+  if (n_users <= 0 || ublocks >= 128 || n_tiles < 128) return 1;   // enough workgroups already, or nothing to split
+  int S = std::min(64, std::min((512 + ublocks - 1) / ublocks, n_tiles / 32));
+  if ((size_t)S * n_users * topk > ((size_t)8 << 20)) S = (int)(((size_t)8 << 20) / ((size_t)n_users * topk));
+  if (S < 2) return 1;
+  const int st = (n_tiles + S - 1) / S;
+  *slice_items = 32 * st;
+  return (n_tiles + st - 1) / st;
+}
+size_t top_product_scratch_entries(int n_users, int n_items, int topk) {
+  int si = 0;
+  const int S = top_product_slices(n_users, n_items, topk, &si);
+  return S > 1 ? (size_t)S * n_users * topk : 0;
+}
+
+// scratch (nullable): top_product_scratch_entries floats + as many ints + n_users ints
 hipError_t launch_top_product(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
                               const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
-                              float glob_mean, int32_t* res, float* scores, hipStream_t s) {
+                              float glob_mean, int32_t* res, float* scores, hipStream_t s, float* scratch) {
+  int slice_items = 0;
+  const int S = scratch ? top_product_slices(n_users, n_items, topk, &slice_items) : 1;
+  if (S <= 1)
+    return launch_top_product_geo(U, V, n_users, n_items, k_rank, topk, nr_ptr, nr_idx, excl, n_excl, glob_mean, res, scores, s, 1,
+                                  0, nullptr);
+  const size_t ent = (size_t)S * n_users * topk;
+  float* sl_scores = scratch;
+  int32_t* sl_idx = reinterpret_cast<int32_t*>(scratch + ent);
+  int* flags = reinterpret_cast<int*>(sl_idx + ent);
+  hipError_t err;
+  if ((err = hipMemsetAsync(flags, 0, (size_t)n_users * sizeof(int), s)) != hipSuccess) return err;
+  if ((err = launch_top_product_geo(U, V, n_users, n_items, k_rank, topk, nr_ptr, nr_idx, excl, n_excl, 0.f, sl_idx, sl_scores, s, S,
+                                    slice_items, nullptr)) != hipSuccess)
+    return err;
+  hipLaunchKernelGGL(top_merge_kernel, dim3(n_users), dim3(64), 0, s, sl_scores, sl_idx, S, n_users, topk, glob_mean, res, scores,
+                     flags);
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  return launch_top_product_geo(U, V, n_users, n_items, k_rank, topk, nr_ptr, nr_idx, excl, n_excl, glob_mean, res, scores, s, 1, 0,
+                                flags);
+}
+
+namespace {
+hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
+                                  const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
+                                  float glob_mean, int32_t* res, float* scores, hipStream_t s, int n_slices, int slice_items,
+                                  const int* user_flags) {
   const int KP = (k_rank > 128 && k_rank <= 256) ? 256 : padded_rank(k_rank);   // (ranks 129..256: one user block per wave)
   if (!KP || topk < 1 || topk > kTopMaxK) return hipErrorInvalidValue;
   if (n_users <= 0) return hipSuccess;
@@ -744,8 +894,8 @@ hipError_t launch_top_product(const float* U, const float* V, int n_users, int n
                                    (int)lds)) != hipSuccess)                                                 \
       return err;                                                                                            \
     const int grid = (n_users + (USERS) - 1) / (USERS);                                                      \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, s, U, V, n_users, n_items, k_rank, topk, nr_ptr, nr_idx, \
-                       excl, n_excl, glob_mean, res, scores);                                                \
+    hipLaunchKernelGGL(kern, dim3(grid, n_slices), dim3(THREADS), lds, s, U, V, n_users, n_items, k_rank, topk, nr_ptr, \
+                       nr_idx, excl, n_excl, glob_mean, res, scores, slice_items, user_flags);               \
     return hipGetLastError();                                                                                \
   }
   // Geometry, best first: the four waves share the item tile and own 64 / 32 users each (256 / 128 users per workgroup:
@@ -805,5 +955,6 @@ hipError_t launch_top_product(const float* U, const float* V, int n_users, int n
 #undef RSP_TOPK_GO
   return hipErrorInvalidValue;
 }
+}  // namespace
 
 }  // namespace rsparse_hip

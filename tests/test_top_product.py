@@ -76,7 +76,10 @@ def _hip_top_product(x, y, k, nr=None, exclude=(), glob_mean=0.0):
                                           # with 256 / 128 users per workgroup, one tile per wave with 64 / 32, two waves with
                                           # 32 (k up to 256 at rank 128) -- and the scalar staging path (rank % 4 != 0)
                                           (128, 300, 5000, 10), (128, 100, 3000, 100), (128, 70, 4000, 200),
-                                          (64, 300, 2000, 256), (128, 33, 2000, 256), (30, 140, 900, 5), (128, 40, 1000, 120)])
+                                          (64, 300, 2000, 256), (128, 33, 2000, 256), (30, 140, 900, 5), (128, 40, 1000, 120),
+                                          # few users over many items: the items are split over the workgroups and the slices'
+                                          # lists merged (one user: 64 slices; 1000 users: 16)
+                                          (128, 1, 70000, 10), (64, 3, 20000, 100), (128, 1000, 9000, 10), (16, 37, 5000, 256)])
 def test_hip_matches_oracle(rank, nr, nc, k):
     rng = np.random.default_rng(rank + nr)
     x = rng.standard_normal((nr, rank)).astype(np.float32).astype(np.float64)
@@ -133,6 +136,34 @@ def test_hip_tied_scores_follow_the_heap(k):
                                          exclude=kw.get("exclude", ()))
             got_i, got_s = _hip_top_product(x, y, k, **kw)
             assert np.array_equal(got_i, ref_i) and np.array_equal(got_s, ref_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [3, 40])
+def test_hip_split_items_with_ties_falls_back_to_the_heap(k):
+    """The split launch (few users, many items) merges per-slice lists; membership at the k-th score is ambiguous when more
+    candidates sit there than places -- then the user is recomputed by the unsplit kernel, which follows the reference's heap.
+    Integer-valued factors over 6000 items (ties everywhere), with and without exclusion lists; plus k larger than the number of
+    admissible items (NA fill through the merge)."""
+    rng = np.random.default_rng(7 + k)
+    for n_users in (1, 9, 70):
+        x = rng.integers(0, 3, (n_users, 4)).astype(np.float64)
+        y = rng.integers(0, 3, (4, 6000)).astype(np.float64)
+        nr = sp.random(n_users, 6000, density=0.01, format="csr", random_state=np.random.RandomState(k))
+        nr.sort_indices()
+        for kw in ({}, {"nr": nr, "exclude": [3, 77, 5999]}):
+            ref_i, ref_s = O.top_product(x, y, k, *((kw["nr"].indptr, kw["nr"].indices) if kw else (None, None)),
+                                         exclude=kw.get("exclude", ()))
+            got_i, got_s = _hip_top_product(x, y, k, **kw)
+            assert np.array_equal(got_i, ref_i) and np.array_equal(got_s, ref_s)
+    # almost everything excluded: fewer admissible items than k
+    x = rng.standard_normal((2, 8))
+    y = rng.standard_normal((8, 5000))
+    excl = list(range(1, 5001 - 2))                      # 1-based: all but the last two items
+    ref_i, ref_s = O.top_product(x, y, k, exclude=excl)
+    got_i, got_s = _hip_top_product(x, y, k, exclude=excl)
+    assert np.array_equal(got_i, ref_i) and np.array_equal(np.isnan(got_s), np.isnan(ref_s))
+    assert (got_i[:, 2:] == O.NA_INTEGER).all()
 
 
 @pytest.mark.gpu

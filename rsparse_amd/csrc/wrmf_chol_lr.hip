@@ -1606,9 +1606,11 @@ hipError_t launch_als_chol_lr(const AlsArgs& a, const int32_t* rows, int n_rows,
 }
 
 
-// explicit feedback, ranks 64 and 128, no bias operands: the rows of 1..kCholLrMax ratings in push-through form
+// explicit feedback, ranks 64 and 128, no bias operands, lambda > 0 (with the reference's default lambda = 0 the k x k system of a
+// row of n < k ratings is singular: that case keeps the k x k kernels and their general-solver fall-back, which report it): the
+// rows of 1..kCholLrMax ratings in push-through form
 bool chol_lrx_supported(const AlsArgs& a, bool implicit) {
-  return !implicit && (a.k == 64 || a.k == 128) && !a.rhs_vals && !a.loss_tgt && !a.rhs_init &&
+  return !implicit && (a.k == 64 || a.k == 128) && !a.rhs_vals && !a.loss_tgt && !a.rhs_init && a.lambda > 0.f &&
          (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
 }
 

@@ -22,6 +22,10 @@
 // This is the parity path of the *_double entry points, built for correctness in double first: it moves k1^2 flops per
 // non-zero (the fp32 conjugate-gradient kernels move 8 k (cg_steps + 1)) and one row occupies a workgroup.  The bench line
 // (fp32, BASELINE.json) does not run through it.
+//
+// The one configuration with its own kernel is the constructor's default -- plain conjugate gradient, no biases, rank <= 64
+// (f64_cg_wave_kernel below, round 4): one wave per row, the operator applied from the gathered vectors as the reference
+// does (no k1 x k1 matrix), 4.5x the generic kernel at rank 10.  Everything else goes through the workgroup-per-row family.
 #include <algorithm>
 
 #include <type_traits>

@@ -1,6 +1,7 @@
 """Test-only stand-in for rsparse_amd.engine.HipBackend that runs the CPU oracle on CPU tensors,
 so the multi-rank control flow of ShardedALS (sharding, Gramian all-reduce, factor all-gather,
-loss all-reduce) can run under gloo without a GPU.  Never imported by the product."""
+loss all-reduce) can run under gloo without a GPU, and so can the one-rank driver of WRMF.fit_transform
+(tests/test_wrmf_single.py).  Never imported by the product."""
 import numpy as np
 import torch
 
@@ -30,6 +31,40 @@ class OracleBackend:
 
     def make_csc(self, n_rows, n_cols, p, i, x):
         return _Csc(n_rows, n_cols, p, i, x)
+
+    # ---- what only the one-rank path of WRMF.fit_transform asks of its backend (HipBackend: kernels of wrmf_ingest.hip /
+    # wrmf_bias.hip behind the C ABI) -------------------------------------------------------------------------------------
+    def values_to_float(self, x64):
+        return x64.to(torch.float32)
+
+    def transpose_csc(self, n_rows, n_cols, p, i, x):
+        tp, ti, tx = O.csc_transpose(n_rows, n_cols, p.numpy(), i.numpy(), x.numpy())
+        return torch.from_numpy(tp), torch.from_numpy(ti), torch.from_numpy(tx)
+
+    def subtract_mean(self, x, x_other=None):
+        m = float(x.to(torch.float64).mean()) if x.numel() else 0.0
+        x -= m
+        if x_other is not None:
+            x_other -= m
+        return m
+
+    def _init_biases(self, fn, csc_ui, csc_iu, user_bias, item_bias, *args, **kw):
+        x1, x2 = csc_ui.x, csc_iu.x                      # float64 copies; the oracle removes the mean from them in place
+        ub, ib = user_bias.numpy(), item_bias.numpy()    # views: filled in place
+        gb = fn((csc_ui.p, csc_ui.i, x1), (csc_iu.p, csc_iu.i, x2), ub, ib, *args, **kw)
+        csc_ui._x.copy_(torch.from_numpy(x1))
+        csc_iu._x.copy_(torch.from_numpy(x2))
+        return gb
+
+    def initialize_biases_explicit(self, csc_ui, csc_iu, user_bias, item_bias, lambda_, dynamic_lambda, non_negative,
+                                   calculate_global_bias):
+        return self._init_biases(O.init_biases_explicit, csc_ui, csc_iu, user_bias, item_bias, lambda_, dynamic_lambda,
+                                 non_negative, calculate_global_bias)
+
+    def initialize_biases_implicit(self, csc_ui, csc_iu, user_bias, item_bias, lambda_, non_negative,
+                                   calculate_global_bias=False):
+        return self._init_biases(O.init_biases_implicit, csc_ui, csc_iu, user_bias, item_bias, lambda_, non_negative,
+                                 calculate_global_bias=calculate_global_bias)
 
     @staticmethod
     def _f(t):  # (n, k) row-major tensor -> (k, n) column-major numpy view

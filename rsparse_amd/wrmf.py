@@ -153,8 +153,16 @@ class WRMF:
         if ws > 1:
             return self._fit_transform_sharded(x, n_iter, convergence_tol, ws, me)
         be = self._backend()
-        c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))               # :184-188
-        c_ui.sort_indices()
+        # A canonical CSR matrix IS the item-user orientation (c_iu = t_shallow(as.csr.matrix(c_ui)), :190): it is uploaded as
+        # it stands and the device produces c_ui from it, instead of the host converting to CSC first (1.4 s of 5e7 non-zeros
+        # on one core, more than ten iterations of the fit) and the device converting back.  Same arrays on the device either
+        # way.  A user-supplied `preprocess` is defined on the CsparseMatrix (:184-188) and keeps the conversion.
+        by_rows = sp.issparse(x) and x.format == "csr" and self._preprocess is _identity and x.has_canonical_format
+        if by_rows:
+            c_ui = x if x.dtype == np.float64 else x.astype(np.float64)            # (named for what it holds, not its layout)
+        else:
+            c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))           # :184-188
+            c_ui.sort_indices()
         if (self._feedback != "explicit" or self._non_negative) and c_ui.nnz and c_ui.data.min() < 0:
             raise ValueError("all(c_ui@x >= 0) is not TRUE")                       # :195-197
         n_user, n_item = c_ui.shape
@@ -186,9 +194,12 @@ class WRMF:
         # one orientation crosses the boundary (f64 values as in dgCMatrix@x); the item-user orientation
         # c_iu = t_shallow(as.csr.matrix(c_ui)) (:190) and the f32 values are produced on the device
         x64 = be.to_device(c_ui.data, torch.float64)
-        d_ui = (be.to_device(c_ui.indptr, torch.int32), be.to_device(c_ui.indices, torch.int32),
-                x64 if self._f64 else be.values_to_float(x64))
-        d_iu = be.transpose_csc(n_user, n_item, *d_ui)
+        up = (be.to_device(c_ui.indptr, torch.int32), be.to_device(c_ui.indices, torch.int32),
+              x64 if self._f64 else be.values_to_float(x64))
+        if by_rows:
+            d_iu, d_ui = up, be.transpose_csc(n_item, n_user, *up)
+        else:
+            d_ui, d_iu = up, be.transpose_csc(n_user, n_item, *up)
         als = ShardedALS(be, n_user, n_item, k, d_ui, d_iu, c_ui.nnz,
                          feedback=self._feedback, lambda_=self._lambda, dynamic_lambda=self._dynamic_lambda,
                          cg_steps=self._cg_steps, with_bias=self._with_bias)

@@ -27,7 +27,9 @@ class OracleBackend:
     name = "oracle"
 
     def to_device(self, a, dtype):
-        return torch.as_tensor(a, dtype=dtype).contiguous()
+        # a COPY, as an upload is: what the driver then changes in place (the global mean leaving the values) must not
+        # reach the caller's arrays
+        return torch.as_tensor(a, dtype=dtype).clone().contiguous()
 
     def make_csc(self, n_rows, n_cols, p, i, x):
         return _Csc(n_rows, n_cols, p, i, x)

@@ -183,3 +183,81 @@ def test_refit_warm_starts_from_components():
     c._init_user_factors = U0
     c.fit_transform(m, n_iter=2, convergence_tol=-1)
     assert rel_fro(c.components, first) < 1e-12 and rel_fro(a.components, first) > 1e-4   # the start mattered
+
+
+def test_csr_input_is_uploaded_as_it_stands_and_gives_the_same_device_arrays():
+    """A canonical CSR matrix is the item-user orientation already (R/model_WRMF.R:190): fit_transform uploads it and has the
+    device produce the user-item one, instead of converting on the host.  Both routes must hand the SAME arrays to the
+    solver (bit for bit: index and value work), whatever the index / value types of the input; anything that is not a
+    canonical CSR matrix, and any model with a `preprocess`, keeps the conversion."""
+    from oracle_backend import OracleBackend
+    from rsparse_amd import WRMF
+
+    class Spy(OracleBackend):
+        def __init__(self):
+            self.made, self.transposed = [], []
+
+        def make_csc(self, n_rows, n_cols, p, i, x):
+            self.made.append((n_rows, n_cols, p.numpy().copy(), i.numpy().copy(), x.numpy().copy()))
+            return super().make_csc(n_rows, n_cols, p, i, x)
+
+        def transpose_csc(self, n_rows, n_cols, p, i, x):
+            self.transposed.append((n_rows, n_cols))
+            return super().transpose_csc(n_rows, n_cols, p, i, x)
+
+    def uploads(x, **kw):
+        be = Spy()
+        model = WRMF(rank=4, lambda_=0.1, feedback="implicit", precision="float", backend=be, rng=3, **kw)
+        model.fit_transform(x, n_iter=1, convergence_tol=-1)
+        return be
+
+    m, _ = _problem()
+    m = sp.lil_matrix(m, dtype=np.float64)
+    m[5, :] = 0                      # a user and an item without data
+    m[:, 7] = 0
+    m = sp.csr_matrix(m)
+    m.eliminate_zeros()
+    m.sort_indices()
+    n_user, n_item = m.shape
+    want = uploads(sp.csc_matrix(m))
+    assert want.transposed == [(n_user, n_item)]                       # the CSC route: c_iu made on the device
+    as_f32 = m.astype(np.float32)
+    as_i64 = m.copy()
+    as_i64.indptr, as_i64.indices = as_i64.indptr.astype(np.int64), as_i64.indices.astype(np.int64)
+    for name, x in (("f64", m), ("f32", as_f32), ("int64 indices", as_i64)):
+        assert x.format == "csr" and x.has_canonical_format
+        got = uploads(x)
+        assert got.transposed == [(n_item, n_user)], name                # the CSR route: c_ui made on the device
+        assert len(got.made) == len(want.made) > 0
+        for g, w in zip(got.made, want.made):
+            assert g[:2] == w[:2], name
+            for a, b in zip(g[2:], w[2:]):
+                assert a.dtype == b.dtype and np.array_equal(a, b), name
+    # not canonical: unsorted indices, duplicates -> the host conversion, as before
+    rng = np.random.default_rng(0)
+    shuffled = m.copy()
+    for r in range(n_user):
+        lo, hi = shuffled.indptr[r], shuffled.indptr[r + 1]
+        perm = rng.permutation(hi - lo)
+        shuffled.indices[lo:hi], shuffled.data[lo:hi] = shuffled.indices[lo:hi][perm], shuffled.data[lo:hi][perm]
+    shuffled.has_sorted_indices = False
+    shuffled.has_canonical_format = False
+    got = uploads(shuffled)
+    assert got.transposed == [(n_user, n_item)]
+    for g, w in zip(got.made, want.made):
+        assert all(np.array_equal(a, b) for a, b in zip(g[2:], w[2:]))
+    # a model with a preprocess function sees the CsparseMatrix, whatever came in
+    seen = []
+
+    def pre(c):
+        seen.append(c.format)
+        return c
+    got = uploads(m, preprocess=pre)
+    assert seen == ["csc"] and got.transposed == [(n_user, n_item)]
+    # the input is not modified -- neither its types nor, when the global mean leaves the resident values (:278-282), its data
+    assert as_f32.dtype == np.float32 and as_i64.indices.dtype == np.int64
+    before = m.data.copy()
+    model = WRMF(rank=4, lambda_=0.1, feedback="explicit", solver="cholesky", with_global_bias=True, precision="double",
+                 backend=OracleBackend(), rng=3)
+    model.fit_transform(m, n_iter=1, convergence_tol=-1)
+    assert model.global_bias == pytest.approx(before.mean(), rel=1e-12) and np.array_equal(m.data, before)

@@ -254,6 +254,10 @@ class WRMF:
         the Gramian / loss sums does)."""
         import torch.distributed as dist
         be = self._backend()
+        # (a canonical CSR matrix is c_iu already -- its transpose is a CSC matrix over the same arrays --, which saves the host
+        # the second of its two conversions; see fit_transform)
+        by_rows = sp.issparse(x) and x.format == "csr" and self._preprocess is _identity and x.has_canonical_format
+        c_iu = sp.csc_matrix(x.T, dtype=np.float64) if by_rows else None
         c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))
         c_ui.sort_indices()
         if (self._feedback != "explicit" or self._non_negative) and c_ui.nnz and c_ui.data.min() < 0:
@@ -293,11 +297,15 @@ class WRMF:
             self.global_bias = float(np.mean(c_ui.data)) if c_ui.nnz else 0.0
             c_ui = c_ui.copy()
             c_ui.data -= self.global_bias
+            if c_iu is not None:
+                c_iu = c_iu.copy()                                                 # (it shares its arrays with the caller's x)
+                c_iu.data -= self.global_bias
         elif self._with_global_bias:                                               # :285-287
             sm = float(c_ui.data.sum())
             self.global_bias = sm / (sm + float(n_user) * float(n_item) - float(c_ui.nnz))
-        c_iu = sp.csc_matrix(c_ui.T)          # t_shallow(as.csr.matrix(c_ui)), :190 (host side: only blocks are uploaded)
-        c_iu.sort_indices()
+        if c_iu is None:
+            c_iu = sp.csc_matrix(c_ui.T)      # t_shallow(as.csr.matrix(c_ui)), :190 (host side: only blocks are uploaded)
+            c_iu.sort_indices()
         cnt_item = torch.from_numpy(np.diff(c_ui.indptr).astype(np.int64))
         cnt_user = torch.from_numpy(np.diff(c_iu.indptr).astype(np.int64))
         lay_u, lay_i = ShardedALS.layouts(n_user, n_item, ws, cnt_user, cnt_item, n_sub=self._n_sub)

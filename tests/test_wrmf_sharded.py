@@ -191,3 +191,46 @@ def test_wrmf_two_ranks_with_user_item_biases(tmp_path, feedback, solver, gb):
     nt = sp.csc_matrix(new.T); nt.sort_indices()
     ref_new = ref.transform(nt.indptr.astype(np.int32), nt.indices.astype(np.int32), nt.data.astype(np.float64))
     assert rel_fro(rs[0]["new"], ref_new) < tol
+
+
+def test_csr_input_gives_the_sharded_fit_the_same_blocks():
+    """A canonical CSR input spares the host one of its two conversions (it is c_iu already); the blocks every rank uploads
+    must be the arrays the CSC route produces, and the caller's matrix must survive the explicit global mean."""
+    import torch.distributed as dist
+    sys.path.insert(0, str(ROOT / "tests"))
+    from oracle_backend import OracleBackend
+    from rsparse_amd import WRMF
+
+    class Spy(OracleBackend):
+        def __init__(self):
+            self.made = []
+
+        def make_csc(self, n_rows, n_cols, p, i, x):
+            self.made.append((n_rows, n_cols, p.numpy().copy(), i.numpy().copy(), x.numpy().copy()))
+            return super().make_csc(n_rows, n_cols, p, i, x)
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        m, _ = _problem()
+        m = sp.csr_matrix(m, dtype=np.float64)
+        m.sort_indices()
+        assert m.has_canonical_format
+        before = m.data.copy()
+        for feedback, gb in (("implicit", False), ("explicit", True)):
+            runs = []
+            for x in (m, sp.csc_matrix(m), m.astype(np.float32)):
+                be = Spy()
+                model = WRMF(rank=4, lambda_=0.1, feedback=feedback, solver="cholesky", with_global_bias=gb, precision="float",
+                             backend=be, rng=3, n_sub=2)
+                model._fit_transform_sharded(x, 1, -1, 1, 0)     # the multi-rank driver on a one-rank group
+                runs.append((be.made, model.global_bias))
+            for made, g in runs[1:]:
+                assert g == runs[0][1] and len(made) == len(runs[0][0]) > 0
+                for a, b in zip(made, runs[0][0]):
+                    assert a[:2] == b[:2] and all(np.array_equal(u, v) and u.dtype == v.dtype for u, v in zip(a[2:], b[2:]))
+            assert (runs[0][1] != 0.0) == gb
+        assert np.array_equal(m.data, before)
+    finally:
+        dist.destroy_process_group()

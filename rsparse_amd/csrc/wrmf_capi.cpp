@@ -503,10 +503,21 @@ int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_i
   return RSPARSE_HIP_OK;
 }
 
+// rows whose failure counts were taken off the device on behalf of a LATER reader (rsparse_hip_take_numeric_failures adds them)
+int64_t g_fail_carry[2] = {0, 0};   // unresolved, re-solved by the general solver
+
 // wrmf_implicit.hpp:108-109: a global bias below sqrt(eps) of the element type T is treated as zero (float: 3.45e-4,
 // double: 1.49e-8; the device layer holds floats, the stateless *_double entry point passes dbl = true)
 bool has_global_bias(double global_bias, bool dbl = false) {
   return global_bias >= std::sqrt(dbl ? DBL_EPSILON : (double)FLT_EPSILON);
+}
+
+// Ranks that are not a multiple of 4 run on zero-padded copies: a padded coordinate sees a right-hand side of 0
+// against lambda_use on the diagonal (implicit: the ridge of the padded Gramian, written as 1) and stays 0.  With explicit
+// feedback, lambda = 0 (the reference's default) and the exact solver that diagonal is 0: every padded system would be
+// singular where the true one is not.  Those fits keep the true rank on the LDS-tile kernels.
+bool zero_padding_is_neutral(bool implicit, unsigned solver, double lambda) {
+  return implicit || solver != RSPARSE_SOLVER_CHOLESKY || lambda != 0.0;
 }
 
 int check_variant(unsigned solver, int with_biases, double global_bias, bool implicit = true) {
@@ -542,7 +553,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (rc) return rc;
   if ((rc = g_ws.ensure_device())) return rc;
   const DevCSC& d = conf->d;
-  if (rank % 4 != 0 && rank < 128) {
+  if (rank % 4 != 0 && rank < 128 && zero_padding_is_neutral(implicit, solver, lambda)) {
     // A rank that is not a multiple of 4 (the reference's default is 10): the register-resident kernels take their vectors in
     // 16-byte pieces, and the LDS-tile fallback that took these ranks through round 3 is several times slower.  Coordinates of
     // zeros change nothing (wrmf_bias.hip, launch_pad_rows: the same argument as for the biased half-iterations), so the
@@ -823,7 +834,8 @@ int run_half_iteration_explicit_biased(const rsparse_hip_csc* conf, const float*
   const int xb = is_x_bias_last_row ? rank - 1 : 0;  // row of X holding the x biases       (:59-64)
   const int ioff = is_x_bias_last_row ? 1 : 0;       // first kept entry of the warm start  (:90)
   const int ooff = is_x_bias_last_row ? 0 : 1;       // head / tail of Y.col(i)             (:115-127)
-  const int k1p = std::min((k1 + 3) & ~3, RSPARSE_HIP_MAX_RANK);   // the copies are padded to a multiple of 4 (wrmf_bias.hip: why)
+  // the copies are padded to a multiple of 4 (wrmf_bias.hip: why) -- unless the padding would make the systems singular
+  const int k1p = zero_padding_is_neutral(false, solver, lambda) ? std::min((k1 + 3) & ~3, RSPARSE_HIP_MAX_RANK) : k1;
   const size_t nx = (size_t)d.n_rows * k1p, ny = (size_t)d.n_cols * k1p, nv = (size_t)std::max<int64_t>(d.nnz, 1);
   if ((rc = g_ws.ensure_bias(nx + ny + nv + 16))) return rc;
   float* Xp = g_ws.bias_buf;
@@ -966,10 +978,9 @@ int stateless(bool implicit, int n_rows, int n_cols, const int32_t* col_ptrs, co
     HIP_TRY(upload(dW, cnt_X, (size_t)n_rows));
   }
   if ((rc = g_ws.ensure_device())) return rc;
-  {   // counters left behind by earlier device-resident calls are not this call's
-    int64_t stale = 0;
-    rsparse_hip_take_numeric_failures(&stale, nullptr);
-  }
+  // counters left behind by earlier device-resident calls are not this call's: set aside here, handed back when this call
+  // ends (a stateless call between a resident fit's half-iterations and its check must not swallow the fit's failures)
+  StaleFailures stale_guard;
   const bool gbias = implicit && has_global_bias(global_bias, sizeof(TX) == sizeof(double));
   DevBuf dBase;
   if (gbias && !with_biases) {
@@ -1047,6 +1058,11 @@ namespace rsparse_hip {
 int capi_fail(int code, const std::string& msg) { return fail(code, msg); }
 int capi_hip_fail(hipError_t e, const char* what) { return hip_fail(e, what); }
 int* capi_fail_counters() { return g_ws.ensure_device() ? nullptr : g_ws.fails; }
+void capi_fail_carry_add(int64_t unresolved, int64_t fallback) {
+  g_fail_carry[0] += unresolved;
+  g_fail_carry[1] += fallback;
+}
+StaleFailures::StaleFailures() { rsparse_hip_take_numeric_failures(&unresolved, &fallback); }
 void prof_note(hipEvent_t* ev_slot, const void* kernel_fn) {
   if (!ev_slot || !g_prof.on) return;
   const ptrdiff_t i = ev_slot - g_prof.ev;
@@ -1610,8 +1626,10 @@ int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, in
 
 int rsparse_hip_take_numeric_failures(int64_t* unresolved_out, int64_t* fallback_out) {
   if (!unresolved_out) return fail(RSPARSE_HIP_ERR_INVALID, "unresolved_out is NULL");
-  *unresolved_out = 0;
-  if (fallback_out) *fallback_out = 0;
+  // counts a stateless call found on the device when it started and set aside (see StaleFailures): still the resident layer's
+  *unresolved_out = g_fail_carry[0];
+  if (fallback_out) *fallback_out = g_fail_carry[1];
+  g_fail_carry[0] = g_fail_carry[1] = 0;
   if (!g_ws.fails) return RSPARSE_HIP_OK;
   int v[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpy(v, g_ws.fails, sizeof(v), hipMemcpyDeviceToHost));   // (synchronises with the device)
@@ -1619,8 +1637,8 @@ int rsparse_hip_take_numeric_failures(int64_t* unresolved_out, int64_t* fallback
   // rows beyond the list's capacity could not be handed over: they count as unresolved, not as re-solved
   const int64_t lost = v[0] > kFailCap ? (int64_t)v[0] - kFailCap : 0;
   const int64_t sent = (int64_t)std::min(v[0], kFailCap) + v[2];
-  *unresolved_out = (int64_t)v[1] + v[3] + lost;
-  if (fallback_out) *fallback_out = sent;
+  *unresolved_out += (int64_t)v[1] + v[3] + lost;
+  if (fallback_out) *fallback_out += sent;
   return RSPARSE_HIP_OK;
 }
 

@@ -140,6 +140,17 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a generic LDS pointer = LDS byte address
+}
+// LDS-DMA, one dword per lane: LDS destination = M0 + lane * 4 (wave-uniform base), source = each lane's own pointer.  Counts in
+// vmcnt like a load; the compiler does not know about it, which is harmless as long as nothing is issued between it and
+// the explicit wait that precedes the first read of its destination (older operations complete first)
+__device__ __forceinline__ void dma4(const void* g, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory", "m0");
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // DMF: 0 = dense product on the vector units (G in LDS as fp32), 1 = on the matrix cores with this wave's rows of G as fp16
 // terms in REGISTERS (rows <= 32 non-zeros: 64 registers are free), 2 = the same with the fp16 terms in LDS, stored in
 // fragment order (rows of 33..64 non-zeros: the gathered vectors take 128 registers, G's 64 KB of LDS hold the terms instead
@@ -159,13 +170,19 @@ struct QSmem {
   // the paddings shift consecutive rows by four banks, so the operand reads / result writes of four rows do not collide
   static constexpr int dmf_ps = KP + 8, dmf_os = KP + 4;
   static constexpr size_t dmf_floats = DMF ? (size_t)WAVES * dmf_ps + (size_t)WAVES * dmf_os : 0;
-  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats + pre_floats + dmf_floats) * 4 + 16;
+  // resident rows on teams of more than RSP_IDX_PREFETCH_MAXWPR waves: the next row's indices / values (one per lane) land here
+  // by LDS-DMA during the current row's sweeps -- those kernels have no two registers to hold them (KFULL instantiations)
+  static constexpr size_t pfx_floats = (!STREAM && WPR > RSP_IDX_PREFETCH_MAXWPR && CAPQ * 4 == 64) ? (size_t)WAVES * 2 * 64 : 0;
+  static constexpr size_t bytes = (gram_floats + vec_floats + red_floats + tsv_floats + pre_floats + dmf_floats + pfx_floats) * 4 + 16;
 };
 
 // GB: implicit feedback with a global bias (cg_solver_implicit_global_bias, wrmf_implicit.hpp:35-57,203): the first
 // residual is  X_nnz (c - c1 % (X_nnz^T x + global_bias)) - XtX x + global_bias_base  (a.gbias, a.rhs_init), every row is
 // solved -- empty ones too (:178) -- and the loss compares x_j.y with 1 - global_bias (a.loss_tgt_const, :262-264).
-template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, int DMF = 0, bool GB = false>
+// KFULL: the rank IS the padded rank (k == KP: ranks 32 / 64 / 128).  The gathered vectors are then the destination registers of
+// unconditional loads -- no select behind them --, so nothing has to wait for the whole gather: the first sweep of a resident row
+// starts on the quads that have arrived (the warm start is requested BEFORE the vectors) while the rest is still in flight.
+template <int KP, int CAPQ, int WAVES, int WPR, int STREAM, bool IMPLICIT, int DMF = 0, bool GB = false, bool KFULL = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows,
                                                              int rows_per_team, size_t loss_slot0) {
   using G_ = QG<KP>;
@@ -184,6 +201,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   float* sRedL = sRed + (WPR > 1 ? 2 * WAVES * KP : 0);              // [2][WAVES]
   float* sTsv = sVec + SM::vec_floats + SM::red_floats;              // [WAVES][2][CAP]
   float* sPre = sTsv + SM::tsv_floats;                               // [WAVES][PQ][4][KP]  (streamed kernels)
+  float* sPfx = sPre + SM::pre_floats;                               // [WAVES][2][64]  (DMAPF; never next to the DMF areas)
   _Float16* sPh = reinterpret_cast<_Float16*>(sPre + SM::pre_floats);   // DMF: [WAVES][KP + 8] high fp16 terms
   _Float16* sPl = sPh + WAVES * SM::dmf_ps;                             //      [WAVES][KP + 8] low terms
   float* sOut = reinterpret_cast<float*>(sPl + WAVES * SM::dmf_ps);     //      [WAVES][KP + 4] G v (times the scales)
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int g = lane >> 4, i = lane & 15;
   const int team = wv / WPR, tw = wv % WPR;
-  const int k = a.k;
+  const int k = KFULL ? KP : a.k;
   if constexpr (IMPLICIT && DMF == 0) {
     for (int e = tid; e < KP * KP; e += WAVES * 64) {
       const int r = e / KP, c = e % KP;
@@ -351,11 +369,37 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     constexpr bool TSAVE = STREAM == 0 && CAPQ >= RSP_TSAVE_MINCAPQ;
     constexpr bool GVFIRST = STREAM == 0 && CAPQ >= RSP_GVFIRST_MINCAPQ;
     constexpr bool IDXPF = CAP <= 64 && ((STREAM == 0 && WPR <= RSP_IDX_PREFETCH_MAXWPR) || (STREAM == 1 && IMPLICIT && RSP_STREAM_IDX_PREFETCH));
+    // the LDS-DMA variant of the same prefetch for the kernels that have no registers for it (see QSmem::pfx_floats)
+#ifdef RSP_NO_DMAPF   // dev builds: A/B of the LDS-DMA prefetch alone
+    constexpr bool DMAPF = false;
+#else
+    constexpr bool DMAPF = KFULL && !IDXPF && SM::pfx_floats > 0;
+#endif
+    int* pfxI = reinterpret_cast<int*>(sPfx) + wv * 128;
+    float* pfxC = sPfx + wv * 128 + 64;
     int pf_pos = -1;   // streamed rows: chunk the prefetch registers belong to
     auto gather_q = [&](auto nq_tag, const int base, const int n, const bool from_pf = false) {
       constexpr int NQG = decltype(nq_tag)::value;
       int id[NQG > 0 ? NQG : 1];
-      if (IDXPF && from_pf) {
+      if constexpr (DMAPF) {
+        // one path: the indices / values come from the wave's LDS slot, where the previous row's sweeps left them; a row
+        // that was not announced (the team's first) fetches them the same way and waits
+        if (!from_pf && n > 0) {
+          const int j = base + min(lane, n - 1);
+          dma4(a.row_idx + j, lds_addr(pfxI));
+          dma4(a.vals + j, lds_addr(pfxC));
+          wait_vm0();
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < NQG; q++) {
+          const int j = max(min(4 * q + g, n - 1), 0);
+          id[q] = pfxI[j];
+          cv[q] = (!ZPAD || 4 * q + g < n) ? pfxC[j] : 0.f;
+        }
+        if constexpr (TSAVE) cl[0] = lane < n ? pfxC[lane] : 0.f;
+        wave_sync();
+      } else if (IDXPF && from_pf) {
         // lane-major prefetch registers -> quad layout through the wave's t-slots (dead between two rows)
         int* xi = reinterpret_cast<int*>(tacc);
         wave_sync();
@@ -364,7 +408,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         wave_sync();
 #pragma unroll
         for (int q = 0; q < NQG; q++) {
-          const int j = min(4 * q + g, n - 1);
+          const int j = max(min(4 * q + g, n - 1), 0);
           id[q] = xi[j];
           cv[q] = (!ZPAD || 4 * q + g < n) ? tcur[j] : 0.f;
         }
@@ -373,7 +417,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       } else {
 #pragma unroll
         for (int q = 0; q < NQG; q++) {
-          const int j = min(4 * q + g, n - 1);
+          const int j = max(min(4 * q + g, n - 1), 0);
           id[q] = a.row_idx[base + j];
           const float c = a.vals[base + j];
           cv[q] = (!ZPAD || 4 * q + g < n) ? c : 0.f;
@@ -389,10 +433,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 #pragma unroll
         for (int b = 0; b < NV; b++) {
           const int off = b * 16 * VW + i * VW;
-          const piece_t pc = *reinterpret_cast<const piece_t*>(src + min(off, k - VW));
-          const float* pf = reinterpret_cast<const float*>(&pc);
+          if constexpr (KFULL) {
+            const piece_t pc = *reinterpret_cast<const piece_t*>(src + off);
+            const float* pf = reinterpret_cast<const float*>(&pc);
 #pragma unroll
-          for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
+            for (int c = 0; c < VW; c++) xt[q][b * VW + c] = pf[c];
+          } else {
+            const piece_t pc = *reinterpret_cast<const piece_t*>(src + min(off, k - VW));
+            const float* pf = reinterpret_cast<const float*>(&pc);
+#pragma unroll
+            for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
+          }
         }
       }
     };
@@ -432,6 +483,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       }
     };
 
+    float x[RPN], r[RPN], p[RPN], ap[RPN];
+    auto load_warm_start = [&]() {
+#pragma unroll
+      for (int b = 0; b < NV; b++) {
+        const int off = b * 16 * VW + i * VW;
+        piece_t pc;
+        float* pf = reinterpret_cast<float*>(&pc);
+#pragma unroll
+        for (int c = 0; c < VW; c++) pf[c] = 0.f;
+        if (have && off < k) pc = *reinterpret_cast<const piece_t*>(yrow + off);  // warm start
+#pragma unroll
+        for (int c = 0; c < VW; c++) x[b * VW + c] = pf[c];
+      }
+    };
+    // KFULL: the warm start is requested before the row's vectors (loads return in order), so that the first sweep can
+    // run behind the gather quad block by quad block instead of waiting for the warm start = for everything before it
+    constexpr bool WS_FIRST = KFULL && resident;
+    if constexpr (WS_FIRST) load_warm_start();
     if constexpr (resident) {
       // balanced shares: every wave of the team takes ceil(cnt / WPR) non-zeros rounded up to a quad-pass block (16),
       // so the team's sweep time is that of the average wave, not of a full one next to idle ones
@@ -441,23 +510,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       const int per = min(CAP, (((cnt + WPR - 1) / WPR) + 15) & ~15);
 #endif
       ccnt = max(0, min(per, cnt - tw * per));
-      if (ccnt > 0) gather(p1 + tw * per, ccnt, pf_cnt == ccnt);
+      if constexpr (WS_FIRST) {
+        // no branch around the gather: at a join the compiler has to assume that the warm start is the NEWEST load in
+        // flight and drains the queue where it is first used.  A wave without a share gathers the all-zero row (n = 0)
+        gather(ccnt > 0 ? p1 + tw * per : p1, ccnt, ccnt > 0 && pf_cnt == ccnt);
+      } else {
+        if (ccnt > 0) gather(p1 + tw * per, ccnt, pf_cnt == ccnt);
+      }
       pf_cnt = -1;
     }
 
     CQ_T(0)   // row switch + gather
-    float x[RPN], r[RPN], p[RPN], ap[RPN];
-#pragma unroll
-    for (int b = 0; b < NV; b++) {
-      const int off = b * 16 * VW + i * VW;
-      piece_t pc;
-      float* pf = reinterpret_cast<float*>(&pc);
-#pragma unroll
-      for (int c = 0; c < VW; c++) pf[c] = 0.f;
-      if (have && off < k) pc = *reinterpret_cast<const piece_t*>(yrow + off);  // warm start
-#pragma unroll
-      for (int c = 0; c < VW; c++) x[b * VW + c] = pf[c];
-    }
+    if constexpr (!WS_FIRST) load_warm_start();
 
     // one pass over the resident quads: t = X_nnz^T v, then acc += X_nnz w  (or the loss terms)
     auto quad_pass = [&](const float(&v)[RPN], const int mode, float(&acc)[RPN], float& lacc, float* tsave) {
@@ -802,6 +866,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         }
       }
     }
+    if constexpr (DMAPF) {
+      if (it + 1 < rows_per_team && row_index(it + 1) < n_rows) {
+        const int np1 = rfl(p1_c), ncnt = rfl(p2_c) - np1;
+        const int nper = min(CAP, (((ncnt + WPR - 1) / WPR) + 15) & ~15);
+        const int ncc = max(0, min(nper, ncnt - tw * nper));
+        if (ncc > 0) {   // (the slot's previous content was consumed by this row's gather)
+          const int j = np1 + tw * nper + min(lane, ncc - 1);
+          dma4(a.row_idx + j, lds_addr(pfxI));
+          dma4(a.vals + j, lds_addr(pfxC));
+          pf_cnt = ncc;
+        }
+      }
+    }
     CQ_T(3)   // staging issue / index prefetch
 #pragma unroll
     for (int rr = 0; rr < RPN; rr++) p[rr] = r[rr];
@@ -850,6 +927,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     CQ_T(4)
     sweep(x, 2, ap, rl, live);
     CQ_T(2)
+    if constexpr (DMAPF) wait_vm0();   // the announced row's indices have long landed; nothing of this wave's is in flight after this
     if (live && tw == 0) {
       const float xx = dot16(x, x);
       wloss += IMPLICIT ? (double)rl + a.lambda_loss * (double)xx : (double)(rl + lam_use * xx);
@@ -912,7 +990,20 @@ bool dense_mfma_enabled() {
 #endif
 }
 
-template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT, bool GB, int DMF = 0>
+// dev builds (-DRSP_AB): RSPARSE_HIP_KFULL=0 keeps the instantiations that drain the gather before the first sweep
+bool kfull_enabled() {
+#ifdef RSP_AB
+  static const bool on = [] {
+    const char* e = std::getenv("RSPARSE_HIP_KFULL");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+#else
+  return true;
+#endif
+}
+
+template <int KP, int WAVES, int CAPQ, int WPR, int STREAM, bool IMPLICIT, bool GB, int DMF = 0, bool KFULL = false>
 hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int grid, size_t slot0, hipStream_t s,
                          hipEvent_t* ev_slot) {
   if (n_rows <= 0) return hipSuccess;
@@ -921,8 +1012,13 @@ hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int 
     if (dense_mfma_enabled())
       return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, GB, CAPQ == 8 ? 1 : 2>(a, rows, n_rows, grid, slot0, s, ev_slot);
   }
+  // the rank is the padded rank (32 / 64 / 128): the instantiation whose first sweep runs behind the gather
+  if constexpr (!KFULL && STREAM == 0 && !GB) {
+    if (a.k == KP && kfull_enabled())
+      return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, GB, DMF, true>(a, rows, n_rows, grid, slot0, s, ev_slot);
+  }
   constexpr int TEAMS = WAVES / WPR;
-  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF, GB>;
+  auto kern = als_cgq_kernel<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF, GB, KFULL>;
   const size_t lds = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF>::bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

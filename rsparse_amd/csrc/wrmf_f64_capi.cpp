@@ -210,8 +210,7 @@ int stateless_double(bool implicit, int n_rows, int n_cols, const int32_t* col_p
   }
   int rc = g_w64.ensure();
   if (rc) return rc;
-  int64_t stale = 0;
-  rsparse_hip_take_numeric_failures(&stale, nullptr);   // counters left by earlier device-resident calls are not this call's
+  StaleFailures stale_guard;   // counters left by earlier device-resident calls are not this call's (handed back at the end)
   rsparse_hip_csc_f64 conf;
   conf.n_rows = n_rows; conf.n_cols = n_cols; conf.nnz = nnz;
   conf.col_ptrs = dP.as<int32_t>(); conf.row_idx = dI.as<int32_t>(); conf.vals = dV.as<double>();

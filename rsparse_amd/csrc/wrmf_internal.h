@@ -293,5 +293,15 @@ void prof_note(hipEvent_t* ev_slot, const void* kernel_fn);
 int capi_fail(int code, const std::string& msg);
 int capi_hip_fail(hipError_t e, const char* what);
 int* capi_fail_counters();
+// RAII for the stateless entry points: takes the failure counts an earlier device-resident call left on the device when the
+// stateless call starts (they are not its own) and hands them back to the next reader when it ends
+void capi_fail_carry_add(int64_t unresolved, int64_t fallback);
+struct StaleFailures {
+  int64_t unresolved = 0, fallback = 0;
+  StaleFailures();
+  ~StaleFailures() { capi_fail_carry_add(unresolved, fallback); }
+  StaleFailures(const StaleFailures&) = delete;
+  StaleFailures& operator=(const StaleFailures&) = delete;
+};
 
 }  // namespace rsparse_hip

@@ -577,6 +577,36 @@ def test_singular_systems_are_an_error_or_a_consistent_solution():
     assert np.all(np.isfinite(Y2))
 
 
+@pytest.mark.parametrize("k,with_biases", [(10, False), (50, False), (7, False), (12, True), (64, True), (11, True)])
+def test_explicit_cholesky_with_lambda_zero_at_ranks_that_get_padded(k, with_biases):
+    """lambda = 0 is the reference's default.  Ranks that are not a multiple of 4 (and every biased fit, whose solves run at
+    rank - 1) run on zero-padded copies -- whose padded coordinates have lambda_use on the diagonal, i.e. NOTHING here: such a
+    fit has to keep the true rank (every row came back as singular).  Rows hold more ratings than factors, so the
+    true systems are regular, and the oracle's exact solve is the answer."""
+    rng = np.random.default_rng(400 + k)
+    n_item = 900
+    lens = rng.integers(k + 8, 5 * k + 40, 260)
+    csc, X, Y0 = _rows_of_lengths(lens, n_item, k, seed=500 + k, scale=0.4)
+    n_rows, n_cols, p, i, x = csc
+    x = rng.integers(1, 6, x.size).astype(np.float64)
+    csc = (n_rows, n_cols, p, i, x)
+    cnt = np.bincount(i, minlength=n_item).astype(np.float64)
+    if with_biases:                      # the layout of the driver: ones in the first row of X, the x biases in the last
+        X[0, :] = 1.0
+        Y0[-1, :] = 1.0
+    X64, Y64 = np.asfortranarray(X, dtype=np.float64), np.asfortranarray(Y0, dtype=np.float64)
+    lref = O.als_explicit(p, i, x, X64, Y64, cnt, 0.0, 0, 3, False, with_biases=with_biases, is_x_bias_last_row=True)
+    Y = Y0.copy(order="F")
+    loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), 0.0, 1, 0, 3, False, "float", with_biases, True)
+    err = np.linalg.norm(Y - Y64, axis=0) / np.maximum(np.linalg.norm(Y64, axis=0), 1e-30)
+    # fp32 arithmetic on an unregularised system: the yardstick is the oracle's own fp32 run (cond ~ 1e2..1e3 here)
+    Y32 = Y0.copy(order="F")
+    O.als_explicit(p, i, x, X, Y32, cnt.astype(np.float32), 0.0, 0, 3, False, with_biases=with_biases, is_x_bias_last_row=True)
+    e32 = np.linalg.norm(Y32 - Y64, axis=0) / np.maximum(np.linalg.norm(Y64, axis=0), 1e-30)
+    assert err.max() < max(TOL, 3 * e32.max()), (float(err.max()), float(e32.max()), int(lens[err.argmax()]))
+    assert abs(loss - lref) <= 1e-3 * abs(lref) + 1e-7
+
+
 @pytest.mark.parametrize("k,implicit", [(128, True), (64, True), (64, False)])
 def test_one_giant_row_is_split_across_workgroups(k, implicit):
     """A row far longer than a workgroup's share of the long rows is cut into segments that different workgroups stream;

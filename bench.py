@@ -298,11 +298,12 @@ def main():
     def step():
         # both losses stay on the device until the iteration is over: one host sync per iteration (the R driver reads
         # the user-half loss for its convergence test, R/model_WRMF.R:327-335)
-        li = als.half_iteration("items", U, V, solver, want_loss="device")
-        lu = als.half_iteration("users", U, V, solver, want_loss="device")
+        li = als.half_iteration("items", U, V, solver, want_loss="device", defer_exchange=True)
+        lu = als.half_iteration("users", U, V, solver, want_loss="device", defer_exchange=True)
         return float(li), float(lu)
 
     def barrier():
+        als.finish()          # (the last exchange of the last half-iteration belongs to the timed region)
         if ws > 1:
             dist.barrier()
         torch.cuda.synchronize()

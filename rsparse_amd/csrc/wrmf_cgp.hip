@@ -69,7 +69,9 @@ struct PairSmem {
   static constexpr size_t bytes = (size_t)2 * 8 * ps * 2 + (size_t)8 * os * 4 + (size_t)4 * 64 * 4 + 16;
 };
 
-template <bool GB>
+// KFULL (rank 128): unconditional vector loads and the warm start requested before them -- the first sweep's publish / dense
+// product run while the vectors are in flight and its quad pass takes them as they arrive (als_cgq_kernel's KFULL)
+template <bool GB, bool KFULL = false>
 __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n_rows, int iters,
                                                         size_t loss_slot0) {
   constexpr int KP = 128, RPN = 8, VW = 4, NV = 2, NQ = 8;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
   float* sTsv = sOut + 8 * SM::os;                              // [4][2][32]  x_j . y accumulated / of the current step
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int g = lane >> 4, i = lane & 15, H = lane >> 5, g2 = g & 1;
-  const int k = a.k;
+  const int k = KFULL ? KP : a.k;
   const float gbias = GB ? a.gbias : 0.f, ltgt = GB ? a.loss_tgt_const : 1.f;
   for (int e = tid; e < 4 * 64; e += 256) sTsv[e] = 0.f;
   // this wave's 32 rows of G as A operands of v_mfma_f32_16x16x32_f16 (tile t = rows 32 wv + 16 t + (lane & 15), step ks =
@@ -161,6 +163,19 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
     // does any of the wave's two rows reach the second block of slots (8..15)?  (wave-uniform)
     const bool blk2 = max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 32)) > 8;
 
+    float x[RPN], r[RPN], p[RPN], ap[RPN];
+    auto load_warm_start = [&]() {
+#pragma unroll
+      for (int b = 0; b < NV; b++) {
+        const int off = b * 16 * VW + i * VW;
+        float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have && off < k) pc = *reinterpret_cast<const float4*>(yrow + off);  // warm start
+        const float* pf = reinterpret_cast<const float*>(&pc);
+#pragma unroll
+        for (int c = 0; c < VW; c++) x[b * VW + c] = pf[c];
+      }
+    };
+    if constexpr (KFULL) load_warm_start();
     // ---- gather: all index loads, then all vector loads; slots beyond the row read the zero row and carry c = 0 ----
     float xt[NQ][RPN], cv[NQ];
     {
@@ -180,26 +195,24 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
 #pragma unroll
         for (int b = 0; b < NV; b++) {
           const int off = b * 16 * VW + i * VW;
-          float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (q < 4 || blk2) pc = *reinterpret_cast<const float4*>(src + min(off, k - VW));
-          const float* pf = reinterpret_cast<const float*>(&pc);
+          if constexpr (KFULL) {   // (no branch: slots of the second block that nobody uses read the all-zero row, id = 0)
+            const float4 pc = *reinterpret_cast<const float4*>(src + off);
+            const float* pf = reinterpret_cast<const float*>(&pc);
 #pragma unroll
-          for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
+            for (int c = 0; c < VW; c++) xt[q][b * VW + c] = pf[c];
+          } else {
+            float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < 4 || blk2) pc = *reinterpret_cast<const float4*>(src + min(off, k - VW));
+            const float* pf = reinterpret_cast<const float*>(&pc);
+#pragma unroll
+            for (int c = 0; c < VW; c++) xt[q][b * VW + c] = off < k ? pf[c] : 0.f;
+          }
         }
       }
     }
     const float cl = (g2 == 0 && i < cnt) ? a.vals[p1 + i] : 0.f;   // confidence of non-zero i of the half's row (loss)
 
-    float x[RPN], r[RPN], p[RPN], ap[RPN];
-#pragma unroll
-    for (int b = 0; b < NV; b++) {
-      const int off = b * 16 * VW + i * VW;
-      float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (have && off < k) pc = *reinterpret_cast<const float4*>(yrow + off);  // warm start
-      const float* pf = reinterpret_cast<const float*>(&pc);
-#pragma unroll
-      for (int c = 0; c < VW; c++) x[b * VW + c] = pf[c];
-    }
+    if constexpr (!KFULL) load_warm_start();
 
     // mode 0: out = X_nnz (c - c1 % (X_nnz^T v + g)) - G v (+ base); mode 1: out = X_nnz (c1 % X_nnz^T v) + G v; mode 2: loss
     auto sweep = [&](const float(&v)[RPN], const int mode, float(&out)[RPN], float& loss_out) {
@@ -258,20 +271,30 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
 #pragma unroll
         for (int q0 = 0; q0 < NQ; q0 += 4) {
           if (q0 == 0 || blk2) {   // wave-uniform
+            // (the four quads' dot chains and DPP reductions interleaved: see quad_pass in wrmf_cgq.hip)
             float t[4];
+            f32x2 s2[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              f32x2 s2 = {0.f, 0.f};
+            for (int u = 0; u < 4; u++) s2[u] = f32x2{0.f, 0.f};
 #pragma unroll
-              for (int rr = 0; rr < RPN; rr += 2) {
+            for (int rr = 0; rr < RPN; rr += 2) {
+              const f32x2 va = {v[rr], v[rr + 1]};
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
                 const f32x2 xa = {xt[q0 + u][rr], xt[q0 + u][rr + 1]};
-                const f32x2 va = {v[rr], v[rr + 1]};
-                s2 = __builtin_elementwise_fma(xa, va, s2);
+                s2[u] = __builtin_elementwise_fma(xa, va, s2[u]);
               }
-              t[u] = s2.x + s2.y;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) t[u] = p_row16_sum(t[u]);
+            for (int u = 0; u < 4; u++) t[u] = s2[u].x + s2[u].y;
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] += dpp<0xB1>(t[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] += dpp<0x4E>(t[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] += dpp<0x141>(t[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] += dpp<0x140>(t[u]);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
               const int q = q0 + u;
@@ -404,13 +427,16 @@ hipError_t launch_als_cgp(const AlsArgs& a, const int32_t* rows, int n_rows, siz
   const long pairs = ((long)n_rows + 1) / 2;
   const int iters = (int)((pairs + (long)grid * 4 - 1) / ((long)grid * 4));
   const bool gb = a.gbias != 0.f;
-  auto k0 = als_cgp_kernel<false>;
-  auto k1 = als_cgp_kernel<true>;
-  const void* fn = gb ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k0);
+  auto k0 = als_cgp_kernel<false, false>;
+  auto k0f = als_cgp_kernel<false, true>;
+  auto k1 = als_cgp_kernel<true, false>;
+  const bool full = !gb && a.k == 128;
+  const void* fn = gb ? reinterpret_cast<const void*>(k1) : (full ? reinterpret_cast<const void*>(k0f) : reinterpret_cast<const void*>(k0));
   hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairSmem::bytes);
   if (err != hipSuccess) return err;
   (void)ev_slot;   // (the bucket's segment is named after its main kernel)
   if (gb) hipLaunchKernelGGL(k1, dim3(grid), dim3(256), PairSmem::bytes, s, a, rows, n_rows, iters, loss_slot0);
+  else if (full) hipLaunchKernelGGL(k0f, dim3(grid), dim3(256), PairSmem::bytes, s, a, rows, n_rows, iters, loss_slot0);
   else hipLaunchKernelGGL(k0, dim3(grid), dim3(256), PairSmem::bytes, s, a, rows, n_rows, iters, loss_slot0);
   return hipGetLastError();
 }

@@ -110,6 +110,35 @@ __device__ __forceinline__ float groups_sum(float v) {
   return v;
 }
 
+// The same sum for FOUR registers at once, as a reduce-scatter: row g of the result holds the total of a_g.  Fed two
+// DIFFERENT registers a lane swap is already the exchange step of both -- (a0, a1) -> rows (a0: 0+1, a1: 0+1, a0: 2+3, a1: 2+3)
+// -- so four registers cost 3 swaps + 3 adds instead of 8 + 8 (+ 8 copies: the swap overwrites both operands).  The pairing
+// is groups_sum's, (0 + 1) + (2 + 3): the totals are bit for bit the same.
+__device__ __forceinline__ float groups_reduce_scatter4(const float a0, const float a1, const float a2, const float a3) {
+  const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+  const float c = __uint_as_float(s01[0]) + __uint_as_float(s01[1]);
+  const auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a2), __float_as_uint(a3), false, false);
+  const float d = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);
+  const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+// ... and back: row g of `r` to every row of out[g]
+__device__ __forceinline__ void groups_all_gather4(const float r, float& o0, float& o1, float& o2, float& o3) {
+  const unsigned u = __float_as_uint(r);
+  const auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);            // rows (0, 1, 0, 1), (2, 3, 2, 3)
+  const auto lo = __builtin_amdgcn_permlane16_swap(h[0], h[0], false, false);     // rows (0, 0, 0, 0), (1, 1, 1, 1)
+  const auto hi = __builtin_amdgcn_permlane16_swap(h[1], h[1], false, false);
+  o0 = __uint_as_float(lo[0]);
+  o1 = __uint_as_float(lo[1]);
+  o2 = __uint_as_float(hi[0]);
+  o3 = __uint_as_float(hi[1]);
+}
+#ifndef RSP_NO_GRS
+#define RSP_GRS 1
+#else
+#define RSP_GRS 0
+#endif
+
 // ---- dense product on the matrix cores (DMF instantiation: one-wave rows of <= 32 non-zeros at rank 65..128) ----
 // The four rows a workgroup solves side by side share every G v product: G is held in REGISTERS as two fp16 terms
 // (wave w owns rows [32w, 32w + 32) as A operands of v_mfma_f32_16x16x32_f16), the four vectors are published to LDS as
@@ -190,6 +219,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   using piece_t = typename Piece<VW>::type;
   using SM = QSmem<KP, CAPQ, WAVES, WPR, STREAM, IMPLICIT, DMF>;
   static_assert(WAVES % WPR == 0, "teams must tile the workgroup");
+  constexpr bool GRS = RSP_GRS && RPN == 8 && VW == 4;   // the four-registers-at-once group reductions (rank 65..128)
+  auto groups_all_reduce8 = [](float(&a8)[RPN]) {
+    if constexpr (RPN == 8) {
+      const float r0 = groups_reduce_scatter4(a8[0], a8[1], a8[2], a8[3]);
+      const float r1 = groups_reduce_scatter4(a8[4], a8[5], a8[6], a8[7]);
+      groups_all_gather4(r0, a8[0], a8[1], a8[2], a8[3]);
+      groups_all_gather4(r1, a8[4], a8[5], a8[6], a8[7]);
+    }
+  };
   static_assert(!DMF || (IMPLICIT && KP == 128 && WAVES == 4 && WPR == 1 && STREAM == 0), "DMF geometry");
   static_assert(DMF != 1 || CAPQ == 8, "register-resident G terms: only the 8-quad kernel has the 64 registers");
   static_assert(!GB || IMPLICIT, "the global bias of explicit feedback is removed from the data (R/model_WRMF.R:278-282)");
@@ -510,6 +548,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       const int per = min(CAP, (((cnt + WPR - 1) / WPR) + 15) & ~15);
 #endif
       ccnt = max(0, min(per, cnt - tw * per));
+#ifdef RSP_GATHER_PRIO   // dev builds: a gathering wave issues ahead of the waves that sweep on the same SIMD
+      __builtin_amdgcn_s_setprio(3);
+#endif
       if constexpr (WS_FIRST) {
         // no branch around the gather: at a join the compiler has to assume that the warm start is the NEWEST load in
         // flight and drains the queue where it is first used.  A wave without a share gathers the all-zero row (n = 0)
@@ -518,6 +559,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         if (ccnt > 0) gather(p1 + tw * per, ccnt, pf_cnt == ccnt);
       }
       pf_cnt = -1;
+#ifdef RSP_GATHER_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
 
     CQ_T(0)   // row switch + gather
@@ -531,6 +575,33 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       for (int q0 = 0; q0 < CAPQ; q0 += QB) {
         if (4 * q0 < ccnt) {  // wave-uniform
           float t[QB];
+#ifndef RSP_NO_QUAD_ILV
+          // the four quads' dot chains and DPP reductions written INTERLEAVED: a packed FMA / DPP add and the instruction
+          // that consumes its result need one / two wait states, which four independent chains fill with work
+          // (tools/dbg/loop_mix.py counted 21 hazard s_nops per 79-instruction quad block in the chain-after-chain order)
+          f32x2 s2[QB];
+#pragma unroll
+          for (int u = 0; u < QB; u++) s2[u] = f32x2{0.f, 0.f};
+#pragma unroll
+          for (int rr = 0; rr < RPN; rr += 2) {
+            const f32x2 va = {v[rr], v[rr + 1]};
+#pragma unroll
+            for (int u = 0; u < QB; u++) {
+              const f32x2 xa = {xt[q0 + u][rr], xt[q0 + u][rr + 1]};
+              s2[u] = __builtin_elementwise_fma(xa, va, s2[u]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < QB; u++) t[u] = s2[u].x + s2[u].y;
+#pragma unroll
+          for (int u = 0; u < QB; u++) t[u] += dpp<0xB1>(t[u]);   // quad_perm:[1,0,3,2]
+#pragma unroll
+          for (int u = 0; u < QB; u++) t[u] += dpp<0x4E>(t[u]);   // quad_perm:[2,3,0,1]
+#pragma unroll
+          for (int u = 0; u < QB; u++) t[u] += dpp<0x141>(t[u]);  // row_half_mirror
+#pragma unroll
+          for (int u = 0; u < QB; u++) t[u] += dpp<0x140>(t[u]);  // row_mirror
+#else
 #pragma unroll
           for (int u = 0; u < QB; u++) {
             // two interleaved partial sums -> v_pk_fma_f32 (RPN is even for every supported rank)
@@ -545,6 +616,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
           }
 #pragma unroll
           for (int u = 0; u < QB; u++) t[u] = row16_sum(t[u]);
+#endif
 #pragma unroll
           for (int u = 0; u < QB; u++) {
             const int q = q0 + u;
@@ -751,8 +823,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
         if constexpr (!GVFIRST) dense_part();
         if constexpr (!DMF) {
           if (mode != 2) {
+            if constexpr (GRS) {
+              if constexpr (WPR == 1) groups_all_reduce8(acc);   // (teams: scattered where the partials are published)
+            } else {
 #pragma unroll
-            for (int rr = 0; rr < RPN; rr++) acc[rr] = groups_sum(acc[rr]);
+              for (int rr = 0; rr < RPN; rr++) acc[rr] = groups_sum(acc[rr]);
+            }
           } else {
             lacc = groups_sum(lacc);
           }
@@ -769,8 +845,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 #pragma unroll
             for (int c = 0; c < VW; c++) acc[b * VW + c] = fmaf(f, o[c], acc[b * VW + c]);
           }
+          if constexpr (GRS) {
+            groups_all_reduce8(acc);
+          } else {
 #pragma unroll
-          for (int rr = 0; rr < RPN; rr++) acc[rr] = groups_sum(acc[rr]);
+            for (int rr = 0; rr < RPN; rr++) acc[rr] = groups_sum(acc[rr]);
+          }
         } else {
           lacc = groups_sum(lacc);
         }
@@ -778,7 +858,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
       if constexpr (WPR > 1) {
         float* red = sRed + buf * WAVES * KP;
         if (mode != 2) {
-          if (g == 0) {
+          if constexpr (GRS) {
+            // the groups' partial sums meet on the way to LDS: row g of r0 / r1 = the wave's total of register g / 4 + g, i.e.
+            // of the vector elements 4 i + g and 64 + 4 i + g -- every lane publishes two floats (a permutation of the 128)
+            const float r0 = groups_reduce_scatter4(acc[0], acc[1], acc[2], acc[3]);
+            const float r1 = groups_reduce_scatter4(acc[4], acc[5], acc[6], acc[7]);
+            red[wv * KP + 4 * i + g] = r0;
+            red[wv * KP + 64 + 4 * i + g] = r1;
+          } else if (g == 0) {
 #pragma unroll
             for (int b = 0; b < NV; b++) {
               piece_t pc;

@@ -61,6 +61,78 @@ def default_subblocks(world_size):
     return 1 if world_size <= 1 else 4
 
 
+def _staged(t, group):
+    """gloo moves host memory only: a device tensor goes through the host (the dry-run configuration of several ranks on one
+    GPU, and nothing else -- RCCL takes device tensors as they are)"""
+    return t.is_cuda and torch.distributed.get_backend(group) == "gloo"
+
+
+def all_to_all_v(inp, in_splits, out_splits, group):
+    """all_to_all_single with per-rank sizes: `inp` = the pieces for rank 0, 1, ... back to back (in_splits elements each);
+    returns what the ranks sent here, in rank order (out_splits elements each)."""
+    out = torch.empty(int(sum(out_splits)), dtype=inp.dtype, device=inp.device)
+    if _staged(inp, group):
+        host = torch.empty(out.shape, dtype=inp.dtype)
+        torch.distributed.all_to_all_single(host, inp.cpu(), list(out_splits), list(in_splits), group=group)
+        out.copy_(host)
+    else:
+        torch.distributed.all_to_all_single(out, inp.contiguous(), list(out_splits), list(in_splits), group=group)
+    return out
+
+
+def all_reduce_any(t, group, op=None):
+    """all_reduce of a small tensor wherever it lives (staged through the host under gloo)"""
+    op = torch.distributed.ReduceOp.SUM if op is None else op
+    if _staged(t, group):
+        host = t.cpu()
+        torch.distributed.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        torch.distributed.all_reduce(t, op=op, group=group)
+    return t
+
+
+def item_block_from_user_blocks(be, group, ws, me, n_user, user_bounds, item_bounds, p, i, x):
+    """The second orientation of a sharded fit without any rank holding the whole matrix (R/model_WRMF.R:190 is
+    `c_iu = t(as.csr(c_ui))` on ONE host; here the matrix exists only as row blocks).
+
+    p / i / x : this rank's USER block as a CSC by user on the device (p int32 from 0, i = global item ids ascending inside a
+    user, x the resident values).  Every rank cuts its block by the item ranges of all ranks (per user a run of consecutive
+    entries, the ids being sorted) and sends range s to rank s: per-user counts, item ids relative to the range, values --
+    three all-to-alls of exactly the matrix's bytes.  What arrives, in rank order, IS the CSC by user of the (my items) x
+    (all users) sub-matrix, users ascending because the blocks are contiguous in rank order; one on-device transposition
+    (wrmf_ingest.hip) turns it into the CSC by item that the item half solves.  Returns (p, i, x) of that block:
+    columns = my items, row indices = GLOBAL user ids ascending."""
+    dev = i.device
+    n_my = int(p.numel()) - 1
+    assert n_my == user_bounds[me][1] - user_bounds[me][0]
+    i64, p64 = i.to(torch.int64), p.to(torch.int64)
+    cnts, idxs, vals = [], [], []
+    pre = torch.zeros(int(i.numel()) + 1, dtype=torch.int64, device=dev)
+    for s in range(ws):
+        lo, hi = item_bounds[s]
+        mask = (i64 >= lo) & (i64 < hi)
+        torch.cumsum(mask, 0, out=pre[1:])
+        cnts.append((pre[p64[1:]] - pre[p64[:-1]]).to(torch.int32))
+        idxs.append((i64[mask] - lo).to(torch.int32))
+        vals.append(x[mask])
+    send_nnz = torch.tensor([int(t.numel()) for t in idxs], dtype=torch.int64, device=dev)
+    recv_nnz = all_to_all_v(send_nnz, [1] * ws, [1] * ws, group).tolist()
+    n_users_of = [b - a for a, b in user_bounds]
+    cnt_all = all_to_all_v(torch.cat(cnts), [n_my] * ws, n_users_of, group)          # (n_user,) entries per user, global order
+    idx_all = all_to_all_v(torch.cat(idxs), send_nnz.tolist(), recv_nnz, group)
+    val_all = all_to_all_v(torch.cat(vals), send_nnz.tolist(), recv_nnz, group)
+    total = int(sum(recv_nnz))
+    if total >= 2 ** 31:
+        raise ValueError("a rank's item block holds %d non-zeros: more than int32 column pointers address" % total)
+    p_all = torch.zeros(n_user + 1, dtype=torch.int32, device=dev)
+    p_all[1:] = torch.cumsum(cnt_all.to(torch.int64), 0).to(torch.int32)
+    n_item_mine = item_bounds[me][1] - item_bounds[me][0]
+    if n_item_mine == 0 or total == 0:   # a rank without items (fewer items with entries than ranks), or without entries
+        return torch.zeros(n_item_mine + 1, dtype=torch.int32, device=dev), idx_all[:0], val_all[:0]
+    return be.transpose_csc(n_item_mine, n_user, p_all, idx_all, val_all)
+
+
 class Layout:
     """Who owns which rows of one factor matrix, and where they are stored.
 
@@ -449,6 +521,13 @@ class ShardedALS:
         if self.coll:
             torch.distributed.all_reduce(t, group=self.group)
 
+    def finish(self):
+        """make the current stream wait for the exchanges a half_iteration left running (the last slab's all-gather):
+        call before reading a factor matrix outside half_iteration()"""
+        for w in getattr(self, "_pending", ()):
+            w.wait()
+        self._pending = []
+
     def _gather_slab(self, S, lay, j):
         """In-place all-gather of sub-block j of every rank (one contiguous slab of S); returns a work handle or None."""
         if not self.coll:
@@ -547,6 +626,7 @@ class ShardedALS:
         be, lu, li = self.be, self.lay_user, self.lay_item
         dev = user_bias.device
         gb = 0.0
+        self.finish()
 
         def total(t):   # sum over all ranks of a local float64 scalar tensor
             self._all_reduce(t)
@@ -593,10 +673,12 @@ class ShardedALS:
             self._gather_vec(user_bias, lu)
         return gb
 
-    def half_iteration(self, side, U, V, solver, G=None, want_loss=True):
+    def half_iteration(self, side, U, V, solver, G=None, want_loss=True, defer_exchange=False):
         """side 'items': solve V (item factors) given U; side 'users': solve U given V (both in storage order).
         Returns loss/nnz as the reference reports it: a python float (want_loss=True, synchronises), a 0-d device
-        tensor (want_loss='device': no host sync, fetch it when convenient) or None."""
+        tensor (want_loss='device': no host sync, fetch it when convenient) or None.
+        defer_exchange: leave the wait for the LAST sub-block's all-gather to the next half_iteration (which waits before
+        its first solve, i.e. after its own Gramian partial) -- the caller then calls finish() before it reads U / V itself."""
         if side == "items":
             F, layF, S, layS, subs, cnt_F = U, self.lay_user, V, self.lay_item, self.sub_items, self.cnt_user
         else:
@@ -618,15 +700,21 @@ class ShardedALS:
         self.absmax_of = None   # F's owner may change it before the next Gramian
         if self.global_bias:
             extra["global_bias"] = self.global_bias
+        # the exchanges of the PREVIOUS half may still be running (their waits are deferred to here: what came in between --
+        # that half's loss, this half's Gramian partial over the rank's own rows -- reads nothing they write)
+        self.finish()
         for j, (c0, c1, sub) in enumerate(subs):
             if c1 > c0:
                 a = layS.sub_start(self.me, j)
                 self.be.half_iteration(sub, self.implicit, F, S[a:a + (c1 - c0)], G, self.lambda_, solver,
                                        self.cg_steps, self.dynamic_lambda, self.scal_sub[j:j + 1], blr, **extra)
             works.append(self._gather_slab(S, layS, j))
-        for w in works:
+        # every slab but the last is waited for here; the last one's wait is deferred to the next reader of S -- the next
+        # half_iteration's first solve, initialize_biases, or finish() (callers that read S themselves call it)
+        for w in (works[:-1] if defer_exchange else works):
             if w is not None:
                 w.wait()
+        self._pending = [w for w in works[-1:] if w is not None] if defer_exchange else []
         self.scal[1:2] = self.scal_sub.sum()
         if not want_loss:
             return None

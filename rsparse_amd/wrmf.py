@@ -248,21 +248,36 @@ class WRMF:
         # the returned embeddings come from one more exact solve, not from U (:355-359)
         return self._transform(als.csc_users, n_user)
 
+    def _user_rows(self, x):
+        """the users x items matrix as a canonical CSR (row = user) with float64 values, touching as little as possible: a
+        canonical CSR input is used as it stands; a user `preprocess` is defined on the CsparseMatrix (:184-188) and costs
+        the two conversions around it"""
+        if self._preprocess is not _identity:
+            x = sp.csr_matrix(self._preprocess(sp.csc_matrix(x, dtype=np.float64)))
+        elif not (sp.issparse(x) and x.format == "csr"):
+            x = sp.csr_matrix(x, dtype=np.float64)
+        if not x.has_canonical_format:
+            x = x.copy()
+            x.sum_duplicates()
+        return x
+
     def _fit_transform_sharded(self, x, n_iter, convergence_tol, ws, me):
         """fit_transform over `ws` ranks (see fit_transform).  Same sequence of half-iterations, initial factors and
         stopping rule as the one-rank path; the factors of a row do not depend on the number of ranks (only the order of
-        the Gramian / loss sums does)."""
+        the Gramian / loss sums does).
+
+        No rank converts or holds the matrix in both orientations: a rank SLICES its users' rows out of the CSR input (views
+        of the caller's arrays), uploads that block, and the ranks build the item-major blocks among themselves on the
+        devices (engine.item_block_from_user_blocks: three all-to-alls of the matrix's bytes + one on-device transposition
+        per rank).  Host work per rank before the first iteration: one pass over the row pointers."""
+        import time
         import torch.distributed as dist
+        from .engine import all_reduce_any, balanced_bounds, item_block_from_user_blocks
+        t_host0 = time.perf_counter()
         be = self._backend()
-        # (a canonical CSR matrix is c_iu already -- its transpose is a CSC matrix over the same arrays --, which saves the host
-        # the second of its two conversions; see fit_transform)
-        by_rows = sp.issparse(x) and x.format == "csr" and self._preprocess is _identity and x.has_canonical_format
-        c_iu = sp.csc_matrix(x.T, dtype=np.float64) if by_rows else None
-        c_ui = self._preprocess(sp.csc_matrix(x, dtype=np.float64))
-        c_ui.sort_indices()
-        if (self._feedback != "explicit" or self._non_negative) and c_ui.nnz and c_ui.data.min() < 0:
-            raise ValueError("all(c_ui@x >= 0) is not TRUE")
-        n_user, n_item = c_ui.shape
+        x = self._user_rows(x)
+        n_user, n_item = x.shape
+        nnz = int(x.nnz)
         k = self._rank
         # the SAME initial factors on every rank: drawn once from the model's generator ...  (copies: the broadcast below
         # writes into them, and the caller's arrays are not ours to change)
@@ -290,36 +305,48 @@ class WRMF:
             t = torch.from_numpy(buf).to(dev0)
             dist.broadcast(t, src=dist.get_global_rank(self._group, 0) if self._group is not None else 0, group=self._group)
             buf[...] = t.cpu().numpy()
+        # ---- my users' rows: a slice of the caller's CSR arrays, uploaded as the CSC-by-user block it already is ----
+        cnt_user = torch.from_numpy(np.diff(x.indptr).astype(np.int64))
+        bounds_u = balanced_bounds(cnt_user, ws)
+        u0, u1 = bounds_u[me]
+        lo, hi = int(x.indptr[u0]), int(x.indptr[u1])
+        p_iu = be.to_device(np.asarray(x.indptr[u0:u1 + 1], dtype=np.int64) - lo, torch.int32)
+        i_iu = be.to_device(x.indices[lo:hi], torch.int32)
+        x64 = be.to_device(x.data[lo:hi], torch.float64)
+        self.host_seconds_before_first_iteration = time.perf_counter() - t_host0   # (slicing + upload of the own block)
+        # sums that span the matrix: own block, then one all-reduce (identical on every rank; the order of the sum differs
+        # from a one-rank numpy.sum by rounding only)
+        stats = torch.zeros(3, dtype=torch.float64, device=dev0)       # [min < 0 flag, sum, unused]
+        if hi > lo:
+            stats[0] = float(bool(x64.min() < 0))
+            stats[1] = x64.sum()
+        all_reduce_any(stats, self._group)
+        if (self._feedback != "explicit" or self._non_negative) and float(stats[0]) > 0:
+            raise ValueError("all(c_ui@x >= 0) is not TRUE")                       # :195-197, on every rank together
         self.global_bias = 0.0
         if self._with_bias:
             pass                                                                   # :259-277: initialize_biases below owns the global bias
-        elif self._with_global_bias and self._feedback == "explicit":              # :278-282, on the host: the mean is global
-            self.global_bias = float(np.mean(c_ui.data)) if c_ui.nnz else 0.0
-            c_ui = c_ui.copy()
-            c_ui.data -= self.global_bias
-            if c_iu is not None:
-                c_iu = c_iu.copy()                                                 # (it shares its arrays with the caller's x)
-                c_iu.data -= self.global_bias
+        elif self._with_global_bias and self._feedback == "explicit":              # :278-282: the mean leaves the data
+            self.global_bias = float(stats[1]) / nnz if nnz else 0.0
+            x64 -= self.global_bias
         elif self._with_global_bias:                                               # :285-287
-            sm = float(c_ui.data.sum())
-            self.global_bias = sm / (sm + float(n_user) * float(n_item) - float(c_ui.nnz))
-        if c_iu is None:
-            c_iu = sp.csc_matrix(c_ui.T)      # t_shallow(as.csr.matrix(c_ui)), :190 (host side: only blocks are uploaded)
-            c_iu.sort_indices()
-        cnt_item = torch.from_numpy(np.diff(c_ui.indptr).astype(np.int64))
-        cnt_user = torch.from_numpy(np.diff(c_iu.indptr).astype(np.int64))
-        lay_u, lay_i = ShardedALS.layouts(n_user, n_item, ws, cnt_user, cnt_item, n_sub=self._n_sub)
-
-        def block(m, lo, hi):
-            b = m[:, lo:hi]
-            return (be.to_device(b.indptr, torch.int32), be.to_device(b.indices, torch.int32),
-                    be.to_device(b.data.astype(ndt), tdt))
-        als = ShardedALS(be, n_user, n_item, k, block(c_ui, *lay_i.bounds[me]), block(c_iu, *lay_u.bounds[me]), c_ui.nnz,
+            sm = float(stats[1])
+            self.global_bias = sm / (sm + float(n_user) * float(n_item) - float(nnz))
+        x_iu = x64 if self._f64 else (be.values_to_float(x64) if hasattr(be, "values_to_float") and x64.is_cuda else x64.to(tdt))
+        del x64
+        # ---- items: global counts from the blocks' counts, nnz-balanced bounds, then the exchange ----
+        cnt_item = torch.bincount(i_iu.to(torch.int64), minlength=n_item)
+        all_reduce_any(cnt_item, self._group)
+        lay_u, lay_i = ShardedALS.layouts(n_user, n_item, ws, cnt_user, cnt_item.cpu(), n_sub=self._n_sub)
+        assert lay_u.bounds == bounds_u
+        c_iu_blk = (p_iu, i_iu, x_iu)
+        c_ui_blk = item_block_from_user_blocks(be, self._group, ws, me, n_user, lay_u.bounds, lay_i.bounds, *c_iu_blk)
+        als = ShardedALS(be, n_user, n_item, k, c_ui_blk, c_iu_blk, nnz,
                          feedback=self._feedback, lambda_=self._lambda, dynamic_lambda=self._dynamic_lambda,
                          cg_steps=self._cg_steps, group=self._group, world_size=ws, my_rank=me, lay_user=lay_u,
                          lay_item=lay_i, with_bias=self._with_bias)
         als.cnt_user = be.to_device(cnt_user.numpy().astype(ndt), tdt)
-        als.cnt_item = be.to_device(cnt_item.numpy().astype(ndt), tdt)
+        als.cnt_item = cnt_item.to(tdt)
         U = lay_u.from_global(lay_u.alloc(k, dev0, tdt), be.to_device(U0, tdt))
         V = lay_i.from_global(lay_i.alloc(k, dev0, tdt), be.to_device(V0, tdt))
         if self._with_bias:                                                        # :259-277, sweep by sweep over the shards
@@ -335,12 +362,13 @@ class WRMF:
         loss_prev = float("inf")
         self.losses = []
         for it in range(int(n_iter)):
-            li = als.half_iteration("items", U, V, self._solver_code)
-            lu = als.half_iteration("users", U, V, self._solver_code)
+            li = als.half_iteration("items", U, V, self._solver_code, defer_exchange=True)
+            lu = als.half_iteration("users", U, V, self._solver_code, defer_exchange=True)
             self.losses.append((li, lu))
             if (loss_prev / lu if lu != 0 else float("inf")) - 1 < convergence_tol:   # every rank sees the same loss
                 break
             loss_prev = lu
+        als.finish()
         self._check_numeric()
         # the returned embeddings: one more exact solve from zeros against the final item factors (:355-359), sharded like
         # a user half-iteration
@@ -352,6 +380,7 @@ class WRMF:
             res[:, 0] = 1.0                                                         # :427-429
         solver = 0 if self._solver_code == 1 else self._solver_code
         als.half_iteration("users", res, V, solver, G=XtX, want_loss=False)
+        als.finish()
         self._check_numeric()
         # what transform() / predict() need afterwards: a plain (n_item, rank) replica of the item factors on every rank
         self._V = lay_i.to_global(V).contiguous()
@@ -368,23 +397,32 @@ class WRMF:
         balanced by non-zeros; (0, n) on one rank"""
         ws, me = self._dist()
         if ws <= 1:
+            self._row_bounds = [(0, x_csr.shape[0])]
             return 0, x_csr.shape[0], ws
         from .engine import balanced_bounds
-        a, b = balanced_bounds(torch.from_numpy(np.diff(x_csr.indptr).astype(np.int64)), ws)[me]
+        self._row_bounds = balanced_bounds(torch.from_numpy(np.diff(x_csr.indptr).astype(np.int64)), ws)
+        a, b = self._row_bounds[me]
         return a, b, ws
 
-    def _share_rows(self, block, a, n_new, fill=0):
-        """every rank computed rows [a, a + len(block)) of an (n_new, ...) result: assemble the whole on every rank (one
-        all-reduce of a tensor that is `fill`-free outside the rank's own rows)"""
+    def _share_rows(self, block, bounds, n_new):
+        """every rank computed the rows bounds[rank] of an (n_new, ...) result: assemble the whole on every rank with ONE
+        all-gather of equal, padded blocks (an all-reduce of a zero-filled full tensor moved twice the bytes)"""
         import torch.distributed as dist
-        full = torch.zeros((n_new,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
-        full[a:a + block.shape[0]] = block
-        if full.is_cuda and dist.get_backend(self._group) == "gloo":   # dry-run configuration (ranks sharing one GPU)
-            host = full.cpu()
-            dist.all_reduce(host, group=self._group)
-            full.copy_(host)
+        ws, me = self._dist()
+        B = max(1, max(b - a for a, b in bounds))
+        mine = torch.zeros((B,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        mine[:block.shape[0]] = block
+        out = torch.empty((ws * B,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        if out.is_cuda and dist.get_backend(self._group) == "gloo":   # dry-run configuration (ranks sharing one GPU)
+            host = out.cpu()
+            dist.all_gather_into_tensor(host, mine.cpu(), group=self._group)
+            out.copy_(host)
         else:
-            dist.all_reduce(full, group=self._group)
+            dist.all_gather_into_tensor(out, mine, group=self._group)
+        full = torch.empty((n_new,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        for r, (a, b) in enumerate(bounds):
+            if b > a:
+                full[a:b] = out[r * B:r * B + (b - a)]
         return full
 
     def _transform_device(self, x_csr):
@@ -399,7 +437,7 @@ class WRMF:
         be = self._backend()
         csc = be.make_csc(xt.shape[0], xt.shape[1], *self._upload_csc(xt))
         res = self._transform_dev(csc, mine.shape[0])
-        return self._share_rows(res, a, x_csr.shape[0]) if ws > 1 else res
+        return self._share_rows(res, self._row_bounds, x_csr.shape[0]) if ws > 1 else res
 
     def _transform_dev(self, csc_users, n_new):
         """R/model_WRMF.R:412-452: one user half-iteration from zeros against the final item factors,
@@ -467,7 +505,7 @@ class WRMF:
                 None if d_ex is None else d_ex.data_ptr(), int(excl.size), float(self.global_bias),
                 res.data_ptr(), sc.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)))
         if ws > 1:
-            res, sc = self._share_rows(res, a, n_new), self._share_rows(sc, a, n_new)
+            res, sc = self._share_rows(res, self._row_bounds, n_new), self._share_rows(sc, self._row_bounds, n_new)
         idx = res.cpu().numpy().astype(np.int64)
         idx = np.where(idx == -2147483648, -1, idx - 1)       # R is 1-based with NA_integer_
         out = idx.view(TopItems)

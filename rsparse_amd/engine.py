@@ -312,6 +312,33 @@ class HipBackend:
                                                                 int(bool(dynamic_lambda)), loss_out.data_ptr(),
                                                                 self._stream()))
 
+    def top_product(self, U, V, k, nr_p, nr_j, exclude0, glob_mean):
+        """top_product (src/matrix_top_product.cpp:20-102) for the rows of U (n x rank) against V (n_item x rank), both on the
+        device: (indices int32 n x k, 1-based with NA_integer_; scores float64 n x k).  nr_p / nr_j: the rows' not_recommend
+        entries as CSR slots (or None), exclude0: sorted 0-based item ids excluded for every row (or None)."""
+        n, rank = U.shape
+        n_item = V.shape[0]
+        U32 = U.to(torch.float32).contiguous()
+        V32 = self._v32(V)
+        res = torch.empty((n, k), dtype=torch.int32, device=U.device)
+        sc = torch.empty((n, k), dtype=torch.float32, device=U.device)
+        _lib.check(self.lib.rsparse_hip_top_product_device(
+            U32.data_ptr(), V32.data_ptr(), n, n_item, rank, k,
+            None if nr_p is None else nr_p.data_ptr(), None if nr_j is None else nr_j.data_ptr(),
+            None if exclude0 is None else exclude0.data_ptr(), 0 if exclude0 is None else int(exclude0.numel()),
+            float(glob_mean), res.data_ptr(), sc.data_ptr(), self._stream()))
+        return res, sc.to(torch.float64)
+
+    def _v32(self, V):
+        """the fp32 replica of a factor matrix the fp64 layer holds (kept until the matrix changes: ADVICE r04 -- `predict` of
+        one user paid an n_item x rank conversion per call)"""
+        if V.dtype == torch.float32:
+            return V
+        key = (V.data_ptr(), V._version, tuple(V.shape))
+        if getattr(self, "_v32_key", None) != key:
+            self._v32_cache, self._v32_key = V.to(torch.float32).contiguous(), key
+        return self._v32_cache
+
     def initialize_biases_explicit(self, csc_ui, csc_iu, user_bias, item_bias, lambda_, dynamic_lambda, non_negative,
                                    calculate_global_bias):
         """wrmf_utils.hpp:32-84 on the device; with calculate_global_bias the resident values of both handles

@@ -492,18 +492,11 @@ class WRMF:
                 nr_p = be.to_device(nr.indptr, torch.int32)
                 nr_j = be.to_device(nr.indices, torch.int32)
         d_ex = be.to_device(excl, torch.int32) if excl.size else None
-        res = torch.empty((n_mine, k), dtype=torch.int32, device=emb.device)
-        sc = torch.empty((n_mine, k), dtype=torch.float32, device=emb.device)
-        lib = be.lib
         if n_mine > 0:
-            # scores are fp32 on the device whatever the model's precision (the reference multiplies in double; stated)
-            emb_mine = emb[a:b].to(torch.float32).contiguous()
-            V32 = self._V if self._V.dtype == torch.float32 else self._V.to(torch.float32)
-            _lib.check(lib.rsparse_hip_top_product_device(
-                emb_mine.data_ptr(), V32.data_ptr(), n_mine, n_item, self._rank, k,
-                None if nr_p is None else nr_p.data_ptr(), None if nr_j is None else nr_j.data_ptr(),
-                None if d_ex is None else d_ex.data_ptr(), int(excl.size), float(self.global_bias),
-                res.data_ptr(), sc.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)))
+            res, sc = be.top_product(emb[a:b], self._V, k, nr_p, nr_j, d_ex, float(self.global_bias))
+        else:
+            res = torch.empty((0, k), dtype=torch.int32, device=emb.device)
+            sc = torch.empty((0, k), dtype=torch.float64, device=emb.device)
         if ws > 1:
             res, sc = self._share_rows(res, self._row_bounds, n_new), self._share_rows(sc, self._row_bounds, n_new)
         idx = res.cpu().numpy().astype(np.int64)

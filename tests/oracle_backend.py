@@ -43,6 +43,12 @@ class OracleBackend:
         tp, ti, tx = O.csc_transpose(n_rows, n_cols, p.numpy(), i.numpy(), x.numpy())
         return torch.from_numpy(tp), torch.from_numpy(ti), torch.from_numpy(tx)
 
+    def top_product(self, U, V, k, nr_p, nr_j, exclude0, glob_mean):
+        res, sc = O.top_product(U.numpy().astype(np.float64), V.numpy().astype(np.float64).T, k,
+                                None if nr_p is None else nr_p.numpy(), None if nr_j is None else nr_j.numpy(),
+                                () if exclude0 is None else (exclude0.numpy() + 1).tolist(), glob_mean)
+        return torch.from_numpy(res), torch.from_numpy(np.nan_to_num(sc, nan=0.0))
+
     def subtract_mean(self, x, x_other=None):
         m = float(x.to(torch.float64).mean()) if x.numel() else 0.0
         x -= m

@@ -234,3 +234,89 @@ def test_csr_input_gives_the_sharded_fit_the_same_blocks():
         assert np.array_equal(m.data, before)
     finally:
         dist.destroy_process_group()
+
+
+def _skewed_problem():
+    """one user holds a quarter of the entries and one item is in most rows: cut into eight nnz-balanced blocks, some ranks
+    own NO users and some NO items (an empty block: no solve, a zero-row slab in every exchange, nothing to send in the
+    all-to-all that builds the item blocks)"""
+    rng = np.random.default_rng(23)
+    n_user, n_item = 90, 81
+    lens = rng.integers(1, 3, n_user)
+    lens[17] = 78
+    rows = np.repeat(np.arange(n_user), lens)
+    cols = np.concatenate([rng.choice(np.arange(1, n_item), size=l, replace=False) for l in lens])
+    vals = 1.0 + rng.geometric(0.5, size=rows.size)
+    m = sp.csr_matrix((vals, (rows, cols)), shape=(n_user, n_item)).tolil()
+    m[:, 0] = 2.0                     # item 0: nearly every user
+    m[::7, 0] = 0.0
+    m = sp.csr_matrix(m)
+    m.eliminate_zeros()
+    m.sort_indices()
+    new = sp.csr_matrix((rng.random((19, n_item)) < 0.2) * 1.0)
+    return m, new
+
+
+def _worker8(rank, ws, port, feedback, solver, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")   # 8 ranks on as many cores
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    from oracle_backend import OracleBackend
+    from rsparse_amd import WRMF
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        m, new = _skewed_problem()
+        rng = np.random.default_rng(5)
+        k = 8
+        model = WRMF(rank=k, lambda_=0.1, feedback=feedback, solver=solver, precision="float", backend=OracleBackend(),
+                     rng=100 + rank, n_sub=(8, 4))                      # (differently seeded ranks: rank 0's factors win)
+        model._init_user_factors = (rng.standard_normal((m.shape[0], k)) * 0.01).astype(np.float32) if rank == 0 else None
+        if solver != "conjugate_gradient" and rank == 0:
+            model.components = (rng.standard_normal((k, m.shape[1])) * 0.01).astype(np.float32)
+        elif solver != "conjugate_gradient":
+            model.components = np.zeros((k, m.shape[1]), dtype=np.float32)
+        emb = model.fit_transform(m, n_iter=2, convergence_tol=-1)
+        top = model.predict(new, 5)
+        torch.save({"emb": emb, "new": model.transform(new), "components": model.components, "losses": model.losses,
+                    "top": np.asarray(top), "host_s": model.host_seconds_before_first_iteration},
+                   os.path.join(out_dir, "e%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("feedback,solver", [("implicit", "conjugate_gradient"), ("explicit", "cholesky")])
+def test_wrmf_eight_ranks_with_empty_blocks(tmp_path, feedback, solver):
+    """World size 8 through the class: n_sub = (8, 4), ranks whose user block or item block is empty,
+    the item blocks built by all-to-all from the user blocks (no rank holds the matrix in both orientations), initial
+    factors from rank 0 only -- against the one-process oracle driver."""
+    import torch.multiprocessing as mp
+    from oracle import wrmf_oracle as O
+    from rsparse_amd.engine import balanced_bounds
+    m, new = _skewed_problem()
+    bu = balanced_bounds(np.diff(m.indptr), 8)
+    bi = balanced_bounds(np.diff(sp.csc_matrix(m).indptr), 8)
+    assert any(b == a for a, b in bu) and any(b == a for a, b in bi)           # the case under test
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker8, args=(8, port, feedback, solver, str(tmp_path)), nprocs=8, join=True)
+    rs = [torch.load(tmp_path / ("e%d.pt" % r), weights_only=False) for r in range(8)]
+    for r in range(1, 8):
+        for key in ("emb", "new", "components", "top"):
+            assert np.array_equal(rs[0][key], rs[r][key]), (key, r)
+        assert rs[0]["losses"] == rs[r]["losses"]
+    rng = np.random.default_rng(5)
+    k = 8
+    U0 = (rng.standard_normal((m.shape[0], k)) * 0.01).astype(np.float32)
+    V0 = None if solver == "conjugate_gradient" else (rng.standard_normal((k, m.shape[1])) * 0.01).astype(np.float32)
+    c = sp.csc_matrix(m); c.sort_indices()
+    ref = O.OracleWRMF(k, lam=0.1, feedback=feedback, solver=solver, dtype=np.float32, n_threads=4)
+    ref_emb = ref.fit_transform(m.shape[0], m.shape[1], c.indptr.astype(np.int32), c.indices.astype(np.int32),
+                                c.data.astype(np.float64), U0.T.copy(), n_iter=2, convergence_tol=-1, init_components=V0)
+    assert rel_fro(rs[0]["components"], ref.components) < 5e-5
+    assert rel_fro(rs[0]["emb"], ref_emb) < 5e-5
+    assert np.allclose([l[1] for l in rs[0]["losses"]], [l[1] for l in ref.losses], rtol=5e-5)
+    nt = sp.csc_matrix(new.T); nt.sort_indices()
+    ref_new = ref.transform(nt.indptr.astype(np.int32), nt.indices.astype(np.int32), nt.data.astype(np.float64))
+    assert rel_fro(rs[0]["new"], ref_new) < 5e-5
+    assert rs[0]["top"].shape == (new.shape[0], 5)
+    assert all(r["host_s"] < 5.0 for r in rs)

@@ -311,8 +311,9 @@ int rsparse_hip_weighted_sumsq_device(const float* d_X, int rank, int64_t n, con
  * not_recommend as dgRMatrix slots p (nr+1) / j (sorted per row), NULL = nothing to filter; exclude: 1-based
  * item indices excluded for every row.  res: nr x k column-major 1-based indices (NA_integer_ where fewer
  * than k items are admissible), scores: nr x k column-major (+ glob_mean), best first; equal scores keep the
- * reference's order (larger index first).  Scores are computed in fp32 on the device (the reference
- * multiplies in double).  k > 256 -> ERR_UNSUPPORTED.  n_threads is accepted and ignored. */
+ * reference's order (larger index first).  The candidates (k + max(8, k / 4) per row) come from an fp32 matrix-core pass,
+ * their scores are recomputed in double from x and y as given and the reference's heap is replayed over them
+ * (rsparse_hip_top_product_f64_device below).  k > 256 -> ERR_UNSUPPORTED.  n_threads is accepted and ignored. */
 int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, int rank, unsigned k,
                             unsigned n_threads, const int32_t* not_recommend_p,
                             const int32_t* not_recommend_j, const int32_t* exclude, int n_exclude,
@@ -324,6 +325,19 @@ int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_use
                                    int k, const int32_t* d_not_recommend_p, const int32_t* d_not_recommend_j,
                                    const int32_t* d_exclude0, int n_exclude, double glob_mean,
                                    int32_t* d_res, float* d_scores, void* stream);
+
+/* `$predict` that ORDERS like the reference.  find_top_product casts both factor matrices to double before the product
+ * (R/utils.R:35-36) and top_product takes arma::mat (src/matrix_top_product.cpp:20): the fp32 pass above only nominates -- it keeps
+ * the k + extra best items of every user (extra < 0: max(8, k / 4); never more than 256 candidates) --, their scores are
+ * recomputed in double from d_U64 / d_V64 (n x rank row-major doubles; both NULL: from the fp32 factors widened) and the
+ * reference's heap is replayed over the candidates in ascending item order: strict `>` replacement, equal scores with the
+ * larger index first, and when more candidates sit AT the k-th score than places, the ones the reference's heap keeps.
+ * Exact whenever every item whose double score reaches the k-th best is among the candidates.  d_scores: n_users x k doubles. */
+int rsparse_hip_top_product_f64_device(const float* d_U, const float* d_V, const double* d_U64, const double* d_V64,
+                                       int n_users, int n_items, int rank, int k, int extra,
+                                       const int32_t* d_not_recommend_p, const int32_t* d_not_recommend_j,
+                                       const int32_t* d_exclude0, int n_exclude, double glob_mean, int32_t* d_res,
+                                       double* d_scores, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (3) fp64 device layer: als_implicit<double> / als_explicit<double> with the data resident in HBM

@@ -65,6 +65,8 @@ SIGNATURES = {
     "rsparse_hip_weighted_sumsq_device": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp]),
     "rsparse_hip_top_product": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_uint, _c_uint, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp]),
     "rsparse_hip_top_product_device": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _vp]),
+    "rsparse_hip_top_product_f64_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp,
+                                                    _c_int, _c_dbl, _vp, _vp, _vp]),
     "rsparse_hip_csc_f64_create_device": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "rsparse_hip_csc_f64_destroy": (_c_int, [_vp]),
     "rsparse_hip_gramian_f64_device": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp, _vp, _vp]),

@@ -1566,6 +1566,33 @@ int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_use
   return RSPARSE_HIP_OK;
 }
 
+int rsparse_hip_top_product_f64_device(const float* d_U, const float* d_V, const double* d_U64, const double* d_V64,
+                                       int n_users, int n_items, int rank, int k, int extra, const int32_t* d_nr_p,
+                                       const int32_t* d_nr_j, const int32_t* d_excl0, int n_exclude, double glob_mean,
+                                       int32_t* d_res, double* d_scores, void* stream) {
+  if (!d_U || !d_V || !d_res || !d_scores) return fail(RSPARSE_HIP_ERR_INVALID, "NULL matrix or output");
+  if ((d_U64 == nullptr) != (d_V64 == nullptr)) return fail(RSPARSE_HIP_ERR_INVALID, "the double factors come as a pair");
+  if (n_users < 0 || n_items < 0 || rank <= 0 || k < 1) return fail(RSPARSE_HIP_ERR_INVALID, "bad dimensions");
+  if (rank > RSPARSE_HIP_MAX_RANK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "rank > 256 is not on the device path");
+  if (k > RSPARSE_HIP_MAX_TOPK) return fail(RSPARSE_HIP_ERR_UNSUPPORTED, "k > 256 is not on the device path");
+  if (n_users == 0) return RSPARSE_HIP_OK;
+  // candidates per user: k + extra (default: a quarter of k, at least 8), never more than the kernel's 256 or the items
+  if (extra < 0) extra = std::max(8, k / 4);
+  const int kc = std::max(k, std::min(std::min(k + extra, RSPARSE_HIP_MAX_TOPK), std::max(n_items, 1)));
+  int rc = g_ws.ensure_bias(top_product_f64_scratch_words(n_users, kc, k));   // (nothing else uses this buffer meanwhile)
+  if (rc) return rc;
+  float* split = nullptr;   // few users over many items: the nominating pass splits the items over the workgroups
+  const size_t ent = top_product_scratch_entries(n_users, n_items, kc);
+  if (ent > 0) {
+    if ((rc = g_ws.ensure_pad(2 * ent + (size_t)n_users + 16))) return rc;
+    split = g_ws.pad_buf;
+  }
+  hipError_t e = launch_top_product_f64(d_U, d_V, d_U64, d_V64, n_users, n_items, rank, k, kc, d_nr_p, d_nr_p ? d_nr_j : nullptr,
+                                        d_excl0, n_exclude, glob_mean, d_res, d_scores, (hipStream_t)stream, g_ws.bias_buf, split);
+  if (e != hipSuccess) return hip_fail(e, "launch_top_product_f64");
+  return RSPARSE_HIP_OK;
+}
+
 int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, int rank, unsigned k, unsigned n_threads,
                             const int32_t* nr_p, const int32_t* nr_j, const int32_t* exclude, int n_exclude,
                             double glob_mean, int32_t* res, double* scores) {
@@ -1577,8 +1604,12 @@ int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, in
   if (n_exclude < 0 || (n_exclude > 0 && !exclude)) return fail(RSPARSE_HIP_ERR_INVALID, "bad exclude");
   // x is nr x rank column-major -> row-major fp32; y (rank x nc column-major) already has item vectors contiguous
   std::vector<float> U((size_t)nr * rank), V((size_t)nc * rank);
+  std::vector<double> U64((size_t)nr * rank);
   for (int j = 0; j < nr; j++)
-    for (int r = 0; r < rank; r++) U[(size_t)j * rank + r] = (float)x[(size_t)r * nr + j];
+    for (int r = 0; r < rank; r++) {
+      U64[(size_t)j * rank + r] = x[(size_t)r * nr + j];
+      U[(size_t)j * rank + r] = (float)x[(size_t)r * nr + j];
+    }
   for (size_t e = 0; e < V.size(); e++) V[e] = (float)y[e];
   std::vector<int32_t> ex;
   for (int e = 0; e < n_exclude; e++)
@@ -1586,13 +1617,17 @@ int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, in
   std::sort(ex.begin(), ex.end());
   ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
   const int64_t nr_nnz = (nr_p && nr > 0) ? (int64_t)nr_p[nr] : 0;
-  DevBuf dU, dV, dP, dJ, dE, dR, dS;
+  DevBuf dU, dV, dU64, dV64, dP, dJ, dE, dR, dS;
   HIP_TRY(dU.alloc(U.size() * 4));
   HIP_TRY(dV.alloc(V.size() * 4));
+  HIP_TRY(dU64.alloc(U64.size() * 8));
+  HIP_TRY(dV64.alloc(V.size() * 8));
   HIP_TRY(dR.alloc((size_t)nr * k * 4));
-  HIP_TRY(dS.alloc((size_t)nr * k * 4));
+  HIP_TRY(dS.alloc((size_t)nr * k * 8));
   if (!U.empty()) HIP_TRY(hipMemcpy(dU.p, U.data(), U.size() * 4, hipMemcpyHostToDevice));
   if (!V.empty()) HIP_TRY(hipMemcpy(dV.p, V.data(), V.size() * 4, hipMemcpyHostToDevice));
+  if (!U64.empty()) HIP_TRY(hipMemcpy(dU64.p, U64.data(), U64.size() * 8, hipMemcpyHostToDevice));
+  if (!V.empty()) HIP_TRY(hipMemcpy(dV64.p, y, V.size() * 8, hipMemcpyHostToDevice));   // rank x nc column-major = item vectors contiguous
   const bool filter = nr_nnz > 0 && nr_j;   // `not_empty_filter_matrix`, matrix_top_product.cpp:33
   if (filter) {
     HIP_TRY(dP.alloc(((size_t)nr + 1) * 4));
@@ -1604,22 +1639,23 @@ int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, in
     HIP_TRY(dE.alloc(ex.size() * 4));
     HIP_TRY(hipMemcpy(dE.p, ex.data(), ex.size() * 4, hipMemcpyHostToDevice));
   }
-  int rc = rsparse_hip_top_product_device(dU.as<float>(), dV.as<float>(), nr, nc, rank, (int)k,
-                                          filter ? dP.as<int32_t>() : nullptr, filter ? dJ.as<int32_t>() : nullptr,
-                                          ex.empty() ? nullptr : dE.as<int32_t>(), (int)ex.size(), glob_mean,
-                                          dR.as<int32_t>(), dS.as<float>(), nullptr);
+  // candidates from the fp32 pass, scores and order from the doubles as given (find_top_product multiplies arma::mat)
+  int rc = rsparse_hip_top_product_f64_device(dU.as<float>(), dV.as<float>(), dU64.as<double>(), dV64.as<double>(), nr, nc,
+                                              rank, (int)k, -1, filter ? dP.as<int32_t>() : nullptr,
+                                              filter ? dJ.as<int32_t>() : nullptr, ex.empty() ? nullptr : dE.as<int32_t>(),
+                                              (int)ex.size(), glob_mean, dR.as<int32_t>(), dS.as<double>(), nullptr);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
   std::vector<int32_t> hr((size_t)nr * k);
-  std::vector<float> hs((size_t)nr * k);
+  std::vector<double> hs((size_t)nr * k);
   if (!hr.empty()) {
     HIP_TRY(hipMemcpy(hr.data(), dR.p, hr.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hs.data(), dS.p, hs.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hs.data(), dS.p, hs.size() * 8, hipMemcpyDeviceToHost));
   }
   for (int j = 0; j < nr; j++)
     for (unsigned c = 0; c < k; c++) {
       res[(size_t)c * nr + j] = hr[(size_t)j * k + c];
-      scores[(size_t)c * nr + j] = (double)hs[(size_t)j * k + c];
+      scores[(size_t)c * nr + j] = hs[(size_t)j * k + c];
     }
   return RSPARSE_HIP_OK;
 }

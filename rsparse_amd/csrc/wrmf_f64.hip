@@ -568,8 +568,12 @@ __device__ __forceinline__ int f64_from_step_lane(const int v, const int g) {
   }
 }
 
-template <int W, bool IMPLICIT>
+// EPL = coordinates per lane: 1 up to rank 64; 2 (W = 64: lane l holds the coordinates l and 64 + l) for ranks 65..128 -- round 5:
+// the reference's default precision at the BASELINE ranks (R/model_WRMF.R:82) ran on the generic kernel's k^2 flops per
+// non-zero until then, and WRMF kept such fits in fp32 behind a warning.
+template <int W, bool IMPLICIT, int EPL = 1>
 __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, int n_hi, int slot0) {   // rows of n_lo < n <= n_hi non-zeros
+  static_assert(EPL == 1 || W == 64, "two coordinates per lane: the whole wave holds one vector");
   constexpr int NPS = 64 / W;   // non-zeros per step
   constexpr int BS = 16;        // steps per batch: their vectors are requested together, the next batch's before this one is used
   constexpr int NBATCH = W / BS;
@@ -579,21 +583,38 @@ __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, i
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int k = a.k;
   const int l = lane & (W - 1), g = lane / W;
-  const bool lk = l < k;
-  const int lc = min(l, k - 1);
+  bool lk[EPL];
+  int lc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; e++) {
+    lk[e] = l + 64 * e < k;
+    lc[e] = min(l + 64 * e, k - 1);
+  }
   if (IMPLICIT) {
     for (int e = tid; e < k * k; e += 256) sG[e] = a.XtX[e];
     __syncthreads();
   }
-  // (G v)_l, v one coordinate per lane (replicated in the groups): v_m from lane m of the wave
-  auto gmv = [&](const double v) {
-    double s0 = 0.0;
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    for (int m = 0; m < k; m++) {
-      const double vm = __hiloint2double(__builtin_amdgcn_readlane(hi, m), __builtin_amdgcn_readlane(lo, m));
-      s0 = fma(sG[lc + (size_t)m * k], vm, s0);
+  struct Vec { double c[EPL]; };
+  // (G v)_l, v one coordinate per lane and register (replicated in the groups): v_m from lane m % 64, register m / 64
+  auto gmv = [&](const Vec v) {
+    Vec s0;
+    int lo[EPL], hi[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+      s0.c[e] = 0.0;
+      lo[e] = __double2loint(v.c[e]);
+      hi[e] = __double2hiint(v.c[e]);
     }
-    return lk ? s0 : 0.0;
+#pragma unroll
+    for (int e2 = 0; e2 < EPL; e2++)
+      for (int m = 0; m < min(64, k - 64 * e2); m++) {
+        const double vm = __hiloint2double(__builtin_amdgcn_readlane(hi[e2], m), __builtin_amdgcn_readlane(lo[e2], m));
+#pragma unroll
+        for (int e = 0; e < EPL; e++) s0.c[e] = fma(sG[lc[e] + (size_t)(m + 64 * e2) * k], vm, s0.c[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < EPL; e++) s0.c[e] = lk[e] ? s0.c[e] : 0.0;
+    return s0;
   };
   double wloss = 0.0;
   for (int row = blockIdx.x * 4 + wv; row < a.n_cols; row += gridDim.x * 4) {
@@ -601,15 +622,19 @@ __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, i
     double* yrow = a.Y + (size_t)row * k;
     if (!(n > n_lo && n <= n_hi)) continue;   // another launch's row
     if (n <= 0) {   // empty column -> zeros (wrmf_implicit.hpp:272-283, wrmf_explicit.hpp:133-144)
-      if (lane < k) yrow[lane] = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPL; e++)
+        if (lane + 64 * e < k) yrow[lane + 64 * e] = 0.0;
       continue;
     }
     const double lam_use = IMPLICIT ? a.lambda : a.lambda * (a.dynamic_lambda ? (double)n : 1.0);
     // One pass over the row's vectors: out_l = sum_j coef(c_j, x_j . v) x_j[l], or (MODE 2) sum_j lw_j (lt_j - x_j . v)^2 in every lane.
     // A chunk is 64 non-zeros: lane (g, st) holds the index and the value of the non-zero st * NPS + g, the one group g gathers in step st.
-    auto pass = [&](const double v, auto mode_tag) {
+    auto pass = [&](const Vec v, auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;   // 0: first residual, 1: operator, 2: loss
-      double acc = 0.0;
+      Vec acc;
+#pragma unroll
+      for (int e = 0; e < EPL; e++) acc.c[e] = 0.0;
       // (index, value) of the lane's non-zero of the chunk at c0, requested two chunks ahead of its use; the vectors of a batch of
       // 16 steps one batch ahead, across chunk boundaries: a row of 500 non-zeros is 8 chunks x 5 passes, and every chunk used to
       // cost two exposed round trips (its indices, then its vectors)
@@ -622,20 +647,21 @@ __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, i
           cjh = __double2hiint(cj);
         }
       };
-      auto fetch = [&](auto bt, const int idj, const int nst, double (&dst)[BS]) {
+      auto fetch = [&](auto bt, const int idj, const int nst, double (&dst)[BS][EPL]) {
         constexpr int B = decltype(bt)::value;
         if (B * BS < nst) {   // wave-uniform
           static_for_f64<BS>([&](auto ut) {
             constexpr int U = decltype(ut)::value, ST = B * BS + U;
             const int id = f64_from_step_lane<W, ST>(idj, g);   // (steps beyond the chunk repeat its last non-zero: weight 0)
-            dst[U] = a.X[(size_t)id * k + lc];
+#pragma unroll
+            for (int e = 0; e < EPL; e++) dst[U][e] = a.X[(size_t)id * k + lc[e]];
           });
         }
       };
       int id0 = 0, c0l = 0, c0h = 0, id1 = 0, c1l = 0, c1h = 0, id2 = 0, c2l = 0, c2h = 0;
       meta(0, id0, c0l, c0h);
       meta(64, id1, c1l, c1h);
-      double cur[BS], nxt[BS];
+      double cur[BS][EPL], nxt[BS][EPL];
       fetch(std::integral_constant<int, 0>{}, id0, (min(64, n) + NPS - 1) / NPS, cur);
       for (int c0 = 0; c0 < n; c0 += 64) {
         const int cn = min(64, n - c0);
@@ -654,51 +680,89 @@ __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, i
             static_for_f64<BS>([&](auto ut) {
               constexpr int U = decltype(ut)::value, ST = B * BS + U;
               if (ST < nst) {   // wave-uniform
-                const double yv = lk ? cur[U] : 0.0;
+                double yv[EPL];
+                double part = 0.0;
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                  yv[e] = lk[e] ? cur[U][e] : 0.0;
+                  part = fma(yv[e], v.c[e], part);
+                }
                 const bool in = ST * NPS + g < cn;
                 const double c = __hiloint2double(f64_from_step_lane<W, ST>(c0h, g), f64_from_step_lane<W, ST>(c0l, g));
-                const double t = f64_group_sum<W>(yv * v);
+                const double t = f64_group_sum<W>(part);
                 if constexpr (MODE == 2) {
                   const double dlt = (IMPLICIT ? 1.0 : c) - t;
-                  acc += in ? (IMPLICIT ? c : 1.0) * dlt * dlt : 0.0;
+                  acc.c[0] += in ? (IMPLICIT ? c : 1.0) * dlt * dlt : 0.0;
                 } else {
                   double coef;
                   if constexpr (MODE == 0) coef = IMPLICIT ? c - (c - 1.0) * t : c - t;
                   else coef = IMPLICIT ? (c - 1.0) * t : t;
-                  acc = fma(in ? coef : 0.0, yv, acc);
+                  coef = in ? coef : 0.0;
+#pragma unroll
+                  for (int e = 0; e < EPL; e++) acc.c[e] = fma(coef, yv[e], acc.c[e]);
                 }
               }
             });
 #pragma unroll
-            for (int u = 0; u < BS; u++) cur[u] = nxt[u];
+            for (int u = 0; u < BS; u++)
+#pragma unroll
+              for (int e = 0; e < EPL; e++) cur[u][e] = nxt[u][e];
           }
         });
         id0 = id1; c0l = c1l; c0h = c1h;
         id1 = id2; c1l = c2l; c1h = c2h;
       }
       // the groups' shares (loss: every lane of a group holds the group's term)
-      return f64_across_groups<W>(acc);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) acc.c[e] = f64_across_groups<W>(acc.c[e]);
+      return acc;
     };
     // sums over the coordinates (one group's lanes; the groups hold copies)
-    auto dot = [&](const double u, const double v) { return f64_group_sum<W>(lk ? u * v : 0.0); };
+    auto dot = [&](const Vec u, const Vec v) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPL; e++) sacc = fma(lk[e] ? u.c[e] : 0.0, v.c[e], sacc);
+      return f64_group_sum<W>(sacc);
+    };
 
-    double x = lk ? yrow[l] : 0.0;   // warm start
-    double r = pass(x, std::integral_constant<int, 0>{}) - (IMPLICIT ? gmv(x) : lam_use * x);
-    double pv = r;
+    Vec x, r, pv;
+#pragma unroll
+    for (int e = 0; e < EPL; e++) x.c[e] = lk[e] ? yrow[l + 64 * e] : 0.0;   // warm start
+    {
+      const Vec t0 = pass(x, std::integral_constant<int, 0>{});
+      Vec g0;
+      if constexpr (IMPLICIT) g0 = gmv(x);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) r.c[e] = t0.c[e] - (IMPLICIT ? g0.c[e] : lam_use * x.c[e]);
+    }
+    pv = r;
     double rsold = dot(r, r);
     for (int it = 0; it < a.cg_steps; it++) {
-      const double ap = pass(pv, std::integral_constant<int, 1>{}) + (IMPLICIT ? gmv(pv) : lam_use * pv);
+      Vec ap = pass(pv, std::integral_constant<int, 1>{});
+      {
+        Vec g1;
+        if constexpr (IMPLICIT) g1 = gmv(pv);
+#pragma unroll
+        for (int e = 0; e < EPL; e++) ap.c[e] += IMPLICIT ? g1.c[e] : lam_use * pv.c[e];
+      }
       const double alpha = rsold / dot(pv, ap);
-      x = fma(alpha, pv, x);
-      r = fma(-alpha, ap, r);
+#pragma unroll
+      for (int e = 0; e < EPL; e++) {
+        x.c[e] = fma(alpha, pv.c[e], x.c[e]);
+        r.c[e] = fma(-alpha, ap.c[e], r.c[e]);
+      }
       const double rsnew = dot(r, r);
       if (rsnew < kCgTolD) break;
-      pv = fma(pv, rsnew / rsold, r);
+      const double beta = rsnew / rsold;
+#pragma unroll
+      for (int e = 0; e < EPL; e++) pv.c[e] = fma(pv.c[e], beta, r.c[e]);
       rsold = rsnew;
     }
-    if (lane < k) yrow[lane] = x;   // (group 0)
-    const double lrow = pass(x, std::integral_constant<int, 2>{});
-    wloss += lrow + lam_use * dot(x, x);
+#pragma unroll
+    for (int e = 0; e < EPL; e++)
+      if (lane + 64 * e < k && (EPL > 1 || lane < k)) yrow[lane + 64 * e] = x.c[e];   // (group 0)
+    const Vec lrow = pass(x, std::integral_constant<int, 2>{});
+    wloss += lrow.c[0] + lam_use * dot(x, x);
   }
   if (lane == 0) sLoss[wv] = wloss;
   __syncthreads();
@@ -707,24 +771,28 @@ __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, i
 
 bool f64_cg_wave_supported(const F64Args& a) {
   return a.solver == 1 && a.xb < 0 && !a.rhs_init && a.gbias == 0.0 && a.k1 == a.k && a.xoff == 0 && a.ioff == 0 && a.ooff == 0 &&
-         !a.solve_empty && a.k >= 1 && a.k <= 64;
+         !a.solve_empty && a.k >= 1 && a.k <= 128;
 }
 
 // slots: the loss partials a.loss_partials[0 .. slots) are this call's (all written or zeroed)
 // (Measured and not kept: the row's vectors resident in registers across the five passes -- one wave per row up to 256 non-zeros,
 //  the four waves of a workgroup sharing a row up to 1024 -- lost to the streaming kernel on both sides of the 1M x 100k matrix:
 //  200..256 registers and 64 unrolled steps per pass against 140 registers here; users 6.4 -> 12.5 ms, items 19 -> 23 ms.)
-template <int W>
+template <int W, int EPL = 1>
 hipError_t launch_f64_cg_wave_w(const F64Args& a, int slots, hipStream_t s) {
-  const size_t lds = a.implicit ? (size_t)a.k * a.k * sizeof(double) : 0;
+  const size_t lds = a.implicit ? (size_t)a.k * a.k * sizeof(double) : 0;   // (rank 128: 128 KB, one workgroup per CU)
   hipError_t err;
   const int grid = std::max(1, std::min((a.n_cols + 3) / 4, slots));
   if (grid < slots && (err = hipMemsetAsync(a.loss_partials + grid, 0, (size_t)(slots - grid) * sizeof(double), s)) != hipSuccess)
     return err;
   if (a.implicit) {
-    hipLaunchKernelGGL((f64_cg_wave_kernel<W, true>), dim3(grid), dim3(256), lds, s, a, -1, 0x7fffffff, 0);
+    auto kern = f64_cg_wave_kernel<W, true, EPL>;
+    if (lds > 48 * 1024 &&
+        (err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+      return err;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, -1, 0x7fffffff, 0);
   } else {
-    hipLaunchKernelGGL((f64_cg_wave_kernel<W, false>), dim3(grid), dim3(256), lds, s, a, -1, 0x7fffffff, 0);
+    hipLaunchKernelGGL((f64_cg_wave_kernel<W, false, EPL>), dim3(grid), dim3(256), lds, s, a, -1, 0x7fffffff, 0);
   }
   return hipGetLastError();
 }
@@ -864,7 +932,8 @@ hipError_t launch_f64_als(const F64Args& a, hipStream_t s) {
   if (f64_cg_wave_supported(a)) {   // the plain conjugate-gradient half-iteration: one wave per row, four rows per workgroup
     if (a.k <= 16) return launch_f64_cg_wave_w<16>(a, grid, s);
     if (a.k <= 32) return launch_f64_cg_wave_w<32>(a, grid, s);
-    return launch_f64_cg_wave_w<64>(a, grid, s);
+    if (a.k <= 64) return launch_f64_cg_wave_w<64>(a, grid, s);
+    return launch_f64_cg_wave_w<64, 2>(a, grid, s);   // ranks 65..128: two coordinates per lane (round 5)
   }
   if (g.NT == 64) {
     auto kern = f64_als_kernel<64>;

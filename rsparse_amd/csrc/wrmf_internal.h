@@ -264,6 +264,14 @@ hipError_t launch_f32_to_f64(const float* in, double* out, size_t n, hipStream_t
 hipError_t launch_top_product(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
                               const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
                               float glob_mean, int32_t* res, float* scores, hipStream_t s, float* scratch = nullptr);
+// `$predict` ordered like the reference's double product (wrmf_topk.hip): kc >= topk candidates per user from the fp32 kernel,
+// re-scored in double (U64 / V64, or the fp32 factors widened when they are null), the reference's heap replayed over them;
+// scratch: top_product_f64_scratch_words(n_users, kc, topk) 4-byte words; split_scratch as launch_top_product's (for kc)
+size_t top_product_f64_scratch_words(int n_users, int kc, int topk);
+hipError_t launch_top_product_f64(const float* U32, const float* V32, const double* U64, const double* V64, int n_users,
+                                  int n_items, int rank, int topk, int kc, const int32_t* nr_ptr, const int32_t* nr_idx,
+                                  const int32_t* excl, int n_excl, double glob_mean, int32_t* res, double* scores, hipStream_t s,
+                                  float* scratch, float* split_scratch);
 // a call for few users over many items is split over the items (wrmf_topk.hip): floats of scratch it wants
 // (2 x entries + n_users), 0 = not split
 size_t top_product_scratch_entries(int n_users, int n_items, int topk);

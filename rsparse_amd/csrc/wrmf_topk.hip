@@ -828,6 +828,219 @@ hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, i
                                   const int* user_flags);
 }
 
+// ---- `$predict` that orders like the reference: candidates re-scored in double ----
+// find_top_product casts both factor matrices to double before the product (R/utils.R:35-36) and top_product takes arma::mat
+// (src/matrix_top_product.cpp:20): fp32 scores can swap items whose scores differ by ~1e-7 relative.  The fp32 matrix-core pass
+// therefore only NOMINATES: it keeps the kc = k + extra best items of every user; one wave per user then recomputes those kc
+// scores in double (from the double factors where the model holds them, else from the fp32 ones widened), and replays the
+// reference's heap over the candidates in ascending item order.  That replay is the reference's result as long as every
+// item whose double score reaches the k-th best is among the candidates: the final heap depends only on those items (items
+// below the k-th score are evicted before any of them and never block one).  Equal scores: the larger index first; more
+// candidates AT the k-th score than places: the survivors are the ones the heap keeps -- an arrival at the bound does not
+// enter a full heap, a better arrival evicts the bound's smallest index.
+// amb_out (pass 1, nullable): set for a user whose candidate list may not hold every item at the k-th score -- the list is full,
+// its last entry sits AT that score, better items exist and the bound has more candidates than places: items of the bound
+// that the larger heap of the fp32 pass evicted would have changed which of them the reference's heap keeps.  Such users are
+// recomputed by the fp32 kernel with the reference's heap at capacity k (launch_top_product_f64) and only sorted here
+// (pass 2: only_flagged = the same array, kc == topk).
+template <class TF>
+__global__ __launch_bounds__(256) void top_rescore_kernel(const TF* __restrict__ U, const TF* __restrict__ V, int n_users,
+                                                          int rank, int kc, int topk, const int32_t* __restrict__ cand,
+                                                          double glob_mean, int32_t* __restrict__ res,
+                                                          double* __restrict__ scores, int* __restrict__ amb_out,
+                                                          const int* __restrict__ only_flagged) {
+  __shared__ double sU[4][256];
+  __shared__ double sS[4][kTopMaxK];      // candidate scores
+  __shared__ int sI[4][kTopMaxK];         // candidate items (0-based; -1 = none)
+  __shared__ int sO[4][kTopMaxK];         // S (score >= v_k) in ascending item order: candidate slots
+  __shared__ int sQ[4][kTopMaxK];         // replay: the bound's candidates inside the heap, oldest first
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + wv;
+  if (u >= n_users) return;
+  if (only_flagged && !only_flagged[u]) return;
+  double* uu = sU[wv];
+  double* cs = sS[wv];
+  int* ci = sI[wv];
+  for (int r = lane; r < rank; r += 64) uu[r] = (double)U[(size_t)u * rank + r];
+  for (int c = lane; c < kc; c += 64) {
+    const int ix = cand[(size_t)u * kc + c];
+    ci[c] = ix == INT32_MIN ? -1 : ix - 1;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // scores: the wave walks the candidates, lane l takes the elements l, l + 64, ... of the item's vector
+  for (int c = 0; c < kc; c++) {
+    const int it = ci[c];
+    double acc = 0.0;
+    if (it >= 0)
+      for (int r = lane; r < rank; r += 64) acc = fma(uu[r], (double)V[(size_t)it * rank + r], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) cs[c] = acc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // position of every candidate in the order (score descending, item descending); n_valid of them exist
+  int n_valid = 0;
+  for (int c = 0; c < kc; c++) n_valid += ci[c] >= 0 ? 1 : 0;
+  const int kk = min(topk, n_valid);
+  auto before = [&](const int a, const int b) {   // a ahead of b
+    return cs[a] > cs[b] || (cs[a] == cs[b] && ci[a] > ci[b]);
+  };
+  constexpr int PER = kTopMaxK / 64;
+  int pos[PER];
+#pragma unroll
+  for (int e = 0; e < PER; e++) {
+    const int c = lane + 64 * e;
+    int p = -1;
+    if (c < kc && ci[c] >= 0) {
+      p = 0;
+      for (int o = 0; o < kc; o++) p += (ci[o] >= 0 && o != c && before(o, c)) ? 1 : 0;
+    }
+    pos[e] = p;
+  }
+  // the k-th best score, how many candidates beat it (g) and how many sit at it (nt)
+  double vk = 0.0;
+  int g = 0, nt = 0;
+  if (kk > 0) {
+    int who = -1;
+#pragma unroll
+    for (int e = 0; e < PER; e++)
+      if (pos[e] == kk - 1) who = lane + 64 * e;
+    const unsigned long long m = __ballot(who >= 0);
+    const int src = __ffsll((long long)m) - 1;
+    who = __shfl(who, src);
+    vk = cs[who];
+    double vmin = vk;
+    for (int c = 0; c < kc; c++) {
+      g += (ci[c] >= 0 && cs[c] > vk) ? 1 : 0;
+      nt += (ci[c] >= 0 && cs[c] == vk) ? 1 : 0;
+      if (ci[c] >= 0) vmin = fmin(vmin, cs[c]);
+    }
+    if (amb_out && lane == 0 && n_valid == kc && kc > topk && vmin == vk && g > 0 && g + nt > kk) amb_out[u] = 1;
+  }
+  int32_t* ru = res + (size_t)u * topk;
+  double* su = scores + (size_t)u * topk;
+  if (g + nt <= kk) {
+    // no more candidates at the bound than places: the first kk positions are the answer
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+      const int c = lane + 64 * e;
+      if (pos[e] >= 0 && pos[e] < kk) {
+        ru[pos[e]] = ci[c] + 1;
+        su[pos[e]] = cs[c] + glob_mean;
+      }
+    }
+  } else {
+    // replay of the heap over S = {score >= v_k} in ascending item order (rare: exact ties at the bound)
+    int* so = sO[wv];
+    int* q = sQ[wv];
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+      const int c = lane + 64 * e;
+      if (c < kc && ci[c] >= 0 && cs[c] >= vk) {
+        int r = 0;
+        for (int o = 0; o < kc; o++) r += (ci[o] >= 0 && cs[o] >= vk && ci[o] < ci[c]) ? 1 : 0;
+        so[r] = c;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int head = 0, tail = 0;
+    if (lane == 0) {
+      int cnt = 0;
+      for (int e = 0; e < g + nt; e++) {
+        const int c = so[e];
+        if (cs[c] > vk) {
+          if (cnt < kk) cnt++;
+          else head++;               // evicts the smallest (score, item) pair: the bound's oldest = smallest index
+        } else if (cnt < kk) {
+          q[tail++] = c;
+          cnt++;
+        }
+      }
+    }
+    head = __shfl(head, 0);
+    tail = __shfl(tail, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+      const int c = lane + 64 * e;
+      if (pos[e] >= 0 && cs[c] > vk) {   // better than the bound: positions 0 .. g - 1 as they stand
+        ru[pos[e]] = ci[c] + 1;
+        su[pos[e]] = cs[c] + glob_mean;
+      }
+    }
+    // the survivors at the bound, larger index first: q[head .. tail) is ascending in item
+    for (int e = head + lane; e < tail; e += 64) {
+      const int c = q[e];
+      const int at = g + (tail - 1 - e);
+      ru[at] = ci[c] + 1;
+      su[at] = cs[c] + glob_mean;
+    }
+  }
+  for (int c = kk + lane; c < topk; c += 64) {   // fewer admissible items than k: NA_integer_ / NA_real_
+    ru[c] = INT32_MIN;
+    su[c] = __longlong_as_double(0x7ff8000000000000ll);
+  }
+}
+
+// The whole `$predict` that orders like the reference.  U32 / V32: the fp32 factors (the nominating pass); U64 / V64: the double
+// ones (nullable as a pair: the fp32 factors widened).  scratch: n_users * (kc + topk) ints + as many floats + n_users ints
+// (top_product_f64_scratch_words).  Steps: (1) the fp32 kernel keeps kc = k + extra candidates per user; (2) one wave per user
+// recomputes their scores in double and replays the reference's heap (top_rescore_kernel), flagging the users whose candidate
+// list may be missing items at the k-th score; (3) the workgroups of the fp32 kernel that hold a flagged user run again at
+// capacity k -- the reference's own heap, exact ties included -- and (4) those users' k items are re-scored and sorted.  No host
+// round trip: without flagged users (3) and (4) are launches whose workgroups return at once.
+size_t top_product_f64_scratch_words(int n_users, int kc, int topk) {
+  return (size_t)n_users * ((size_t)2 * kc + 2 * topk + 1) + 64;
+}
+template <class TF>
+hipError_t launch_top_product_f64_t(const float* U32, const float* V32, const TF* U, const TF* V, int n_users, int n_items,
+                                    int rank, int topk, int kc, const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl,
+                                    int n_excl, double glob_mean, int32_t* res, double* scores, hipStream_t s, float* scratch,
+                                    float* split_scratch) {
+  if (n_users <= 0) return hipSuccess;
+  if (kc < topk || kc > kTopMaxK || topk < 1 || rank < 1 || rank > 256) return hipErrorInvalidValue;
+  int32_t* cand = reinterpret_cast<int32_t*>(scratch);
+  float* cand_sc = scratch + (size_t)n_users * kc;
+  int32_t* res2 = reinterpret_cast<int32_t*>(cand_sc + (size_t)n_users * kc);
+  float* sc2 = reinterpret_cast<float*>(res2 + (size_t)n_users * topk);
+  int* flags = reinterpret_cast<int*>(sc2 + (size_t)n_users * topk);
+  hipError_t err;
+  if ((err = launch_top_product(U32, V32, n_users, n_items, rank, kc, nr_ptr, nr_idx, excl, n_excl, 0.f, cand, cand_sc, s,
+                                split_scratch)) != hipSuccess)
+    return err;
+  if ((err = hipMemsetAsync(flags, 0, (size_t)n_users * sizeof(int), s)) != hipSuccess) return err;
+  const dim3 grid((n_users + 3) / 4);
+  hipLaunchKernelGGL(top_rescore_kernel<TF>, grid, dim3(256), 0, s, U, V, n_users, rank, kc, topk, cand, glob_mean, res, scores,
+                     flags, static_cast<const int*>(nullptr));
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  if (kc > topk) {
+    if ((err = launch_top_product_geo(U32, V32, n_users, n_items, rank, topk, nr_ptr, nr_idx, excl, n_excl, 0.f, res2, sc2, s, 1, 0,
+                                      flags)) != hipSuccess)
+      return err;
+    hipLaunchKernelGGL(top_rescore_kernel<TF>, grid, dim3(256), 0, s, U, V, n_users, rank, topk, topk, res2, glob_mean, res, scores,
+                       static_cast<int*>(nullptr), flags);
+    if ((err = hipGetLastError()) != hipSuccess) return err;
+  }
+  return hipSuccess;
+}
+hipError_t launch_top_product_f64(const float* U32, const float* V32, const double* U64, const double* V64, int n_users,
+                                  int n_items, int rank, int topk, int kc, const int32_t* nr_ptr, const int32_t* nr_idx,
+                                  const int32_t* excl, int n_excl, double glob_mean, int32_t* res, double* scores, hipStream_t s,
+                                  float* scratch, float* split_scratch) {
+  if (U64 && V64)
+    return launch_top_product_f64_t<double>(U32, V32, U64, V64, n_users, n_items, rank, topk, kc, nr_ptr, nr_idx, excl, n_excl,
+                                            glob_mean, res, scores, s, scratch, split_scratch);
+  return launch_top_product_f64_t<float>(U32, V32, U32, V32, n_users, n_items, rank, topk, kc, nr_ptr, nr_idx, excl, n_excl,
+                                         glob_mean, res, scores, s, scratch, split_scratch);
+}
+
 // how a call is split: slices of `slice_items` items (a multiple of 32), 1 = not at all
 int top_product_slices(int n_users, int n_items, int topk, int* slice_items) {
   *slice_items = 0;

@@ -320,14 +320,21 @@ class HipBackend:
         n_item = V.shape[0]
         U32 = U.to(torch.float32).contiguous()
         V32 = self._v32(V)
+        # the fp32 matrix-core pass nominates k + max(8, k / 4) candidates per row; their scores are recomputed in double
+        # (from the double factors when the model holds them: find_top_product multiplies in double, R/utils.R:35-36) and
+        # the reference's heap is replayed over them
+        f64 = U.dtype == torch.float64 and V.dtype == torch.float64
+        U64 = U.contiguous() if f64 else None
+        V64 = V.contiguous() if f64 else None
         res = torch.empty((n, k), dtype=torch.int32, device=U.device)
-        sc = torch.empty((n, k), dtype=torch.float32, device=U.device)
-        _lib.check(self.lib.rsparse_hip_top_product_device(
-            U32.data_ptr(), V32.data_ptr(), n, n_item, rank, k,
+        sc = torch.empty((n, k), dtype=torch.float64, device=U.device)
+        _lib.check(self.lib.rsparse_hip_top_product_f64_device(
+            U32.data_ptr(), V32.data_ptr(), None if U64 is None else U64.data_ptr(), None if V64 is None else V64.data_ptr(),
+            n, n_item, rank, k, -1,
             None if nr_p is None else nr_p.data_ptr(), None if nr_j is None else nr_j.data_ptr(),
             None if exclude0 is None else exclude0.data_ptr(), 0 if exclude0 is None else int(exclude0.numel()),
             float(glob_mean), res.data_ptr(), sc.data_ptr(), self._stream()))
-        return res, sc.to(torch.float64)
+        return res, sc
 
     def _v32(self, V):
         """the fp32 replica of a factor matrix the fp64 layer holds (kept until the matrix changes: ADVICE r04 -- `predict` of

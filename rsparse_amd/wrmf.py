@@ -39,10 +39,14 @@ class TopItems(np.ndarray):
 
 
 class WRMF:
-    # precision = "double" (the reference's default, R/model_WRMF.R:82) runs the fp64 layer of the library up to this rank
-    # (counting the two bias coordinates); above it the fp32 kernels are used and a RuntimeWarning says so.  The fp64 path
-    # is the parity path (one workgroup per row, k^2 flops per non-zero): set WRMF.f64_max_rank = 128 to take it always.
+    # precision = "double" (the reference's default, R/model_WRMF.R:82) runs the fp64 layer of the library
+    #   * up to rank 128 for the plain conjugate-gradient fit (no biases, no global bias: the constructor's default solver;
+    #     one wave per row, the operator applied from the gathered vectors -- round 5: ranks 65..128 two coordinates per lane),
+    #   * up to f64_max_rank (counting the two bias coordinates) for every other variant: those run the generic fp64 kernel
+    #     (one workgroup per row, k^2 flops per non-zero) -- set WRMF.f64_max_rank = 128 to take it always;
+    # above that the fp32 kernels are used and a RuntimeWarning says so.  The library's fp64 layer ends at rank 128.
     f64_max_rank = 63
+    f64_max_rank_cg = 128
 
     def __init__(self, rank=10, lambda_=0.0, dynamic_lambda=True, init=None, preprocess=_identity,
                  feedback="implicit", solver="conjugate_gradient", with_user_item_bias=False,
@@ -72,13 +76,15 @@ class WRMF:
         self._lambda, self._dynamic_lambda = float(lambda_), bool(dynamic_lambda)
         self._cg_steps = int(cg_steps)
         self._rank = int(rank) + (2 if self._with_bias else 0)                     # :159-163
-        self._f64 = precision == "double" and self._rank <= self.f64_max_rank
+        plain_cg = solver == "conjugate_gradient" and not with_user_item_bias and not with_global_bias
+        lim = min(128, max(self.f64_max_rank, self.f64_max_rank_cg if plain_cg else 0))   # (the fp64 layer ends at 128)
+        self._f64 = precision == "double" and self._rank <= lim
         if precision == "double" and not self._f64:
             import warnings
-            warnings.warn("rsparse_amd.WRMF(precision='double') at rank %d > WRMF.f64_max_rank = %d: the device path computes "
+            warnings.warn("rsparse_amd.WRMF(precision='double') at rank %d > %d: the device path computes "
                           "in fp32 (the reference's precision='float' arithmetic); inputs and results are converted at the "
                           "boundary.  Pass precision='float' to silence this, or raise WRMF.f64_max_rank (<= 128) to run "
-                          "the fp64 kernels." % (self._rank, self.f64_max_rank), RuntimeWarning, stacklevel=2)
+                          "the generic fp64 kernels." % (self._rank, lim), RuntimeWarning, stacklevel=2)
         self._preprocess = preprocess
         self.components = init
         self.global_bias = 0.0

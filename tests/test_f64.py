@@ -275,6 +275,34 @@ def test_wrmf_double_runs_in_double(ml_train):
     assert np.array_equal(emb, model.transform(train))
     top = model.predict(train[:50], 7)
     assert top.shape == (50, 7)
-    # above WRMF.f64_max_rank the fp32 kernels run, and the constructor says so
+    # above WRMF.f64_max_rank the variants without a wave kernel run in fp32, and the constructor says so; the plain
+    # conjugate-gradient fit stays in double up to rank 128 (round 5)
     with pytest.warns(RuntimeWarning, match="fp32"):
-        WRMF(rank=64, precision="double")
+        WRMF(rank=64, precision="double", solver="cholesky")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert WRMF(rank=128, precision="double")._f64 and WRMF(rank=64, precision="double")._f64
+
+
+@pytest.mark.parametrize("k,feedback", [(96, "implicit"), (128, "implicit"), (128, "explicit"), (72, "explicit")])
+def test_wrmf_double_at_the_baseline_ranks(ml_train, k, feedback):
+    """precision = "double" (the reference's default, R/model_WRMF.R:82) at ranks 65..128 -- the plain
+    conjugate-gradient fit runs the fp64 wave kernel (two coordinates per lane) through the class: no warning, 1e-9 against the
+    fp64 oracle driver.  (The exact solve that ends fit_transform is the generic fp64 kernel.)"""
+    import warnings
+    from rsparse_amd import WRMF
+    n_user, n_item, p, i, x = ml_train
+    train = sp.csc_matrix((x, i, p), shape=(n_user, n_item))
+    rng = np.random.default_rng(k)
+    U0 = rng.standard_normal((n_user, k)) * 0.01
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model = WRMF(rank=k, lambda_=0.1, feedback=feedback, solver="conjugate_gradient", precision="double")
+    assert model._f64
+    model._init_user_factors = U0
+    emb = model.fit_transform(train, n_iter=2, convergence_tol=-1)
+    ref = O.OracleWRMF(k, lam=0.1, feedback=feedback, solver="conjugate_gradient", dtype=np.float64, n_threads=8)
+    ref_emb = ref.fit_transform(n_user, n_item, p, i, x, U0.T.copy(), n_iter=2, convergence_tol=-1)
+    assert emb.dtype == np.float64 and rel_fro(emb, ref_emb) < 1e-9
+    assert rel_fro(model.components, ref.components) < 1e-9
+    assert np.allclose([l[1] for l in model.losses], [l[1] for l in ref.losses], rtol=1e-10)

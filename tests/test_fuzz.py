@@ -4,7 +4,7 @@
   not multiples of the packing, empty classes, confidences at exactly 1, factor scales 1e-3..10, lambda 0.01..10, rows on both
   sides of the 64-non-zero boundary.  Bound: max(1e-4, 3 x the fp32 oracle's own distance from the fp64 oracle) per row -- with
   lambda = 0.01 and factors of size 10 plain fp32 arithmetic on the k x k system is off by 1e-1, the device is not;
-* the fp64 conjugate-gradient wave kernel (wrmf_f64.hip): rows of 0..700 non-zeros (several 64-non-zero chunks), ranks 3..64,
+* the fp64 conjugate-gradient wave kernel (wrmf_f64.hip): rows of 0..700 non-zeros (several 64-non-zero chunks), ranks 3..128 (65..128: two coordinates per lane, round 5),
   0..5 CG steps.  Bound: 1e-9 per row.
 """
 import numpy as np
@@ -65,7 +65,7 @@ def test_low_rank_wave_kernels_on_random_shapes(trial):
 def test_f64_cg_wave_kernel_on_random_shapes(trial):
     rng = np.random.default_rng(500 + trial)
     implicit = trial % 2 == 0
-    k = int(rng.choice([3, 10, 16, 17, 24, 32, 33, 50, 64]))
+    k = int(rng.choice([3, 10, 16, 17, 24, 32, 33, 50, 64, 65, 96, 100, 127, 128]))
     n_rows, n_item = int(rng.integers(1, 120)), 900
     lens, p, idx = _rows(rng, n_rows, int(rng.choice([5, 70, 130, 260, 700])), n_item)
     x = (1.0 + rng.gamma(1.0, 2.0, size=idx.size)) if implicit else np.round(1.0 + 4.0 * rng.random(idx.size))

@@ -69,7 +69,7 @@ def test_collective_branches_on_a_one_rank_nccl_group(tmp_path):
     # sub-blocked storage + collectives change nothing but the order of the Gramian / loss sums (k x k through doubles)
     for key in ("U", "V", "res"):
         err = float((a[key] - b[key]).norm() / a[key].norm())
-        assert err < 1e-4, (key, err)      # (2e-5 measured: the k x k sums round differently, three CG steps carry it)
+        assert err < 5e-5, (key, err)      # (2e-5 measured: the k x k sums round differently, three CG steps carry it)
     for (x1, y1), (x2, y2) in zip(a["losses"], b["losses"]):
         assert abs(x1 - x2) <= 1e-6 * abs(x1) and abs(y1 - y2) <= 1e-6 * abs(y1)
     assert out["max"] == 3.5

@@ -167,6 +167,62 @@ def test_hip_split_items_with_ties_falls_back_to_the_heap(k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rank,nr,nc,k", [(128, 300, 6000, 10), (128, 130, 6000, 100), (64, 77, 3000, 10), (10, 500, 1682, 100),
+                                          (36, 3, 30000, 10), (128, 40, 2500, 250)])
+def test_hip_orders_like_the_double_product(rank, nr, nc, k):
+    """find_top_product multiplies in double (R/utils.R:35-36): the device's candidates come from an fp32 pass, but scores and
+    ORDER are those of the double product -- indices equal to the oracle's everywhere, not only where fp32 separates the scores."""
+    rng = np.random.default_rng(7 * rank + k)
+    x = rng.standard_normal((nr, rank))
+    y = rng.standard_normal((rank, nc))
+    notrec = sp.random(nr, nc, density=0.03, random_state=5, format="csr")
+    for args in (dict(), dict(nr=notrec, exclude=[2, 9, nc], glob_mean=3.5)):
+        ref_i, ref_s = O.top_product(x, y, k, *(None, None) if "nr" not in args else (notrec.indptr, notrec.indices),
+                                     exclude=args.get("exclude", ()), glob_mean=args.get("glob_mean", 0.0))
+        got_i, got_s = _hip_top_product(x, y, k, **args)
+        assert np.array_equal(got_i, ref_i)
+        assert np.allclose(got_s, ref_s, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_near_ties_resolve_in_double():
+    """Pairs of items whose vectors differ by 1e-9 relative: equal scores in fp32 (where the larger index would come first),
+    ordered by the double product in the reference."""
+    rng = np.random.default_rng(3)
+    rank, nc, k = 64, 400, 20
+    y = rng.standard_normal((rank, nc))
+    for j in range(0, nc, 2):                      # item j + 1 = item j, a hair smaller or larger
+        y[:, j + 1] = y[:, j] * (1.0 + (1e-9 if (j // 2) % 2 else -1e-9))
+    x = rng.standard_normal((60, rank))
+    ref_i, ref_s = O.top_product(x, y, k)
+    got_i, got_s = _hip_top_product(x, y, k)
+    assert np.array_equal(got_i, ref_i)
+    assert np.allclose(got_s, ref_s, rtol=1e-13, atol=0)
+    f32 = (x.astype(np.float32) @ y.astype(np.float32))
+    assert (f32[:, 0::2] == f32[:, 1::2]).mean() > 0.5          # the case under test: fp32 does not separate the pairs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [10, 100])
+def test_wrmf_predict_orders_like_the_reference_on_movielens(movielens, ml_train, k):
+    """every movielens user, k = 10 and 100, precision = "double" -- the indices `predict` returns equal
+    the oracle's top_product of the model's own double factors."""
+    from rsparse_amd import WRMF
+    n_user, n_item, tp, ti, tx = ml_train
+    train = sp.csc_matrix((tx, ti, tp), shape=(n_user, n_item)).tocsr()
+    for precision in ("double", "float"):
+        m = WRMF(rank=10, lambda_=0.1, feedback="implicit", solver="conjugate_gradient", precision=precision, rng=1)
+        emb = m.fit_transform(train, n_iter=3, convergence_tol=-1)
+        preds = m.predict(train, k)
+        nr = train.copy(); nr.sort_indices()
+        ref_i, ref_s = O.top_product(np.asarray(emb, dtype=np.float64), np.asarray(m.components, dtype=np.float64), k,
+                                     nr.indptr, nr.indices)
+        ref0 = np.where(ref_i == O.NA_INTEGER, -1, ref_i - 1)
+        assert np.array_equal(np.asarray(preds), ref0), precision
+        assert np.allclose(preds.scores, np.nan_to_num(ref_s), rtol=1e-12 if precision == "double" else 1e-6)
+
+
+@pytest.mark.gpu
 def test_wrmf_predict(movielens, ml_train):
     """test-wrmf.R:59-61: predict(cv, k = K) has nrow(cv) rows and K columns; never recommends seen items."""
     from conftest import csc_drop_rows

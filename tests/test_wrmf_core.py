@@ -123,6 +123,58 @@ def test_wrmf_core(movielens, ml_train, feedback, solver, lam, bias, precision):
     assert max(errs.values()) <= tol, (cell, errs, yard, tol)
 
 
+# the seven precision = "float" cells whose five-iteration yardstick exceeds 1e-4 (profiles/r04/wrmf_core_parity_table.md)
+NOISY = [("implicit", "nnls", 0.1, True), ("implicit", "nnls", 0.0, True), ("explicit", "conjugate_gradient", 1000.0, False),
+         ("explicit", "nnls", 0.1, False), ("explicit", "nnls", 0.1, True), ("explicit", "conjugate_gradient", 0.1, True),
+         ("implicit", "nnls", 0.1, False)]
+
+
+@pytest.mark.parametrize("feedback,solver,lam,bias", NOISY)
+def test_noisy_float_cells_after_one_iteration(movielens, ml_train, feedback, solver, lam, bias):
+    """in the cells above a regression of tens of percent would pass the five-iteration rule (2 x a
+    yardstick that is itself 3e-4 ... 4e-2).  After ONE iteration -- item half, user half, the exact solve fit_transform ends
+    with: three solves from inputs that have not yet drifted apart -- the fp32 trajectories have not diverged, and the device
+    has to be within max(1e-4, 1.5 x) of what the reference-shaped fp32 arithmetic itself loses there (both against the fp64
+    oracle; the yardstick of four of the seven cells is below 1e-4 at this point, so for them the bound IS 1e-4)."""
+    from rsparse_amd import WRMF
+    train, cv, (n_user, n_item, tp, ti, tx) = _data(movielens, ml_train)
+    rng = np.random.default_rng(int(lam * 10) + 7 * bias + len(solver))
+    rank0 = 8
+    rank = rank0 + 2 * bias
+    U0 = (rng.standard_normal((n_user, rank)) * 0.01).astype(np.float32)
+    V0 = (rng.standard_normal((rank, n_item)) * 0.01).astype(np.float32)
+    init = None if solver == "conjugate_gradient" else V0.copy()
+    model = WRMF(rank=rank0, lambda_=lam, feedback=feedback, solver=solver, with_user_item_bias=bias, precision="float", init=init)
+    model._init_user_factors = U0
+    emb = model.fit_transform(train, n_iter=1, convergence_tol=-1)
+    fits = {}
+    for dt in (np.float64, np.float32):
+        ref = O.OracleWRMF(rank0, lam=lam, feedback=feedback, solver=solver, dtype=dt, n_threads=8, with_user_item_bias=bias)
+        ref_emb = ref.fit_transform(n_user, n_item, tp, ti, tx, U0.T.astype(dt), n_iter=1, convergence_tol=-1,
+                                    init_components=None if solver == "conjugate_gradient" else V0.astype(dt))
+        fits[dt] = (ref, ref_emb)
+    ref, ref_emb = fits[np.float64]
+    errs = _fit_errors(model.components, emb, model.losses, ref, ref_emb)
+    yard = _fit_errors(fits[np.float32][0].components, fits[np.float32][1], fits[np.float32][0].losses, ref, ref_emb)
+    mult = 1.5
+    if solver == "nnls":
+        # NNLS stops where a sweep's largest relative step falls below 1e-4: which sweep that is flips with the last bits of the
+        # squared system, so ONE fp32 fit is a fragile yardstick even after one iteration (measured: device 8.2e-3 against
+        # 2.0e-3 on the user embeddings of implicit / lambda 0.1, both with item factors at 4e-6).  As in tests/test_nnls.py the
+        # bound is 3 x the reference-shaped fp32 arithmetic, here the largest of three fits from one-ulp-scale perturbations
+        mult, prng = 3.0, np.random.default_rng(99)
+        for _ in range(2):
+            Up = (U0 * (1 + np.float32(2.0 ** -22) * prng.choice([-1, 1], size=U0.shape).astype(np.float32))).astype(np.float32)
+            r32 = O.OracleWRMF(rank0, lam=lam, feedback=feedback, solver=solver, dtype=np.float32, n_threads=8, with_user_item_bias=bias)
+            e32 = r32.fit_transform(n_user, n_item, tp, ti, tx, Up.T.copy(), n_iter=1, convergence_tol=-1, init_components=V0.copy())
+            y = _fit_errors(r32.components, e32, r32.losses, ref, ref_emb)
+            yard = {q: max(yard[q], y[q]) for q in y}
+    tol = max(1e-4, mult * max(yard.values()))
+    _record("one-iteration|%s|%s|%g|%d" % (feedback, solver, lam, bias), {"rank": rank0, "device": errs, "fp32_oracle": yard,
+                                                                         "fp32_fits": 1, "bound": tol})
+    assert max(errs.values()) <= tol, (errs, yard, tol)
+
+
 def test_wrmf_implicit_cg_with_biases_is_rejected():
     """Outside the reference's grid (test-wrmf.R:16-21 keeps with_user_item_bias = FALSE for conjugate_gradient): the
     reference drops a row of the warm start twice on that path (wrmf_implicit.hpp:189,197) and cannot run it; the

@@ -14,10 +14,18 @@ from rsparse_amd import WRMF, synth
 d = synth.make_dataset(1_000_000, 100_000, device="cpu", feedback="implicit")
 p, i, x = (t.numpy() for t in d["c_iu"])
 m = sp.csc_matrix((x.astype(np.float64), i, p), shape=(100_000, 1_000_000)).T.tocsr()
-for precision, rank, solver in (("double", 10, "conjugate_gradient"), ("float", 10, "conjugate_gradient"),
-                                ("double", 32, "conjugate_gradient"), ("float", 32, "conjugate_gradient"),
-                                ("double", 60, "conjugate_gradient"), ("float", 60, "conjugate_gradient"),
-                                ("double", 10, "cholesky"), ("float", 10, "cholesky")):
+CASES = (("double", 10, "conjugate_gradient"), ("float", 10, "conjugate_gradient"),
+         ("double", 32, "conjugate_gradient"), ("float", 32, "conjugate_gradient"),
+         ("double", 60, "conjugate_gradient"), ("float", 60, "conjugate_gradient"),
+         ("double", 10, "cholesky"), ("float", 10, "cholesky"))
+if len(sys.argv) > 1:   # precision:rank[:solver] ...   e.g.  double:128 float:128   (round 5: the BASELINE ranks in double)
+    CASES = tuple((a.split(":")[0], int(a.split(":")[1]), (a.split(":") + ["conjugate_gradient"])[2]) for a in sys.argv[1:])
+BUDGET_S = float(os.environ.get("RSPARSE_TOOL_BUDGET_S", "600"))
+T_START = time.perf_counter()
+for precision, rank, solver in CASES:
+    if time.perf_counter() - T_START > BUDGET_S:
+        print("budget of %.0f s spent: stopping before %s rank %d" % (BUDGET_S, precision, rank), flush=True)
+        break
     model = WRMF(rank=rank, lambda_=0.1, feedback="implicit", solver=solver, precision=precision, rng=1)
     model.fit_transform(m, n_iter=1, convergence_tol=-1)
     ts = []

@@ -590,8 +590,21 @@ __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, i
     lk[e] = l + 64 * e < k;
     lc[e] = min(l + 64 * e, k - 1);
   }
+  // XtX in LDS: k x k up to rank 64; ranks 65..128 keep the lower triangle only (row i at i (i + 1) / 2: 66 KB instead of 128 KB at
+  // rank 128, so that two workgroups fit a CU -- one wave per SIMD left the latency of every lane-crossing sum exposed)
+  constexpr bool TRI = EPL > 1;
+  int tl[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; e++) tl[e] = lc[e] * (lc[e] + 1) / 2;
   if (IMPLICIT) {
-    for (int e = tid; e < k * k; e += 256) sG[e] = a.XtX[e];
+    for (int e = tid; e < k * k; e += 256) {
+      if constexpr (TRI) {
+        const int i = e / k, j = e - i * k;
+        if (j <= i) sG[i * (i + 1) / 2 + j] = a.XtX[e];
+      } else {
+        sG[e] = a.XtX[e];
+      }
+    }
     __syncthreads();
   }
   struct Vec { double c[EPL]; };
@@ -609,8 +622,13 @@ __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, i
     for (int e2 = 0; e2 < EPL; e2++)
       for (int m = 0; m < min(64, k - 64 * e2); m++) {
         const double vm = __hiloint2double(__builtin_amdgcn_readlane(hi[e2], m), __builtin_amdgcn_readlane(lo[e2], m));
+        const int mm = m + 64 * e2;
+        const int tm = mm * (mm + 1) / 2;
 #pragma unroll
-        for (int e = 0; e < EPL; e++) s0.c[e] = fma(sG[lc[e] + (size_t)(m + 64 * e2) * k], vm, s0.c[e]);
+        for (int e = 0; e < EPL; e++) {
+          const int at = TRI ? (lc[e] >= mm ? tl[e] + mm : tm + lc[e]) : lc[e] + mm * k;   // XtX is symmetric
+          s0.c[e] = fma(sG[at], vm, s0.c[e]);
+        }
       }
 #pragma unroll
     for (int e = 0; e < EPL; e++) s0.c[e] = lk[e] ? s0.c[e] : 0.0;
@@ -780,7 +798,7 @@ bool f64_cg_wave_supported(const F64Args& a) {
 //  200..256 registers and 64 unrolled steps per pass against 140 registers here; users 6.4 -> 12.5 ms, items 19 -> 23 ms.)
 template <int W, int EPL = 1>
 hipError_t launch_f64_cg_wave_w(const F64Args& a, int slots, hipStream_t s) {
-  const size_t lds = a.implicit ? (size_t)a.k * a.k * sizeof(double) : 0;   // (rank 128: 128 KB, one workgroup per CU)
+  const size_t lds = !a.implicit ? 0 : (EPL > 1 ? (size_t)a.k * (a.k + 1) / 2 : (size_t)a.k * a.k) * sizeof(double);   // (rank 128: 66 KB)
   hipError_t err;
   const int grid = std::max(1, std::min((a.n_cols + 3) / 4, slots));
   if (grid < slots && (err = hipMemsetAsync(a.loss_partials + grid, 0, (size_t)(slots - grid) * sizeof(double), s)) != hipSuccess)

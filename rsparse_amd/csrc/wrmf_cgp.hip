@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           const int r = 32 * wv + 16 * t + m, c = 32 * ks + 8 * kb + e;
-          gmax = fmaxf(gmax, (r < k && c < k) ? fabsf(a.XtX[(size_t)r * k + c]) : 0.f);
+          {   // (clamped address, select afterwards: a per-lane `cond ? load : 0` is a branch with a wait per element)
+            const float gv = a.XtX[(size_t)min(r, k - 1) * k + min(c, k - 1)];
+            gmax = fmaxf(gmax, (r < k && c < k) ? fabsf(gv) : 0.f);
+          }
         }
     for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
     const int ge = p_scale_exp(gmax);
@@ -114,8 +117,10 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           const int r = 32 * wv + 16 * t + m, c = 32 * ks + 8 * kb + e;
-          const float g0 = (r < k && c < k) ? a.XtX[(size_t)r * k + c] : 0.f;
-          const float g1 = (r < k && c + 1 < k) ? a.XtX[(size_t)r * k + c + 1] : 0.f;
+          const float g0v = a.XtX[(size_t)min(r, k - 1) * k + min(c, k - 1)];
+          const float g0 = (r < k && c < k) ? g0v : 0.f;
+          const float g1v = a.XtX[(size_t)min(r, k - 1) * k + min(c + 1, k - 1)];
+          const float g1 = (r < k && c + 1 < k) ? g1v : 0.f;
           p_split(g0 * gs, g1 * gs, hi[e / 2], lo[e / 2]);
         }
         const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, l4 = {lo[0], lo[1], lo[2], lo[3]};
@@ -179,14 +184,26 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
     // ---- gather: all index loads, then all vector loads; slots beyond the row read the zero row and carry c = 0 ----
     float xt[NQ][RPN], cv[NQ];
     {
+      // (the loads WITHOUT a per-lane predicate: `in ? load : 0` compiles to a branch per slot with the address arithmetic of
+      //  the vector load -- and its wait for the index -- inside: up to eight index round trips one after the other per pair of
+      //  rows, found in the listing in round 5.  A slot outside its row reads entry 0 of the matrix and drops the result.)
       int id[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         const int s = 2 * q + g2;
-        const bool in = s < cnt;
-        const int j = p1 + (in ? s : 0);
-        id[q] = (in && (q < 4 || blk2)) ? a.row_idx[j] : 0;
-        cv[q] = (in && (q < 4 || blk2)) ? a.vals[j] : 0.f;
+        const int j = s < cnt ? p1 + s : 0;
+        id[q] = 0;
+        cv[q] = 0.f;
+        if (q < 4 || blk2) {   // wave-uniform
+          id[q] = a.row_idx[j];
+          cv[q] = a.vals[j];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const bool in = 2 * q + g2 < cnt;
+        id[q] = in ? id[q] : 0;
+        cv[q] = in ? cv[q] : 0.f;
       }
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
@@ -195,8 +212,11 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
 #pragma unroll
         for (int b = 0; b < NV; b++) {
           const int off = b * 16 * VW + i * VW;
-          if constexpr (KFULL) {   // (no branch: slots of the second block that nobody uses read the all-zero row, id = 0)
-            const float4 pc = *reinterpret_cast<const float4*>(src + off);
+          if constexpr (KFULL) {
+            // the first block without a branch; the second only when one of the wave's two rows reaches it (half of the rows of
+            // this launch have at most 8 non-zeros: gathering the zero row for them cost 0.4 ms of the launch's 5.7)
+            float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < 4 || blk2) pc = *reinterpret_cast<const float4*>(src + off);
             const float* pf = reinterpret_cast<const float*>(&pc);
 #pragma unroll
             for (int c = 0; c < VW; c++) xt[q][b * VW + c] = pf[c];

@@ -249,9 +249,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
   const int team = wv / WPR, tw = wv % WPR;
   const int k = KFULL ? KP : a.k;
   if constexpr (IMPLICIT && DMF == 0) {
-    for (int e = tid; e < KP * KP; e += WAVES * 64) {
-      const int r = e / KP, c = e % KP;
-      sG[e] = (r < k && c < k) ? a.XtX[(size_t)r * k + c] : 0.f;
+    // (eight loads in flight per thread: one load, one wait, one store per trip was 32 L2 round trips per workgroup start)
+    constexpr int GU = (KP * KP) % (8 * WAVES * 64) == 0 ? 8 : ((KP * KP) % (2 * WAVES * 64) == 0 ? 2 : 1);
+    static_assert((KP * KP) % (GU * WAVES * 64) == 0, "the Gramian copy walks whole batches");
+    for (int e0 = tid; e0 < KP * KP; e0 += GU * WAVES * 64) {
+      float gv[GU];
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int e = e0 + u * WAVES * 64, r = e / KP, c = e % KP;
+        gv[u] = a.XtX[(size_t)min(r, k - 1) * k + min(c, k - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int e = e0 + u * WAVES * 64, r = e / KP, c = e % KP;
+        sG[e] = (r < k && c < k) ? gv[u] : 0.f;
+      }
     }
   }
   for (int e = tid; e < (int)(SM::vec_floats + SM::red_floats + SM::tsv_floats); e += WAVES * 64) sVec[e] = 0.f;
@@ -287,7 +299,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           const int r = 32 * wv + 16 * t + m, c = 32 * ks + 8 * kb + e;
-          gmax = fmaxf(gmax, (r < k && c < k) ? fabsf(a.XtX[(size_t)r * k + c]) : 0.f);
+          {   // (clamped address, select afterwards: a per-lane `cond ? load : 0` is a branch with a wait per element)
+            const float gv = a.XtX[(size_t)min(r, k - 1) * k + min(c, k - 1)];
+            gmax = fmaxf(gmax, (r < k && c < k) ? fabsf(gv) : 0.f);
+          }
         }
     for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
     const int ge = fp16_scale_exp(gmax);
@@ -301,8 +316,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           const int r = 32 * wv + 16 * t + m, c = 32 * ks + 8 * kb + e;
-          const float g0 = (r < k && c < k) ? a.XtX[(size_t)r * k + c] : 0.f;
-          const float g1 = (r < k && c + 1 < k) ? a.XtX[(size_t)r * k + c + 1] : 0.f;
+          const float g0v = a.XtX[(size_t)min(r, k - 1) * k + min(c, k - 1)];
+          const float g0 = (r < k && c < k) ? g0v : 0.f;
+          const float g1v = a.XtX[(size_t)min(r, k - 1) * k + min(c + 1, k - 1)];
+          const float g1 = (r < k && c + 1 < k) ? g1v : 0.f;
           split_f16(g0 * gs, g1 * gs, hi[e / 2], lo[e / 2]);
         }
         const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, l4 = {lo[0], lo[1], lo[2], lo[3]};

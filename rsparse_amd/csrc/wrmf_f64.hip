@@ -568,11 +568,46 @@ __device__ __forceinline__ int f64_from_step_lane(const int v, const int g) {
   }
 }
 
+// Sixteen per-lane doubles p[0..15] summed over the 64 lanes, TRANSPOSED: lane L ends with the wave's sum of p[L >> 2] (the four
+// lanes of a quad hold copies).  Every stage halves the number of values a lane carries: a lane swap fed two DIFFERENT registers
+// is the exchange step of both (lanes of the low half keep the first one's sum, the high half the second's), then the same inside
+// the rows of 16 lanes with a select and one DPP move.  15 additions and 15 exchanges per lane for 16 sums, where sixteen
+// butterflies (f64_group_sum) take 96 of each -- the lane-crossing sum of a non-zero's dot product was most of the fp64
+// conjugate-gradient kernel's instructions at rank 65..128 (round 5).
+__device__ __forceinline__ double f64_transposed_sum16(double (&p)[16], const int lane) {
+  auto swap32 = [](const double a, const double b) {
+    const auto sl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto sh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)sh[0], (int)sl[0]) + __hiloint2double((int)sh[1], (int)sl[1]);
+  };
+  auto swap16 = [](const double a, const double b) {
+    const auto sl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto sh = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)sh[0], (int)sl[0]) + __hiloint2double((int)sh[1], (int)sl[1]);
+  };
+  double s8[8], s4[4], s2[2];
+#pragma unroll
+  for (int u = 0; u < 8; u++) s8[u] = swap32(p[u], p[u + 8]);       // half h: non-zero u + 8 h
+#pragma unroll
+  for (int u = 0; u < 4; u++) s4[u] = swap16(s8[u], s8[u + 4]);     // row r: non-zero u + 4 (r & 1) + 8 (r >> 1)
+  const bool b8 = (lane & 8) != 0, b4 = (lane & 4) != 0;
+#pragma unroll
+  for (int u = 0; u < 2; u++) {                                     // lanes with bit 8: u + 2
+    const double keep = b8 ? s4[u + 2] : s4[u], send = b8 ? s4[u] : s4[u + 2];
+    s2[u] = keep + f64_dpp<0x128>(send);                            // row_ror:8 = the lane 8 away inside the row
+  }
+  const double keep = b4 ? s2[1] : s2[0], send = b4 ? s2[0] : s2[1];
+  double t = keep + f64_dpp<0x141>(send);                           // row_half_mirror: lane i <-> 7 - i of its half row
+  t += f64_dpp<0xB1>(t);                                            // quad_perm:[1,0,3,2]
+  t += f64_dpp<0x4E>(t);                                            // quad_perm:[2,3,0,1]
+  return t;
+}
+
 // EPL = coordinates per lane: 1 up to rank 64; 2 (W = 64: lane l holds the coordinates l and 64 + l) for ranks 65..128 -- round 5:
 // the reference's default precision at the BASELINE ranks (R/model_WRMF.R:82) ran on the generic kernel's k^2 flops per
 // non-zero until then, and WRMF kept such fits in fp32 behind a warning.
 template <int W, bool IMPLICIT, int EPL = 1>
-__global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, int n_hi, int slot0) {   // rows of n_lo < n <= n_hi non-zeros
+__global__ __launch_bounds__(256, EPL == 2 ? 2 : 1) void f64_cg_wave_kernel(F64Args a, int n_lo, int n_hi, int slot0) {   // rows of n_lo < n <= n_hi non-zeros
   static_assert(EPL == 1 || W == 64, "two coordinates per lane: the whole wave holds one vector");
   constexpr int NPS = 64 / W;   // non-zeros per step
   constexpr int BS = 16;        // steps per batch: their vectors are requested together, the next batch's before this one is used
@@ -695,6 +730,37 @@ __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, i
             } else if (nst1 > 0) {
               fetch(std::integral_constant<int, 0>{}, id1, nst1, nxt);
             }
+            if constexpr (EPL == 2) {
+              // ranks 65..128: the batch's sixteen dot products by ONE transposed reduction (lane L: non-zero L >> 2 of the batch),
+              // the coefficients formed sixteen at a time, handed back lane by lane for the sum over the vectors
+              double part[BS];
+              static_for_f64<BS>([&](auto ut) {
+                constexpr int U = decltype(ut)::value;
+                part[U] = fma(lk[1] ? cur[U][1] : 0.0, v.c[1], (lk[0] ? cur[U][0] : 0.0) * v.c[0]);
+              });
+              const double t = f64_transposed_sum16(part, lane);
+              const int st = B * BS + (lane >> 2);                        // the lane's non-zero of the chunk
+              const double c = __hiloint2double(__shfl(c0h, st), __shfl(c0l, st));
+              const bool in = st < cn;
+              if constexpr (MODE == 2) {
+                const double dlt = (IMPLICIT ? 1.0 : c) - t;
+                acc.c[0] += (in && (lane & 3) == 0) ? (IMPLICIT ? c : 1.0) * dlt * dlt : 0.0;   // (one lane of the quad counts it)
+              } else {
+                double coef;
+                if constexpr (MODE == 0) coef = IMPLICIT ? c - (c - 1.0) * t : c - t;
+                else coef = IMPLICIT ? (c - 1.0) * t : t;
+                coef = in ? coef : 0.0;
+                const int ch = __double2hiint(coef), cl = __double2loint(coef);
+                static_for_f64<BS>([&](auto ut) {
+                  constexpr int U = decltype(ut)::value, ST = B * BS + U;
+                  if (ST < nst) {   // wave-uniform
+                    const double cu = __hiloint2double(__builtin_amdgcn_readlane(ch, 4 * U), __builtin_amdgcn_readlane(cl, 4 * U));
+#pragma unroll
+                    for (int e = 0; e < EPL; e++) acc.c[e] = fma(cu, lk[e] ? cur[U][e] : 0.0, acc.c[e]);
+                  }
+                });
+              }
+            } else
             static_for_f64<BS>([&](auto ut) {
               constexpr int U = decltype(ut)::value, ST = B * BS + U;
               if (ST < nst) {   // wave-uniform
@@ -733,6 +799,7 @@ __global__ __launch_bounds__(256) void f64_cg_wave_kernel(F64Args a, int n_lo, i
       // the groups' shares (loss: every lane of a group holds the group's term)
 #pragma unroll
       for (int e = 0; e < EPL; e++) acc.c[e] = f64_across_groups<W>(acc.c[e]);
+      if constexpr (EPL == 2 && MODE == 2) acc.c[0] = f64_group_sum<64>(acc.c[0]);   // (the terms sit one per quad there)
       return acc;
     };
     // sums over the coordinates (one group's lanes; the groups hold copies)

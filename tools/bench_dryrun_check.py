@@ -11,6 +11,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -19,14 +20,20 @@ ap.add_argument("--ranks", type=int, default=8)
 ap.add_argument("--users", type=int, default=400_000)
 ap.add_argument("--items", type=int, default=40_000)
 ap.add_argument("--rank", type=int, default=128)
+ap.add_argument("--timeout", type=int, default=420, help="seconds per bench.py run")
 a = ap.parse_args()
 common = ["--users", str(a.users), "--items", str(a.items), "--rank", str(a.rank), "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
 
 
 def run(n, env_extra):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n)] + common, env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=900)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n)] + common, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=a.timeout)
+    except subprocess.TimeoutExpired as e:
+        raise SystemExit("bench.py --gpus %d did not finish in %d s; stderr tail:\n%s" % (n, a.timeout, (e.stderr or b"")[-3000:]))
+    print("bench.py --gpus %d: %.0f s" % (n, time.perf_counter() - t0), flush=True)
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
         raise SystemExit("bench.py --gpus %d failed (rc %d):\n%s" % (n, r.returncode, r.stderr[-3000:]))

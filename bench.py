@@ -278,6 +278,8 @@ def main():
                      cg_steps=args.cg_steps, world_size=ws, my_rank=rank, lay_user=lay_u, lay_item=lay_i)
     if not implicit:   # nnz per user / item: weights of the explicit regulariser (wrmf_explicit.hpp:160-170)
         als.cnt_user, als.cnt_item = cnt_user, cnt_item
+    else:              # the confidences of a fit never change (R/model_WRMF.R:184-191): as WRMF.fit_transform tells the library
+        als.freeze_values()
     shard_nnz = [int(c_iu_blk[1].numel()), int(c_ui_blk[1].numel())]
     # initial factors (in storage order; the values of a row do not depend on the number of ranks): U ~ N(0, 0.01^2);
     # item factors zero for CG, N(0, 0.01^2) otherwise (R/model_WRMF.R:204-231)

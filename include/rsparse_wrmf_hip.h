@@ -178,6 +178,14 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m);
 int rsparse_hip_csc_transpose_device(int n_rows, int n_cols, const int32_t* d_p, const int32_t* d_i,
                                      const float* d_x, int32_t* d_pt, int32_t* d_it, float* d_xt, void* stream);
 int rsparse_hip_values_to_float_device(int64_t n, const double* d_src, float* d_dst, void* stream);
+/* frozen != 0: the caller promises that the values of the handle (its own copy, or the adopted device array) do not change until
+ * the promise is withdrawn (frozen = 0) or the handle destroyed -- what holds for `c_ui@x` / `c_iu@x` during a fit with implicit
+ * feedback (R/model_WRMF.R:184-191: the matrices are prepared once).  The half-iterations then take the statistics of the values
+ * that the fp16 matrix-core kernels scale their operands by (max confidence, "some confidence < 1") from ONE scan per handle
+ * instead of one per call (0.46 ms per half-iteration at 5e8 non-zeros).  Results do not depend on it.  Library calls that
+ * change values through a handle (rsparse_hip_initialize_biases_explicit_device) require frozen = 0. */
+int rsparse_hip_csc_freeze_values(rsparse_hip_csc* m, int frozen);
+
 /* info_out: [0] n_rows, [1] n_cols, [2] nnz, [3] rows with more than [7] non-zeros ("long" rows),
  * [4] longest row, [5] non-zeros in long rows, [6] empty rows, [7] per-wave tile capacity (32),
  * [8..13] rows and [14..19] non-zeros per CG launch bucket, [20] launch-table id, [21] segments of the long rows that

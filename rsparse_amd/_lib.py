@@ -37,6 +37,7 @@ SIGNATURES = {
     "rsparse_hip_gramian_absmax_device": (_c_int, [_vp, _c_int, _c_i64, _c_dbl, _vp, _vp, _vp, _vp]),
     "rsparse_hip_csc_destroy": (_c_int, [_vp]),
     "rsparse_hip_csc_info": (_c_int, [_vp, ctypes.POINTER(_c_i64)]),
+    "rsparse_hip_csc_freeze_values": (_c_int, [_vp, _c_int]),
     "rsparse_hip_als_implicit_bias_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_int, _vp, _vp]),
     "rsparse_hip_als_implicit_global_bias_device": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_dbl, _c_uint, _c_uint, _c_int,
                                                              _c_int, _c_dbl, _c_int, _vp, _vp, _vp]),

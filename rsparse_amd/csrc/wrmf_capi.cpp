@@ -539,6 +539,17 @@ struct BiasTerms {   // implicit feedback with user/item biases and / or a globa
   float gbias = 0.f;   // conjugate gradient with a global bias: the bias itself (rhs_init = global_bias_base)
 };
 
+// launch_ne_stats for the values of handle d: a handle whose values are frozen (rsparse_hip_csc_freeze_values) is scanned once
+hipError_t take_value_stats(const DevCSC& d, const float* d_X, int64_t nx, hipStream_t s, const float* d_absmax) {
+  if (d.vals_frozen && !d.vstats && hipMalloc(&d.vstats, 2 * sizeof(unsigned)) != hipSuccess) d.vstats = nullptr;
+  if (d.vals_frozen && d.vstats && d.vstats_valid)
+    return launch_ne_stats(d_X, nx, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax, d.vstats, nullptr);
+  hipError_t e = launch_ne_stats(d_X, nx, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax, nullptr,
+                                 (d.vals_frozen && d.vstats) ? d.vstats : nullptr);
+  if (e == hipSuccess && d.vals_frozen && d.vstats) d.vstats_valid = true;
+  return e;
+}
+
 // d_absmax (nullable, device float): max |X| supplied by the caller -- X is then not scanned for the fp16 operand scales
 int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* d_X, float* d_Y,
                        const float* d_XtX, int rank, double lambda, unsigned solver, unsigned cg_steps,
@@ -689,7 +700,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   }
   if ((cgq || ne_chol) && implicit && qs.ne_wg > 0 && ne_supported(rank) && (!bias || gb_cg)) {
     // operand scales of the fp16 normal-equation kernel (and whether it may run at all), decided on the device
-    hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax);
+    hipError_t se = take_value_stats(d, d_X, (int64_t)d.n_rows * rank, s, d_absmax);
     if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
     a.ne_stats = g_ws.ne_stats;
     if (gb_cg && cgq) {   // the long rows' share of the first residual: base - g X_nnz (c - 1), one more pass over them
@@ -717,7 +728,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     if ((rc = g_ws.ensure_lr())) return rc;
     if (!a.ne_stats) {   // (with the long rows on the normal-equation kernel the full statistics were just taken)
       // max |X| too: the low-rank kernel scales its fp16 operand terms by it
-      hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax);
+      hipError_t se = take_value_stats(d, d_X, (int64_t)d.n_rows * rank, s, d_absmax);
       if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
     }
     a.lr_rows = d.q_order + d.q_lr_first; a.n_lr = d.q_n_lr; a.lr_flags = g_ws.ne_stats + 2; a.lr_M = g_ws.lr_M;
@@ -728,7 +739,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (chol && d.q_order && d.q_n_lr > 0 && chol_lrx_supported(a, implicit)) {
     // explicit feedback, ranks 64 / 128: the rows of 1..64 ratings in push-through form, one wave per pass
     if (!a.ne_stats && !a.wave_stats) {
-      hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax);
+      hipError_t se = take_value_stats(d, d_X, (int64_t)d.n_rows * rank, s, d_absmax);
       if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
     }
     a.wave_stats = g_ws.ne_stats;
@@ -739,7 +750,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (chol && chol_wave_supported(rank) && padded_rank(rank) == 64) {
     // rank 33..64, one wave per row: the assembly runs on the matrix cores from fp16 operand terms scaled by max |X| (and max c)
     if (!a.ne_stats && !a.wave_stats) {
-      hipError_t se = launch_ne_stats(d_X, (int64_t)d.n_rows * rank, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax);
+      hipError_t se = take_value_stats(d, d_X, (int64_t)d.n_rows * rank, s, d_absmax);
       if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
     }
     a.wave_stats = g_ws.ne_stats;
@@ -847,6 +858,7 @@ int run_half_iteration_explicit_biased(const rsparse_hip_csc* conf, const float*
   e = launch_bias_shift_values(d.vals, d.row_idx, d_X, rank, xb, d.nnz, vp, s);
   if (e != hipSuccess) return hip_fail(e, "launch_bias_shift_values");
   rsparse_hip_csc shifted = *conf;   // same sparsity and schedule, shifted ratings (a view: never destroyed)
+  shifted.d.vals_frozen = false; shifted.d.vstats_valid = false; shifted.d.vstats = nullptr;   // (its values are this call's)
   shifted.d.vals = vp;
   shifted.d.owns_matrix = false;
   rc = run_half_iteration(&shifted, false, Xp, Yp, nullptr, k1p, lambda, solver, cg_steps, dynamic_lambda,
@@ -1211,12 +1223,20 @@ int rsparse_hip_csc_destroy(rsparse_hip_csc* m) {
     if (d.q_nec_split_rows) (void)hipFree(d.q_nec_split_rows);
     if (d.q_nec_split_ptr) (void)hipFree(d.q_nec_split_ptr);
   }
+  if (d.vstats) (void)hipFree(d.vstats);
   if (d.owns_matrix) {
     if (d.col_ptrs) (void)hipFree(const_cast<int32_t*>(d.col_ptrs));
     if (d.row_idx) (void)hipFree(const_cast<int32_t*>(d.row_idx));
     if (d.vals) (void)hipFree(const_cast<float*>(d.vals));
   }
   delete m;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_csc_freeze_values(rsparse_hip_csc* m, int frozen) {
+  if (!m) return fail(RSPARSE_HIP_ERR_INVALID, "NULL handle");
+  m->d.vals_frozen = frozen != 0;
+  m->d.vstats_valid = false;   // (a fresh promise starts from a fresh scan)
   return RSPARSE_HIP_OK;
 }
 
@@ -1487,6 +1507,8 @@ int rsparse_hip_initialize_biases_explicit_device(rsparse_hip_csc* c_ui, rsparse
   double global_bias = 0.0;
   hipError_t e;
   if (calculate_global_bias && a.nnz > 0) {   // wrmf_utils.hpp:41-52: mean of the values, removed from both orientations
+    if (a.vals_frozen || b.vals_frozen)
+      return fail(RSPARSE_HIP_ERR_INVALID, "the values of a frozen handle cannot lose their mean (rsparse_hip_csc_freeze_values)");
     if ((e = launch_values_sum(a.vals, a.nnz, g_ws.partials, g_ws.scalars + 2, s)) != hipSuccess)
       return hip_fail(e, "launch_values_sum");
     const double inv = 1.0 / (double)a.nnz;

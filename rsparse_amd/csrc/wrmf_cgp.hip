@@ -101,8 +101,10 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
         for (int e = 0; e < 8; e++) {
           const int r = 32 * wv + 16 * t + m, c = 32 * ks + 8 * kb + e;
           {   // (clamped address, select afterwards: a per-lane `cond ? load : 0` is a branch with a wait per element)
+            // (... and a MULTIPLY by the 0 / 1 mask, not a select: hipcc sinks a load whose value only one side of a select uses
+            //  back under the condition)
             const float gv = a.XtX[(size_t)min(r, k - 1) * k + min(c, k - 1)];
-            gmax = fmaxf(gmax, (r < k && c < k) ? fabsf(gv) : 0.f);
+            gmax = fmaxf(gmax, fabsf(gv) * ((r < k && c < k) ? 1.f : 0.f));
           }
         }
     for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
@@ -118,9 +120,9 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
         for (int e = 0; e < 8; e += 2) {
           const int r = 32 * wv + 16 * t + m, c = 32 * ks + 8 * kb + e;
           const float g0v = a.XtX[(size_t)min(r, k - 1) * k + min(c, k - 1)];
-          const float g0 = (r < k && c < k) ? g0v : 0.f;
+          const float g0 = g0v * ((r < k && c < k) ? 1.f : 0.f);
           const float g1v = a.XtX[(size_t)min(r, k - 1) * k + min(c + 1, k - 1)];
-          const float g1 = (r < k && c + 1 < k) ? g1v : 0.f;
+          const float g1 = g1v * ((r < k && c + 1 < k) ? 1.f : 0.f);
           p_split(g0 * gs, g1 * gs, hi[e / 2], lo[e / 2]);
         }
         const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, l4 = {lo[0], lo[1], lo[2], lo[3]};

@@ -64,6 +64,12 @@ struct DevCSC {
   int64_t nnz_long = 0;
   int n_empty = 0;
   bool owns_matrix = false;
+  // rsparse_hip_csc_freeze_values: the caller promises that the values do not change while the flag is set; the statistics of
+  // the values that the fp16 kernels scale their operands by (max c, "some c < 1": launch_ne_stats) are then scanned once per
+  // handle instead of once per half-iteration.  vstats: 2 words on the device, valid once vstats_valid
+  mutable bool vals_frozen = false;
+  mutable bool vstats_valid = false;
+  mutable unsigned* vstats = nullptr;
 };
 
 struct AlsArgs {
@@ -172,8 +178,11 @@ constexpr int kNeMaxSeg = 16;        // segments per split row
 constexpr int kNeMaxSegTotal = 64;   // ... per matrix
 constexpr int kNeSegFloats = 4 * (11 * 16 * 64 + 128 + 2);   // per segment: 4 waves x (<= 11 accumulator tiles + b + sum c)
 // absmax_hint (nullable, device float): max |X| supplied by the caller -- X is then not scanned
+// cached_vstats (nullable, 2 device words = stats[1..2] of an earlier scan of the same values): the values are not read;
+// save_vstats (nullable): receives stats[1..2] of this scan
 hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s,
-                           const float* absmax_hint = nullptr);
+                           const float* absmax_hint = nullptr, const unsigned* cached_vstats = nullptr,
+                           unsigned* save_vstats = nullptr);
 struct QSchedule;
 hipError_t launch_als_ne(const AlsArgs& a, const QSchedule& q, bool implicit, double* row_loss, hipStream_t s,
                          hipEvent_t* ev_slot = nullptr);

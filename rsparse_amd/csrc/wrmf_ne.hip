@@ -1409,11 +1409,20 @@ bool ne_supported(int k) { return k > 32 && k <= 128 && k % 4 == 0; }
 
 // wg_rows / wg_ptr: per-workgroup row lists (host-balanced, wrmf_capi.cpp build_ne_lists); row_loss: one double per
 // entry of wg_rows
+__global__ void ne_stats_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src) {
+  if (threadIdx.x < 2) dst[threadIdx.x] = src[threadIdx.x];
+}
 hipError_t launch_ne_stats(const float* X, int64_t nx, const float* vals, int64_t nnz, unsigned* stats, hipStream_t s,
-                           const float* absmax_hint) {
+                           const float* absmax_hint, const unsigned* cached_vstats, unsigned* save_vstats) {
   hipError_t err = hipMemsetAsync(stats, 0, 4 * sizeof(unsigned), s);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(ne_stats_kernel, dim3(2048), dim3(256), 0, s, X, nx, vals, nnz, stats, absmax_hint);
+  // (frozen values whose statistics are known: only X is looked at -- or nothing, when the caller also knows max |X|: one small grid)
+  const bool skip_vals = cached_vstats != nullptr;
+  const int grid = (skip_vals && absmax_hint) ? 1 : 2048;
+  hipLaunchKernelGGL(ne_stats_kernel, dim3(grid), dim3(256), 0, s, X, nx, vals, skip_vals ? (int64_t)0 : nnz, stats, absmax_hint);
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  if (skip_vals) hipLaunchKernelGGL(ne_stats_words_kernel, dim3(1), dim3(64), 0, s, stats + 1, cached_vstats);
+  else if (save_vstats) hipLaunchKernelGGL(ne_stats_words_kernel, dim3(1), dim3(64), 0, s, save_vstats, stats + 1);
   return hipGetLastError();
 }
 

@@ -457,6 +457,12 @@ class _CscHandle:
         self.n_rows, self.n_cols = n_rows, n_cols
         self.f64 = bool(f64)   # a handle of the fp64 layer (rsparse_hip_csc_f64): no launch schedule, no info()
 
+    def freeze_values(self, frozen=True):
+        """the values will not change until further notice: their statistics are scanned once, not per half-iteration
+        (rsparse_hip_csc_freeze_values; no-op on the fp64 layer)"""
+        if not self.f64:
+            _lib.check(self.lib.rsparse_hip_csc_freeze_values(self.h, int(bool(frozen))))
+
     def info(self):
         if self.f64:
             raise RuntimeError("csc_info describes the fp32 launch schedule; an fp64 handle has none")
@@ -706,6 +712,14 @@ class ShardedALS:
                 sub, item_bias, self.n_item, isum, um[c0:c1], ua[c0:c1], non_negative, gb, user_bias[a:a + (c1 - c0)]))
             self._gather_vec(user_bias, lu)
         return gb
+
+    def freeze_values(self, frozen=True):
+        """Implicit feedback: the confidences never change during a fit (the explicit global mean and the bias initialisation
+        do change explicit values, in place) -- tell the library, so that it scans them once per handle instead of once per
+        half-iteration.  Called by the drivers once the values are final."""
+        for h in [self.csc_items, self.csc_users] + [t[2] for t in self.sub_items] + [t[2] for t in self.sub_users]:
+            if hasattr(h, "freeze_values"):
+                h.freeze_values(frozen)
 
     def half_iteration(self, side, U, V, solver, G=None, want_loss=True, defer_exchange=False):
         """side 'items': solve V (item factors) given U; side 'users': solve U given V (both in storage order).

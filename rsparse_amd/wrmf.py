@@ -234,6 +234,7 @@ class WRMF:
             self.global_bias = sm / (sm + float(n_user) * float(n_item) - float(c_ui.nnz))
         if self._feedback == "implicit":
             als.global_bias = self.global_bias
+            als.freeze_values()      # the confidences are final: their statistics are scanned once per handle
         loss_prev = float("inf")
         self.losses = []
         for it in range(int(n_iter)):
@@ -365,6 +366,7 @@ class WRMF:
                 self.global_bias = gb
         if self._feedback == "implicit":
             als.global_bias = self.global_bias
+            als.freeze_values()      # the confidences are final: their statistics are scanned once per handle
         loss_prev = float("inf")
         self.losses = []
         for it in range(int(n_iter)):

@@ -607,6 +607,43 @@ def test_explicit_cholesky_with_lambda_zero_at_ranks_that_get_padded(k, with_bia
     assert abs(loss - lref) <= 1e-3 * abs(lref) + 1e-7
 
 
+def test_frozen_values_are_scanned_once_and_thawed_values_again():
+    """rsparse_hip_csc_freeze_values: with the promise set the statistics of the values (max confidence, "some confidence < 1":
+    the operand scales and the kernel choice of the fp16 normal-equation path) come from one scan per handle -- same bits as
+    without it --; withdrawn, a change of the values is seen again (here: confidences below 1 appear, which sends the long rows
+    to the bf16 kernel; a stale flag would take sqrt(c - 1) of negative numbers)."""
+    from rsparse_amd.engine import HipBackend
+    rng = np.random.default_rng(77)
+    k, n_fix = 128, 5000
+    lens = np.concatenate([rng.integers(600, 1500, 40), rng.integers(1, 200, 300)])
+    csc, X, Y0 = _rows_of_lengths(lens, n_fix, k, seed=78, scale=0.1)
+    n_rows, n_cols, p, i, x = csc
+    be = HipBackend(0)
+    dp, di = be.to_device(p, torch.int32), be.to_device(i, torch.int32)
+    dx = be.to_device(x.astype(np.float32), torch.float32)
+    h = be.make_csc(n_fix, n_cols, dp, di, dx)
+    Xd = be.to_device(np.ascontiguousarray(X.T), torch.float32)
+    G = torch.zeros((k, k), dtype=torch.float32, device=Xd.device)
+    be.gramian(Xd, 0.1, G, None)
+    loss = torch.zeros(1, dtype=torch.float64, device=Xd.device)
+
+    def solve():
+        Y = be.to_device(np.ascontiguousarray(Y0.T), torch.float32)
+        be.half_iteration(h, True, Xd, Y, G, 0.1, 1, 3, False, loss)
+        return Y.cpu().numpy(), float(loss)
+    y_plain, l_plain = solve()
+    h.freeze_values(True)
+    y1, l1 = solve()
+    y2, l2 = solve()
+    assert np.array_equal(y_plain, y1) and np.array_equal(y1, y2) and l_plain == l1 == l2
+    h.freeze_values(False)
+    dx.mul_(0.25)                               # confidences below 1 now
+    y3, l3 = solve()
+    Yref, lref = _oracle64((n_fix, n_cols, p, i, x * 0.25), X, Y0, 0.1, 1, 3, True)
+    err = np.linalg.norm(y3.T - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, float(err.max())
+
+
 @pytest.mark.parametrize("k,implicit", [(128, True), (64, True), (64, False)])
 def test_one_giant_row_is_split_across_workgroups(k, implicit):
     """A row far longer than a workgroup's share of the long rows is cut into segments that different workgroups stream;

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(W * 64) void als_cg_long_kernel(AlsArgs a, size_t l
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int KP>
-__global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __restrict__ X, int k, int64_t n,
+__global__ __launch_bounds__(256, 2) void gramian_partial_kernel(const float* __restrict__ X, int k, int64_t n,
                                                               float* __restrict__ partials,
                                                               unsigned* __restrict__ absmax_bits) {
   constexpr int NT = KP / 32, U = 4;
@@ -385,18 +385,40 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
   float amax = 0.f;   // max |x| of what this lane reads: the matrix is read here anyway (wrmf_ne.hip wants its scale)
-  for (int64_t n0 = gw * 2 * U; n0 < n; n0 += nw * 2 * U) {
-    float av[U][NT];
+  // Software pipeline (round 5): the next trip's 16 loads are in flight while this trip's 40 matrix instructions run -- one trip
+  // was load, wait, multiply: 2 us of memory latency in front of 1.1 us of MFMA, 2.7 ms for the 10 M x 128 Gramian of config 3.
+  // The loads are unconditional (clamped address, 0 / 1 mask multiplied in: a select's load is sunk back under its condition).
+  auto fetch = [&](const int64_t n0, float (&dst)[U][NT]) {   // raw values; take() masks them where they are consumed
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t ent = n0 + 2 * u + half;
+      const int64_t er = ent < n ? ent : n - 1;
 #pragma unroll
-      for (int mt = 0; mt < NT; mt++) {
-        const int aidx = mt * 32 + col;
-        av[u][mt] = (ent < n && aidx < k) ? X[ent * k + aidx] : 0.f;
-        amax = fmaxf(amax, fabsf(av[u][mt]));
-      }
+      for (int mt = 0; mt < NT; mt++) dst[u][mt] = X[er * k + min(mt * 32 + col, k - 1)];
     }
+  };
+  auto take = [&](const int64_t n0, const float (&src)[U][NT], float (&dst)[U][NT]) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const bool in = n0 + 2 * u + half < n;
+#pragma unroll
+      for (int mt = 0; mt < NT; mt++) dst[u][mt] = src[u][mt] * ((in && mt * 32 + col < k) ? 1.f : 0.f);
+    }
+  };
+  float av[U][NT], nx[U][NT];
+  const int64_t stride = nw * 2 * U;
+  int64_t n0 = gw * 2 * U;
+  if (n0 < n) {
+    fetch(n0, nx);
+    take(n0, nx, av);
+  }
+  for (; n0 < n; n0 += stride) {
+    const bool more = n0 + stride < n;
+    if (more) fetch(n0 + stride, nx);
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int mt = 0; mt < NT; mt++) amax = fmaxf(amax, fabsf(av[u][mt]));
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
@@ -404,6 +426,7 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
 #pragma unroll
         for (int nt = 0; nt <= mt; nt++)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], av[u][nt], acc[mt][nt], 0, 0, 0);
+    if (more) take(n0 + stride, nx, av);
   }
   if (absmax_bits) {   // non-negative floats order like their bit patterns
 #pragma unroll

@@ -146,6 +146,36 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
   }
   if (iters > 1 && ridx(1) < n_rows) row_n = rows[ridx(1)];
 
+  // KFULL: the indices / values of a pair of rows are requested during the PREVIOUS pair's sweeps (the first pair's here): the
+  // gather at the row switch is then one HBM round trip -- the vectors -- instead of two (what the one- and two-wave kernels of
+  // wrmf_cgq.hip have done since round 2; this kernel sits at 238 registers: 17 more).  All eight
+  // slots of a lane are requested whatever the rows' lengths (a slot outside its row reads entry 0 and is dropped).
+  int idn[NQ];
+  float cvn[NQ], cln = 0.f;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    idn[q] = 0;
+    cvn[q] = 0.f;
+  }
+  auto request_indices = [&](const bool valid, const int np1, const int ncnt) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int s = 2 * q + g2;
+      const int j = (valid && s < ncnt) ? np1 + s : 0;
+      idn[q] = a.row_idx[j];
+      cvn[q] = a.vals[j];
+    }
+    cln = a.vals[(valid && i < ncnt) ? np1 + i : 0];
+  };
+  auto settle_indices = [&]() {   // a use the compiler cannot move: the wait for the request sits HERE
+    asm volatile("" : "+v"(idn[0]), "+v"(idn[1]), "+v"(idn[2]), "+v"(idn[3]), "+v"(idn[4]), "+v"(idn[5]), "+v"(idn[6]), "+v"(idn[7]));
+    asm volatile("" : "+v"(cvn[0]), "+v"(cvn[1]), "+v"(cvn[2]), "+v"(cvn[3]), "+v"(cvn[4]), "+v"(cvn[5]), "+v"(cvn[6]), "+v"(cvn[7]), "+v"(cln));
+  };
+  if constexpr (KFULL) {
+    request_indices(iters > 0 && ridx(0) < n_rows, p1_c, p2_c - p1_c);
+    settle_indices();   // (once per wave: the first pair pays the round trip)
+  }
+
   for (int it = 0; it < iters; ++it) {
     const bool have = ridx(it) < n_rows;
     const int row = have ? row_c : 0, p1 = have ? p1_c : 0, p2 = have ? p2_c : 0;
@@ -192,13 +222,18 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
       int id[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
-        const int s = 2 * q + g2;
-        const int j = s < cnt ? p1 + s : 0;
-        id[q] = 0;
-        cv[q] = 0.f;
-        if (q < 4 || blk2) {   // wave-uniform
-          id[q] = a.row_idx[j];
-          cv[q] = a.vals[j];
+        if constexpr (KFULL) {
+          id[q] = idn[q];
+          cv[q] = cvn[q];
+        } else {
+          const int s = 2 * q + g2;
+          const int j = s < cnt ? p1 + s : 0;
+          id[q] = 0;
+          cv[q] = 0.f;
+          if (q < 4 || blk2) {   // wave-uniform
+            id[q] = a.row_idx[j];
+            cv[q] = a.vals[j];
+          }
         }
       }
 #pragma unroll
@@ -232,7 +267,10 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
         }
       }
     }
-    const float cl = (g2 == 0 && i < cnt) ? a.vals[p1 + i] : 0.f;   // confidence of non-zero i of the half's row (loss)
+    // confidence of non-zero i of the half's row (loss)
+    float cl;
+    if constexpr (KFULL) cl = (g2 == 0 && i < cnt) ? cln : 0.f;
+    else cl = (g2 == 0 && i < cnt) ? a.vals[p1 + i] : 0.f;
 
     if constexpr (!KFULL) load_warm_start();
 
@@ -372,6 +410,8 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
 
     float dummy = 0.f;
     sweep(x, 0, r, dummy);
+    if constexpr (KFULL)   // (p1_c / p2_c are the next pair's since the top of this iteration)
+      request_indices(it + 1 < iters && ridx(it + 1) < n_rows, p1_c, p2_c - p1_c);
 #pragma unroll
     for (int rr = 0; rr < RPN; rr++) p[rr] = r[rr];
     float rsold = dot16(r, r);
@@ -403,6 +443,11 @@ __global__ __launch_bounds__(256, 2) void als_cgp_kernel(AlsArgs a, const int32_
     }
     float rl = 0.f;
     sweep(x, 2, ap, rl);
+    if constexpr (KFULL) {
+      // settle the prefetched indices / values here (requested four sweeps ago): left to the next pair's first use, the wait would
+      // sit behind that pair's warm-start request and behind this pair's store -- the vectors would be requested a round trip late
+      settle_indices();
+    }
     if (live) {
       const float xx = dot16(x, x);
       wloss += (double)rl + a.lambda_loss * (double)xx;

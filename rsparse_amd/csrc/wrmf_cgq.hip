@@ -1034,6 +1034,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void als_cgq_kernel(AlsArgs a, const
     sweep(x, 2, ap, rl, live);
     CQ_T(2)
     if constexpr (DMAPF) wait_vm0();   // the announced row's indices have long landed; nothing of this wave's is in flight after this
+    if constexpr (IDXPF && STREAM == 0) {
+      // settle the prefetch registers HERE (their loads were issued three sweeps ago): left to the next row's first use, the
+      // wait sits behind that row's warm-start request -- loads return in order -- and the vectors are requested a round trip late
+      asm volatile("" : "+v"(pf_id), "+v"(pf_c));
+    }
     if (live && tw == 0) {
       const float xx = dot16(x, x);
       wloss += IMPLICIT ? (double)rl + a.lambda_loss * (double)xx : (double)(rl + lam_use * xx);

@@ -31,7 +31,18 @@ struct F64Args {
   double* loss_partials;    // one double per workgroup
   int* fail_counter;    // [2] += rows re-solved by the general solver, [3] += rows singular for it too
   double* m2_scratch;   // NNLS when two matrices do not fit the LDS: per workgroup KP * (KP + 1) doubles
+  // conjugate gradient, rows of more than long_min non-zeros ("long rows", wrmf_f64.hip): cut into chunks of chunk_len non-zeros
+  // that run as waves of their own, pass by pass -- one wave per row left a half-iteration waiting for its longest row
+  int long_min;                 // rows up to this length stay with the wave-per-row kernel
+  int chunk_len;
+  int n_long, n_chunks;
+  const int32_t* long_rows;     // [n_long] the rows, ascending
+  const int32_t* long_chunk0;   // [n_long + 1] first chunk of each
+  const int32_t* chunk_long;    // [n_chunks] position in long_rows
+  const int32_t* chunk_off;     // [n_chunks] first non-zero of the chunk within its row
+  double* long_scratch;         // f64_long_scratch_doubles(): the chunks' partial sums, r and p of every long row, its scalars
 };
+size_t f64_long_scratch_doubles(int k, int n_long, int n_chunks);
 
 constexpr int kF64MaxGrid = 256 * 48;      // workgroups of the per-row kernel (grid-stride over the rows; the small-rank kernel is one wave and little LDS: up to 32 per CU are resident)
 constexpr int kF64GramBlocks = 256;        // partial Gramians

@@ -603,15 +603,146 @@ __device__ __forceinline__ double f64_transposed_sum16(double (&p)[16], const in
   return t;
 }
 
+template <int EPL> struct F64Vec { double c[EPL]; };
+
+// One pass over n non-zeros at p1 (a row, or a chunk of a long row): out_l = sum_j coef(c_j, x_j . v) x_j[l], or (MODE 2) sum_j lw_j (lt_j - x_j . v)^2 in
+// every lane.  MODE 0: first residual, 1: operator, 2: loss.  A chunk is 64 non-zeros: lane (g, st) holds the index and the value of the
+// non-zero st * NPS + g, the one group g gathers in step st.  lk / lc: the lane's coordinates (valid, clamped), l / g: lane within its group, group.
+template <int W, bool IMPLICIT, int EPL, int MODE>
+__device__ __forceinline__ F64Vec<EPL> f64_row_pass(const F64Args& a, const int k, const int p1, const int n, const F64Vec<EPL> v,
+                                                    const bool (&lk)[EPL], const int (&lc)[EPL], const int l, const int g, const int lane) {
+  using Vec = F64Vec<EPL>;
+  constexpr int NPS = 64 / W;   // non-zeros per step
+  constexpr int BS = 16;        // steps per batch: their vectors are requested together, the next batch's before this one is used
+  constexpr int NBATCH = W / BS;
+  Vec acc;
+#pragma unroll
+  for (int e = 0; e < EPL; e++) acc.c[e] = 0.0;
+  // (index, value) of the lane's non-zero of the chunk at c0, requested two chunks ahead of its use; the vectors of a batch of
+  // 16 steps one batch ahead, across chunk boundaries: a row of 500 non-zeros is 8 chunks x 5 passes, and every chunk used to
+  // cost two exposed round trips (its indices, then its vectors)
+  auto meta = [&](const int c0, int& idj, int& cjl, int& cjh) {
+    if (c0 < n) {   // wave-uniform
+      const int mine = min(l * NPS + g, n - c0 - 1);
+      idj = a.row_idx[p1 + c0 + mine];
+      const double cj = a.vals[p1 + c0 + mine];
+      cjl = __double2loint(cj);
+      cjh = __double2hiint(cj);
+    }
+  };
+  auto fetch = [&](auto bt, const int idj, const int nst, double (&dst)[BS][EPL]) {
+    constexpr int B = decltype(bt)::value;
+    if (B * BS < nst) {   // wave-uniform
+      static_for_f64<BS>([&](auto ut) {
+        constexpr int U = decltype(ut)::value, ST = B * BS + U;
+        const int id = f64_from_step_lane<W, ST>(idj, g);   // (steps beyond the chunk repeat its last non-zero: weight 0)
+#pragma unroll
+        for (int e = 0; e < EPL; e++) dst[U][e] = a.X[(size_t)id * k + lc[e]];
+      });
+    }
+  };
+  int id0 = 0, c0l = 0, c0h = 0, id1 = 0, c1l = 0, c1h = 0, id2 = 0, c2l = 0, c2h = 0;
+  meta(0, id0, c0l, c0h);
+  meta(64, id1, c1l, c1h);
+  double cur[BS][EPL], nxt[BS][EPL];
+  fetch(std::integral_constant<int, 0>{}, id0, (min(64, n) + NPS - 1) / NPS, cur);
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int cn = min(64, n - c0);
+    const int nst = (cn + NPS - 1) / NPS;                                       // steps of this chunk (<= W)
+    const int nst1 = c0 + 64 < n ? (min(64, n - c0 - 64) + NPS - 1) / NPS : 0;   // ... of the next one
+    meta(c0 + 128, id2, c2l, c2h);
+    static_for_f64<NBATCH>([&](auto bt) {
+      constexpr int B = decltype(bt)::value;
+      if (B * BS < nst) {   // wave-uniform
+        // the batch after this one: of this chunk, or the first of the next chunk
+        if ((B + 1) * BS < nst) {
+          if constexpr (B + 1 < NBATCH) fetch(std::integral_constant<int, (B + 1 < NBATCH ? B + 1 : 0)>{}, id0, nst, nxt);
+        } else if (nst1 > 0) {
+          fetch(std::integral_constant<int, 0>{}, id1, nst1, nxt);
+        }
+        if constexpr (W == 64) {
+          // ranks 33..128 (the whole wave holds one vector): the batch's sixteen dot products by ONE transposed reduction
+          // (lane L: non-zero L >> 2 of the batch), the coefficients formed sixteen at a time, handed back lane by lane for
+          // the sum over the vectors.  (Ranks 33..64 kept the per-non-zero butterfly -- six fp64 exchange stages each --
+          // until the end of round 5, and a rank-64 fit took as long as a rank-128 one: profiles/r05/r5z_f64_per_iteration.txt.)
+          double part[BS];
+          static_for_f64<BS>([&](auto ut) {
+            constexpr int U = decltype(ut)::value;
+            part[U] = (lk[0] ? cur[U][0] : 0.0) * v.c[0];
+#pragma unroll
+            for (int e = 1; e < EPL; e++) part[U] = fma(lk[e] ? cur[U][e] : 0.0, v.c[e], part[U]);
+          });
+          const double t = f64_transposed_sum16(part, lane);
+          const int st = B * BS + (lane >> 2);                        // the lane's non-zero of the chunk
+          const double c = __hiloint2double(__shfl(c0h, st), __shfl(c0l, st));
+          const bool in = st < cn;
+          if constexpr (MODE == 2) {
+            const double dlt = (IMPLICIT ? 1.0 : c) - t;
+            acc.c[0] += (in && (lane & 3) == 0) ? (IMPLICIT ? c : 1.0) * dlt * dlt : 0.0;   // (one lane of the quad counts it)
+          } else {
+            double coef;
+            if constexpr (MODE == 0) coef = IMPLICIT ? c - (c - 1.0) * t : c - t;
+            else coef = IMPLICIT ? (c - 1.0) * t : t;
+            coef = in ? coef : 0.0;
+            const int ch = __double2hiint(coef), cl = __double2loint(coef);
+            static_for_f64<BS>([&](auto ut) {
+              constexpr int U = decltype(ut)::value, ST = B * BS + U;
+              if (ST < nst) {   // wave-uniform
+                const double cu = __hiloint2double(__builtin_amdgcn_readlane(ch, 4 * U), __builtin_amdgcn_readlane(cl, 4 * U));
+#pragma unroll
+                for (int e = 0; e < EPL; e++) acc.c[e] = fma(cu, lk[e] ? cur[U][e] : 0.0, acc.c[e]);
+              }
+            });
+          }
+        } else
+        static_for_f64<BS>([&](auto ut) {
+          constexpr int U = decltype(ut)::value, ST = B * BS + U;
+          if (ST < nst) {   // wave-uniform
+            double yv[EPL];
+            double part = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+              yv[e] = lk[e] ? cur[U][e] : 0.0;
+              part = fma(yv[e], v.c[e], part);
+            }
+            const bool in = ST * NPS + g < cn;
+            const double c = __hiloint2double(f64_from_step_lane<W, ST>(c0h, g), f64_from_step_lane<W, ST>(c0l, g));
+            const double t = f64_group_sum<W>(part);
+            if constexpr (MODE == 2) {
+              const double dlt = (IMPLICIT ? 1.0 : c) - t;
+              acc.c[0] += in ? (IMPLICIT ? c : 1.0) * dlt * dlt : 0.0;
+            } else {
+              double coef;
+              if constexpr (MODE == 0) coef = IMPLICIT ? c - (c - 1.0) * t : c - t;
+              else coef = IMPLICIT ? (c - 1.0) * t : t;
+              coef = in ? coef : 0.0;
+#pragma unroll
+              for (int e = 0; e < EPL; e++) acc.c[e] = fma(coef, yv[e], acc.c[e]);
+            }
+          }
+        });
+#pragma unroll
+        for (int u = 0; u < BS; u++)
+#pragma unroll
+          for (int e = 0; e < EPL; e++) cur[u][e] = nxt[u][e];
+      }
+    });
+    id0 = id1; c0l = c1l; c0h = c1h;
+    id1 = id2; c1l = c2l; c1h = c2h;
+  }
+  // the groups' shares (loss: every lane of a group holds the group's term)
+#pragma unroll
+  for (int e = 0; e < EPL; e++) acc.c[e] = f64_across_groups<W>(acc.c[e]);
+  if constexpr (W == 64 && MODE == 2) acc.c[0] = f64_group_sum<64>(acc.c[0]);   // (the terms sit one per quad there)
+  return acc;
+}
+
 // EPL = coordinates per lane: 1 up to rank 64; 2 (W = 64: lane l holds the coordinates l and 64 + l) for ranks 65..128 -- round 5:
 // the reference's default precision at the BASELINE ranks (R/model_WRMF.R:82) ran on the generic kernel's k^2 flops per
 // non-zero until then, and WRMF kept such fits in fp32 behind a warning.
 template <int W, bool IMPLICIT, int EPL = 1>
 __global__ __launch_bounds__(256, EPL == 2 ? 2 : 1) void f64_cg_wave_kernel(F64Args a, int n_lo, int n_hi, int slot0) {   // rows of n_lo < n <= n_hi non-zeros
   static_assert(EPL == 1 || W == 64, "two coordinates per lane: the whole wave holds one vector");
-  constexpr int NPS = 64 / W;   // non-zeros per step
-  constexpr int BS = 16;        // steps per batch: their vectors are requested together, the next batch's before this one is used
-  constexpr int NBATCH = W / BS;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sG = reinterpret_cast<double*>(smem_raw);   // XtX (implicit), k x k
   __shared__ double sLoss[4];
@@ -642,7 +773,7 @@ __global__ __launch_bounds__(256, EPL == 2 ? 2 : 1) void f64_cg_wave_kernel(F64A
     }
     __syncthreads();
   }
-  struct Vec { double c[EPL]; };
+  using Vec = F64Vec<EPL>;
   // (G v)_l, v one coordinate per lane and register (replicated in the groups): v_m from lane m % 64, register m / 64
   auto gmv = [&](const Vec v) {
     Vec s0;
@@ -681,126 +812,8 @@ __global__ __launch_bounds__(256, EPL == 2 ? 2 : 1) void f64_cg_wave_kernel(F64A
       continue;
     }
     const double lam_use = IMPLICIT ? a.lambda : a.lambda * (a.dynamic_lambda ? (double)n : 1.0);
-    // One pass over the row's vectors: out_l = sum_j coef(c_j, x_j . v) x_j[l], or (MODE 2) sum_j lw_j (lt_j - x_j . v)^2 in every lane.
-    // A chunk is 64 non-zeros: lane (g, st) holds the index and the value of the non-zero st * NPS + g, the one group g gathers in step st.
     auto pass = [&](const Vec v, auto mode_tag) {
-      constexpr int MODE = decltype(mode_tag)::value;   // 0: first residual, 1: operator, 2: loss
-      Vec acc;
-#pragma unroll
-      for (int e = 0; e < EPL; e++) acc.c[e] = 0.0;
-      // (index, value) of the lane's non-zero of the chunk at c0, requested two chunks ahead of its use; the vectors of a batch of
-      // 16 steps one batch ahead, across chunk boundaries: a row of 500 non-zeros is 8 chunks x 5 passes, and every chunk used to
-      // cost two exposed round trips (its indices, then its vectors)
-      auto meta = [&](const int c0, int& idj, int& cjl, int& cjh) {
-        if (c0 < n) {   // wave-uniform
-          const int mine = min(l * NPS + g, n - c0 - 1);
-          idj = a.row_idx[p1 + c0 + mine];
-          const double cj = a.vals[p1 + c0 + mine];
-          cjl = __double2loint(cj);
-          cjh = __double2hiint(cj);
-        }
-      };
-      auto fetch = [&](auto bt, const int idj, const int nst, double (&dst)[BS][EPL]) {
-        constexpr int B = decltype(bt)::value;
-        if (B * BS < nst) {   // wave-uniform
-          static_for_f64<BS>([&](auto ut) {
-            constexpr int U = decltype(ut)::value, ST = B * BS + U;
-            const int id = f64_from_step_lane<W, ST>(idj, g);   // (steps beyond the chunk repeat its last non-zero: weight 0)
-#pragma unroll
-            for (int e = 0; e < EPL; e++) dst[U][e] = a.X[(size_t)id * k + lc[e]];
-          });
-        }
-      };
-      int id0 = 0, c0l = 0, c0h = 0, id1 = 0, c1l = 0, c1h = 0, id2 = 0, c2l = 0, c2h = 0;
-      meta(0, id0, c0l, c0h);
-      meta(64, id1, c1l, c1h);
-      double cur[BS][EPL], nxt[BS][EPL];
-      fetch(std::integral_constant<int, 0>{}, id0, (min(64, n) + NPS - 1) / NPS, cur);
-      for (int c0 = 0; c0 < n; c0 += 64) {
-        const int cn = min(64, n - c0);
-        const int nst = (cn + NPS - 1) / NPS;                                       // steps of this chunk (<= W)
-        const int nst1 = c0 + 64 < n ? (min(64, n - c0 - 64) + NPS - 1) / NPS : 0;   // ... of the next one
-        meta(c0 + 128, id2, c2l, c2h);
-        static_for_f64<NBATCH>([&](auto bt) {
-          constexpr int B = decltype(bt)::value;
-          if (B * BS < nst) {   // wave-uniform
-            // the batch after this one: of this chunk, or the first of the next chunk
-            if ((B + 1) * BS < nst) {
-              if constexpr (B + 1 < NBATCH) fetch(std::integral_constant<int, (B + 1 < NBATCH ? B + 1 : 0)>{}, id0, nst, nxt);
-            } else if (nst1 > 0) {
-              fetch(std::integral_constant<int, 0>{}, id1, nst1, nxt);
-            }
-            if constexpr (EPL == 2) {
-              // ranks 65..128: the batch's sixteen dot products by ONE transposed reduction (lane L: non-zero L >> 2 of the batch),
-              // the coefficients formed sixteen at a time, handed back lane by lane for the sum over the vectors
-              double part[BS];
-              static_for_f64<BS>([&](auto ut) {
-                constexpr int U = decltype(ut)::value;
-                part[U] = fma(lk[1] ? cur[U][1] : 0.0, v.c[1], (lk[0] ? cur[U][0] : 0.0) * v.c[0]);
-              });
-              const double t = f64_transposed_sum16(part, lane);
-              const int st = B * BS + (lane >> 2);                        // the lane's non-zero of the chunk
-              const double c = __hiloint2double(__shfl(c0h, st), __shfl(c0l, st));
-              const bool in = st < cn;
-              if constexpr (MODE == 2) {
-                const double dlt = (IMPLICIT ? 1.0 : c) - t;
-                acc.c[0] += (in && (lane & 3) == 0) ? (IMPLICIT ? c : 1.0) * dlt * dlt : 0.0;   // (one lane of the quad counts it)
-              } else {
-                double coef;
-                if constexpr (MODE == 0) coef = IMPLICIT ? c - (c - 1.0) * t : c - t;
-                else coef = IMPLICIT ? (c - 1.0) * t : t;
-                coef = in ? coef : 0.0;
-                const int ch = __double2hiint(coef), cl = __double2loint(coef);
-                static_for_f64<BS>([&](auto ut) {
-                  constexpr int U = decltype(ut)::value, ST = B * BS + U;
-                  if (ST < nst) {   // wave-uniform
-                    const double cu = __hiloint2double(__builtin_amdgcn_readlane(ch, 4 * U), __builtin_amdgcn_readlane(cl, 4 * U));
-#pragma unroll
-                    for (int e = 0; e < EPL; e++) acc.c[e] = fma(cu, lk[e] ? cur[U][e] : 0.0, acc.c[e]);
-                  }
-                });
-              }
-            } else
-            static_for_f64<BS>([&](auto ut) {
-              constexpr int U = decltype(ut)::value, ST = B * BS + U;
-              if (ST < nst) {   // wave-uniform
-                double yv[EPL];
-                double part = 0.0;
-#pragma unroll
-                for (int e = 0; e < EPL; e++) {
-                  yv[e] = lk[e] ? cur[U][e] : 0.0;
-                  part = fma(yv[e], v.c[e], part);
-                }
-                const bool in = ST * NPS + g < cn;
-                const double c = __hiloint2double(f64_from_step_lane<W, ST>(c0h, g), f64_from_step_lane<W, ST>(c0l, g));
-                const double t = f64_group_sum<W>(part);
-                if constexpr (MODE == 2) {
-                  const double dlt = (IMPLICIT ? 1.0 : c) - t;
-                  acc.c[0] += in ? (IMPLICIT ? c : 1.0) * dlt * dlt : 0.0;
-                } else {
-                  double coef;
-                  if constexpr (MODE == 0) coef = IMPLICIT ? c - (c - 1.0) * t : c - t;
-                  else coef = IMPLICIT ? (c - 1.0) * t : t;
-                  coef = in ? coef : 0.0;
-#pragma unroll
-                  for (int e = 0; e < EPL; e++) acc.c[e] = fma(coef, yv[e], acc.c[e]);
-                }
-              }
-            });
-#pragma unroll
-            for (int u = 0; u < BS; u++)
-#pragma unroll
-              for (int e = 0; e < EPL; e++) cur[u][e] = nxt[u][e];
-          }
-        });
-        id0 = id1; c0l = c1l; c0h = c1h;
-        id1 = id2; c1l = c2l; c1h = c2h;
-      }
-      // the groups' shares (loss: every lane of a group holds the group's term)
-#pragma unroll
-      for (int e = 0; e < EPL; e++) acc.c[e] = f64_across_groups<W>(acc.c[e]);
-      if constexpr (EPL == 2 && MODE == 2) acc.c[0] = f64_group_sum<64>(acc.c[0]);   // (the terms sit one per quad there)
-      return acc;
+      return f64_row_pass<W, IMPLICIT, EPL, decltype(mode_tag)::value>(a, k, p1, n, v, lk, lc, l, g, lane);
     };
     // sums over the coordinates (one group's lanes; the groups hold copies)
     auto dot = [&](const Vec u, const Vec v) {
@@ -859,6 +872,192 @@ bool f64_cg_wave_supported(const F64Args& a) {
          !a.solve_empty && a.k >= 1 && a.k <= 128;
 }
 
+// ---- long rows ----
+// The wave-per-row kernel finishes when its longest row does: the 1M x 100k matrix of the timing tools has an item with 154,282
+// ratings, 48 k batches of sixteen gathers on ONE wave -- 58 ms (rank 64) / 80 ms (rank 128) of a launch whose other 99,999 rows take
+// 12 (profiles/r05/r5p_*).  Rows beyond long_min non-zeros are therefore cut into chunks of chunk_len, listed when the matrix
+// handle is made (wrmf_f64_capi.cpp: the column pointers are on the host there), and the five passes of their conjugate gradient
+// run as launches of their own: every chunk a wave (f64_long_pass_kernel: the same f64_row_pass, partial sums to scratch), then one
+// wave per long row adds the partials IN CHUNK ORDER and does the step's vector updates (f64_long_update_kernel).  Deterministic:
+// no atomics, the order of every sum is fixed by the table.
+// scratch: [n_chunks x k] partial sums | [n_long x k] r | [n_long x k] p | [n_long x 4] rsold, stopped, loss, -
+
+template <int W, bool IMPLICIT, int EPL, int MODE>
+__global__ __launch_bounds__(256, EPL == 2 ? 2 : 1) void f64_long_pass_kernel(F64Args a) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k = a.k;
+  const int l = lane & (W - 1), g = lane / W;
+  const int c = blockIdx.x * 4 + wv;
+  if (c >= a.n_chunks) return;
+  bool lk[EPL];
+  int lc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; e++) {
+    lk[e] = l + 64 * e < k;
+    lc[e] = min(l + 64 * e, k - 1);
+  }
+  const int li = a.chunk_long[c], off = a.chunk_off[c], row = a.long_rows[li];
+  const int p1 = a.col_ptrs[row], n = min(a.chunk_len, a.col_ptrs[row + 1] - p1 - off);
+  double* part = a.long_scratch + (size_t)c * k;
+  const double* pvec = a.long_scratch + ((size_t)a.n_chunks + a.n_long) * k + (size_t)li * k;
+  const double* sc = a.long_scratch + ((size_t)a.n_chunks + 2 * (size_t)a.n_long) * k + 4 * (size_t)li;
+  if (MODE == 1 && sc[1] != 0.0) return;   // the row's iteration has stopped (rsnew below the tolerance)
+  const double* vsrc = MODE == 1 ? pvec : a.Y + (size_t)row * k;   // first residual and loss: at the row's own vector
+  F64Vec<EPL> v;
+#pragma unroll
+  for (int e = 0; e < EPL; e++) v.c[e] = lk[e] ? vsrc[lc[e]] : 0.0;
+  const F64Vec<EPL> acc = f64_row_pass<W, IMPLICIT, EPL, MODE>(a, k, p1 + off, n, v, lk, lc, l, g, lane);
+  if constexpr (MODE == 2) {
+    if (lane == 0) part[0] = acc.c[0];
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPL; e++)
+      if (lane < W && lk[e]) part[l + 64 * e] = acc.c[e];
+  }
+}
+
+// stage 0: after the first-residual pass; 1: after an operator pass (one conjugate-gradient step); 2: after the loss pass
+template <bool IMPLICIT>
+__global__ __launch_bounds__(256) void f64_long_update_kernel(F64Args a, int stage) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = a.k;
+  const int li = blockIdx.x * 4 + wv;
+  if (li >= a.n_long) return;
+  bool lk[2];
+  int lc[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    lk[e] = lane + 64 * e < k;
+    lc[e] = min(lane + 64 * e, k - 1);
+  }
+  using Vec = F64Vec<2>;
+  const int row = a.long_rows[li];
+  const int n = a.col_ptrs[row + 1] - a.col_ptrs[row];
+  const double lam_use = IMPLICIT ? a.lambda : a.lambda * (a.dynamic_lambda ? (double)n : 1.0);
+  double* yrow = a.Y + (size_t)row * k;
+  double* rvec = a.long_scratch + (size_t)a.n_chunks * k + (size_t)li * k;
+  double* pvec = rvec + (size_t)a.n_long * k;
+  double* sc = a.long_scratch + ((size_t)a.n_chunks + 2 * (size_t)a.n_long) * k + 4 * (size_t)li;
+  if (stage == 1 && sc[1] != 0.0) return;
+  const int c0 = a.long_chunk0[li], c1 = a.long_chunk0[li + 1];
+  auto load = [&](const double* src) {
+    Vec v;
+#pragma unroll
+    for (int e = 0; e < 2; e++) v.c[e] = lk[e] ? src[lc[e]] : 0.0;
+    return v;
+  };
+  auto store = [&](double* dst, const Vec v) {
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+      if (lk[e]) dst[lane + 64 * e] = v.c[e];
+  };
+  auto dot = [&](const Vec u, const Vec v) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int e = 0; e < 2; e++) sacc = fma(lk[e] ? u.c[e] : 0.0, v.c[e], sacc);
+    return f64_group_sum<64>(sacc);
+  };
+  if (stage == 2) {
+    double s = 0.0;
+    for (int c = c0; c < c1; c++) s += a.long_scratch[(size_t)c * k];
+    const Vec x = load(yrow);
+    const double ls = s + lam_use * dot(x, x);
+    if (lane == 0) sc[2] = ls;
+    return;
+  }
+  Vec t;
+  t.c[0] = t.c[1] = 0.0;
+  for (int c = c0; c < c1; c++) {   // the chunks' shares, in chunk order
+    const double* part = a.long_scratch + (size_t)c * k;
+#pragma unroll
+    for (int e = 0; e < 2; e++) t.c[e] += lk[e] ? part[lc[e]] : 0.0;
+  }
+  // (G v)_l, G = XtX (k x k, symmetric) from global memory: a few hundred rows per launch
+  auto gmv = [&](const Vec v) {
+    Vec s0;
+    s0.c[0] = s0.c[1] = 0.0;
+    const int lo[2] = {__double2loint(v.c[0]), __double2loint(v.c[1])}, hi[2] = {__double2hiint(v.c[0]), __double2hiint(v.c[1])};
+#pragma unroll
+    for (int e2 = 0; e2 < 2; e2++)
+#pragma unroll 8
+      for (int m = 0; m < min(64, k - 64 * e2); m++) {
+        const double vm = __hiloint2double(__builtin_amdgcn_readlane(hi[e2], m), __builtin_amdgcn_readlane(lo[e2], m));
+        const size_t col = (size_t)(m + 64 * e2) * k;
+#pragma unroll
+        for (int e = 0; e < 2; e++) s0.c[e] = fma(a.XtX[col + lc[e]], vm, s0.c[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < 2; e++) s0.c[e] = lk[e] ? s0.c[e] : 0.0;
+    return s0;
+  };
+  Vec x = load(yrow);
+  if (stage == 0) {
+    Vec g0;
+    if constexpr (IMPLICIT) g0 = gmv(x);
+    Vec r;
+#pragma unroll
+    for (int e = 0; e < 2; e++) r.c[e] = t.c[e] - (IMPLICIT ? g0.c[e] : lam_use * x.c[e]);
+    const double rsold = dot(r, r);
+    store(rvec, r);
+    store(pvec, r);
+    if (lane == 0) {
+      sc[0] = rsold;
+      sc[1] = 0.0;
+    }
+    return;
+  }
+  Vec r = load(rvec), pv = load(pvec);
+  const double rsold = sc[0];
+  {
+    Vec g1;
+    if constexpr (IMPLICIT) g1 = gmv(pv);
+#pragma unroll
+    for (int e = 0; e < 2; e++) t.c[e] += IMPLICIT ? g1.c[e] : lam_use * pv.c[e];
+  }
+  const double alpha = rsold / dot(pv, t);
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    x.c[e] = fma(alpha, pv.c[e], x.c[e]);
+    r.c[e] = fma(-alpha, t.c[e], r.c[e]);
+  }
+  const double rsnew = dot(r, r);
+  store(yrow, x);
+  store(rvec, r);
+  if (rsnew < kCgTolD) {
+    if (lane == 0) sc[1] = 1.0;
+    return;
+  }
+  const double beta = rsnew / rsold;
+#pragma unroll
+  for (int e = 0; e < 2; e++) pv.c[e] = fma(pv.c[e], beta, r.c[e]);
+  store(pvec, pv);
+  if (lane == 0) sc[0] = rsnew;
+}
+
+// the long rows' loss terms, in row order, onto a slot the wave-per-row launch has already written
+__global__ __launch_bounds__(64) void f64_long_loss_kernel(F64Args a, int slot) {
+  if (threadIdx.x != 0) return;
+  const double* sc = a.long_scratch + ((size_t)a.n_chunks + 2 * (size_t)a.n_long) * a.k;
+  double s = 0.0;
+  for (int li = 0; li < a.n_long; li++) s += sc[4 * (size_t)li + 2];
+  a.loss_partials[slot] += s;
+}
+
+template <int W, bool IMPLICIT, int EPL>
+hipError_t launch_f64_long_rows(const F64Args& a, int slots, hipStream_t s) {
+  const dim3 gp((a.n_chunks + 3) / 4), gu((a.n_long + 3) / 4), b(256);
+  hipLaunchKernelGGL((f64_long_pass_kernel<W, IMPLICIT, EPL, 0>), gp, b, 0, s, a);
+  hipLaunchKernelGGL(f64_long_update_kernel<IMPLICIT>, gu, b, 0, s, a, 0);
+  for (int it = 0; it < a.cg_steps; it++) {
+    hipLaunchKernelGGL((f64_long_pass_kernel<W, IMPLICIT, EPL, 1>), gp, b, 0, s, a);
+    hipLaunchKernelGGL(f64_long_update_kernel<IMPLICIT>, gu, b, 0, s, a, 1);
+  }
+  hipLaunchKernelGGL((f64_long_pass_kernel<W, IMPLICIT, EPL, 2>), gp, b, 0, s, a);
+  hipLaunchKernelGGL(f64_long_update_kernel<IMPLICIT>, gu, b, 0, s, a, 2);
+  hipLaunchKernelGGL(f64_long_loss_kernel, dim3(1), dim3(64), 0, s, a, slots - 1);
+  return hipGetLastError();
+}
+
 // slots: the loss partials a.loss_partials[0 .. slots) are this call's (all written or zeroed)
 // (Measured and not kept: the row's vectors resident in registers across the five passes -- one wave per row up to 256 non-zeros,
 //  the four waves of a workgroup sharing a row up to 1024 -- lost to the streaming kernel on both sides of the 1M x 100k matrix:
@@ -868,6 +1067,7 @@ hipError_t launch_f64_cg_wave_w(const F64Args& a, int slots, hipStream_t s) {
   const size_t lds = !a.implicit ? 0 : (EPL > 1 ? (size_t)a.k * (a.k + 1) / 2 : (size_t)a.k * a.k) * sizeof(double);   // (rank 128: 66 KB)
   hipError_t err;
   const int grid = std::max(1, std::min((a.n_cols + 3) / 4, slots));
+  const int n_hi = a.n_long > 0 ? a.long_min : 0x7fffffff;   // (longer rows: launch_f64_long_rows)
   if (grid < slots && (err = hipMemsetAsync(a.loss_partials + grid, 0, (size_t)(slots - grid) * sizeof(double), s)) != hipSuccess)
     return err;
   if (a.implicit) {
@@ -875,11 +1075,12 @@ hipError_t launch_f64_cg_wave_w(const F64Args& a, int slots, hipStream_t s) {
     if (lds > 48 * 1024 &&
         (err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
       return err;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, -1, 0x7fffffff, 0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, -1, n_hi, 0);
   } else {
-    hipLaunchKernelGGL((f64_cg_wave_kernel<W, false, EPL>), dim3(grid), dim3(256), lds, s, a, -1, 0x7fffffff, 0);
+    hipLaunchKernelGGL((f64_cg_wave_kernel<W, false, EPL>), dim3(grid), dim3(256), lds, s, a, -1, n_hi, 0);
   }
-  return hipGetLastError();
+  if ((err = hipGetLastError()) != hipSuccess || a.n_long <= 0) return err;
+  return a.implicit ? launch_f64_long_rows<W, true, EPL>(a, slots, s) : launch_f64_long_rows<W, false, EPL>(a, slots, s);
 }
 
 // ---- Gramian: partial[b] = sum over the block's columns of x x^T (lower-triangle tiles), then a fixed-order reduction ----
@@ -1002,6 +1203,7 @@ F64Geo f64_geometry(int k1, int solver) {
 
 }  // namespace
 
+size_t f64_long_scratch_doubles(int k, int n_long, int n_chunks) { return ((size_t)n_chunks + 2 * (size_t)n_long) * k + 4 * (size_t)n_long; }
 int f64_als_grid(int n_cols) { return std::max(1, std::min(n_cols, kF64MaxGrid)); }
 bool f64_needs_m2_scratch(int k1, int solver) { return solver == 2 && !f64_geometry(k1, solver).m2_in_lds; }
 size_t f64_m2_doubles_per_wg(int k1) {

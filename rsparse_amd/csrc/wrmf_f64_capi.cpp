@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,10 @@ struct rsparse_hip_csc_f64 {
   double* vals = nullptr;
   bool owns = false;
   int device = 0;
+  // the rows the conjugate-gradient path cuts into chunks (wrmf_f64.hip, "long rows"): listed once, from the column pointers
+  int long_min = 0x7fffffff, chunk_len = 0, n_long = 0, n_chunks = 0;
+  int32_t* long_table = nullptr;   // device: long_rows [n_long] | long_chunk0 [n_long + 1] | chunk_long [n_chunks] | chunk_off [n_chunks]
+  ~rsparse_hip_csc_f64() { if (long_table) (void)hipFree(long_table); }
 };
 
 namespace {
@@ -36,6 +41,41 @@ int fail(int code, const std::string& msg) { return capi_fail(code, msg); }
 
 constexpr size_t kRhsInitDoubles = (size_t)256 * 128 + 128;
 
+// Rows of more than kF64LongRowMin non-zeros leave the wave-per-row kernel (a 2048-row is 128 batches x 5 passes ~ 1 ms of one wave; the
+// longest row of the 1M x 100k timing matrix, 154 k, was 58-80 ms); RSPARSE_HIP_F64_LONG_ROW / _CHUNK override (tests: small matrices)
+constexpr int kF64LongRowMin = 2048, kF64LongRowChunk = 1024;
+
+int list_long_rows(rsparse_hip_csc_f64& m, const int32_t* host_col_ptrs) {
+  int lmin = kF64LongRowMin, chunk = kF64LongRowChunk;
+  if (const char* e = std::getenv("RSPARSE_HIP_F64_LONG_ROW")) lmin = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("RSPARSE_HIP_F64_LONG_CHUNK")) chunk = std::max(1, std::atoi(e));
+  m.long_min = lmin; m.chunk_len = chunk; m.n_long = m.n_chunks = 0;
+  std::vector<int32_t> rows, chunk0, cl, co;
+  for (int c = 0; c < m.n_cols; c++) {
+    const int n = host_col_ptrs[(size_t)c + 1] - host_col_ptrs[(size_t)c];
+    if (n <= lmin) continue;
+    chunk0.push_back((int32_t)cl.size());
+    for (int off = 0; off < n; off += chunk) {
+      cl.push_back((int32_t)rows.size());
+      co.push_back(off);
+    }
+    rows.push_back(c);
+  }
+  if (rows.empty()) return RSPARSE_HIP_OK;
+  chunk0.push_back((int32_t)cl.size());
+  std::vector<int32_t> all;
+  all.reserve(rows.size() + chunk0.size() + 2 * cl.size());
+  all.insert(all.end(), rows.begin(), rows.end());
+  all.insert(all.end(), chunk0.begin(), chunk0.end());
+  all.insert(all.end(), cl.begin(), cl.end());
+  all.insert(all.end(), co.begin(), co.end());
+  HIP_TRY(hipMalloc(&m.long_table, all.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(m.long_table, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  m.n_long = (int)rows.size();
+  m.n_chunks = (int)cl.size();
+  return RSPARSE_HIP_OK;
+}
+
 // grow-only scratch of the fp64 path (one host thread drives the library, as in wrmf_capi.cpp)
 struct WorkspaceF64 {
   double* gram = nullptr;
@@ -45,11 +85,22 @@ struct WorkspaceF64 {
   double* rinit = nullptr;      // 256 x 128 partials + the k1 entries of rhs_init
   double* m2 = nullptr;
   size_t m2_n = 0;
+  double* longs = nullptr;      // the long rows' partial sums and vectors (f64_long_scratch_doubles)
+  size_t longs_n = 0;
   int device = -1;
   void release() {
-    for (double** q : {&gram, &partials, &scalars, &rinit, &m2})
+    for (double** q : {&gram, &partials, &scalars, &rinit, &m2, &longs})
       if (*q) { (void)hipFree(*q); *q = nullptr; }
-    gram_n = m2_n = 0;
+    gram_n = m2_n = longs_n = 0;
+  }
+  int ensure_longs(size_t n) {
+    if (n > longs_n) {
+      if (longs) (void)hipFree(longs);
+      longs = nullptr; longs_n = 0;
+      HIP_TRY(hipMalloc(&longs, n * sizeof(double)));
+      longs_n = n;
+    }
+    return RSPARSE_HIP_OK;
   }
   int ensure() {
     int dev = 0;
@@ -156,6 +207,18 @@ int f64_half_iteration(const rsparse_hip_csc_f64* conf, bool implicit, const dou
     if ((rc = g_w64.ensure_m2((size_t)grid * f64_m2_doubles_per_wg(a.k1)))) return rc;
     a.m2_scratch = g_w64.m2;
   }
+  a.long_min = 0x7fffffff; a.chunk_len = 0; a.n_long = a.n_chunks = 0;
+  a.long_rows = a.long_chunk0 = a.chunk_long = a.chunk_off = nullptr;
+  a.long_scratch = nullptr;
+  if (conf->n_long > 0 && solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT) {   // (only the wave-per-row path looks at these)
+    if ((rc = g_w64.ensure_longs(f64_long_scratch_doubles(rank, conf->n_long, conf->n_chunks)))) return rc;
+    a.long_min = conf->long_min; a.chunk_len = conf->chunk_len; a.n_long = conf->n_long; a.n_chunks = conf->n_chunks;
+    a.long_rows = conf->long_table;
+    a.long_chunk0 = a.long_rows + conf->n_long;
+    a.chunk_long = a.long_chunk0 + conf->n_long + 1;
+    a.chunk_off = a.chunk_long + conf->n_chunks;
+    a.long_scratch = g_w64.longs;
+  }
   if ((e = launch_f64_als(a, s)) != hipSuccess) return capi_hip_fail(e, "launch_f64_als");
   if ((e = launch_sum_partials(g_w64.partials, (size_t)grid, out, s)) != hipSuccess) return capi_hip_fail(e, "launch_sum_partials");
   return RSPARSE_HIP_OK;
@@ -214,6 +277,7 @@ int stateless_double(bool implicit, int n_rows, int n_cols, const int32_t* col_p
   rsparse_hip_csc_f64 conf;
   conf.n_rows = n_rows; conf.n_cols = n_cols; conf.nnz = nnz;
   conf.col_ptrs = dP.as<int32_t>(); conf.row_idx = dI.as<int32_t>(); conf.vals = dV.as<double>();
+  if ((rc = list_long_rows(conf, col_ptrs))) return rc;
   const bool gbias = implicit && !with_biases && global_bias >= std::sqrt(DBL_EPSILON);
   const double* base_in = nullptr;
   double* base_out = nullptr;
@@ -299,6 +363,10 @@ int rsparse_hip_csc_f64_create_device(int n_rows, int n_cols, const int32_t* d_c
   }
   m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
   m->col_ptrs = d_col_ptrs; m->row_idx = d_row_indices; m->vals = const_cast<double*>(d_values);
+  if (int rc = list_long_rows(*m, hp.data())) {
+    delete m;
+    return rc;
+  }
   *out = m;
   return RSPARSE_HIP_OK;
 }

@@ -93,6 +93,67 @@ def test_implicit_double_cg_steps(cg_steps):
         assert np.array_equal(Y[:, live], Y0[:, live])
 
 
+@pytest.mark.parametrize("k", [10, 24, 48, 64, 100, 128])
+@pytest.mark.parametrize("feedback", ["implicit", "explicit"])
+@pytest.mark.parametrize("long_min,chunk", [(8, 5), (40, 64), (100, 37)])
+def test_double_cg_long_rows_in_chunks(monkeypatch, k, feedback, long_min, chunk):
+    """conjugate gradient, rows beyond RSPARSE_HIP_F64_LONG_ROW non-zeros cut into chunks that run as waves of their own
+    (wrmf_f64.hip, "long rows": the production threshold is 2048 / 1024, far beyond a test matrix -- lowered here so that most rows
+    take that path; chunk lengths that are no multiple of the 64-non-zero step, a last chunk of one non-zero).  Same bound
+    as the wave-per-row kernel, the loss too; then the same call with the path off gives the same rows to 1e-12."""
+    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_ROW", str(long_min))
+    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_CHUNK", str(chunk))
+    n_user = 300 if k > 64 else 600
+    csc, X, Y0 = _problem(n_user, 400, k, seed=7 * k + long_min, mean_deg=40, feedback=feedback, scale=0.1 if feedback == "implicit" else 0.3)
+    n_rows, n_cols, p, i, x = csc
+    n = np.diff(p)
+    assert (n > long_min).sum() > 20 and (n <= long_min).sum() > 0 and n.max() > 3 * chunk
+    lam = 0.1
+    Yref = Y0.copy(order="F")
+    Y = Y0.copy(order="F")
+    if feedback == "implicit":
+        G = O.gramian(X, lam)
+        lref = O.als_implicit(p, i, x, X, Yref, G, lam, 1, 3, n_threads=8)
+        run = lambda Yo: als.als_implicit(csc, X, Yo, lam, 1, 1, 3, "double", False, False, XtX=G)
+    else:
+        cnt = np.diff(sp.csc_matrix((x, i, p), shape=(n_rows, n_cols)).tocsr().indptr).astype(np.float64)
+        lref = O.als_explicit(p, i, x, X, Yref, cnt, lam, 1, 3, True, n_threads=8)
+        run = lambda Yo: als.als_explicit(csc, X, Yo, cnt, lam, 1, 1, 3, True, "double", False, False)
+    loss = run(Y)
+    err = _row_err(Y, Yref)
+    assert err.max() < 1e-9, (int(err.argmax()), int(n[err.argmax()]), float(err.max()))
+    assert abs(loss - lref) <= 1e-9 * abs(lref)
+    assert np.all(Y[:, n == 0] == 0)
+    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_ROW", "1000000")
+    Y1 = Y0.copy(order="F")
+    loss1 = run(Y1)
+    assert _row_err(Y, Y1).max() < 1e-12 and abs(loss - loss1) <= 1e-12 * abs(loss1)
+
+
+def test_double_cg_long_rows_stop_like_short_ones(monkeypatch):
+    """a row whose residual falls below CG_TOL stops iterating (wrmf_implicit.hpp:44): on the chunked path the flag lives in
+    scratch between launches.  Columns of X that are exactly orthonormal directions make the first step exact."""
+    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_ROW", "4")
+    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_CHUNK", "3")
+    k, n_item, n_user = 16, 64, 40
+    rng = np.random.default_rng(5)
+    X = np.zeros((k, n_item), order="F")
+    X[rng.integers(0, k, n_item), np.arange(n_item)] = 1.0          # every item vector a unit coordinate vector
+    rows = [np.sort(rng.choice(n_item, size=rng.integers(1, 30), replace=False)) for _ in range(n_user)]
+    p = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    i = np.concatenate(rows).astype(np.int32)
+    x = 1.0 + rng.random(len(i))
+    lam = 0.1
+    G = O.gramian(X, lam)
+    Y0 = np.asfortranarray(rng.standard_normal((k, n_user)) * 0.1)
+    Yref = Y0.copy(order="F")
+    lref = O.als_implicit(p, i, x, X, Yref, G, lam, 1, 20, n_threads=4)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit((n_item, n_user, p, i, x), X, Y, lam, 1, 1, 20, "double", False, False, XtX=G)
+    assert _row_err(Y, Yref).max() < 1e-9
+    assert abs(loss - lref) <= 1e-9 * abs(lref)
+
+
 @pytest.mark.parametrize("k", [6, 16, 40, 64, 128])
 @pytest.mark.parametrize("solver", [0, 1, 2])
 @pytest.mark.parametrize("dynamic_lambda", [True, False])

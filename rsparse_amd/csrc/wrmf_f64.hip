@@ -57,6 +57,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {   // butterfly: every l
   return v;
 }
 
+// v of lane `src` (wave-uniform) in every lane
+__device__ __forceinline__ double f64_readlane_uniform(const double v, const int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
 // sum over the workgroup, every thread gets it; all threads must call it.  red: NT / 64 doubles
 template <int NT>
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -111,8 +116,75 @@ __device__ __forceinline__ void rank_update_tiles(double* A, int lda, const doub
   }
 }
 
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+// The same update on the matrix cores: 16 x 16 tiles of the lower triangle (the whole diagonal tiles: their upper halves come out
+// as the mirror image), one tile per wave and trip, four non-zeros per v_mfma_f64_16x16x4_f64 -- lane l hands over A[l & 15][l >> 4]
+// and B[l >> 4][l & 15] and holds C/D[(l >> 4) + 4 r][l & 15], r < 4 (cdna_hip_programming.md: not the f32 map).  One instruction
+// does the work of sixteen v_fma_f64; a workgroup of the generic kernel has its CU to itself (the matrix fills the LDS), so the
+// instructions a row issues ARE its time (profiles/r05/r5_f64_generic_kernel_phases.txt).
+// (The tile indices live in scalar registers -- the wave's number through readfirstlane --, and a tile that lies wholly inside the
+//  matrix takes a path without masks: with one wave per SIMD the bookkeeping around the two to four matrix instructions of a tile,
+//  not the instructions themselves, was its time -- 1800 cycles a tile, r5_f64_generic_kernel_phases.txt.)
 template <int NT>
-__global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, int m2_in_lds) {
+__device__ __forceinline__ void rank_update_mfma(double* A, int lda, int kp, const double* xs, const double* w, int cn) {
+  constexpr int NW = NT / 64;
+  const int lane = threadIdx.x & 63, r16 = lane & 15, q4 = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int t16 = (kp + 15) >> 4, cn4 = cn & ~3;
+  int ti = 0, tj = wv;   // tiles (ti, tj), tj <= ti, row by row: this wave's first, then every NW-th
+  while (tj > ti) {
+    tj -= ti + 1;
+    ti++;
+  }
+  while (ti < t16) {
+    const int ra = 16 * ti + r16, rb = 16 * tj + r16;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    double* pc = A + (16 * ti + q4) + (size_t)rb * lda;
+    if (16 * (ti + 1) <= kp) {   // (uniform) the whole tile exists
+      const double* xa = xs + ra + q4 * kp;
+      const double* xb = xs + rb + q4 * kp;
+      const double* wq = w + q4;
+      for (int kk = 0; kk < cn4; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[kk * kp], wq[kk] * xb[kk * kp], acc, 0, 0, 0);
+      if (cn4 < cn) {
+        const bool vj = cn4 + q4 < cn;
+        const int jo = vj ? cn4 : cn4 - 4 >= 0 ? cn4 - 4 : 0;   // (a lane beyond the chunk reads a slot that exists; its products are zeroed)
+        const double av = xa[jo * kp], bv = wq[jo] * xb[jo * kp];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vj ? av : 0.0, vj ? bv : 0.0, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) pc[4 * r] += acc[r];
+    } else {
+      const bool va = ra < kp, vb = rb < kp;
+      const double* xa = xs + min(ra, kp - 1);
+      const double* xb = xs + min(rb, kp - 1);
+      for (int kk = 0; kk < cn; kk += 4) {
+        const int j = min(kk + q4, cn - 1);
+        const bool vj = kk + q4 < cn;
+        const double av = xa[j * kp], bv = w[j] * xb[j * kp];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((va && vj) ? av : 0.0, (vb && vj) ? bv : 0.0, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (16 * ti + q4 + 4 * r < kp && vb) pc[4 * r] += acc[r];
+    }
+    tj += NW;
+    while (tj > ti) {
+      tj -= ti + 1;
+      ti++;
+    }
+  }
+}
+
+// (dev build -DRSP_F64_PROF, tools/gpu_f64_phases.sh: s_memtime ticks of workgroup 0 per phase of a row, printed at the end)
+#ifdef RSP_F64_PROF
+#define F64_T(j) { const unsigned long long _t1 = __builtin_amdgcn_s_memtime(); prof_t[j] += _t1 - _tl; _tl = _t1; }
+#else
+#define F64_T(j)
+#endif
+
+template <int NT>
+__global__ __launch_bounds__(NT, 2) void f64_als_kernel(F64Args a, int KP, int CH, int m2_in_lds) {   // (two waves per SIMD: two workgroups of 256 at rank 33..64, one of 512 beyond)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   constexpr int NW = NT / 64;
@@ -130,9 +202,7 @@ __global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, 
   double* ap = p + KP;
   double* sv = ap + KP;     // X_nnz (c - 1): the global-bias term of the first CG residual
   double* invd = sv + KP;   // Cholesky: 1 / L_jj
-  double* d0 = invd + KP;   // the diagonal and the right-hand side before the factorisation (general-solver fallback)
-  double* b0 = d0 + KP;
-  double* red = b0 + KP;    // 8
+  double* red = invd + 3 * (size_t)KP;   // 8 (two vectors' room unused: the general solver re-assembles the system it falls back on)
   double* xs = red + 8;     // [CH][KP] staged factor vectors of the current chunk
   double* cw = xs + (size_t)CH * KP;   // per staged non-zero: weight of x x^T
   double* rw = cw + CH;                // ... of x in the right-hand side
@@ -148,6 +218,11 @@ __global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, 
   const int CG = NT / RT, ri = tid & (RT - 1), cgi = tid / RT;
 
   double wloss = 0.0;   // thread 0: loss terms of this workgroup's rows, in row order
+#ifdef RSP_F64_PROF
+  unsigned long long prof_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long _tl = __builtin_amdgcn_s_memtime();
+  int prof_rows = 0;
+#endif
 
   auto stage = [&](const int p1, const int c0, const int cn) {
     if (tid < cn) {
@@ -168,9 +243,22 @@ __global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, 
       }
     }
     __syncthreads();
-    for (int e = tid; e < cn * KP; e += NT) {
-      const int j = e / KP, t = e - j * KP;
-      xs[e] = t < k1 ? a.X[(size_t)sidx[j] * k + a.xoff + t] : 0.0;
+    // four vectors per wave and trip, all eight loads requested before the first is stored (the rank is at most 128: lane l
+    // holds the coordinates l and 64 + l) -- a workgroup owns the CU here, nothing else hides a round trip
+    for (int j0 = wv * 4; j0 < cn; j0 += NW * 4) {
+      double v[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double* base = a.X + (size_t)sidx[min(j0 + u, cn - 1)] * k + a.xoff;
+        v[u][0] = base[min(lane, k1 - 1)];
+        v[u][1] = base[min(lane + 64, k1 - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (j0 + u < cn) {
+          if (lane < KP) xs[(j0 + u) * KP + lane] = lane < k1 ? v[u][0] : 0.0;
+          if (lane + 64 < KP) xs[(j0 + u) * KP + lane + 64] = lane + 64 < k1 ? v[u][1] : 0.0;
+        }
     }
     __syncthreads();
   };
@@ -194,47 +282,63 @@ __global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, 
       continue;
     }
     const double lam_use = a.implicit ? a.lambda : a.lambda * (a.dynamic_lambda ? (double)n : 1.0);   // wrmf_explicit.hpp:78
-    __syncthreads();   // the previous row's readers are done with the LDS
-    for (int e = tid; e < KP * LDA; e += NT) {
-      const int c = e / LDA, i = e - c * LDA;
-      A[e] = (a.implicit && i < k1 && c < k1) ? a.XtX[i + (size_t)c * k1] : 0.0;
-    }
-    for (int t = tid; t < KP; t += NT) {
-      rhs[t] = (a.rhs_init && t < k1) ? a.rhs_init[t] : 0.0;
-      sv[t] = 0.0;
-      x[t] = t < k1 ? yrow[a.ioff + t] : 0.0;   // warm start (CG, NNLS): Y.col(i), drop_row(init, !is_x_bias_last_row)
-    }
-    __syncthreads();
-    // ---- assembly ----
-    for (int c0 = 0; c0 < n; c0 += CH) {
-      const int cn = min(CH, n - c0);
-      stage(p1, c0, cn);
-      rank_update_tiles<NT>(A, LDA, xs, KP, cw, cn, ntiles);
-      for (int t = tid; t < k1; t += NT) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int j = 0; j < cn; j++) {
-          const double xv = xs[j * KP + t];
-          s1 = fma(rw[j], xv, s1);
-          s2 = fma(cw[j], xv, s2);
+    // the row's system into the LDS: lower triangle of A (+ whole diagonal tiles), rhs, sv
+    auto assemble = [&]() {
+      __syncthreads();   // the previous readers are done with the LDS
+      F64_T(7)
+      for (int i0 = 0; i0 < LDA; i0 += 64) {   // XtX (or zeros): eight columns per wave and trip, their loads in flight together
+        const int i = i0 + lane;
+        for (int c0 = wv * 8; c0 < KP; c0 += NW * 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = a.implicit ? a.XtX[min(i, k1 - 1) + (size_t)min(c0 + u, k1 - 1) * k1] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (c0 + u < KP && i < LDA) A[i + (size_t)(c0 + u) * LDA] = (i < k1 && c0 + u < k1) ? v[u] : 0.0;
         }
-        rhs[t] += s1;
-        sv[t] += s2;
+      }
+      for (int t = tid; t < KP; t += NT) {
+        rhs[t] = (a.rhs_init && t < k1) ? a.rhs_init[t] : 0.0;
+        sv[t] = 0.0;
+        x[t] = t < k1 ? yrow[a.ioff + t] : 0.0;   // warm start (CG, NNLS): Y.col(i), drop_row(init, !is_x_bias_last_row)
       }
       __syncthreads();
-    }
-    if (!a.implicit)
-      for (int t = tid; t < k1; t += NT) A[t + (size_t)t * LDA] += lam_use;   // lhs.diag() += lambda_use
-    __syncthreads();
-    for (int e = tid; e < KP * KP; e += NT) {   // mirror the lower triangle
-      const int c = e / KP, i = e - c * KP;
-      if (i < c) A[i + (size_t)c * LDA] = A[c + (size_t)i * LDA];
-    }
-    for (int t = tid; t < KP; t += NT) {
-      d0[t] = A[t + (size_t)t * LDA];
-      b0[t] = rhs[t];
-    }
-    __syncthreads();
+      F64_T(0)
+      for (int c0 = 0; c0 < n; c0 += CH) {
+        const int cn = min(CH, n - c0);
+        stage(p1, c0, cn);
+        F64_T(12)
+        rank_update_mfma<NT>(A, LDA, KP, xs, cw, cn);
+        F64_T(13)
+        for (int t = tid; t < k1; t += NT) {
+          double s1 = 0.0, s2 = 0.0;
+          for (int j = 0; j < cn; j++) {
+            const double xv = xs[j * KP + t];
+            s1 = fma(rw[j], xv, s1);
+            s2 = fma(cw[j], xv, s2);
+          }
+          rhs[t] += s1;
+          sv[t] += s2;
+        }
+        __syncthreads();
+        F64_T(14)
+      }
+      F64_T(1)
+      if (!a.implicit)
+        for (int t = tid; t < k1; t += NT) A[t + (size_t)t * LDA] += lam_use;   // lhs.diag() += lambda_use
+      __syncthreads();
+    };
+    // the upper triangle (conjugate gradient and NNLS multiply by the whole matrix, the general solver eliminates on it; the
+    // Cholesky factorisation never looks there)
+    auto mirror = [&]() {
+      for (int c = wv; c < KP; c += NW)
+        for (int i = lane; i < c; i += 64) A[i + (size_t)c * LDA] = A[c + (size_t)i * LDA];
+      __syncthreads();
+    };
+    assemble();
+    if (cg || nnls) mirror();
 
+    F64_T(2)
     if (cg) {
       // ---- conjugate gradient on the assembled system (wrmf_implicit.hpp:8-57, wrmf_explicit.hpp:8-31) ----
       double part = 0.0;
@@ -352,56 +456,177 @@ __global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, 
       }
       __syncthreads();
     } else {
-      // ---- Cholesky, right-looking; z = L^-1 rhs rides along in x ----
+      // ---- Cholesky, right-looking in blocks of 8 columns; z = L^-1 rhs rides along in x ----
+      // (Column by column -- two barriers and a rank-1 sweep of the LDS per column -- the factorisation was 300 of the 360 us a
+      // rank-128 row took, and WRMF's closing exact solve of 1M users 1.4 s: profiles/r05/r5q_*.  A block's 8 x 8 diagonal tile is
+      // factored by EVERY thread for itself, in registers -- the same bits everywhere, no exchange --, then a thread solves its own row
+      // of the panel against it and the trailing matrix takes the block's eight rank-1 terms in one sweep of 4 x 4 register tiles:
+      // two barriers per block.)
       bool ok = true;
-      for (int j = 0; j < k1; j++) {
-        __syncthreads();
-        const double d = A[j + (size_t)j * LDA];
-        if (!(d > 0.0)) {
-          ok = false;
-          break;
+      constexpr int NB = 8;
+      // one block of columns; FULL: all eight exist (every block but the last of a rank that is no multiple of 8)
+      auto block = [&](auto full_t, const int jb) {
+        constexpr bool FULL = decltype(full_t)::value;
+        const int nb = FULL ? NB : k1 - jb, j2 = jb + nb;
+        // the tile is factored by the waves that own rows of the panel (and wave 0, which writes the factor back): two waves of a
+        // SIMD factoring the same tile side by side took twice as long for nothing (eight waves: ranks beyond 64)
+        double L[NB][NB], dinv[NB], z[NB];
+        if (wv == 0 || wv * 64 < k1 - j2) {
+#pragma unroll
+          for (int c = 0; c < NB; c++)
+#pragma unroll
+            for (int rr = c; rr < NB; rr++)   // (columns beyond the matrix: an identity tail keeps the loops whole)
+              L[rr][c] = (FULL || (rr < nb && c < nb)) ? A[(jb + min(rr, nb - 1)) + (size_t)(jb + min(c, nb - 1)) * LDA] : (rr == c ? 1.0 : 0.0);
+#pragma unroll
+          for (int c = 0; c < NB; c++) z[c] = (FULL || c < nb) ? rhs[jb + min(c, nb - 1)] : 0.0;
+          bool bad = false;
+#pragma unroll
+          for (int c = 0; c < NB; c++) {
+            const double d = L[c][c];
+            bad = bad || !(d > 0.0);
+            const double di = rsqrt(d);   // (one reciprocal square root on the pivot chain instead of a square root and a division: 128 of them in a row)
+            dinv[c] = di;
+#pragma unroll
+            for (int rr = c + 1; rr < NB; rr++) L[rr][c] *= di;
+#pragma unroll
+            for (int c2 = c + 1; c2 < NB; c2++)
+#pragma unroll
+              for (int rr = c2; rr < NB; rr++) L[rr][c2] = fma(-L[rr][c], L[c2][c], L[rr][c2]);
+            double zc = z[c];
+#pragma unroll
+            for (int q = 0; q < c; q++) zc = fma(-L[c][q], z[q], zc);
+            z[c] = zc * di;
+          }
+          if (tid == 0) spiv[1] = bad ? 1 : 0;   // (every wave that factors sees the same tile; the others read the verdict)
+          F64_T(8)
+          if (!bad)
+            for (int i = j2 + tid; i < k1; i += NT) {   // the panel: row i of L against the tile, in registers
+              double lr[NB], av[NB];
+              double bi = rhs[i];
+#pragma unroll
+              for (int c = 0; c < NB; c++) av[c] = (FULL || c < nb) ? A[i + (size_t)(jb + min(c, nb - 1)) * LDA] : 0.0;
+#pragma unroll
+              for (int c = 0; c < NB; c++) {
+                double v = av[c];
+#pragma unroll
+                for (int q = 0; q < c; q++) v = fma(-lr[q], L[c][q], v);
+                lr[c] = v * dinv[c];
+                if (FULL || c < nb) A[i + (size_t)(jb + c) * LDA] = lr[c];
+                bi = fma(-lr[c], z[c], bi);
+              }
+              rhs[i] = bi;
+            }
         }
-        const double dinv = 1.0 / sqrt(d);
-        for (int i = j + 1 + tid; i < k1; i += NT) A[i + (size_t)j * LDA] *= dinv;
-        if (tid == 0) {
-          invd[j] = dinv;
-          x[j] = rhs[j] * dinv;
+        __syncthreads();   // the panel is in place (and nobody reads the diagonal tile any more)
+        F64_T(9)
+        if (spiv[1]) return false;
+        if (tid == 0) {   // the tile's factor
+#pragma unroll
+          for (int c = 0; c < NB; c++)
+            if (FULL || c < nb) {
+              invd[jb + c] = dinv[c];
+              x[jb + c] = z[c];
+#pragma unroll
+              for (int rr = c + 1; rr < NB; rr++)
+                if (FULL || rr < nb) A[(jb + rr) + (size_t)(jb + c) * LDA] = L[rr][c];
+            }
         }
-        __syncthreads();
-        const double zj = x[j];
-        const double* Lj = A + (size_t)j * LDA;
-        for (int i = j + 1 + ri; i < k1; i += RT) {
-          const double li = Lj[i];
-          for (int c = j + 1 + cgi; c <= i; c += CG) A[i + (size_t)c * LDA] = fma(-li, Lj[c], A[i + (size_t)c * LDA]);
-          if (cgi == 0) rhs[i] = fma(-li, zj, rhs[i]);
+        if (FULL && j2 < k1) {
+          // trailing matrix -= panel panel^T on the matrix cores: 16 x 16 tiles from (j2, j2) on, two instructions each (K = 8);
+          // the last tile row hangs over the matrix when KP - j2 is no multiple of 16: those tiles take the masked path
+          const int r16 = lane & 15, q4 = lane >> 4;
+          const int wvs = __builtin_amdgcn_readfirstlane(wv);
+          const int t16 = (KP - j2 + 15) >> 4;
+          const double* pan = A + (size_t)(jb + q4) * LDA;   // column jb + q4 of the panel (the second instruction: four columns on)
+          int ti = 0, tj = wvs;
+          while (tj > ti) {
+            tj -= ti + 1;
+            ti++;
+          }
+          while (ti < t16) {
+            const int ra = j2 + 16 * ti + r16, rb = j2 + 16 * tj + r16;
+            f64x4 cc;
+            if (j2 + 16 * (ti + 1) <= KP) {   // (uniform)
+              double* pc = A + (j2 + 16 * ti + q4) + (size_t)rb * LDA;
+              const double a0 = pan[ra], a1 = pan[ra + 4 * (size_t)LDA], b0v = pan[rb], b1v = pan[rb + 4 * (size_t)LDA];
+#pragma unroll
+              for (int r = 0; r < 4; r++) cc[r] = pc[4 * r];
+              cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0v, cc, 0, 0, 0);
+              cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1v, cc, 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; r++) pc[4 * r] = cc[r];
+            } else {
+              const int rac = min(ra, KP - 1), rbc = min(rb, KP - 1);
+              double* pc = A + (j2 + 16 * ti + q4) + (size_t)rbc * LDA;
+              const double a0 = pan[rac], a1 = pan[rac + 4 * (size_t)LDA], b0v = pan[rbc], b1v = pan[rbc + 4 * (size_t)LDA];
+              bool vc[4];
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                vc[r] = j2 + 16 * ti + q4 + 4 * r < KP && rb < KP;
+                cc[r] = vc[r] ? pc[4 * r] : 0.0;
+              }
+              cc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra < KP ? -a0 : 0.0, rb < KP ? b0v : 0.0, cc, 0, 0, 0);
+              cc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra < KP ? -a1 : 0.0, rb < KP ? b1v : 0.0, cc, 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (vc[r]) pc[4 * r] = cc[r];
+            }
+            tj += NW;
+            while (tj > ti) {
+              tj -= ti + 1;
+              ti++;
+            }
+          }
         }
+        F64_T(10)
+        return true;
+      };
+      for (int jb = 0; jb < k1 && ok; jb += NB) {
+        __syncthreads();   // the previous block's trailing update has landed
+        F64_T(11)
+        ok = k1 - jb >= NB ? block(std::true_type{}, jb) : block(std::false_type{}, jb);
       }
       __syncthreads();
+      F64_T(3)
       if (ok) {
         if (wv == 0) {   // L^T y = z: lane l holds entries l and l + 64
           double z0 = lane < k1 ? x[lane] : 0.0, z1 = lane + 64 < k1 ? x[lane + 64] : 0.0;
-          for (int m = k1 - 1; m >= 0; m--) {
-            const int src = m & 63;
-            const bool hi = m >= 64;
-            const double ym = __shfl(hi ? z1 : z0, src) * invd[m];
-            if (lane == src) {
-              if (hi) z1 = ym; else z0 = ym;
-            }
-            if (lane < m) z0 = fma(-A[m + (size_t)lane * LDA], ym, z0);
-            if (lane + 64 < m) z1 = fma(-A[m + (size_t)(lane + 64) * LDA], ym, z1);
+          // 1 / L_mm and row m of L wait in registers (the row a step ahead, zeroed beyond the diagonal), and a lane's entry is final
+          // once its own step has passed (y_m = z_m / L_mm, formed at the end as in the step): the chain of a step is a product, a
+          // lane read and an fma -- it was two LDS round trips, two selects and a compare as well
+          const double i0 = lane < k1 ? invd[lane] : 0.0, i1 = lane + 64 < k1 ? invd[lane + 64] : 0.0;
+          const int c0l = min(lane, KP - 1), c1l = min(lane + 64, KP - 1);
+          // (Rows four steps ahead, in rings of registers, were slower: 1.43 -> 1.82 M ticks per 82 rows at rank 128.)
+          int m = k1 - 1;
+          double a0 = A[m + (size_t)c0l * LDA], a1 = A[m + (size_t)c1l * LDA];
+          a1 = lane + 64 < m ? a1 : 0.0;
+          for (; m >= 64; m--) {   // (lane < m throughout)
+            const int mn = m - 1;
+            const double n0 = A[mn + (size_t)c0l * LDA], n1r = A[mn + (size_t)c1l * LDA];
+            const double n1 = lane + 64 < mn ? n1r : 0.0;
+            const double ym = f64_readlane_uniform(z1 * i1, m - 64);
+            z0 = fma(-a0, ym, z0);
+            z1 = fma(-a1, ym, z1);
+            a0 = n0;
+            a1 = n1;
           }
-          if (lane < k1) x[lane] = z0;
-          if (lane + 64 < k1) x[lane + 64] = z1;
+          a0 = lane < m ? a0 : 0.0;
+          for (; m >= 0; m--) {
+            const int mn = max(m - 1, 0);
+            const double n0r = A[mn + (size_t)c0l * LDA];
+            const double n0 = lane < mn ? n0r : 0.0;
+            const double ym = f64_readlane_uniform(z0 * i0, m);
+            z0 = fma(-a0, ym, z0);
+            a0 = n0;
+          }
+          if (lane < k1) x[lane] = z0 * i0;
+          if (lane + 64 < k1) x[lane + 64] = z1 * i1;
         }
         __syncthreads();
       } else {
-        // ---- the general solver (gesv's order: partial pivoting, first largest entry) on the restored system ----
-        for (int e = tid; e < KP * KP; e += NT) {
-          const int c = e / KP, i = e - c * KP;
-          if (i > c) A[i + (size_t)c * LDA] = A[c + (size_t)i * LDA];
-          else if (i == c) A[i + (size_t)c * LDA] = d0[i];
-        }
-        for (int t = tid; t < KP; t += NT) rhs[t] = b0[t];
+        // ---- the general solver (gesv's order: partial pivoting, first largest entry): the system once more, whole ----
+        assemble();
+        mirror();
         bool singular = false;
         for (int c = 0; c < k1; c++) {
           __syncthreads();
@@ -459,7 +684,7 @@ __global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, 
             for (int m = k1 - 1; m >= 0; m--) {
               const int src = m & 63;
               const bool hi = m >= 64;
-              const double ym = __shfl(hi ? z1 : z0, src) / A[m + (size_t)m * LDA];
+              const double ym = f64_readlane_uniform(hi ? z1 : z0, src) / A[m + (size_t)m * LDA];
               if (lane == src) {
                 if (hi) z1 = ym; else z0 = ym;
               }
@@ -480,26 +705,51 @@ __global__ __launch_bounds__(NT) void f64_als_kernel(F64Args a, int KP, int CH, 
       }
     }
 
+    F64_T(4)
     // ---- write back, loss term (wrmf_implicit.hpp:254-270, wrmf_explicit.hpp:113-132) ----
     for (int t = tid; t < k1; t += NT) yrow[a.ooff + t] = x[t];
+    // (the row's vectors once more, straight from memory: a wave takes four non-zeros per trip, no staging, no barrier)
     double lpart = 0.0;
-    for (int c0 = 0; c0 < n; c0 += CH) {
-      const int cn = min(CH, n - c0);
-      stage(p1, c0, cn);
-      for (int j = wv; j < cn; j += NW) {
-        double s = 0.0;
-        for (int t = lane; t < k1; t += 64) s = fma(xs[j * KP + t], x[t], s);
-        s = wave_sum_d(s);
-        const double dlt = lt[j] - s;
-        lpart += lw[j] * dlt * dlt;
+    {
+      const double x0 = lane < k1 ? x[lane] : 0.0, x1 = lane + 64 < k1 ? x[lane + 64] : 0.0;
+      for (int j0 = wv * 4; j0 < n; j0 += NW * 4) {
+        double v[4][2], cj[4], xbj[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int jj = p1 + min(j0 + u, n - 1);
+          const double* col = a.X + (size_t)a.row_idx[jj] * k;
+          cj[u] = a.vals[jj];
+          v[u][0] = col[a.xoff + min(lane, k1 - 1)];
+          v[u][1] = col[a.xoff + min(lane + 64, k1 - 1)];
+          xbj[u] = a.xb >= 0 ? col[a.xb] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          double sd = lane < k1 ? v[u][0] * x0 : 0.0;
+          sd = lane + 64 < k1 ? fma(v[u][1], x1, sd) : sd;
+          sd = wave_sum_d(sd);
+          const double lwj = a.implicit ? cj[u] : 1.0;                                    // (as `stage` forms them)
+          const double ltj = a.implicit ? (1.0 - a.gbias) - xbj[u] : cj[u] - xbj[u];   // wrmf_implicit.hpp:259-270, wrmf_explicit.hpp:131
+          const double dlt = ltj - sd;
+          lpart += j0 + u < n ? lwj * dlt * dlt : 0.0;
+        }
       }
-      __syncthreads();
     }
     double yy = 0.0;
     for (int t = tid; t < k1; t += NT) yy += x[t] * x[t];
     const double tot = block_sum<NT>((lane == 0 ? lpart : 0.0) + lam_use * yy, red);
     if (tid == 0) wloss += tot;
+    F64_T(5)
+#ifdef RSP_F64_PROF
+    prof_rows++;
+#endif
   }
+#ifdef RSP_F64_PROF
+  if (blockIdx.x == 0 && tid == 0)
+    printf("f64_als_kernel phases (ticks of s_memtime, workgroup 0, %d rows): copy %llu assembly %llu [stage %llu update %llu rhs %llu] mirror %llu solve %llu [tile %llu panel %llu trailing %llu barrier %llu] backsub %llu loss %llu between %llu\n",
+           prof_rows, prof_t[0], prof_t[1] + prof_t[12] + prof_t[13] + prof_t[14], prof_t[12], prof_t[13], prof_t[14], prof_t[2],
+           prof_t[3] + prof_t[8] + prof_t[9] + prof_t[10] + prof_t[11], prof_t[8], prof_t[9], prof_t[10], prof_t[11], prof_t[4], prof_t[5], prof_t[7]);
+#endif
   if (tid == 0) a.loss_partials[blockIdx.x] = wloss;
 }
 
@@ -784,18 +1034,45 @@ __global__ __launch_bounds__(256, EPL == 2 ? 2 : 1) void f64_cg_wave_kernel(F64A
       lo[e] = __double2loint(v.c[e]);
       hi[e] = __double2hiint(v.c[e]);
     }
+    // eight columns of G per trip, their LDS reads requested together: one column per trip -- read, wait, fma -- left a round trip
+    // of the LDS exposed 128 times per product and four products per row (a third of the users' half at rank 128)
+    auto column = [&](auto e2t, const int m, double (&gv)[EPL]) {
+      constexpr int E2 = decltype(e2t)::value;
+      const int mm = m + 64 * E2;
+      const int tm = mm * (mm + 1) / 2;
 #pragma unroll
-    for (int e2 = 0; e2 < EPL; e2++)
-      for (int m = 0; m < min(64, k - 64 * e2); m++) {
-        const double vm = __hiloint2double(__builtin_amdgcn_readlane(hi[e2], m), __builtin_amdgcn_readlane(lo[e2], m));
-        const int mm = m + 64 * e2;
-        const int tm = mm * (mm + 1) / 2;
+      for (int e = 0; e < EPL; e++) {
+        // XtX is symmetric; packed triangle: (row, col) with row >= col at row (row + 1) / 2 + col -- the lane's coordinate of
+        // register e is below 64 for e = 0 and at least 64 for e = 1, so only e == E2 has to compare
+        int at;
+        if constexpr (!TRI) at = lc[e] + mm * k;
+        else at = e == E2 ? (lc[e] >= mm ? tl[e] + mm : tm + lc[e]) : (e > E2 ? tl[e] + mm : tm + lc[e]);
+        gv[e] = sG[at];
+      }
+    };
+    static_for_f64<EPL>([&](auto e2t) {
+      constexpr int E2 = decltype(e2t)::value;
+      const int lim = min(64, k - 64 * E2);
+      int m = 0;
+      for (; m + 8 <= lim; m += 8) {
+        double gv[8][EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; e++) {
-          const int at = TRI ? (lc[e] >= mm ? tl[e] + mm : tm + lc[e]) : lc[e] + mm * k;   // XtX is symmetric
-          s0.c[e] = fma(sG[at], vm, s0.c[e]);
+        for (int u = 0; u < 8; u++) column(e2t, m + u, gv[u]);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const double vm = __hiloint2double(__builtin_amdgcn_readlane(hi[E2], m + u), __builtin_amdgcn_readlane(lo[E2], m + u));
+#pragma unroll
+          for (int e = 0; e < EPL; e++) s0.c[e] = fma(gv[u][e], vm, s0.c[e]);
         }
       }
+      for (; m < lim; m++) {
+        double gv[EPL];
+        column(e2t, m, gv);
+        const double vm = __hiloint2double(__builtin_amdgcn_readlane(hi[E2], m), __builtin_amdgcn_readlane(lo[E2], m));
+#pragma unroll
+        for (int e = 0; e < EPL; e++) s0.c[e] = fma(gv[e], vm, s0.c[e]);
+      }
+    });
 #pragma unroll
     for (int e = 0; e < EPL; e++) s0.c[e] = lk[e] ? s0.c[e] : 0.0;
     return s0;
@@ -1186,7 +1463,9 @@ constexpr size_t kF64LdsBudget = 156 * 1024;
 F64Geo f64_geometry(int k1, int solver) {
   F64Geo g;
   g.KP = std::max(4, (k1 + 3) / 4 * 4);
-  g.NT = g.KP <= 32 ? 64 : 256;
+  // (beyond rank 64 the matrix leaves room for one workgroup per CU: eight waves instead of four, two per SIMD, so that a wave's
+  //  LDS and matrix-core latencies hide behind the other's -- nothing else would)
+  g.NT = g.KP <= 32 ? 64 : g.KP <= 64 ? 256 : 512;
   const size_t mat = (size_t)g.KP * (g.KP + 1);
   const size_t vec = (size_t)9 * g.KP + 8;
   auto bytes = [&](int mats, int ch) { return (mats * mat + vec + (size_t)ch * (g.KP + 4)) * 8 + (size_t)(ch + 4) * 4 + 16; };
@@ -1227,11 +1506,16 @@ hipError_t launch_f64_als(const F64Args& a, hipStream_t s) {
     if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)) != hipSuccess)
       return err;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), g.lds, s, a, g.KP, g.CH, g.m2_in_lds);
-  } else {
+  } else if (g.NT == 256) {
     auto kern = f64_als_kernel<256>;
     if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)) != hipSuccess)
       return err;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), g.lds, s, a, g.KP, g.CH, g.m2_in_lds);
+  } else {
+    auto kern = f64_als_kernel<512>;
+    if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)) != hipSuccess)
+      return err;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), g.lds, s, a, g.KP, g.CH, g.m2_in_lds);
   }
   return hipGetLastError();
 }

@@ -363,6 +363,12 @@ typedef struct rsparse_hip_csc_f64 rsparse_hip_csc_f64;
 int rsparse_hip_csc_f64_create_device(int n_rows, int n_cols, const int32_t* d_col_ptrs, const int32_t* d_row_indices,
                                       const double* d_values, rsparse_hip_csc_f64** out);
 int rsparse_hip_csc_f64_destroy(rsparse_hip_csc_f64* m);
+/* Conjugate gradient in double: a row of more than min_len non-zeros is cut into chunks of chunk_len that run as waves of their
+ * own, pass by pass (wrmf_f64.hip, "long rows": one wave per row left a half-iteration waiting for its longest row; sums in
+ * chunk order, no atomics).  Defaults 2048 / 1024 (0 = restore the default); applies to the handles made -- and the stateless
+ * *_double calls issued -- afterwards.  Results do not depend on it beyond rounding (1e-12); the tests lower it so that small
+ * matrices take the path. */
+int rsparse_hip_set_f64_long_rows(int min_len, int chunk_len);
 
 /* XtX = X X^T + fl(lambda) I in f64 (the ridge is rounded to fp32 in the double build too: float::fl(diag(lambda)),
  * R/model_WRMF.R:476); d_sumsq_out (nullable) = sum(X^2) */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "rsparse_hip_weighted_sumsq_f64_device": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp]),
     "rsparse_hip_profile_enable": (_c_int, [_c_int]),
     "rsparse_hip_set_launch_mode": (_c_int, [_c_int]),
+    "rsparse_hip_set_f64_long_rows": (_c_int, [_c_int, _c_int]),
     "rsparse_hip_profile_last": (_c_int, [ctypes.POINTER(_c_dbl)]),
     "rsparse_hip_profile_last_names": (_c_int, [ctypes.c_char_p, _c_int]),
     "rsparse_hip_take_numeric_failures": (_c_int, [ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),

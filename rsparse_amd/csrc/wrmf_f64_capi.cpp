@@ -6,7 +6,6 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
-#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -41,14 +40,14 @@ int fail(int code, const std::string& msg) { return capi_fail(code, msg); }
 
 constexpr size_t kRhsInitDoubles = (size_t)256 * 128 + 128;
 
-// Rows of more than kF64LongRowMin non-zeros leave the wave-per-row kernel (a 2048-row is 128 batches x 5 passes ~ 1 ms of one wave; the
-// longest row of the 1M x 100k timing matrix, 154 k, was 58-80 ms); RSPARSE_HIP_F64_LONG_ROW / _CHUNK override (tests: small matrices)
+// Rows of more than g_long_row_min non-zeros leave the wave-per-row kernel (a 2048-row is 128 batches x 5 passes ~ 1 ms of one wave; the
+// longest row of the 1M x 100k timing matrix, 154 k, was 58-80 ms); rsparse_hip_set_f64_long_rows changes the two lengths for the
+// handles made afterwards (tests: small matrices)
 constexpr int kF64LongRowMin = 2048, kF64LongRowChunk = 1024;
+int g_long_row_min = kF64LongRowMin, g_long_row_chunk = kF64LongRowChunk;
 
 int list_long_rows(rsparse_hip_csc_f64& m, const int32_t* host_col_ptrs) {
-  int lmin = kF64LongRowMin, chunk = kF64LongRowChunk;
-  if (const char* e = std::getenv("RSPARSE_HIP_F64_LONG_ROW")) lmin = std::max(1, std::atoi(e));
-  if (const char* e = std::getenv("RSPARSE_HIP_F64_LONG_CHUNK")) chunk = std::max(1, std::atoi(e));
+  const int lmin = g_long_row_min, chunk = g_long_row_chunk;
   m.long_min = lmin; m.chunk_len = chunk; m.n_long = m.n_chunks = 0;
   std::vector<int32_t> rows, chunk0, cl, co;
   for (int c = 0; c < m.n_cols; c++) {
@@ -368,6 +367,13 @@ int rsparse_hip_csc_f64_create_device(int n_rows, int n_cols, const int32_t* d_c
     return rc;
   }
   *out = m;
+  return RSPARSE_HIP_OK;
+}
+
+int rsparse_hip_set_f64_long_rows(int min_len, int chunk_len) {
+  if (min_len < 0 || chunk_len < 0) return fail(RSPARSE_HIP_ERR_INVALID, "lengths must be positive (0 = the default)");
+  g_long_row_min = min_len > 0 ? min_len : kF64LongRowMin;
+  g_long_row_chunk = chunk_len > 0 ? chunk_len : kF64LongRowChunk;
   return RSPARSE_HIP_OK;
 }
 

@@ -33,6 +33,17 @@ def _row_err(Y, Yref):
     return np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-300)
 
 
+@pytest.fixture(autouse=True)
+def _default_long_rows():
+    yield
+    _long_rows(0, 0)
+
+
+def _long_rows(min_len, chunk_len):
+    from rsparse_amd import _lib
+    _lib.check(_lib.load().rsparse_hip_set_f64_long_rows(int(min_len), int(chunk_len)))
+
+
 def _bound(solver):
     return 1e-6 if solver == 2 else 1e-9
 
@@ -96,13 +107,12 @@ def test_implicit_double_cg_steps(cg_steps):
 @pytest.mark.parametrize("k", [10, 24, 48, 64, 100, 128])
 @pytest.mark.parametrize("feedback", ["implicit", "explicit"])
 @pytest.mark.parametrize("long_min,chunk", [(8, 5), (40, 64), (100, 37)])
-def test_double_cg_long_rows_in_chunks(monkeypatch, k, feedback, long_min, chunk):
-    """conjugate gradient, rows beyond RSPARSE_HIP_F64_LONG_ROW non-zeros cut into chunks that run as waves of their own
+def test_double_cg_long_rows_in_chunks(k, feedback, long_min, chunk):
+    """conjugate gradient, rows beyond `rsparse_hip_set_f64_long_rows`' first argument cut into chunks that run as waves of their own
     (wrmf_f64.hip, "long rows": the production threshold is 2048 / 1024, far beyond a test matrix -- lowered here so that most rows
     take that path; chunk lengths that are no multiple of the 64-non-zero step, a last chunk of one non-zero).  Same bound
     as the wave-per-row kernel, the loss too; then the same call with the path off gives the same rows to 1e-12."""
-    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_ROW", str(long_min))
-    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_CHUNK", str(chunk))
+    _long_rows(long_min, chunk)
     n_user = 300 if k > 64 else 600
     csc, X, Y0 = _problem(n_user, 400, k, seed=7 * k + long_min, mean_deg=40, feedback=feedback, scale=0.1 if feedback == "implicit" else 0.3)
     n_rows, n_cols, p, i, x = csc
@@ -124,17 +134,16 @@ def test_double_cg_long_rows_in_chunks(monkeypatch, k, feedback, long_min, chunk
     assert err.max() < 1e-9, (int(err.argmax()), int(n[err.argmax()]), float(err.max()))
     assert abs(loss - lref) <= 1e-9 * abs(lref)
     assert np.all(Y[:, n == 0] == 0)
-    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_ROW", "1000000")
+    _long_rows(1000000, 1024)
     Y1 = Y0.copy(order="F")
     loss1 = run(Y1)
     assert _row_err(Y, Y1).max() < 1e-12 and abs(loss - loss1) <= 1e-12 * abs(loss1)
 
 
-def test_double_cg_long_rows_stop_like_short_ones(monkeypatch):
+def test_double_cg_long_rows_stop_like_short_ones():
     """a row whose residual falls below CG_TOL stops iterating (wrmf_implicit.hpp:44): on the chunked path the flag lives in
     scratch between launches.  Columns of X that are exactly orthonormal directions make the first step exact."""
-    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_ROW", "4")
-    monkeypatch.setenv("RSPARSE_HIP_F64_LONG_CHUNK", "3")
+    _long_rows(4, 3)
     k, n_item, n_user = 16, 64, 40
     rng = np.random.default_rng(5)
     X = np.zeros((k, n_item), order="F")

@@ -6,11 +6,13 @@
 // Per row (one workgroup, the row's k1 x k1 system in LDS):
 //     lhs = XtX + X_nnz diag(c - 1) X_nnz^T            (wrmf_implicit.hpp:207-208)     | X_nnz X_nnz^T + lambda_use I
 //     rhs = rhs_init + X_nnz (c - x_b % (c - 1))       (:226, :228-231)                | X_nnz (r - x_b)   (wrmf_explicit.hpp:89,103-106)
-// assembled from the gathered factor vectors in 4 x 4 register tiles of the lower triangle (chunks of the row staged in
-// LDS, every thread owns tiles), then
-//     Cholesky            right-looking LL^T in LDS, the forward substitution riding along, backward substitution by one
-//                         wave; a non-positive pivot sends the row to Gaussian elimination with partial pivoting in the same
-//                         workgroup -- what arma::solve(fast + likely_sympd) falls back to (:236, wrmf_explicit.hpp:108)
+// assembled from the gathered factor vectors (chunks of the row staged in LDS) in 16 x 16 tiles of the lower triangle on
+// v_mfma_f64_16x16x4_f64 (round 5; a wave a tile), then
+//     Cholesky            right-looking LL^T in LDS in blocks of 8 columns: the diagonal tile factored in registers, a thread a
+//                         row of the panel, the trailing update on the matrix cores (round 5); forward substitution riding
+//                         along, backward substitution by one wave; a non-positive pivot sends the row -- assembled once more --
+//                         to Gaussian elimination with partial pivoting in the same workgroup: what
+//                         arma::solve(fast + likely_sympd) falls back to (:236, wrmf_explicit.hpp:108)
 //     conjugate gradient  cg_solver_implicit / _global_bias / cg_solver_explicit (wrmf_implicit.hpp:8-57,
 //                         wrmf_explicit.hpp:8-31) from the warm start, with A p evaluated from the assembled matrix: the same
 //                         operator as XtX p + X_nnz((c-1) % X_nnz^T p), rounded differently at the 1e-16 level; the first
@@ -23,9 +25,10 @@
 // non-zero (the fp32 conjugate-gradient kernels move 8 k (cg_steps + 1)) and one row occupies a workgroup.  The bench line
 // (fp32, BASELINE.json) does not run through it.
 //
-// The one configuration with its own kernel is the constructor's default -- plain conjugate gradient, no biases, rank <= 64
-// (f64_cg_wave_kernel below, round 4): one wave per row, the operator applied from the gathered vectors as the reference
-// does (no k1 x k1 matrix), 4.5x the generic kernel at rank 10.  Everything else goes through the workgroup-per-row family.
+// The one configuration with kernels of its own is the constructor's default -- plain conjugate gradient, no biases
+// (f64_cg_wave_kernel below, round 4; ranks 65..128 and the rows beyond 2048 non-zeros, f64_long_*_kernel, round 5): one wave
+// per row (a wave per chunk of a long row), the operator applied from the gathered vectors as the reference does (no k1 x k1
+// matrix).  Everything else goes through the workgroup-per-row family.
 #include <algorithm>
 
 #include <type_traits>

@@ -1,4 +1,4 @@
-"""CPU tests of the synthetic generator and of the multi-rank control flow (gloo, world_size 2)."""
+"""CPU tests of the synthetic generator and of the multi-rank control flow (gloo, world sizes 2, 4 and 8)."""
 import os
 import socket
 import sys
@@ -148,3 +148,68 @@ def test_ranks_match_single_rank(tmp_path, feedback, solver, ws, skewed):
     if skewed:   # nnz balance of the user blocks: within 25 % of the mean although the row counts differ a lot
         nnz = np.array([r["nnz"] for r in rs], dtype=float)
         assert nnz.max() <= 1.25 * nnz.mean()
+
+
+def _bench_flow(rank, ws, n_user, n_item, k, n_iter):
+    """what bench.py does between its rendezvous and its timed loop, with the oracle backend on the CPU: every rank generates
+    only its own shard (synth.make_shard, blocks balanced by non-zeros), sub-block-major layouts, device-side losses, the last
+    exchange of a half-iteration deferred into the next one, ShardedALS.finish() at the end"""
+    from oracle_backend import OracleBackend
+    if ws == 1:
+        d = synth.make_dataset(n_user, n_item, mean_deg=10, d_max=80, device="cpu")
+        lu, li = ShardedALS.layouts(n_user, n_item, 1)
+        c_ui, c_iu, nnz = d["c_ui"], d["c_iu"], d["nnz"]
+    else:
+        def bounds_fn(cu, ci):
+            a, b = ShardedALS.layouts(n_user, n_item, ws, cu, ci)
+            return a.bounds, (b.bounds if ci is not None else None)
+        d = synth.make_shard(n_user, n_item, ws, rank, bounds_fn, mean_deg=10, d_max=80, device="cpu", block=257)   # (several streamed blocks)
+        lu, li = ShardedALS.layouts(n_user, n_item, ws, d["cnt_user"], d["cnt_item"])
+        c_ui, c_iu, nnz = d["c_ui"], d["c_iu"], d["nnz"]
+    als = ShardedALS(OracleBackend(), n_user, n_item, k, c_ui, c_iu, nnz, feedback="implicit", lambda_=0.1, cg_steps=3,
+                     world_size=ws, my_rank=rank, lay_user=lu, lay_item=li)
+    als.freeze_values()
+    g = torch.Generator().manual_seed(11)
+    U = lu.from_global(lu.alloc(k, "cpu"), torch.randn(n_user, k, generator=g) * 0.01)
+    V = li.alloc(k, "cpu")
+    losses = []
+    for _ in range(n_iter):
+        a = als.half_iteration("items", U, V, 1, want_loss="device", defer_exchange=True)
+        b = als.half_iteration("users", U, V, 1, want_loss="device", defer_exchange=True)
+        losses.append((float(a), float(b)))
+    als.finish()
+    return lu.to_global(U).clone(), li.to_global(V).clone(), losses, int(c_iu[1].numel()), int(nnz)
+
+
+def _bench_worker(rank, ws, port, out_dir, shape):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        U, V, losses, mine, nnz = _bench_flow(rank, ws, *shape)
+        torch.save({"U": U, "V": V, "losses": losses, "mine": mine, "nnz": nnz}, os.path.join(out_dir, "b%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_flow_at_eight_ranks(tmp_path):
+    """`bench.py --gpus 8` minus the GPU: the N = 8 launch of the driver is the one configuration this build cannot run (one GPU
+    per box; eight processes on one device did not get past the rendezvous), so its control flow -- per-rank shard
+    generation, unequal blocks, in-place slab all-gathers, deferred waits -- runs here under gloo with the oracle as the
+    arithmetic, and must reproduce the one-rank run."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT / "tests"))
+    ws, shape = 8, (1500, 260, 8, 2)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_bench_worker, args=(ws, port, str(tmp_path), shape), nprocs=ws, join=True)
+    U1, V1, l1, _, nnz1 = _bench_flow(0, 1, *shape)
+    rs = [torch.load(tmp_path / ("b%d.pt" % r)) for r in range(ws)]
+    assert all(r["nnz"] == nnz1 for r in rs) and sum(r["mine"] for r in rs) == nnz1     # the shards tile the matrix
+    for r in rs[1:]:
+        assert torch.equal(rs[0]["U"], r["U"]) and torch.equal(rs[0]["V"], r["V"]) and rs[0]["losses"] == r["losses"]
+    assert rel_fro(rs[0]["U"].numpy(), U1.numpy()) < 2e-5 and rel_fro(rs[0]["V"].numpy(), V1.numpy()) < 2e-5
+    for (a, b), (c, d) in zip(rs[0]["losses"], l1):
+        assert abs(a - c) <= 1e-5 * abs(c) and abs(b - d) <= 1e-5 * abs(d)
+    mine = np.array([r["mine"] for r in rs], dtype=float)
+    assert mine.max() <= 1.3 * mine.mean()

@@ -213,6 +213,9 @@ def main():
     implicit = args.feedback == "implicit"
     solver = {"cholesky": 0, "cg": 1, "nnls": 2}[args.solver]          # inst/include/wrmf.hpp:16-20 codes
 
+    if os.environ.get("RSPARSE_BENCH_STACKS_AFTER"):   # debugging aid: every rank's Python stack after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RSPARSE_BENCH_STACKS_AFTER"]), exit=True)
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

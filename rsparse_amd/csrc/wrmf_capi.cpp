@@ -542,11 +542,13 @@ struct BiasTerms {   // implicit feedback with user/item biases and / or a globa
 // launch_ne_stats for the values of handle d: a handle whose values are frozen (rsparse_hip_csc_freeze_values) is scanned once
 hipError_t take_value_stats(const DevCSC& d, const float* d_X, int64_t nx, hipStream_t s, const float* d_absmax) {
   if (d.vals_frozen && !d.vstats && hipMalloc(&d.vstats, 2 * sizeof(unsigned)) != hipSuccess) d.vstats = nullptr;
-  if (d.vals_frozen && d.vstats && d.vstats_valid)
+  // (the saved words are ordered behind their scan only on the stream that ran it: a call on another stream scans again and
+  // takes the cache over -- ADVICE r05)
+  if (d.vals_frozen && d.vstats && d.vstats_valid && d.vstats_stream == s)
     return launch_ne_stats(d_X, nx, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax, d.vstats, nullptr);
   hipError_t e = launch_ne_stats(d_X, nx, d.vals, d.nnz, g_ws.ne_stats, s, d_absmax, nullptr,
                                  (d.vals_frozen && d.vstats) ? d.vstats : nullptr);
-  if (e == hipSuccess && d.vals_frozen && d.vstats) d.vstats_valid = true;
+  if (e == hipSuccess && d.vals_frozen && d.vstats) { d.vstats_valid = true; d.vstats_stream = s; }
   return e;
 }
 

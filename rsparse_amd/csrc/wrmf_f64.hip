@@ -21,9 +21,12 @@
 //                         coordinate sweeps in order by one wave (lane = coordinate), stop at 1e-4 / 10000 sweeps
 // and the loss term from a second pass over the row's vectors (L2-resident by then).
 //
-// This is the parity path of the *_double entry points, built for correctness in double first: it moves k1^2 flops per
-// non-zero (the fp32 conjugate-gradient kernels move 8 k (cg_steps + 1)) and one row occupies a workgroup.  The bench line
-// (fp32, BASELINE.json) does not run through it.
+// This generic family is what every *_double entry point and WRMF(precision = "double") run for the exact solver, NNLS and the
+// biased variants at every rank <= 128, and for the exact solve that ends every double fit (round 6: the class no longer
+// falls back to fp32 above rank 63).  It moves k1^2 flops per non-zero (the fp32 conjugate-gradient kernels move
+// 8 k (cg_steps + 1)) and one row occupies a workgroup; since round 5 its Cholesky is blocked (8-column panels, two barriers per
+// block) with the trailing update and the assembly on v_mfma_f64_16x16x4_f64.  The bench line (fp32, BASELINE.json) does not
+// run through it.
 //
 // The one configuration with kernels of its own is the constructor's default -- plain conjugate gradient, no biases
 // (f64_cg_wave_kernel below, round 4; ranks 65..128 and the rows beyond 2048 non-zeros, f64_long_*_kernel, round 5): one wave

@@ -70,6 +70,7 @@ struct DevCSC {
   mutable bool vals_frozen = false;
   mutable bool vstats_valid = false;
   mutable unsigned* vstats = nullptr;
+  mutable hipStream_t vstats_stream = nullptr;   // the stream whose scan wrote vstats: only work queued on it is ordered behind that scan
 };
 
 struct AlsArgs {

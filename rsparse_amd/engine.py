@@ -204,6 +204,7 @@ class HipBackend:
     # which build's cut-off applies to a small implicit global bias on the fp32 layer (wrmf_implicit.hpp:108-109): False =
     # als_implicit<float>'s 3.45e-4, True = als_implicit<double>'s 1.49e-8 (WRMF sets it from its `precision`)
     double_threshold = False
+    top_product_batch = 1 << 18   # rows per `$predict` call of the library (bounds the re-scoring scratch)
 
     def __init__(self, device=None):
         self.lib = _lib.load()
@@ -239,6 +240,9 @@ class HipBackend:
         if x.dtype == torch.float64:
             # the ingest kernels move 32-bit payloads: send each entry's POSITION through them (bits are copied, never
             # computed with) and gather the doubles by the permutation that comes back
+            # (positions >= 0x7f800000 would be NaN bit patterns; a copy keeps those too, but no int32-indexed matrix gets there:
+            # asserted rather than assumed, tests/test_ingest.py::test_transpose_moves_payload_bits_untouched goes past 2^23)
+            assert nnz < 0x7F800000, "transpose_csc: more positions than the 32-bit payload can carry"
             pos = torch.arange(nnz, dtype=torch.int32, device=self.device).view(torch.float32)
             pt, it, perm = self.transpose_csc(n_rows, n_cols, p, i, pos)
             return pt, it, x[perm.view(torch.int32).to(torch.int64)].contiguous()
@@ -328,12 +332,20 @@ class HipBackend:
         V64 = V.contiguous() if f64 else None
         res = torch.empty((n, k), dtype=torch.int32, device=U.device)
         sc = torch.empty((n, k), dtype=torch.float64, device=U.device)
-        _lib.check(self.lib.rsparse_hip_top_product_f64_device(
-            U32.data_ptr(), V32.data_ptr(), None if U64 is None else U64.data_ptr(), None if V64 is None else V64.data_ptr(),
-            n, n_item, rank, k, -1,
-            None if nr_p is None else nr_p.data_ptr(), None if nr_j is None else nr_j.data_ptr(),
-            None if exclude0 is None else exclude0.data_ptr(), 0 if exclude0 is None else int(exclude0.numel()),
-            float(glob_mean), res.data_ptr(), sc.data_ptr(), self._stream()))
+        # in batches of rows: the re-scoring pass takes n * (2 kc + 2 k + 1) words from a grow-only workspace (several GB for a
+        # few million users in one call); a batch bounds it and the next batch reuses it.  The CSR slots of
+        # not_recommend are absolute positions into nr_j, so a batch passes its slice of nr_p unchanged.
+        B = self.top_product_batch
+        for a0 in range(0, max(n, 1), B):
+            nb = min(B, n - a0)
+            if nb <= 0:
+                break
+            _lib.check(self.lib.rsparse_hip_top_product_f64_device(
+                U32[a0:].data_ptr(), V32.data_ptr(), None if U64 is None else U64[a0:].data_ptr(),
+                None if V64 is None else V64.data_ptr(), nb, n_item, rank, k, -1,
+                None if nr_p is None else nr_p[a0:].data_ptr(), None if nr_j is None else nr_j.data_ptr(),
+                None if exclude0 is None else exclude0.data_ptr(), 0 if exclude0 is None else int(exclude0.numel()),
+                float(glob_mean), res[a0:].data_ptr(), sc[a0:].data_ptr(), self._stream()))
         return res, sc
 
     def _v32(self, V):
@@ -341,10 +353,16 @@ class HipBackend:
         one user paid an n_item x rank conversion per call)"""
         if V.dtype == torch.float32:
             return V
-        key = (V.data_ptr(), V._version, tuple(V.shape))
-        if getattr(self, "_v32_key", None) != key:
-            self._v32_cache, self._v32_key = V.to(torch.float32).contiguous(), key
+        # keyed on the tensor OBJECT (held here, so its storage cannot be handed to a later fit's factors while the replica
+        # lives) and on its version; the kernels write factors through raw pointers, which no version counter sees, so
+        # whoever re-solves a matrix it keeps must call `drop_v32()` (WRMF does wherever it assigns `_V`: ADVICE r05)
+        if getattr(self, "_v32_src", None) is not V or self._v32_ver != V._version:
+            self._v32_cache, self._v32_src, self._v32_ver = V.to(torch.float32).contiguous(), V, V._version
         return self._v32_cache
+
+    def drop_v32(self):
+        self._v32_cache = self._v32_src = None
+        self._v32_ver = -1
 
     def initialize_biases_explicit(self, csc_ui, csc_iu, user_bias, item_bias, lambda_, dynamic_lambda, non_negative,
                                    calculate_global_bias):

@@ -126,3 +126,36 @@ def test_csc_create_device_validates_like_the_host_constructor():
     with pytest.raises(_lib.RsparseHipError) as e:
         be.make_csc(4, 2, be.to_device(np.array([0, 3, 2], np.int32), torch.int32), ok[1], ok[2])
     assert e.value.code == _lib.ERR_INVALID
+
+
+@gpu
+def test_transpose_moves_payload_bits_untouched():
+    """The fp64 layer sends each entry's POSITION through the 32-bit ingest as a bit-cast float (engine.py:transpose_csc):
+    the payload must come back bit for bit whatever it looks like as a float -- integers beyond 2^23 (not representable as
+    consecutive floats), subnormal patterns (small integers), and patterns just below the NaN range."""
+    import torch
+    from rsparse_amd.engine import HipBackend
+    be = HipBackend(0)
+    rng = np.random.default_rng(5)
+    m = random_csc(rng, 4000, 900, 0.02)
+    nnz = m.nnz
+    for base in (0, (1 << 23) - 7, (1 << 24) + 1, (1 << 30) + 12345, 0x7F800000 - nnz - 1):
+        bits = (np.arange(nnz, dtype=np.int64) + base).astype(np.int32)
+        p = be.to_device(m.indptr.astype(np.int32), torch.int32)
+        i = be.to_device(m.indices.astype(np.int32), torch.int32)
+        x = be.to_device(bits, torch.int32).view(torch.float32)
+        pt, it, xt = be.transpose_csc(4000, 900, p, i, x)
+        got = xt.view(torch.int32).cpu().numpy()
+        # the host transpose of the same matrix with the payload as int64 data
+        t = sp.csc_matrix(sp.csc_matrix((bits.astype(np.int64), m.indices, m.indptr), shape=(4000, 900)).T)
+        t.sort_indices()
+        assert np.array_equal(it.cpu().numpy(), t.indices.astype(np.int32))
+        assert np.array_equal(got, t.data.astype(np.int32)), base
+    # and through the fp64 branch itself: doubles that differ only below float precision come back in transposed order
+    xd = 1.0 + np.arange(nnz, dtype=np.float64) * 2.0 ** -40
+    p = be.to_device(m.indptr.astype(np.int32), torch.int32)
+    i = be.to_device(m.indices.astype(np.int32), torch.int32)
+    pt, it, xt = be.transpose_csc(4000, 900, p, i, be.to_device(xd, torch.float64))
+    t = sp.csc_matrix(sp.csc_matrix((xd, m.indices, m.indptr), shape=(4000, 900)).T)
+    t.sort_indices()
+    assert np.array_equal(xt.cpu().numpy(), t.data)

@@ -330,7 +330,8 @@ def main():
 
     # ---- per-kernel durations (HIP events inside the library, same stream), separate pass ----
     # segments of rsparse_hip_profile_last: CG -> one per row-length bucket; Cholesky -> [0] normal-equation launch (long
-    # rows, exact solve), [1] low-rank kernel (short rows), [2] k x k kernel; NNLS -> [0].  The kernel NAMES come from the
+    # rows, exact solve), [1] low-rank kernel (short rows), [2] k x k kernel, [3] wave-per-row kernel (rank 65..128, rows of 65..512 non-zeros);
+    # NNLS -> [0].  The kernel NAMES come from the
     # library too (rsparse_hip_profile_last_names: the runtime's symbol table, i.e. what rocprofv3 prints).
     import re
     be.profile(True)
@@ -393,21 +394,25 @@ def main():
                 return (sum(r), sum(z), emp) if seg == 0 else (0, 0, 0)
             ne_ok = k > 32 and k % 4 == 0
             lr_ok = implicit and 96 < k <= 128 and k % 2 == 0
-            cut = 4 if k > 64 else 1                # the normal-equation launch takes the classes [0, cut)
+            mf_ok = ne_ok and 64 < k <= 128         # round 6: the rows of 65..512 non-zeros on the wave-per-row kernel (segment 3)
+            cut = 4 if (k > 64 and not mf_ok) else 1   # the normal-equation launch takes the classes [0, cut)
             if seg == 0:
                 return (sum(r[:cut]), sum(z[:cut]), 0) if ne_ok else (0, 0, 0)
-            lo = cut if ne_ok else 0
+            if seg == 3:
+                return (sum(r[1:4]), sum(z[1:4]), 0) if mf_ok else (0, 0, 0)
+            lo = 4 if mf_ok else (cut if ne_ok else 0)
             if seg == 1:
                 return (r[4] + r[5] - emp, z[4] + z[5], 0) if lr_ok else (0, 0, 0)
             hi = 4 if lr_ok else 6
             return (sum(r[lo:hi]) + (emp if lr_ok else 0), sum(z[lo:hi]), emp)
-        what = {0: "normal-equation launch: rows beyond %d non-zeros assembled on the matrix cores in one pass, blocked LDL^T in LDS" % (64 if k > 64 else 512),
+        what = {0: "normal-equation launch: rows beyond 512 non-zeros assembled on the matrix cores in one pass (long rows split across workgroups), LDL^T in the waves' registers",
+                3: "wave-per-row kernel (rank 65..128): rows of 65..512 non-zeros assembled into the matrix-core accumulators, blocked Cholesky with the trailing updates on v_mfma_f32_32x32x2_f32",
                 1: "low-rank form of the exact solve for rows of 1..64 non-zeros (Woodbury on XtX = L L^T; matrix cores)",
                 2: "k x k kernel: normal equations in registers, blocked Cholesky, two triangular solves"}
         if solver == 2:
             what = {0: "one 256-thread workgroup per row: normal equations assembled in registers, squared in LDS, sequential "
                        "coordinate descent on one wave (flops count the assembly and the squaring, not the data-dependent sweeps)"}
-        for seg in range(3 if solver == 0 else 1):
+        for seg in range(4 if solver == 0 else 1):
             live = [sd for sd in sides if rows_of(sd, seg)[0] > 0 and mean(kern[sd]["bucket"][seg]) > 0]
             if not live:
                 continue

@@ -18,13 +18,52 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-SRC = [CSRC / n for n in ("wrmf_kernels.hip", "wrmf_cgq.hip", "wrmf_cgp.hip", "wrmf_ne.hip", "wrmf_chol.hip", "wrmf_chol_wave.hip", "wrmf_chol_lr.hip",
+SRC = [CSRC / n for n in ("wrmf_kernels.hip", "wrmf_cgq.hip", "wrmf_cgp.hip", "wrmf_ne.hip", "wrmf_chol.hip", "wrmf_chol_wave.hip", "wrmf_chol_mf.hip", "wrmf_chol_lr.hip",
                           "wrmf_topk.hip", "wrmf_ingest.hip", "wrmf_nnls.hip", "wrmf_bias.hip", "wrmf_lu.hip",
                           "wrmf_f64.hip", "wrmf_wide.hip", "wrmf_capi.cpp", "wrmf_f64_capi.cpp")]
-HEADERS = [CSRC / "wrmf_internal.h", CSRC / "wrmf_device.h", CSRC / "wrmf_ldlt.h", CSRC / "wrmf_f64.h", PKG.parent / "include" / "rsparse_wrmf_hip.h"]
+HEADERS = [CSRC / "wrmf_chol_mf.attrs.csv", CSRC / "wrmf_internal.h", CSRC / "wrmf_device.h", CSRC / "wrmf_ldlt.h", CSRC / "wrmf_f64.h", PKG.parent / "include" / "rsparse_wrmf_hip.h"]
 DEPS = SRC + HEADERS
 OUT = PKG / "lib" / "librsparse_wrmf_hip.so"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+# wrmf_chol_mf.hip names its accumulator registers itself (a0..a159, inline asm) and needs hipcc to stay out of the accumulator
+# file: LLVM's function attribute "amdgpu-agpr-alloc"="0" has no source spelling, the ForceFunctionAttrs pass applies it from a
+# csv (function,attribute=value).  The listing of that very compilation is then audited (tools/dbg/acc_audit.py: no
+# compiler-generated accumulator-file instruction, nothing touches a register an asm load has in flight, two waves per SIMD);
+# if the audit fails -- another compiler, a lost flag -- the file is rebuilt with -DMF_SAFE (tiles above hipcc's own share of the
+# accumulator file, one wave per SIMD) and audited again; a build that passes neither is an error, never a silent corruption.
+EXTRA_FLAGS = {"wrmf_chol_mf.hip": ["-mllvm", "-forceattrs-csv-path=" + str(CSRC / "wrmf_chol_mf.attrs.csv")]}
+AUDITED = {"wrmf_chol_mf.hip"}
+
+
+def audit_listing(src, extra, defines, obj):
+    sys.path.insert(0, str(PKG.parent / "tools" / "dbg"))
+    import acc_audit
+    lst = obj.with_suffix(".s")
+
+    def listing(flags, floor):
+        cmd = ["hipcc", *FLAGS, *flags, *["-D" + d for d in defines], "-S", "--cuda-device-only", str(src), "-o", str(lst)]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc -S failed on %s:\n%s" % (src.name, r.stderr[-3000:]))
+        acc, flight, _ = acc_audit.audit(str(lst), quiet=True, acc_floor=floor)
+        return acc, flight, lst.read_text()
+    acc, flight, text = listing(extra, 0)
+    two_waves = ".amdhsa_accum_offset 96" in text and ".amdhsa_next_free_vgpr 256" in text
+    if acc == 0 and flight == 0 and two_waves:
+        return
+    print("  %s: audit of the two-waves-per-SIMD build failed (accumulator-file %d, in-flight %d, layout ok %s): rebuilding with -DMF_SAFE"
+          % (src.name, acc, flight, two_waves), flush=True)
+    safe = ["-DMF_SAFE"]
+    cmd = ["hipcc", *FLAGS, *safe, *["-D" + d for d in defines], "-c", str(src), "-o", str(obj)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s (MF_SAFE):\n%s" % (src.name, r.stderr[-3000:]))
+    # (MF_SAFE: hipcc may spill to a0..a95, the tiles are a96..a255: a compiler access at or above a96 breaks rule 1)
+    acc, flight, text = listing(safe, 96)
+    if acc or flight:
+        raise RuntimeError("%s: the MF_SAFE build fails the audit too (accumulator-file %d, in-flight %d)" % (src.name, acc, flight))
 
 
 def build(force=False, verbose=False, defines=(), out=None):
@@ -54,10 +93,13 @@ def build(force=False, verbose=False, defines=(), out=None):
     def compile_one(so):
         s, o = so
         t0 = time.time()
-        cmd = ["hipcc", *FLAGS, *["-D" + d for d in defines], "-c", str(s), "-o", str(o)]
+        extra = list(EXTRA_FLAGS.get(s.name, []))
+        cmd = ["hipcc", *FLAGS, *extra, *["-D" + d for d in defines], "-c", str(s), "-o", str(o)]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (s.name, r.stderr[-6000:]))
+        if s.name in AUDITED:
+            audit_listing(s, extra, defines, o)
         if verbose:
             print("  %-20s %.1f s" % (s.name, time.time() - t0), flush=True)
 

@@ -135,6 +135,11 @@ struct Workspace {
     }
     return RSPARSE_HIP_OK;
   }
+  float* mf_G = nullptr;      // wrmf_chol_mf.hip at rank 65..127: XtX padded to 128 x 128
+  int ensure_mf() {
+    if (!mf_G) HIP_TRY(hipMalloc(&mf_G, (size_t)128 * 128 * sizeof(float)));
+    return RSPARSE_HIP_OK;
+  }
   float* pad_buf = nullptr;   // ranks that are not a multiple of 4: the padded copies of X, Y, XtX, rhs_init (run_half_iteration)
   size_t pad_floats = 0;
   int ensure_pad(size_t floats) {
@@ -221,6 +226,8 @@ struct Workspace {
     ne_seg_scratch = nullptr; ne_seg_flags = nullptr; ne_seg_slots = 0;
     if (lr_M) (void)hipFree(lr_M);
     lr_M = nullptr;
+    if (mf_G) (void)hipFree(mf_G);
+    mf_G = nullptr;
     if (pad_buf) (void)hipFree(pad_buf);
     pad_buf = nullptr; pad_floats = 0;
     if (zero_row) (void)hipFree(zero_row);
@@ -643,9 +650,18 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   // and solved exactly there (a.ne_chol); wrmf_chol.hip's kernel then skips them
   // (the lower threshold pays at rank 65..128 only: at rank <= 64 wrmf_chol.hip's kernel is cheaper than the fixed cost of
   // the tile solve up to 512 non-zeros -- config 5 with Cholesky 4.5 against 4.1 iterations/s)
-  const bool nec_lists = padded_rank(rank) > 64 && d.q_nec_wg > 0;
-  const bool ne_chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY && !bias && (nec_lists || d.q_ne_wg > 0) && ne_supported(rank) &&
-                       use_cgq(rank, d_X, d_Y);
+  // (round 6, rank 65..128: the rows of 65..512 non-zeros go to the wave-per-row kernel of wrmf_chol_mf.hip instead -- the
+  // normal-equation launch keeps the rows beyond 512, its CG lists; RSPARSE_HIP_CHOL_MF=0 in -DRSP_AB builds: the round-5 routing)
+  bool mf_on = chol_mf_supported(rank);
+#ifdef RSP_AB
+  if (const char* e = std::getenv("RSPARSE_HIP_CHOL_MF")) mf_on = mf_on && std::atoi(e) != 0;
+#endif
+  const bool chol_mf = mf_on && !cg && solver == RSPARSE_SOLVER_CHOLESKY && !bias && d.q_order && ne_supported(rank) &&
+                       use_cgq(rank, d_X, d_Y) && d.q_lr_first > d.q_off[1];
+  const int n_mf = chol_mf ? d.q_lr_first - d.q_off[1] : 0;
+  const bool nec_lists = padded_rank(rank) > 64 && d.q_nec_wg > 0 && !chol_mf;
+  const bool ne_chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY && !bias && (nec_lists || d.q_ne_wg > 0 || chol_mf) &&
+                       ne_supported(rank) && use_cgq(rank, d_X, d_Y);
   if (ne_chol && nec_lists) {   // its own lists: the rows beyond d.q_nec_min non-zeros
     qs.ne_rows = d.q_nec_rows; qs.ne_ptr = d.q_nec_ptr; qs.ne_wg = d.q_nec_wg; qs.ne_entries = d.q_nec_entries;
     qs.ne_split_rows = d.q_nec_split_rows; qs.ne_split_ptr = d.q_nec_split_ptr; qs.ne_nsplit = d.q_nec_nsplit;
@@ -655,7 +671,8 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   const size_t chol_base = chol2_loss_slots(d.n_cols);
   const size_t slots = cgq ? cgq_loss_slots(qs, rank, implicit) : (cg ? cg_loss_slots(d.n_cols, d.n_long)
                                    : (solver == RSPARSE_SOLVER_NNLS ? chol_loss_slots(d.n_cols)
-                                      : chol_base + (ne_chol ? (size_t)(qs.ne_entries + qs.ne_nsplit) : 0) + (size_t)kLuGrid));
+                                      : chol_base + (ne_chol ? (size_t)(qs.ne_entries + qs.ne_nsplit) : 0) +
+                                            (size_t)(chol_mf ? chol_mf_loss_slots(n_mf, implicit) : 0) + (size_t)kLuGrid));
   if ((rc = g_ws.ensure_partials(slots))) return rc;
   double* out = d_loss_rows_out ? d_loss_rows_out : g_ws.scalars;
   if (d.n_cols == 0) {
@@ -683,14 +700,14 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.ne_r0 = nullptr; a.ne_r0_slot = nullptr;
   a.tscr = nullptr; a.stream_off = d.q_stream_off; a.stream_nnz = d.q_nnz[0];
   a.ne_prof = nullptr;
-  a.ne_stats = nullptr; a.wave_stats = nullptr;
+  a.ne_stats = nullptr; a.wave_stats = nullptr; a.mf_XtX = nullptr;
   a.ne_segs = nullptr; a.ne_seg_scratch = nullptr; a.ne_seg_flags = nullptr;
   a.ne_chol = ne_chol ? 1 : 0;
   a.ne_chol_min = nec_lists ? d.q_nec_min : kNeMinLen;
   if (d.q_order && solver == RSPARSE_SOLVER_CHOLESKY) {
     // the k x k kernel's own rows as ranges of the length-sorted order: behind the prefix that the normal-equation launch
     // (or the LONG launch) takes, down to the short rows of the low-rank kernel, and the empty rows at the end
-    const int first = ne_chol ? (nec_lists ? d.q_n_nec : d.q_off[1]) : d.q_n_chol_long;
+    const int first = chol_mf ? d.q_lr_first : (ne_chol ? (nec_lists ? d.q_n_nec : d.q_off[1]) : d.q_n_chol_long);
     a.chol_list = d.q_order;
     a.chol_first = first;
     a.chol_n_main = std::max(0, d.q_lr_first - first);
@@ -700,7 +717,22 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     if ((rc = g_ws.ensure_ne_seg((size_t)ne_nseg))) return rc;
     a.ne_segs = ne_segs; a.ne_seg_scratch = g_ws.ne_seg_scratch; a.ne_seg_flags = g_ws.ne_seg_flags;
   }
-  if ((cgq || ne_chol) && implicit && qs.ne_wg > 0 && ne_supported(rank) && (!bias || gb_cg)) {
+  if (chol_mf) {   // the operand scales of its matrix-core assembly (max |X|, max c)
+    hipError_t se = take_value_stats(d, d_X, (int64_t)d.n_rows * rank, s, d_absmax);
+    if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
+    a.wave_stats = g_ws.ne_stats;
+    if (implicit) {
+      a.ne_stats = g_ws.ne_stats;
+      a.mf_XtX = d_XtX;
+      if (rank != 128) {
+        if ((rc = g_ws.ensure_mf())) return rc;
+        hipError_t pe = launch_pad_gramian(d_XtX, rank, 128, g_ws.mf_G, s);
+        if (pe != hipSuccess) return hip_fail(pe, "launch_pad_gramian");
+        a.mf_XtX = g_ws.mf_G;
+      }
+    }
+  }
+  if (!a.ne_stats && (cgq || ne_chol) && implicit && qs.ne_wg > 0 && ne_supported(rank) && (!bias || gb_cg)) {
     // operand scales of the fp16 normal-equation kernel (and whether it may run at all), decided on the device
     hipError_t se = take_value_stats(d, d_X, (int64_t)d.n_rows * rank, s, d_absmax);
     if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
@@ -762,8 +794,8 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     if (fe != hipSuccess) return hip_fail(fe, "launch_fail_roll");
   }
   hipEvent_t* ev = g_prof.begin();
-  if (chol && ev) HIP_TRY(hipEventRecord(ev[0], s));   // Cholesky: [0] normal-equation launch, [1] low-rank, [2] k x k, [3] loss
-  if (ne_chol) {
+  if (chol && ev) HIP_TRY(hipEventRecord(ev[0], s));   // Cholesky: [0] normal-equation launch, [1] low-rank, [2] k x k, [3] wave-per-row (rank 65..128), [4] loss
+  if (ne_chol && qs.ne_wg > 0) {
     hipError_t ne = launch_als_ne(a, qs, implicit, g_ws.partials + chol_base, s, ev);
     if (ne != hipSuccess) return hip_fail(ne, "launch_als_ne");
   }
@@ -773,6 +805,23 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
                                   ? launch_als_nnls(a, implicit, s, ev)
                                   : launch_als_chol2(a, implicit, s, ev ? ev + 1 : nullptr)));
   if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
+  if (chol_mf) {   // (launch_als_chol2 recorded ev[3] behind its kernels)
+    const size_t mf_base = chol_base + (size_t)(qs.ne_entries + qs.ne_nsplit);
+    hipError_t me = launch_als_chol_mf(a, implicit, d.q_order + d.q_off[1], n_mf, (int)mf_base, s, ev ? ev + 3 : nullptr);
+    if (me != hipSuccess) return hip_fail(me, "launch_als_chol_mf");
+  }
+  if (chol && ev) HIP_TRY(hipEventRecord(ev[4], s));
+#if defined(RSP_NE_PROF) && defined(RSP_MF_PROF)
+  if (chol_mf && std::getenv("RSPARSE_MF_PROF")) {   // phase ticks of wrmf_chol_mf.hip, summed over its waves
+    HIP_TRY(hipStreamSynchronize(s));
+    unsigned long long hp[8];
+    HIP_TRY(hipMemcpy(hp, prof_buf + 8, sizeof(hp), hipMemcpyDeviceToHost));
+    const char* nm[8] = {"zero", "assembly", "finalize", "forward", "backward", "fail/store", "loss", "row-head"};
+    std::fprintf(stderr, "[mf_prof] n_cols %d rows %d: G ticks summed over the waves:", d.n_cols, n_mf);
+    for (int j = 0; j < 8; j++) std::fprintf(stderr, " %s %.3f", nm[j], (double)hp[j] / 1e9);
+    std::fprintf(stderr, "\n");
+  }
+#endif
   if (chol) {
     // rows whose factorisation met a non-positive pivot: the general solver, as arma::solve falls back to (wrmf_lu.hip).
     // The counters are per call: a previous call's count was taken by rsparse_hip_take_numeric_failures or is added to.
@@ -816,7 +865,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   }
 #endif
   if (ev) {
-    const int last = cgq ? 7 : (chol ? 4 : 3);
+    const int last = cgq ? 7 : (chol ? 5 : 3);
     HIP_TRY(hipEventRecord(ev[last], s));
     g_prof.have = true;
     g_prof.nseg = last;

@@ -139,6 +139,7 @@ struct AlsArgs {
   int ne_chol;                   // long rows through wrmf_ne.hip with the exact solve instead of CG (solver == CHOLESKY)
   int ne_chol_min;               // ... the rows of more than this many non-zeros (wrmf_chol.hip skips them)
   const unsigned* ne_stats;      // implicit NE launches: {bits of max |x|, bits of max c, any c < 1} (launch_ne_stats), or nullptr
+  const float* mf_XtX;           // wrmf_chol_mf.hip, implicit feedback: XtX padded to 128 x 128 (identity beyond the rank); = XtX at rank 128
   const unsigned* wave_stats;    // the same block for the wave-per-row kernels at rank 33..64 (operand scales of their matrix-core assembly), or nullptr
   unsigned long long* ne_prof;   // RSP_NE_PROF builds: [workgroup][wave][8] cycle counters of wrmf_ne.hip (else nullptr)
 };
@@ -226,6 +227,16 @@ hipError_t launch_als_chol2(const AlsArgs& a, bool implicit, hipStream_t s, hipE
 // rank <= 64: the main launch of the exact solve as one wave per row (wrmf_chol_wave.hip); same rows, same loss slots
 bool chol_wave_supported(int k);
 hipError_t launch_als_chol_wave(const AlsArgs& a, bool implicit, int grid, int loss_slot0, hipStream_t s, hipEvent_t* ev_slot);
+// rank 65..128 (round 6, wrmf_chol_mf.hip): the rows of kCholLrMax + 1 .. kCholMfMax non-zeros as one wave per row -- assembly on
+// the matrix cores into the accumulator registers, blocked Cholesky with the trailing updates on v_mfma_f32_32x32x2_f32.
+// Needs a.wave_stats (operand scales).  Loss partials [loss_slot0, loss_slot0 + chol_mf_loss_slots(n_rows, implicit))
+constexpr int kCholMfMax = 512;       // = kNeMinLen: beyond it the normal-equation launch (rows split across workgroups) keeps the row
+constexpr int kCholMfGrid = 256 * 32; // workgroups of one wave, grid-stride over the rows (longest first)
+bool chol_mf_supported(int k);
+int chol_mf_grid(int n_rows);
+int chol_mf_loss_slots(int n_rows, bool implicit);
+hipError_t launch_als_chol_mf(const AlsArgs& a, bool implicit, const int32_t* rows, int n_rows, int loss_slot0, hipStream_t s,
+                              hipEvent_t* ev_slot);
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 constexpr int kLuGrid = 64;          // workgroups (and loss slots) of the general-solver fallback
 constexpr int kFailCap = 1 << 16;    // rows it can take per half-iteration call

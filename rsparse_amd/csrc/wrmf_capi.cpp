@@ -235,7 +235,7 @@ struct Workspace {
     gram_floats = 0; partial_slots = 0;
   }
 };
-Workspace g_ws;
+thread_local Workspace g_ws;   // per host thread: the multi-GPU context (wrmf_ctx.cpp) drives one device from one thread each
 
 struct Profiler {
   bool on = false;
@@ -251,7 +251,8 @@ struct Profiler {
     for (auto& k : kern) k = nullptr;
     return ev;
   }
-} g_prof;
+};
+thread_local Profiler g_prof;
 
 struct DevBuf {  // RAII for the stateless entry points
   void* p = nullptr;
@@ -511,7 +512,7 @@ int check_common(int n_rows, int n_cols, const void* col_ptrs, const void* row_i
 }
 
 // rows whose failure counts were taken off the device on behalf of a LATER reader (rsparse_hip_take_numeric_failures adds them)
-int64_t g_fail_carry[2] = {0, 0};   // unresolved, re-solved by the general solver
+thread_local int64_t g_fail_carry[2] = {0, 0};   // unresolved, re-solved by the general solver
 
 // wrmf_implicit.hpp:108-109: a global bias below sqrt(eps) of the element type T is treated as zero (float: 3.45e-4,
 // double: 1.49e-8; the device layer holds floats, the stateless *_double entry point passes dbl = true)

@@ -1162,7 +1162,7 @@ struct BucketStreams {
     return hipSuccess;
   }
 };
-BucketStreams g_bs;
+thread_local BucketStreams g_bs;
 
 // 0: every launch on the caller's stream; 1: every bucket on its own side stream; 2: the long-row launch first on the
 // caller's stream (it occupies every CU's LDS: nothing runs beside it), the resident buckets on side streams after it

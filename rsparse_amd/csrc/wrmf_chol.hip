@@ -434,7 +434,7 @@ struct LongStream {
     return hipEventCreateWithFlags(&done, hipEventDisableTiming);
   }
 };
-LongStream g_long_stream;
+thread_local LongStream g_long_stream;
 
 template <int KP, bool IMPLICIT, bool VEC>
 hipError_t launch_chol2_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {

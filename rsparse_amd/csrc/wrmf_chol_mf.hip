@@ -35,6 +35,7 @@
 //     asm statement: every matrix instruction opens with s_nop 1 (a VALU-written operand), every read of the accumulator
 //     file sits behind an explicit s_nop block (a 16-pass result), see MF_DRAIN.
 // A non-positive pivot sends the row to the general solver (wrmf_lu.hip), exactly as the other exact kernels do.
+#include <cstdio>
 #include <utility>
 
 #pragma clang diagnostic ignored "-Winline-asm"   // (the named accumulator registers are "reserved": that is the point)
@@ -168,6 +169,7 @@ __device__ __forceinline__ void mf_wait(float (&a)[16], float (&b)[16]) {
   mf_tie8(b + 8);
 }
 
+template <int NOPS>
 struct MfSmem {
   float D[64];      // the diagonal block of the current panel, row-major 8 x 8
   float Bp[16];     // the right-hand side of its rows: [hf][row], the two halves' partial sums
@@ -175,6 +177,7 @@ struct MfSmem {
   float B[2][128];  // the right-hand side per row while the panels run: the two halves' partial sums
   float Inv[128];   // 1 / L_cc
   float L8[16][64]; // the factored diagonal blocks (lower triangles), for the backward pass
+  float4 ops[NOPS][64]; // the assembly loop's operands between their split and their products (see there)
   double loss;      // this wave's sum of row terms (kept out of the registers: the kernel runs at exactly 96)
 };
 
@@ -229,7 +232,7 @@ __device__ __forceinline__ void mf_copy_in_update(const float (&Pm)[4][4]) {
 
 template <bool IMPLICIT, bool SYM, bool KFULL>
 __device__ __forceinline__ void als_chol_mf_body(const AlsArgs& a, const int32_t* __restrict__ rows, const int n_rows, const int loss_slot0) {
-  __shared__ __attribute__((aligned(16))) MfSmem sm;
+  __shared__ __attribute__((aligned(16))) MfSmem<SYM ? 8 : 16> sm;
   const int lane = threadIdx.x & 63;
   const int k = a.k;
   const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
@@ -250,24 +253,28 @@ __device__ __forceinline__ void als_chol_mf_body(const AlsArgs& a, const int32_t
 #else
 #define MF_TICK(i)
 #endif
-  // operand scales: powers of two from max |X| and max c (launch_ne_stats), as in wrmf_chol_wave.hip
-  const int ex = mf_scale_exp(fmaxf(__uint_as_float(a.wave_stats[0]), 1e-30f));
-  const float wmax = IMPLICIT ? fmaxf(__uint_as_float(a.wave_stats[1]) - 1.f, 1.f) : 1.f;
-  const int ewb = (int)((__float_as_uint(wmax) >> 23) & 0xffu);
-  const float sx = mf_pow2(ex), sw = mf_pow2(min(253, max(1, 253 - ewb)));   // sw = 2^(126 - ewb) <= 1 / wmax
-  const float un1 = mf_pow2(254 - ex);                                       // 1 / sx
-  const float unw = IMPLICIT ? mf_pow2(254 - min(253, max(1, 253 - ewb))) : 1.f;   // 1 / sw
+  // operand scales: powers of two from max |X| and max c (launch_ne_stats), as in wrmf_chol_wave.hip.  (Through
+  // readfirstlane: loaded values are vector registers to hipcc, and a dozen uniform constants held in vector registers
+  // through every phase are a dozen registers the assembly loop then spills its operands for.)
+  auto uni = [](const float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+  const int ex = rfl(mf_scale_exp(fmaxf(__uint_as_float(a.wave_stats[0]), 1e-30f)));
+  const float wmax = uni(IMPLICIT ? fmaxf(__uint_as_float(a.wave_stats[1]) - 1.f, 1.f) : 1.f);
+  const int ewb = rfl((int)((__float_as_uint(wmax) >> 23) & 0xffu));
+  const float sx = uni(mf_pow2(ex)), sw = uni(mf_pow2(min(253, max(1, 253 - ewb))));   // sw = 2^(126 - ewb) <= 1 / wmax
+  const float un1 = uni(mf_pow2(254 - ex));                                             // 1 / sx
+  const float unw = uni(IMPLICIT ? mf_pow2(254 - min(253, max(1, 253 - ewb))) : 1.f);   // 1 / sw
 
   for (int it = blockIdx.x; it < n_rows; it += gridDim.x) {
     const int row = rfl(rows[it]);
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     float* yrow = a.Y + (size_t)row * k;
-    const float lam_use = IMPLICIT ? 0.f : (float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)(p2 - p1) : 1.0));
+    const float lam_use = IMPLICIT ? 0.f : uni((float)(a.lambda_loss * (a.dynamic_lambda ? (double)(float)(p2 - p1) : 1.0)));
     // the lane id as this row sees it (keeps lane-dependent addresses and compares out of the registers across rows)
+    // (re-derived per PHASE: what a later phase makes of the lane id would otherwise sit in registers through the assembly loop,
+    // which then spilled operand registers and reloaded them behind `s_waitcnt vmcnt(0)` -- in front of the products that are
+    // meant to run while the gather flies)
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const int n = ln & 31, hf = ln >> 5;
-    const bool lk0 = ln < k, lk1 = ln + 64 < k;
     const int lc0 = min(ln, k - 1), lc1 = min(ln + 64, k - 1);
 
     // ---------------- assembly on the matrix cores ----------------
@@ -284,21 +291,46 @@ __device__ __forceinline__ void als_chol_mf_body(const AlsArgs& a, const int32_t
       // data has not landed (it does not know: an asm load's destination counts as written at once) -- build.py's audit
       // demands a listing without a single scratch instruction.
       const int vo0 = 4 * lc0, vo1 = 4 * lc1;
-      const float m0 = lk0 ? 1.f : 0.f, m1 = lk1 ? 1.f : 0.f;
-      f16x8 bh[4], bl[4], ah[4], al[4];
+      const float m0 = ln < k ? 1.f : 0.f, m1 = ln + 64 < k ? 1.f : 0.f;
+      // The operands of a step wait for their products (which run behind the NEXT step's requests) in LDS, not in registers:
+      // as eight register tuples carried around the loop hipcc kept six of them in scratch and reloaded them behind
+      // `s_waitcnt vmcnt(0)` -- i.e. behind the gather the products are meant to overlap (20 registers stayed unused).
+      // 16 KB of LDS traffic per step and wave, counted by lgkmcnt.
+      auto stash = [&](const int t, const f16x8& v) { sm.ops[t][ln] = __builtin_bit_cast(float4, v); };
+      auto fetch_op = [&](const int t) { return __builtin_bit_cast(f16x8, sm.ops[t][ln]); };
       auto products = [&]() {
-        // three products of order < 2, product-outermost: consecutive instructions go to different tiles
-        mf_sfor<3>([&](auto pt) {
-          constexpr int pr = decltype(pt)::value;
-          mf_sfor<4>([&](auto kt) {
-            constexpr int K = decltype(kt)::value;
-            mf_sfor<4 - K>([&](auto st) {
-              constexpr int I = K + decltype(st)::value;
-              if constexpr (SYM) mf_mma16<mf_tid(I, K)>(pr == 2 ? bl[K] : bh[K], pr == 1 ? bl[I] : bh[I]);
-              else mf_mma16<mf_tid(I, K)>(pr == 2 ? al[K] : ah[K], pr == 1 ? bl[I] : bh[I]);
+        f16x8 bh[4], bl[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          bh[t] = fetch_op(t);
+          bl[t] = fetch_op(4 + t);
+        }
+        if constexpr (SYM) {
+          // three products of order < 2, product-outermost: consecutive instructions go to different tiles
+          mf_sfor<3>([&](auto pt) {
+            constexpr int pr = decltype(pt)::value;
+            mf_sfor<4>([&](auto kt) {
+              constexpr int K = decltype(kt)::value;
+              mf_sfor<4 - K>([&](auto st) {
+                constexpr int I = K + decltype(st)::value;
+                mf_mma16<mf_tid(I, K)>(pr == 2 ? bl[K] : bh[K], pr == 1 ? bl[I] : bh[I]);
+              });
             });
           });
-        });
+        } else {
+          // the A side (2^e' (c - 1) 2^e x) one block column at a time
+          mf_sfor<4>([&](auto kt) {
+            constexpr int K = decltype(kt)::value;
+            const f16x8 ah = fetch_op(8 + K), al = fetch_op(12 + K);
+            mf_sfor<3>([&](auto pt) {
+              constexpr int pr = decltype(pt)::value;
+              mf_sfor<4 - K>([&](auto st) {
+                constexpr int I = K + decltype(st)::value;
+                mf_mma16<mf_tid(I, K)>(pr == 2 ? al : ah, pr == 1 ? bl[I] : bh[I]);
+              });
+            });
+          });
+        }
       };
       // lane j (mod 16) holds non-zero j of a step; the slots beyond the row repeat its last non-zero with weight 0.  Index and
       // value are requested a step ahead (two registers) and first looked at when the step's other work is done: one memory
@@ -350,25 +382,36 @@ __device__ __forceinline__ void als_chol_mf_body(const AlsArgs& a, const int32_t
             xs1[s2] *= m1;
           }
         }
-        mf_operands(xs0, bh[0], bl[0], bh[1], bl[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        mf_operands(xs1, bh[2], bl[2], bh[3], bl[3]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!SYM) {
-          // some confidence below 1 (sqrt(c - 1) undefined): the A side carries 2^e' (c - 1) 2^e x, the B side 2^e x
+        {
+          f16x8 h0, l0, h1, l1;
+          mf_operands(xs0, h0, l0, h1, l1);
+          stash(0, h0); stash(4, l0); stash(1, h1); stash(5, l1);
+          __builtin_amdgcn_sched_barrier(0);
+          mf_operands(xs1, h0, l0, h1, l1);
+          stash(2, h0); stash(6, l0); stash(3, h1); stash(7, l1);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!SYM) {
+            // some confidence below 1 (sqrt(c - 1) undefined): the A side carries 2^e' (c - 1) 2^e x, the B side 2^e x
 #pragma unroll
-          for (int s2 = 0; s2 < 16; s2++) {
-            const float w = readlane_f(wj, s2);
-            xs0[s2] *= w;
-            xs1[s2] *= w;
+            for (int s2 = 0; s2 < 16; s2++) {
+              const float w = readlane_f(wj, s2);
+              xs0[s2] *= w;
+              xs1[s2] *= w;
+            }
+            mf_operands(xs0, h0, l0, h1, l1);
+            stash(8, h0); stash(12, l0); stash(9, h1); stash(13, l1);
+            mf_operands(xs1, h0, l0, h1, l1);
+            stash(10, h0); stash(14, l0); stash(11, h1); stash(15, l1);
           }
-          mf_operands(xs0, ah[0], al[0], ah[1], al[1]);
-          mf_operands(xs1, ah[2], al[2], ah[3], al[3]);
         }
         asm volatile("" : "+v"(idn), "+v"(cvn));   // (hipcc's wait for the two lands here, not behind their request)
       }
       products();
     }
+    ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int n = ln & 31, hf = ln >> 5;
+    const bool lk0 = ln < k, lk1 = ln + 64 < k;
     // unscale, + XtX (implicit) / lambda_use I (explicit).  Tile (I, K), lane (n, hf), register v = [row 32 I + n]
     // [column 32 K + rho(v, hf)].  XtX comes padded to 128 x 128 (a.mf_XtX: identity on the padded diagonal; the operands of
     // the padded coordinates were zero), per lane = row with the columns at uniform offsets: no clamps, no selects (a
@@ -626,17 +669,17 @@ __device__ __forceinline__ void als_chol_mf_body(const AlsArgs& a, const int32_t
       const float cvv = a.vals[base + jl];
       float t0 = 0.f, t1 = 0.f;
       if constexpr (KFULL) {
-        // rank 128: the lane's vector in two batches of sixteen 16-byte loads, every load of a batch requested before the
+        // rank 128: the lane's vector in four batches of eight 16-byte loads, every load of a batch requested before the
         // first product (as one loop hipcc waited for each load: 50 k cycles per row for this pass)
 #pragma unroll
-        for (int hb = 0; hb < 2; hb++) {
-          float4 xv[16];
+        for (int hb = 0; hb < 4; hb++) {
+          float4 xv[8];
 #pragma unroll
-          for (int q = 0; q < 16; q++) xv[q] = *reinterpret_cast<const float4*>(xr + 64 * hb + 4 * q);
+          for (int q = 0; q < 8; q++) xv[q] = *reinterpret_cast<const float4*>(xr + 32 * hb + 4 * q);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < 16; q++) {
-            const float4 b = *reinterpret_cast<const float4*>(&sm.U[64 * hb + 4 * q]);
+          for (int q = 0; q < 8; q++) {
+            const float4 b = *reinterpret_cast<const float4*>(&sm.U[32 * hb + 4 * q]);
             t0 = fmaf(xv[q].x, b.x, t0);
             t1 = fmaf(xv[q].y, b.y, t1);
             t0 = fmaf(xv[q].z, b.z, t0);
@@ -704,6 +747,16 @@ hipError_t launch_als_chol_mf(const AlsArgs& a, bool implicit, const int32_t* ro
   if (n_rows <= 0) return hipSuccess;
   if (!a.wave_stats || !chol_mf_supported(a.k)) return hipErrorInvalidValue;
   const int grid = chol_mf_grid(n_rows);
+#ifdef RSP_MF_PROF
+  {
+    int nb = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rsparse_hip_als_chol_mf_implicit, 64, 0);
+    hipFuncAttributes fa{};
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(rsparse_hip_als_chol_mf_implicit));
+    std::fprintf(stderr, "[mf_prof] occupancy %d workgroups of one wave per CU; %d registers, %zu bytes of LDS, %zu of scratch\n", nb,
+                 fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
+  }
+#endif
   const bool full = a.k == 128 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;   // (the full kernels read 16 bytes at a time in their loss pass)
   if (implicit) {
     // (both: the device-side flag decides; the symmetric one is the normal case and is named for the profile)

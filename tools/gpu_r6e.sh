@@ -9,7 +9,7 @@ tail -3 $OUT/pytest.log
 for mf in 0 1; do
   RSPARSE_HIP_CHOL_MF=$mf timeout 600 python tools/gpu_chol_time.py 2>/dev/null | tail -1 | sed "s/^/mf=$mf /"
 done | tee $OUT/chol_time_ab.txt
-RSPARSE_HIP_LIB=$PWD/rsparse_amd/lib/librsparse_wrmf_hip_prof.so RSPARSE_MF_PROF=1 timeout 600 python tools/gpu_chol_time.py 2>&1 >/dev/null | grep mf_prof | tail -2 | tee $OUT/mf_prof.txt
+RSPARSE_HIP_LIB=$PWD/rsparse_amd/lib/librsparse_wrmf_hip_prof.so RSPARSE_MF_PROF=1 timeout 600 python tools/gpu_chol_time.py 2>&1 >/dev/null | grep mf_prof | tail -3 | tee $OUT/mf_prof.txt
 for mf in 1; do
   RSPARSE_HIP_CHOL_MF=$mf timeout 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/config4_mf$mf.json 2> $OUT/config4_mf$mf.err
   python - $OUT/config4_mf$mf.json $mf <<'PY'

@@ -262,13 +262,13 @@ def main():
         cnt_user = torch.diff(data["c_iu"][0]).to(torch.float32)
         cnt_item = torch.diff(data["c_ui"][0]).to(torch.float32)
     else:
-        # every rank generates only its own shard (two streaming passes, rsparse_amd/synth.py:make_shard); the blocks
+        # every rank generates only its own users' rows; the item blocks are exchanged (rsparse_amd/synth.py:make_shard); the blocks
         # are contiguous and balanced by non-zeros, so their row counts differ
         def bounds_fn(cu, ci):
             lu, li = ShardedALS.layouts(args.users, args.items, ws, cu, ci)
             return lu.bounds, (li.bounds if ci is not None else None)
         data = synth.make_shard(args.users, args.items, ws, rank, bounds_fn, seed=args.seed, mean_deg=args.mean_deg,
-                                feedback=args.feedback, device=dev)
+                                feedback=args.feedback, device=dev, be=be, group=None)
         n_user, n_item, nnz = data["n_users"], data["n_items"], data["nnz"]
         cnt_user, cnt_item = data["cnt_user"].to(torch.float32), data["cnt_item"].to(torch.float32)
         lay_u, lay_i = ShardedALS.layouts(n_user, n_item, ws, data["cnt_user"], data["cnt_item"])

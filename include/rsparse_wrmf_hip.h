@@ -441,6 +441,63 @@ int rsparse_hip_profile_last(double ms_out[8]);
  * call).  Reads device memory: synchronises. */
 int rsparse_hip_take_numeric_failures(int64_t* unresolved_out, int64_t* fallback_out);
 
+/* ------------------------------------------------------------------------------------------------
+ * (4) multi-GPU context: the sharded driver inside the library (ABI version 6)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* What the reference's host calls per half-iteration is ONE function that internally drives its OpenMP threads
+ * (`als_implicit_double(c_ui, X, Y, XtX, ...)`, R/model_WRMF.R:111-147 -> src/RcppExports.cpp:371-415,
+ * inst/include/wrmf_implicit.hpp:162-175 `#pragma omp parallel for`); this layer is the same contract over 1..8 GPUs: the caller
+ * stays ONE host thread (an R session), the library runs one persistent host thread per device, shards users and items over
+ * them in contiguous nnz-balanced blocks, keeps full factor replicas, and per half-iteration issues one fused exchange of the
+ * k x k Gramian partials (+ sum(F^2), max |F|), an in-place all-gather of every solved sub-block (overlapped with the next
+ * sub-block's solve on a second stream) and one all-reduce of the loss terms -- SURVEY.md 8(e).  The per-rank arithmetic is
+ * layer (2)'s, row for row: results do not depend on the number of ranks except through the summation order of the Gramian
+ * and of the loss (as the reference's do not depend on OMP_NUM_THREADS except through its loss reduction).
+ *
+ * comm_kind: RSPARSE_HIP_COMM_RCCL -- one device per rank, collectives = RCCL over xGMI (ncclCommInitAll; librccl is loaded
+ * with dlopen when the context is created, a single-GPU user never needs it); RSPARSE_HIP_COMM_SHARED -- the ranks are threads
+ * with streams of their own on ONE device (device_ids may repeat; default: all on device 0) and a collective is a host
+ * barrier + device copies: the transport of the tests and of single-GPU dry runs, everything else is the production code.
+ * device_ids: n_ranks entries, or NULL (RCCL: rank r on device r). */
+typedef struct rsparse_hip_ctx rsparse_hip_ctx;
+#define RSPARSE_HIP_COMM_RCCL 0
+#define RSPARSE_HIP_COMM_SHARED 1
+#define RSPARSE_HIP_SIDE_ITEMS 0 /* solve the item factors given the user factors (R/model_WRMF.R:321) */
+#define RSPARSE_HIP_SIDE_USERS 1 /* solve the user factors given the item factors (:327) */
+int rsparse_hip_ctx_create(int n_ranks, const int* device_ids, int comm_kind, rsparse_hip_ctx** out);
+int rsparse_hip_ctx_destroy(rsparse_hip_ctx* ctx);
+
+/* The interaction matrix in both orientations as the R driver holds them (R/model_WRMF.R:184-191): c_ui = users x items as
+ * dgCMatrix slots (ui_p int32[n_item + 1], ui_i = user ids, ui_x), c_iu = its transpose (iu_p int32[n_user + 1], iu_i = item
+ * ids, iu_x); host arrays, 0-based, row indices ascending inside a column.  Every rank uploads its own blocks only.
+ * n_sub_users / n_sub_items: sub-blocks per rank and half-iteration (0 = default: 1 for one rank, else 4). */
+int rsparse_hip_ctx_set_matrix(rsparse_hip_ctx* ctx, int n_user, int n_item, const int32_t* ui_p, const int32_t* ui_i,
+                               const double* ui_x, const int32_t* iu_p, const int32_t* iu_i, const double* iu_x,
+                               int n_sub_users, int n_sub_items);
+
+/* Factor matrices as the reference passes them: U = rank x n_user, V = rank x n_item, column-major fp32 (every entity's vector
+ * contiguous).  set: host -> every replica; get (either pointer may be NULL): rank 0's replica -> host. */
+int rsparse_hip_ctx_set_factors(rsparse_hip_ctx* ctx, int rank, const float* U, const float* V);
+int rsparse_hip_ctx_get_factors(rsparse_hip_ctx* ctx, float* U, float* V);
+
+/* One half-iteration over all devices: als_implicit<float> / als_explicit<float>, no-bias branch, every solver of layer (2)
+ * (the exact solve that ends a fit -- R/model_WRMF.R:355-359 -- is side = USERS with solver = cholesky after set_factors of
+ * zeros for U).  implicit: the Gramian XtX + fl(lambda) I of the fixed side is formed inside (R/model_WRMF.R:474-486).
+ * *loss_out (nullable) = the loss as the reference reports it: (row terms + lambda * regulariser) / nnz
+ * (wrmf_implicit.hpp:286-304, wrmf_explicit.hpp:146-173).  Synchronous. */
+int rsparse_hip_ctx_half_iteration(rsparse_hip_ctx* ctx, int side, int implicit, double lambda, unsigned solver,
+                                   unsigned cg_steps, int dynamic_lambda, double* loss_out);
+
+/* rsparse_hip_take_numeric_failures summed over the ranks (one decision for the whole context). */
+int rsparse_hip_ctx_take_numeric_failures(rsparse_hip_ctx* ctx, int64_t* unresolved_out, int64_t* fallback_out);
+
+/* info_out: [0] ranks, [1] comm_kind, [2] n_user, [3] n_item, [4] nnz, [5] rank of the factors, [6] / [7] sub-blocks per rank
+ * (users / items), [8] / [9] rows per sub-block, [10] / [11] users / items owned by rank 0, [12] 1 = the collectives are RCCL.
+ * times_out (nullable): of the last half-iteration, the slowest rank's [0] wall milliseconds, [1] milliseconds inside
+ * collective calls (host side: issue time for RCCL, the whole exchange for SHARED). */
+int rsparse_hip_ctx_info(const rsparse_hip_ctx* ctx, int64_t info_out[16], double times_out[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,15 @@ SIGNATURES = {
     "rsparse_hip_profile_last": (_c_int, [ctypes.POINTER(_c_dbl)]),
     "rsparse_hip_profile_last_names": (_c_int, [ctypes.c_char_p, _c_int]),
     "rsparse_hip_take_numeric_failures": (_c_int, [ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
+    # layer (4): the multi-GPU context (wrmf_ctx.cpp)
+    "rsparse_hip_ctx_create": (_c_int, [_c_int, _vp, _c_int, ctypes.POINTER(_vp)]),
+    "rsparse_hip_ctx_destroy": (_c_int, [_vp]),
+    "rsparse_hip_ctx_set_matrix": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int]),
+    "rsparse_hip_ctx_set_factors": (_c_int, [_vp, _c_int, _vp, _vp]),
+    "rsparse_hip_ctx_get_factors": (_c_int, [_vp, _vp, _vp]),
+    "rsparse_hip_ctx_half_iteration": (_c_int, [_vp, _c_int, _c_int, _c_dbl, _c_uint, _c_uint, _c_int, ctypes.POINTER(_c_dbl)]),
+    "rsparse_hip_ctx_take_numeric_failures": (_c_int, [_vp, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
+    "rsparse_hip_ctx_info": (_c_int, [_vp, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_dbl)]),
 }
 
 

@@ -1137,7 +1137,7 @@ void prof_note(hipEvent_t* ev_slot, const void* kernel_fn) {
 extern "C" {
 
 const char* rsparse_hip_last_error(void) { return g_err.c_str(); }
-int rsparse_hip_abi_version(void) { return 5; }
+int rsparse_hip_abi_version(void) { return 6; }
 
 int rsparse_hip_device_count(void) {
   int n = 0;

@@ -47,8 +47,14 @@ __global__ void ctx_sum_kernel(const double* __restrict__ v, int n, double* __re
   *out = s;
 }
 
+__global__ void ctx_add_kernel(const double* __restrict__ src, double* __restrict__ dst) { *dst += *src; }
+
 }  // namespace
 
+hipError_t launch_ctx_add(const double* src, double* dst, hipStream_t s) {
+  hipLaunchKernelGGL(ctx_add_kernel, dim3(1), dim3(1), 0, s, src, dst);
+  return hipGetLastError();
+}
 hipError_t launch_ctx_accumulate(const float* Gpart, const double* sumsq, double* red, int k, hipStream_t s) {
   const int kk = k * k;
   hipLaunchKernelGGL(ctx_accumulate_kernel, dim3((kk + 255) / 256), dim3(256), 0, s, Gpart, sumsq, red, kk);

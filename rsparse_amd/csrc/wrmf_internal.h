@@ -297,6 +297,13 @@ hipError_t launch_top_product_f64(const float* U32, const float* V32, const doub
 // (2 x entries + n_users), 0 = not split
 size_t top_product_scratch_entries(int n_users, int n_items, int topk);
 
+// device helpers of the multi-GPU context (wrmf_ctx_kernels.hip / wrmf_ctx.cpp)
+hipError_t launch_ctx_accumulate(const float* Gpart, const double* sumsq, double* red, int k, hipStream_t s);
+hipError_t launch_ctx_put_absmax(const float* absmax, double* red, int k, hipStream_t s);
+hipError_t launch_ctx_reduce(const double* all, int ws, int k, float ridge, float* G, double* scal0, float* absmax, hipStream_t s);
+hipError_t launch_ctx_sum(const double* v, int n, double* out, hipStream_t s);
+hipError_t launch_ctx_add(const double* src, double* dst, hipStream_t s);   // *dst += *src
+
 int padded_rank(int k);  // 32 / 64 / 128, or 0 if unsupported
 
 // ranks 129..256 (wrmf_wide.hip): every variant of the half-iteration on one kernel family, the row's system a packed lower

@@ -152,63 +152,59 @@ def make_dataset(n_users, n_items, seed=20250222, mean_deg=50.0, d_max=5000, fee
 
 
 def make_shard(n_users, n_items, world_size, rank, bounds_fn, seed=20250222, mean_deg=50.0, d_max=5000,
-               feedback="implicit", device="cpu", block=2_000_000):
-    """One rank's share of the matrix `make_dataset` produces, without ever holding the whole matrix: two streaming
-    passes over the user blocks (the generator is counter-based, so a block is regenerated identically).
+               feedback="implicit", device="cpu", block=2_000_000, be=None, group=None):
+    """One rank's share of the matrix `make_dataset` produces.  NO rank generates more than its own users' rows (round 6;
+    through round 5 every rank streamed over the WHOLE matrix twice -- 2 x 2.6 s of generation that nothing shared at
+    N = 8, and what made eight processes on one device look hung):
 
-      pass 1: per-item non-zero counts (the per-user counts are the degrees, known without generating anything), and
-              the rows of this rank's user block (-> c_iu block, columns = my users);
-      pass 2: the entries whose item falls into this rank's item block (-> c_ui block, columns = my items).
+      1. the per-user counts are the degrees, known without generating anything -> the user bounds;
+      2. the rank generates the rows of ITS user block (the generator is counter-based: a block is identical whoever makes it)
+         = its c_iu block (columns = my users);
+      3. the per-item counts are one all-reduce of the ranks' bincounts -> the item bounds;
+      4. its c_ui block (columns = my items) is built among the ranks exactly as a sharded `WRMF.fit_transform` builds it:
+         `engine.item_block_from_user_blocks` -- three all-to-alls of the matrix's bytes + one on-device transposition.
 
-    `bounds_fn(cnt_user, cnt_item) -> (user_bounds, item_bounds)` decides the blocks (engine.ShardedALS.layouts).
-    Returns dict(nnz, cnt_user, cnt_item, user_bounds, item_bounds, c_iu, c_ui) with the CSC blocks re-based to 0 and
-    GLOBAL row indices."""
+    `be` (a backend with `transpose_csc`: engine.HipBackend, or the tests' CPU stand-in) and `group` (torch.distributed, None =
+    the default group) are needed for steps 3-4 when world_size > 1.  `bounds_fn(cnt_user, cnt_item) -> (user_bounds,
+    item_bounds)` decides the blocks (engine.ShardedALS.layouts).  Returns dict(nnz, cnt_user, cnt_item, user_bounds,
+    item_bounds, c_iu, c_ui) with the CSC blocks re-based to 0 and GLOBAL row indices, bit-identical to slices of
+    `make_dataset`'s matrix."""
     dev = torch.device(device)
     perm = item_permutation(n_items, seed, dev)
     cnt_user = degrees(torch.arange(n_users, dtype=torch.int64, device=dev), seed, mean_deg, d_max, n_items)
-    cnt_item = torch.zeros(n_items, dtype=torch.int64, device=dev)
-    # the user bounds only need the degrees; the item bounds need pass 1
-    ub, _ = bounds_fn(cnt_user, None)
+    ub, _ = bounds_fn(cnt_user, None)   # the user bounds only need the degrees
     u0, u1 = ub[rank]
     keep_p, keep_i, keep_x = [], [], []
     base = 0
-    for b0 in range(0, n_users, block):
-        b1 = min(n_users, b0 + block)
+    cnt_item = torch.zeros(n_items, dtype=torch.int64, device=dev)
+    for b0 in range(u0, u1, block):
+        b1 = min(u1, b0 + block)
         ip, it, v = generate_user_block(b0, b1, n_items, seed, mean_deg, d_max, feedback, dev, perm)
         cnt_item += torch.bincount(it, minlength=n_items)
-        a, c = max(b0, u0), min(b1, u1)
-        if c > a:
-            lo, hi = int(ip[a - b0]), int(ip[c - b0])
-            keep_p.append(ip[a - b0:c - b0] - lo + base)
-            base += hi - lo
-            keep_i.append(it[lo:hi].to(torch.int32))
-            keep_x.append(v[lo:hi])
-    nnz = int(cnt_item.sum())
-    if nnz >= 2 ** 31:
-        raise ValueError("nnz >= 2^31 does not fit the reference's 32-bit index layout")
+        keep_p.append(ip[:-1] + base)
+        base += int(ip[-1])
+        keep_i.append(it.to(torch.int32))
+        keep_x.append(v)
+    if base >= 2 ** 31:
+        raise ValueError("a rank's block holds >= 2^31 non-zeros: more than the reference's 32-bit index layout addresses")
     p_u = torch.cat(keep_p + [torch.tensor([base], dtype=torch.int64, device=dev)]) if keep_p else \
         torch.zeros(1, dtype=torch.int64, device=dev)
     c_iu = (p_u.to(torch.int32), torch.cat(keep_i) if keep_i else torch.zeros(0, dtype=torch.int32, device=dev),
             torch.cat(keep_x) if keep_x else torch.zeros(0, dtype=torch.float32, device=dev))
     del keep_p, keep_i, keep_x
+    if world_size > 1:
+        from . import engine
+        if be is None:
+            raise ValueError("make_shard at world_size > 1 needs a backend (transpose_csc) and a process group")
+        engine.all_reduce_any(cnt_item, group)
+    nnz = int(cnt_item.sum())
+    if nnz >= 2 ** 31:
+        raise ValueError("nnz >= 2^31 does not fit the reference's 32-bit index layout")
     ub, ib = bounds_fn(cnt_user, cnt_item)
-    i0, i1 = ib[rank]
-    rows, items, vals = [], [], []
-    for b0 in range(0, n_users, block):
-        b1 = min(n_users, b0 + block)
-        ip, it, v = generate_user_block(b0, b1, n_items, seed, mean_deg, d_max, feedback, dev, perm)
-        deg = ip[1:] - ip[:-1]
-        row = torch.repeat_interleave(torch.arange(b0, b1, dtype=torch.int64, device=dev), deg)
-        m = (it >= i0) & (it < i1)
-        rows.append(row[m])
-        items.append(it[m])
-        vals.append(v[m])
-    row, item, val = torch.cat(rows), torch.cat(items), torch.cat(vals)
-    del rows, items, vals
-    key, order = torch.sort((item - i0) * n_users + row)     # by item, users ascending inside an item
-    item_s = key // n_users
-    p_i = torch.zeros(i1 - i0 + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(torch.bincount(item_s, minlength=i1 - i0), 0, out=p_i[1:])
-    c_ui = (p_i.to(torch.int32), (key - item_s * n_users).to(torch.int32), val[order])
+    if world_size > 1:
+        c_ui = engine.item_block_from_user_blocks(be, group, world_size, rank, n_users, ub, ib, *c_iu)
+    else:
+        p_i, row_i, val_i = transpose_to_csc(n_users, n_items, p_u, c_iu[1].to(torch.int64), c_iu[2])
+        c_ui = (p_i.to(torch.int32), row_i.to(torch.int32), val_i)
     return {"n_users": n_users, "n_items": n_items, "nnz": nnz, "cnt_user": cnt_user, "cnt_item": cnt_item,
             "user_bounds": ub, "item_bounds": ib, "c_iu": c_iu, "c_ui": c_ui}

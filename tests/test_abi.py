@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names      # python binding covers the header one-to-one
-    assert lib.rsparse_hip_abi_version() == 5
+    assert lib.rsparse_hip_abi_version() == 6
 
 
 def test_header_cites_reference_interfaces():

@@ -163,7 +163,14 @@ def _bench_flow(rank, ws, n_user, n_item, k, n_iter):
         def bounds_fn(cu, ci):
             a, b = ShardedALS.layouts(n_user, n_item, ws, cu, ci)
             return a.bounds, (b.bounds if ci is not None else None)
-        d = synth.make_shard(n_user, n_item, ws, rank, bounds_fn, mean_deg=10, d_max=80, device="cpu", block=257)   # (several streamed blocks)
+        d = synth.make_shard(n_user, n_item, ws, rank, bounds_fn, mean_deg=10, d_max=80, device="cpu", block=57,   # (several generated blocks)
+                             be=OracleBackend())
+        whole = synth.make_dataset(n_user, n_item, mean_deg=10, d_max=80, device="cpu")   # (the test only: the shard = slices of it)
+        (a0, a1), (i0, i1) = d["user_bounds"][rank], d["item_bounds"][rank]
+        for got, (p, i, x), (c0, c1) in ((d["c_iu"], whole["c_iu"], (a0, a1)), (d["c_ui"], whole["c_ui"], (i0, i1))):
+            lo, hi = int(p[c0]), int(p[c1])
+            assert torch.equal(got[0].to(torch.int64), p[c0:c1 + 1].to(torch.int64) - lo)
+            assert torch.equal(got[1].to(torch.int64), i[lo:hi].to(torch.int64)) and torch.equal(got[2], x[lo:hi])
         lu, li = ShardedALS.layouts(n_user, n_item, ws, d["cnt_user"], d["cnt_item"])
         c_ui, c_iu, nnz = d["c_ui"], d["c_iu"], d["nnz"]
     als = ShardedALS(OracleBackend(), n_user, n_item, k, c_ui, c_iu, nnz, feedback="implicit", lambda_=0.1, cg_steps=3,

@@ -18,10 +18,10 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-SRC = [CSRC / n for n in ("wrmf_kernels.hip", "wrmf_cgq.hip", "wrmf_cgp.hip", "wrmf_ne.hip", "wrmf_chol.hip", "wrmf_chol_wave.hip", "wrmf_chol_mf.hip", "wrmf_chol_lr.hip",
+SRC = [CSRC / n for n in ("wrmf_kernels.hip", "wrmf_cgq.hip", "wrmf_cgp.hip", "wrmf_ne.hip", "wrmf_chol.hip", "wrmf_chol_wave.hip", "wrmf_chol_mf.hip", "wrmf_cg_mf.hip", "wrmf_chol_lr.hip",
                           "wrmf_topk.hip", "wrmf_ingest.hip", "wrmf_nnls.hip", "wrmf_bias.hip", "wrmf_lu.hip",
                           "wrmf_f64.hip", "wrmf_wide.hip", "wrmf_ctx_kernels.hip", "wrmf_capi.cpp", "wrmf_f64_capi.cpp", "wrmf_ctx.cpp")]
-HEADERS = [CSRC / "wrmf_chol_mf.attrs.csv", CSRC / "wrmf_internal.h", CSRC / "wrmf_device.h", CSRC / "wrmf_ldlt.h", CSRC / "wrmf_f64.h", PKG.parent / "include" / "rsparse_wrmf_hip.h"]
+HEADERS = [CSRC / "wrmf_chol_mf.attrs.csv", CSRC / "wrmf_mf.h", CSRC / "wrmf_internal.h", CSRC / "wrmf_device.h", CSRC / "wrmf_ldlt.h", CSRC / "wrmf_f64.h", PKG.parent / "include" / "rsparse_wrmf_hip.h"]
 DEPS = SRC + HEADERS
 OUT = PKG / "lib" / "librsparse_wrmf_hip.so"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
@@ -33,8 +33,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # compiler-generated accumulator-file instruction, nothing touches a register an asm load has in flight, two waves per SIMD);
 # if the audit fails -- another compiler, a lost flag -- the file is rebuilt with -DMF_SAFE (tiles above hipcc's own share of the
 # accumulator file, one wave per SIMD) and audited again; a build that passes neither is an error, never a silent corruption.
-EXTRA_FLAGS = {"wrmf_chol_mf.hip": ["-mllvm", "-forceattrs-csv-path=" + str(CSRC / "wrmf_chol_mf.attrs.csv")]}
-AUDITED = {"wrmf_chol_mf.hip"}
+EXTRA_FLAGS = {n: ["-mllvm", "-forceattrs-csv-path=" + str(CSRC / "wrmf_chol_mf.attrs.csv")] for n in ("wrmf_chol_mf.hip", "wrmf_cg_mf.hip")}
+AUDITED = {"wrmf_chol_mf.hip", "wrmf_cg_mf.hip"}
+REG_LIMIT = {"wrmf_cg_mf.hip": 512}   # (one wave per SIMD by design: 320 accumulator registers per row)
 
 
 def audit_listing(src, extra, defines, obj):
@@ -54,7 +55,8 @@ def audit_listing(src, extra, defines, obj):
     # vector registers + the 160 named accumulator registers <= 256: two waves per SIMD.  Demanded of the kernels that run in
     # the normal case; the `_any` instantiations (some confidence below 1: two operand sets) may take a few registers more
     nfree = re.findall(r"\.amdhsa_kernel (\w+)[\s\S]*?\.amdhsa_next_free_vgpr (\d+)", text)
-    two_waves = bool(nfree) and all(int(v) <= 256 for name, v in nfree if "_any" not in name)
+    limit = REG_LIMIT.get(src.name, 256)
+    two_waves = bool(nfree) and all(int(v) <= limit for name, v in nfree if "_any" not in name)
     if acc == 0 and flight == 0 and two_waves:
         return
     print("  %s: audit of the two-waves-per-SIMD build failed (accumulator-file %d, in-flight %d, layout ok %s): rebuilding with -DMF_SAFE"

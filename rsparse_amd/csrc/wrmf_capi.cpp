@@ -471,9 +471,12 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     if (L1.split_rows) (void)hipFree(L1.split_rows);
     if (L1.split_ptr) (void)hipFree(L1.split_ptr);
   }
-  // solver == CHOLESKY: its normal-equation launch may take shorter rows too (RSPARSE_HIP_NE_CHOL_MIN, 64..512)
-  d.q_nec_min = kNeCholMinLen;
-#ifdef RSP_AB   // dev builds: the threshold sweep behind DESIGN.md 3.3
+  // a second set of lists for a longer prefix of the order.  Round 6: the rows beyond kCgMfMax non-zeros -- what is left to the
+  // normal-equation kernel when wrmf_cg_mf.hip takes the rows of 513..kCgMfMax (rank 128, implicit conjugate gradient).
+  // (Rounds 2-5: the rows beyond 64, for solver == CHOLESKY at rank 65..128 -- wrmf_chol_mf.hip has those now; dev builds
+  // still set that threshold with RSPARSE_HIP_NE_CHOL_MIN = 64..512 for A/B runs of the old routing.)
+  d.q_nec_min = kCgMfMax;
+#ifdef RSP_AB
   if (const char* e = std::getenv("RSPARSE_HIP_NE_CHOL_MIN")) d.q_nec_min = std::min(kNeMinLen, std::max(kCholLrMax, std::atoi(e)));
 #endif
   int n_nec = 0;
@@ -485,7 +488,7 @@ int build_q_schedule(DevCSC& d, const int32_t* host_col_ptrs) {
     d.q_nec_split_ptr = d.q_ne_split_ptr; d.q_nec_nsplit = d.q_ne_nsplit;
   } else {
     NeLists L;
-    if (int rc2 = build_ne_lists(order, host_col_ptrs, n_nec, 72, L)) return rc2;
+    if (int rc2 = build_ne_lists(order, host_col_ptrs, n_nec, d.q_nec_min < kNeMinLen ? 72 : 12, L)) return rc2;
     d.q_nec_own = true;
     d.q_nec_rows = L.rows; d.q_nec_ptr = L.ptr; d.q_nec_wg = L.wg; d.q_nec_segs = L.segs; d.q_nec_nseg = L.nseg;
     d.q_nec_entries = L.entries; d.q_nec_split_rows = L.split_rows; d.q_nec_split_ptr = L.split_ptr; d.q_nec_nsplit = L.nsplit;
@@ -647,6 +650,19 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   qs.ne_rows = ne_fine ? d.q_ne_rows : d.q_ne1_rows; qs.ne_ptr = ne_fine ? d.q_ne_ptr : d.q_ne1_ptr;
   qs.ne_wg = ne_fine ? d.q_ne_wg : d.q_ne1_wg; qs.ne_entries = d.q_ne_entries;
   qs.ne_split_rows = d.q_ne_split_rows; qs.ne_split_ptr = d.q_ne_split_ptr; qs.ne_nsplit = d.q_ne_nsplit;
+  // round 6, rank 128, implicit conjugate gradient without bias operands: the rows of 513..kCgMfMax non-zeros of the first bucket on
+  // the wave-per-row kernel of wrmf_cg_mf.hip, the giant rows (a prefix of the order) on the normal-equation kernel's second lists
+  bool cgm_on = cgq && implicit && !bias && cg_mf_supported(rank, implicit) && d.q_nec_min == kCgMfMax;
+#ifdef RSP_AB
+  if (const char* e = std::getenv("RSPARSE_HIP_CG_MF")) cgm_on = cgm_on && std::atoi(e) != 0;
+#endif
+  const bool cg_mf = cgm_on && d.q_order && d.q_off[1] > d.q_n_nec;
+  if (cg_mf) {
+    qs.ne_rows = d.q_nec_rows; qs.ne_ptr = d.q_nec_ptr; qs.ne_wg = d.q_nec_wg; qs.ne_entries = d.q_nec_entries;
+    qs.ne_split_rows = d.q_nec_split_rows; qs.ne_split_ptr = d.q_nec_split_ptr; qs.ne_nsplit = d.q_nec_nsplit;
+    qs.mf_rows = d.q_order + d.q_n_nec;
+    qs.mf_n = d.q_off[1] - d.q_n_nec;
+  }
   // solver == CHOLESKY: the rows beyond 512 non-zeros are assembled by the normal-equation kernel (matrix cores, one pass)
   // and solved exactly there (a.ne_chol); wrmf_chol.hip's kernel then skips them
   // (the lower threshold pays at rank 65..128 only: at rank <= 64 wrmf_chol.hip's kernel is cheaper than the fixed cost of
@@ -659,7 +675,14 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
 #endif
   const bool chol_mf = mf_on && !cg && solver == RSPARSE_SOLVER_CHOLESKY && !bias && d.q_order && ne_supported(rank) &&
                        use_cgq(rank, d_X, d_Y) && d.q_lr_first > d.q_off[1];
-  const int n_mf = chol_mf ? d.q_lr_first - d.q_off[1] : 0;
+  int n_mf = chol_mf ? d.q_lr_first - d.q_off[1] : 0;
+  int mf_first = d.q_off[1];
+#ifdef RSP_AB   // timing experiments: every row beyond 64 non-zeros on the wave-per-row kernel (giant rows included: one wave each)
+  if (chol_mf && std::getenv("RSPARSE_HIP_CHOL_MF_ALL")) {   // (= 2: without the rows beyond 4096 non-zeros, which nobody solves then)
+    mf_first = std::atoi(std::getenv("RSPARSE_HIP_CHOL_MF_ALL")) == 2 ? d.q_n_chol_long : 0;
+    n_mf = d.q_lr_first - mf_first;
+  }
+#endif
   const bool nec_lists = padded_rank(rank) > 64 && d.q_nec_wg > 0 && !chol_mf;
   const bool ne_chol = !cg && solver == RSPARSE_SOLVER_CHOLESKY && !bias && (nec_lists || d.q_ne_wg > 0 || chol_mf) &&
                        ne_supported(rank) && use_cgq(rank, d_X, d_Y);
@@ -667,8 +690,8 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     qs.ne_rows = d.q_nec_rows; qs.ne_ptr = d.q_nec_ptr; qs.ne_wg = d.q_nec_wg; qs.ne_entries = d.q_nec_entries;
     qs.ne_split_rows = d.q_nec_split_rows; qs.ne_split_ptr = d.q_nec_split_ptr; qs.ne_nsplit = d.q_nec_nsplit;
   }
-  const int ne_nseg = (ne_chol && nec_lists) ? d.q_nec_nseg : d.q_ne_nseg;
-  const int32_t* ne_segs = (ne_chol && nec_lists) ? d.q_nec_segs : d.q_ne_segs;
+  const int ne_nseg = ((ne_chol && nec_lists) || cg_mf) ? d.q_nec_nseg : d.q_ne_nseg;
+  const int32_t* ne_segs = ((ne_chol && nec_lists) || cg_mf) ? d.q_nec_segs : d.q_ne_segs;
   const size_t chol_base = chol2_loss_slots(d.n_cols);
   const size_t slots = cgq ? cgq_loss_slots(qs, rank, implicit) : (cg ? cg_loss_slots(d.n_cols, d.n_long)
                                    : (solver == RSPARSE_SOLVER_NNLS ? chol_loss_slots(d.n_cols)
@@ -733,7 +756,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
       }
     }
   }
-  if (!a.ne_stats && (cgq || ne_chol) && implicit && qs.ne_wg > 0 && ne_supported(rank) && (!bias || gb_cg)) {
+  if (!a.ne_stats && (cgq || ne_chol) && implicit && (qs.ne_wg > 0 || qs.mf_n > 0) && ne_supported(rank) && (!bias || gb_cg)) {
     // operand scales of the fp16 normal-equation kernel (and whether it may run at all), decided on the device
     hipError_t se = take_value_stats(d, d_X, (int64_t)d.n_rows * rank, s, d_absmax);
     if (se != hipSuccess) return hip_fail(se, "launch_ne_stats");
@@ -796,7 +819,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   }
   hipEvent_t* ev = g_prof.begin();
   if (chol && ev) HIP_TRY(hipEventRecord(ev[0], s));   // Cholesky: [0] normal-equation launch, [1] low-rank, [2] k x k, [3] wave-per-row (rank 65..128), [4] loss
-  if (ne_chol && qs.ne_wg > 0) {
+  if (ne_chol && qs.ne_wg > 0 && mf_first != 0) {
     hipError_t ne = launch_als_ne(a, qs, implicit, g_ws.partials + chol_base, s, ev);
     if (ne != hipSuccess) return hip_fail(ne, "launch_als_ne");
   }
@@ -808,7 +831,7 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (e != hipSuccess) return hip_fail(e, cgq ? "launch_als_cgq" : (cg ? "launch_als_cg" : "launch_als_chol"));
   if (chol_mf) {   // (launch_als_chol2 recorded ev[3] behind its kernels)
     const size_t mf_base = chol_base + (size_t)(qs.ne_entries + qs.ne_nsplit);
-    hipError_t me = launch_als_chol_mf(a, implicit, d.q_order + d.q_off[1], n_mf, (int)mf_base, s, ev ? ev + 3 : nullptr);
+    hipError_t me = launch_als_chol_mf(a, implicit, d.q_order + mf_first, n_mf, (int)mf_base, s, ev ? ev + 3 : nullptr);
     if (me != hipSuccess) return hip_fail(me, "launch_als_chol_mf");
   }
   if (chol && ev) HIP_TRY(hipEventRecord(ev[4], s));

@@ -1,0 +1,550 @@
+// Conjugate-gradient half-iteration, rows of 513 .. kCgMfMax non-zeros at rank 128, implicit feedback: one WAVE per row, one pass
+// over the row, the normal equations in the wave's matrix-core ACCUMULATOR registers (gfx950, wave64; round 6).
+//
+// Replaces, for those rows, the streaming part of als_ne_kernel (wrmf_ne.hip) -- cg_solver_implicit<T> on the row's k x k system
+// (inst/include/wrmf_implicit.hpp:8-32, the same operator evaluated from the assembled matrix) and the loss term from the
+// accumulators:
+//     M1 = X_nnz diag(c - 1) X_nnz^T,   M2 = X_nnz X_nnz^T,   b = X_nnz c,   sum c
+//     A = XtX + M1;   y = CG(A, b; warm start, cg_steps);   sum_j c_j (1 - x_j.y)^2 = sum c - 2 y.b + y^T (M1 + M2) y.
+// als_ne_kernel moves these rows' bytes at 0.42 of the HBM peak (20 ms per launch on the bench line, the dominant launch of
+// rounds 3-5): four waves consume the same 16-non-zero step from an LDS ring, and 114..227 of a step's 315..500 instructions are
+// scalar bookkeeping of that ring (DESIGN.md 3.2 "Round 5").  The wave-per-row assembly of wrmf_chol_mf.hip has no ring and no
+// partner: a lane reads its two coordinates of each of a step's 16 vectors with asm loads whose addresses are 6 scalar
+// instructions per non-zero, the previous step's matrix instructions run while they fly.  Measured with the exact solver's
+// kernel on the same rows: 4.9 TB/s of algorithmic bytes on the HBM-resident side (profiles/r06/r6k*).  What that kernel lacks
+// for conjugate gradient is the loss-only matrix M2: 20 tiles = 320 accumulator registers.  One wave per SIMD can hold them --
+// the accumulator file a0..a255 takes M1 (tiles 0..9) and six tiles of M2, the other four tiles of M2 are vector registers of
+// the compiler's (a plain accumulate chain: nothing hipcc can get wrong) -- and four waves per CU, each with 32 + 32 loads of its
+// own in flight, are what the memory system needs to stay busy.
+//
+// Per row: stream (M1 from two fp16 terms of 2^e sqrt(c - 1) x, three products; M2 from the leading fp16 term of 2^e x alone, one
+// product: it feeds only the loss, as in wrmf_ne.hip) -> unscale -> conjugate gradient with A p evaluated FROM THE TILES: tile
+// (I, K) of the lower triangle holds, at lane (n, hf), register v, the entry [row 32 I + n][column 32 K + rho(v, hf)], so
+//     (A p)_I += sum over the lane's registers of  tile * p[column]          ("direct": 16 FMAs per tile, then the halves added)
+//     (A p)_K += sum over the LANES of             tile * p[row]   (I > K)   ("transposed": through a 32 x 36 LDS tile)
+// with XtX's tiles added on the fly from a copy in LDS in the same lane / register order (shared by the workgroup's four waves,
+// which otherwise know nothing of each other).  The loss reads y^T M1 y and y^T M2 y off the tiles ("direct" part only).
+// Double scalars rsold / alpha / beta as the reference holds them (:18); the 1e-10 exit (:27).
+#include <cstdio>
+#include <utility>
+
+#pragma clang diagnostic ignored "-Winline-asm"   // (the named accumulator registers are "reserved": that is the point)
+
+#include "wrmf_internal.h"
+#include "wrmf_device.h"
+
+namespace rsparse_hip {
+namespace {
+using namespace dev;
+// the accumulator file is this kernel's alone (forced attribute amdgpu-agpr-alloc=0, see wrmf_chol_mf.hip): a0..a159 = M1's ten tiles
+// (then A = XtX + M1 is NOT formed in them: M1 stays pure for the loss), a160..a255 = tiles 0..5 of M2
+constexpr int MF_A0 = 0;
+#define MF_TOP "a255"
+}  // namespace
+}  // namespace rsparse_hip
+
+#include "wrmf_mf.h"
+
+namespace rsparse_hip {
+namespace {
+
+constexpr float kCgTolMf = 1e-10f;   // CG_TOL, inst/include/wrmf.hpp:22
+// Measured and not kept (profiles/r06/r6o_*): the previous step's matrix instructions in five groups of eight BETWEEN the pieces of
+// this step's vector work, their operands waiting in LDS -- 19.8 ms per launch against 17.3 with the operands in registers and the
+// 40 instructions in one block (the staging writes, 60 operand reads per step and the lost scheduling freedom cost more than the
+// 1280 cycles of matrix-pipe time they were meant to hide).  -DCGM_INTERLEAVE=1 builds it.
+#ifndef CGM_INTERLEAVE
+#define CGM_INTERLEAVE 0
+#endif
+#ifndef CGM_TOUCH
+#define CGM_TOUCH 0
+#endif
+
+// the leading fp16 term alone (M2: one product)
+__device__ __forceinline__ void cgm_operands_hi(const float (&x)[16], f16x8& h0, f16x8& h1) {
+  float b0[8], b1[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[e]), __float_as_uint(x[8 + e]), false, false);
+    b0[e] = __uint_as_float(sw2[0]);
+    b1[e] = __uint_as_float(sw2[1]);
+  }
+  unsigned hh0[4], hh1[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const f32x2 v0 = {b0[2 * q], b0[2 * q + 1]}, v1 = {b1[2 * q], b1[2 * q + 1]};
+    hh0[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, f16x2));
+    hh1[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, f16x2));
+  }
+  h0 = mf_pack(hh0[0], hh0[1], hh0[2], hh0[3]);
+  h1 = mf_pack(hh1[0], hh1[1], hh1[2], hh1[3]);
+}
+
+template <int NOPS>
+struct CgmWave {               // per wave
+  union {
+    float4 ops[2][12][64];     // streaming (SYM): a step's operands between their split and their products, which run interleaved
+                               // with the NEXT step's vector work -- M1 hi [0..3], lo [4..7], M2 hi [8..11]; double-buffered by step parity
+    float T[32 * 36];          // solve: the transposed part of a product: [column][lane], rows padded to 36 floats (conflict-free b128 reads)
+  };
+  float vec[128];              // a vector in "register = column" order's source: p (or y) by coordinate
+  float x0[128];               // warm start
+  float rhs[128];              // b
+  double loss;
+};
+template <int NOPS>
+struct CgmSmem {
+  float4 G[10][64][4];         // XtX's lower tiles in the accumulator's lane / register order: [tile][lane][4 x float4 = 16 registers]
+  CgmWave<NOPS> w[4];
+};
+
+// y_I(n) += sum_v tile[v] * pc[K][v] over the lane's registers, for every lower tile; off-diagonal tiles also feed the transposed
+// part.  RD(t, v) reads element v of tile t.
+template <class RD, class GV, class WV>
+__device__ __forceinline__ void cgm_matvec(RD&& rd, GV&& gtile, WV& sw, const int n, const int hf, const int ln,
+                                           const float (&pr)[4], float (&out)[4]) {
+  // pr[I] = p[32 I + n] (lane = row).  The column-ordered copy: pc[K][v] = p[32 K + rho(v, hf)] from LDS
+  wave_sync();
+  if (hf == 0) {
+#pragma unroll
+    for (int I = 0; I < 4; I++) sw.vec[32 * I + n] = pr[I];
+  }
+  wave_sync();
+  float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+  mf_sfor<4>([&](auto kt) {
+    constexpr int K = decltype(kt)::value;
+    float pc[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 t = *reinterpret_cast<const float4*>(&sw.vec[32 * K + 8 * q + 4 * hf]);
+      pc[4 * q] = t.x; pc[4 * q + 1] = t.y; pc[4 * q + 2] = t.z; pc[4 * q + 3] = t.w;
+    }
+    float ts[16];   // transposed partials of block column K: sum over the tiles (I, K), I > K, of tile[v] * p[32 I + n]
+#pragma unroll
+    for (int v = 0; v < 16; v++) ts[v] = 0.f;
+    mf_sfor<4 - K>([&](auto st) {
+      constexpr int I = K + decltype(st)::value;
+      constexpr int T = mf_tid(I, K);
+      float g[16];
+      gtile(std::integral_constant<int, T>{}, g);
+      mf_sfor<16>([&](auto vt) {
+        constexpr int v = decltype(vt)::value;
+        const float av = rd(std::integral_constant<int, T>{}, std::integral_constant<int, v>{}) + g[v];
+        dsum[I] = fmaf(av, pc[v], dsum[I]);
+        if constexpr (I > K) ts[v] = fmaf(av, pr[I], ts[v]);
+      });
+    });
+    if constexpr (K < 3) {
+      // sum ts[v] over the 32 lanes of each half: through LDS, column rho(v, hf) = row of a 32 x 36 tile
+      wave_sync();
+#pragma unroll
+      for (int v = 0; v < 16; v++) sw.T[(8 * (v >> 2) + 4 * hf + (v & 3)) * 36 + n] = ts[v];
+      wave_sync();
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const float4 t = *reinterpret_cast<const float4*>(&sw.T[n * 36 + 4 * q]);
+        s0 += t.x + t.z;
+        s1 += t.y + t.w;
+      }
+      out[K] = s0 + s1;   // (completed below with the direct part)
+    } else {
+      out[K] = 0.f;
+    }
+  });
+  // the direct part: the two halves of the wave hold the two halves of a row's columns
+#pragma unroll
+  for (int I = 0; I < 4; I++) {
+    const unsigned du = __float_as_uint(dsum[I]);
+    const auto sw2 = __builtin_amdgcn_permlane32_swap(du, du, false, false);   // [0]: the lanes (n, 0)'s value everywhere, [1]: (n, 1)'s
+    out[I] += __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+  }
+}
+
+// sum over a vector held lane = row (four registers, both halves of the wave hold the same values)
+__device__ __forceinline__ float cgm_dot(const float (&a)[4], const float (&b)[4], const int hf) {
+  float s = (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+  return wave_sum(hf == 0 ? s : 0.f);
+}
+
+template <bool SYM>
+__device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* __restrict__ rows, const int n_rows, const int loss_slot0) {
+  extern __shared__ __attribute__((aligned(16))) char cgm_smem[];   // (more than the 64 KB a static array may take)
+  CgmSmem<SYM ? 12 : 20>& sm = *reinterpret_cast<CgmSmem<SYM ? 12 : 20>*>(cgm_smem);
+  const int lane = threadIdx.x & 63, wv = rfl((int)(threadIdx.x >> 6));
+  CgmWave<SYM ? 12 : 20>& sw = sm.w[wv];
+  constexpr int k = 128;
+  {
+    // two instantiations are launched; "some confidence < 1" (word 2 of the values scan) says which one works
+    const bool below_one = a.ne_stats[2] != 0u;
+    if (below_one == SYM) {
+      if (lane == 0) a.loss_partials[loss_slot0 + 4 * blockIdx.x + wv] = 0.0;
+      return;
+    }
+  }
+  // XtX's lower tiles -> LDS in the accumulator's order: tile (I, K), lane (n, hf), register v = XtX[32 K + rho(v, hf)][32 I + n]
+  for (int e = threadIdx.x; e < 10 * 64 * 16; e += 256) {
+    const int t = e / 1024, l = (e >> 4) & 63, v = e & 15;
+    const int I = t >= 6 ? 3 : (t >= 3 ? 2 : (t >= 1 ? 1 : 0)), K = t - I * (I + 1) / 2;
+    const int nn = l & 31, hh = l >> 5;
+    reinterpret_cast<float*>(&sm.G[t][l][0])[v] = a.XtX[(size_t)(32 * K + 8 * (v >> 2) + 4 * hh + (v & 3)) * k + 32 * I + nn];
+  }
+  if (lane == 0) sw.loss = 0.0;
+  __syncthreads();
+
+  auto uni = [](const float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+  const int ex = rfl(mf_scale_exp(fmaxf(__uint_as_float(a.ne_stats[0]), 1e-30f)));
+  const float wmax = uni(fmaxf(__uint_as_float(a.ne_stats[1]) - 1.f, 1.f));
+  const int ewb = rfl((int)((__float_as_uint(wmax) >> 23) & 0xffu));
+  const float sx = uni(mf_pow2(ex)), sw_ = uni(mf_pow2(min(253, max(1, 253 - ewb))));   // sw_ = 2^(126 - ewb) <= 1 / wmax
+  const float un1 = uni(mf_pow2(254 - ex));                                              // 1 / sx
+  const float unw = uni(mf_pow2(254 - min(253, max(1, 253 - ewb))));                     // 1 / sw_
+  const int n_waves = 4 * gridDim.x;
+
+  for (int it = 4 * blockIdx.x + wv; it < n_rows; it += n_waves) {
+    const int row = rfl(rows[it]);
+    const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
+    float* yrow = a.Y + (size_t)row * k;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    // warm start and the accumulators
+    sw.x0[ln] = yrow[ln];
+    sw.x0[64 + ln] = yrow[64 + ln];
+    MF_DRAIN();
+    mf_sfor<256>([&](auto rt) { mf_wr<decltype(rt)::value>(0.f); });
+    f32x16 hi[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) hi[t][e] = 0.f;
+    float u0 = 0.f, u1 = 0.f, csum = 0.f;   // rhs (lane = coordinate), sum of the confidences (lane j: its slots')
+    {
+      // A step = 16 non-zeros, two register buffers.  The NEXT step's vectors are requested first (asm loads: one coordinate per
+      // lane and register, the vector's address scalar arithmetic), then this step's right-hand side, scaling and split into fp16
+      // terms and its 40 matrix instructions run while they fly, then ONE wait.  One wave per SIMD has nobody to hide a stall
+      // behind: with the requests issued only in front of the matrix instructions (the exact solver's loop, two waves per SIMD)
+      // this kernel moved its rows no faster than the one it replaces (18.1 against 20.1 ms, profiles/r06/r6m_*).
+      const int vo0 = 4 * ln, vo1 = 4 * (ln + 64);
+      const int nsteps = (p2 - p1 + 15) >> 4;
+      auto meta_pos = [&](const int st) __attribute__((always_inline)) {   // (steps beyond the row ask for its last entry: no branch; their weight is 0)
+        const int base = p1 + 16 * min(st, nsteps - 1);
+        return base + min(ln & 15, min(16, p2 - base) - 1);
+      };
+      auto request = [&](const int idj, float (&x0)[16], float (&x1)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) {
+          const float* bp = a.X + (size_t)__builtin_amdgcn_readlane(idj, s2) * k;
+          mf_ld(x0[s2], bp, vo0);
+          mf_ld(x1[s2], bp, vo1);
+        }
+      };
+      // index / value of step st + 2 into (idf, cvf): asm loads too, covered by the step's one wait
+      auto request_meta = [&](const int st, int& idf, float& cvf) __attribute__((always_inline)) {
+        const int pos = meta_pos(st);
+        asm volatile("global_load_dword %0, %1, %2" : "=&v"(idf) : "v"(4 * pos), "s"(a.row_idx));
+        asm volatile("global_load_dword %0, %1, %2" : "=&v"(cvf) : "v"(4 * pos), "s"(a.vals));
+      };
+      // SYM: the matrix instructions of step st - 1 (operands in LDS, sw.ops[(st - 1) & 1]) in five groups of eight -- two tiles each,
+      // their three M1 products and one M2 product alternating so that no instruction waits for its predecessor's result --
+      // BETWEEN the five pieces of step st's vector work: one wave per SIMD has nobody else to fill the 32 cycles a matrix
+      // instruction holds the pipe (as one block of 40 behind the vector work they cost 1280 cycles per step on top of it)
+      auto mgroup = [&](auto gt, const int par) __attribute__((always_inline)) {
+        constexpr int G = decltype(gt)::value;
+        constexpr int GI[5][2] = {{0, 1}, {2, 3}, {1, 2}, {3, 2}, {3, 3}}, GK[5][2] = {{0, 0}, {0, 0}, {1, 1}, {1, 2}, {2, 3}};
+        constexpr int I0 = GI[G][0], K0 = GK[G][0], I1 = GI[G][1], K1 = GK[G][1];
+        auto ld = [&](const int t) { return __builtin_bit_cast(f16x8, sw.ops[par][t][ln]); };
+        const f16x8 ahK0 = ld(K0), alK0 = ld(4 + K0), mhK0 = ld(8 + K0), ahI0 = ld(I0), alI0 = ld(4 + I0), mhI0 = ld(8 + I0);
+        const f16x8 ahK1 = ld(K1), alK1 = ld(4 + K1), mhK1 = ld(8 + K1), ahI1 = ld(I1), alI1 = ld(4 + I1), mhI1 = ld(8 + I1);
+        constexpr int T0 = mf_tid(I0, K0), T1 = mf_tid(I1, K1);
+        mf_mma16<T0>(ahK0, ahI0); mf_mma16<T1>(ahK1, ahI1);
+        mf_mma16<T0>(ahK0, alI0); mf_mma16<T1>(ahK1, alI1);
+        mf_mma16<T0>(alK0, ahI0); mf_mma16<T1>(alK1, ahI1);
+        if constexpr (T0 < 6) mf_mma16<10 + T0>(mhK0, mhI0);
+        else hi[T0 - 6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mhK0, mhI0, hi[T0 - 6], 0, 0, 0);
+        if constexpr (T1 < 6) mf_mma16<10 + T1>(mhK1, mhI1);
+        else hi[T1 - 6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mhK1, mhI1, hi[T1 - 6], 0, 0, 0);
+      };
+      auto consume = [&](const int st, const int idj_unused, const float cvr, float (&xs0)[16], float (&xs1)[16]) __attribute__((always_inline)) {
+        (void)idj_unused;
+        const int ccnt = min(16, p2 - (p1 + 16 * st));
+        const bool inl = (ln & 15) < ccnt;
+        const float cvj = inl ? cvr : 0.f;
+        csum += ln < 16 ? cvj : 0.f;
+        const float f2 = inl ? sx : 0.f;                                                       // M2's operand scale
+        float f1;                                                                              // M1's
+        if constexpr (SYM) f1 = inl ? sx * __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_) : 0.f;
+        else f1 = inl ? (cvr - 1.f) * sw_ : 0.f;   // (!SYM: the A side's extra factor on top of the B side's 2^e x)
+        const int par = st & 1, prev = par ^ 1;
+        const bool have_prev = st > 0;   // wave-uniform
+        auto stash = [&](const int t, const f16x8& v) { sw.ops[par][t][ln] = __builtin_bit_cast(float4, v); };
+        // the right-hand side from the raw vectors, which then become 2^e x IN PLACE (no second copy: three buffers of 32
+        // registers are in flight or in use next to the 64 of M2's last four tiles)
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) {
+          const float cv = readlane_f(cvj, s2);
+          u0 = fmaf(cv, xs0[s2], u0);
+          u1 = fmaf(cv, xs1[s2], u1);
+          const float s_m = readlane_f(f2, s2);
+          xs0[s2] *= s_m;
+          xs1[s2] *= s_m;
+        }
+        asm volatile("" : "+v"(u0), "+v"(u1));
+        __builtin_amdgcn_sched_barrier(0);
+        float (&xm0)[16] = xs0;
+        float (&xm1)[16] = xs1;
+        if constexpr (SYM && CGM_INTERLEAVE) {
+          if (have_prev) mgroup(std::integral_constant<int, 0>{}, prev);
+          __builtin_amdgcn_sched_barrier(0);
+          f16x8 h0, l0, h1, l1;
+          cgm_operands_hi(xm0, h0, h1);
+          stash(8, h0); stash(9, h1);
+          cgm_operands_hi(xm1, h0, h1);
+          stash(10, h0); stash(11, h1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (have_prev) mgroup(std::integral_constant<int, 1>{}, prev);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s2 = 0; s2 < 16; s2++) {
+            const float s_a = readlane_f(f1, s2);
+            xs0[s2] *= s_a;
+            xs1[s2] *= s_a;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (have_prev) mgroup(std::integral_constant<int, 2>{}, prev);
+          __builtin_amdgcn_sched_barrier(0);
+          mf_operands(xs0, h0, l0, h1, l1);
+          stash(0, h0); stash(4, l0); stash(1, h1); stash(5, l1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (have_prev) mgroup(std::integral_constant<int, 3>{}, prev);
+          __builtin_amdgcn_sched_barrier(0);
+          mf_operands(xs1, h0, l0, h1, l1);
+          stash(2, h0); stash(6, l0); stash(3, h1); stash(7, l1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (have_prev) mgroup(std::integral_constant<int, 4>{}, prev);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          // The operands stay in registers and the 40 matrix instructions follow the vector work.  SYM: one operand set for M1
+          // (A side = B side).  Some confidence below 1: B side = 2^e x with both terms (M2 uses its leading term), A side =
+          // 2^e' (c - 1) 2^e x.
+          f16x8 ah[4], al[4], mh[4], bh[4], bl[4];
+          auto m2_products = [&]() __attribute__((always_inline)) {   // (first: their operand dies before M1's are built)
+            mf_sfor<4>([&](auto kt) {
+              constexpr int K = decltype(kt)::value;
+              mf_sfor<4 - K>([&](auto st2) {
+                constexpr int I = K + decltype(st2)::value;
+                constexpr int T = mf_tid(I, K);
+                if constexpr (T < 6) mf_mma16<10 + T>(mh[K], mh[I]);
+                else hi[T - 6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[K], mh[I], hi[T - 6], 0, 0, 0);
+              });
+            });
+          };
+          // g = f1 / f2: the factor that turns M2's operand 2^e x into M1's (SYM: sqrt((c - 1) 2^e'); else (c - 1) 2^e')
+          float gj;
+          if constexpr (SYM) gj = inl ? __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_) : 0.f;
+          else gj = f1;
+          if constexpr (SYM) {
+            cgm_operands_hi(xm0, mh[0], mh[1]);
+            cgm_operands_hi(xm1, mh[2], mh[3]);
+            __builtin_amdgcn_sched_barrier(0);
+            m2_products();
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            mf_operands(xm0, bh[0], bl[0], bh[1], bl[1]);
+            mf_operands(xm1, bh[2], bl[2], bh[3], bl[3]);
+#pragma unroll
+            for (int t = 0; t < 4; t++) mh[t] = bh[t];
+            __builtin_amdgcn_sched_barrier(0);
+            m2_products();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 16; s2++) {
+            const float s_a = readlane_f(gj, s2);
+            xs0[s2] *= s_a;
+            xs1[s2] *= s_a;
+          }
+          mf_operands(xs0, ah[0], al[0], ah[1], al[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          mf_operands(xs1, ah[2], al[2], ah[3], al[3]);
+          __builtin_amdgcn_sched_barrier(0);
+          mf_sfor<3>([&](auto pt) {
+            constexpr int pr = decltype(pt)::value;
+            mf_sfor<4>([&](auto kt) {
+              constexpr int K = decltype(kt)::value;
+              mf_sfor<4 - K>([&](auto st2) {
+                constexpr int I = K + decltype(st2)::value;
+                if constexpr (SYM) mf_mma16<mf_tid(I, K)>(pr == 2 ? al[K] : ah[K], pr == 1 ? al[I] : ah[I]);
+                else mf_mma16<mf_tid(I, K)>(pr == 2 ? al[K] : ah[K], pr == 1 ? bl[I] : bh[I]);
+              });
+            });
+          });
+        }
+      };
+      // TWO register buffers.  Per step s: the index / value pair of step s + 3 is requested (asm loads like the vectors: hipcc's
+      // own wait for a plain load would drain the queue), the 32 vector pieces of step s + 1 into the other buffer, step s is
+      // consumed, one `s_waitcnt vmcnt(0)`.  Measured and not kept: (i) a THIRD register buffer -- 96 + 64 (M2's last tiles) + a
+      // step's operands do not fit 256 vector registers, hipcc answered with 31 scratch accesses per step (compiled, not run);
+      // (ii) -DCGM_TOUCH=1: one load instruction per step that touches the 64 cache lines of step s + 2's vectors so that they are
+      // on their way into L2 two steps ahead: 17.7 ms per launch against 17.3 (profiles/r06/r6p_*).
+      auto wait_all = [&](float (&x0)[16], float (&x1)[16], int& id_, float& cv_, float& dummy) __attribute__((always_inline)) {
+        mf_wait(x0, x1);
+        asm volatile("" : "+v"(id_), "+v"(cv_), "+v"(dummy));
+      };
+      float xa0[16], xa1[16], xb0[16], xb1[16];
+      int m0i = a.row_idx[meta_pos(0)], m1i = a.row_idx[meta_pos(1)], m2i = a.row_idx[meta_pos(2)], m3i = 0;
+      float m0c = a.vals[meta_pos(0)], m1c = a.vals[meta_pos(1)], m2c = a.vals[meta_pos(2)], m3c = 0.f;
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(m0i), "+v"(m1i), "+v"(m2i), "+v"(m0c), "+v"(m1c), "+v"(m2c));
+      request(m0i, xa0, xa1);
+      {
+        int idd = 0; float cvd = 0.f, dd = 0.f;
+        wait_all(xa0, xa1, idd, cvd, dd);
+      }
+      const int tl = 128 * (ln & 3);   // (CGM_TOUCH) this lane's line of the vector it touches
+      (void)tl;
+      // sub-step: metas (m0, m1, m2) = steps (s, s + 1, s + 2), all landed; cur = buffer of step s, nxt = the other one
+      auto substep = [&](const int st, float (&cur0)[16], float (&cur1)[16], float (&nxt0)[16], float (&nxt1)[16]) __attribute__((always_inline)) {
+        request_meta(st + 3, m3i, m3c);
+        float dummy = 0.f;
+#if CGM_TOUCH
+        {
+          const int idt = __shfl(m2i, ln >> 2);   // (lane j mod 16 holds non-zero j: lanes 0..15 serve all 64)
+          const float* tp = a.X + (size_t)idt * k;
+          asm volatile("global_load_dword %0, %1, off offset:0" : "=&v"(dummy) : "v"(reinterpret_cast<const char*>(tp) + tl));
+        }
+#endif
+        request(m1i, nxt0, nxt1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(st, m0i, m0c, cur0, cur1);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_all(nxt0, nxt1, m3i, m3c, dummy);
+        m0i = m1i; m0c = m1c; m1i = m2i; m1c = m2c; m2i = m3i; m2c = m3c;   // (all landed: a register in flight is never moved)
+      };
+      for (int st = 0; st < nsteps; st += 2) {
+        substep(st, xa0, xa1, xb0, xb1);
+        if (st + 1 >= nsteps) break;   // wave-uniform
+        substep(st + 1, xb0, xb1, xa0, xa1);
+      }
+      if constexpr (SYM && CGM_INTERLEAVE) {   // the last step's matrix instructions
+        const int par = (nsteps - 1) & 1;
+        mf_sfor<5>([&](auto gt) { mgroup(gt, par); });
+      }
+      wave_sync();   // (the operands' LDS becomes the solve's)
+    }
+    // ---- unscale (powers of two: exact); the right-hand side and the warm start per lane = row ----
+    ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int n = ln & 31, hf = ln >> 5;
+    const float un_m1 = (un1 * un1) * (SYM ? unw : unw), un_m2 = un1 * un1;
+    MF_DRAIN();
+    mf_sfor<160>([&](auto rt) {
+      constexpr int R = decltype(rt)::value;
+      mf_wr<R>(mf_rd<R>() * un_m1);
+    });
+    mf_sfor<96>([&](auto rt) {
+      constexpr int R = 160 + decltype(rt)::value;
+      mf_wr<R>(mf_rd<R>() * un_m2);
+    });
+#pragma unroll
+    for (int t = 0; t < 4; t++) hi[t] *= un_m2;
+    wave_sync();
+    sw.rhs[ln] = u0;
+    sw.rhs[64 + ln] = u1;
+    wave_sync();
+    float b[4], x[4];
+#pragma unroll
+    for (int I = 0; I < 4; I++) {
+      b[I] = sw.rhs[32 * I + n];
+      x[I] = sw.x0[32 * I + n];
+    }
+    auto rd_m1 = [&](auto tt, auto vt) { return mf_rd<16 * decltype(tt)::value + decltype(vt)::value>(); };
+    auto g_tile = [&](auto tt, float (&g)[16]) {
+      constexpr int T = decltype(tt)::value;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 t = sm.G[T][ln][q];
+        g[4 * q] = t.x; g[4 * q + 1] = t.y; g[4 * q + 2] = t.z; g[4 * q + 3] = t.w;
+      }
+    };
+    auto g_none = [&](auto, float (&g)[16]) {
+#pragma unroll
+      for (int v = 0; v < 16; v++) g[v] = 0.f;
+    };
+    // ---- cg_solver_implicit (wrmf_implicit.hpp:8-32) on A = XtX + M1 ----
+    float r[4], p[4], ap[4];
+    cgm_matvec(rd_m1, g_tile, sw, n, hf, ln, x, ap);
+#pragma unroll
+    for (int I = 0; I < 4; I++) { r[I] = b[I] - ap[I]; p[I] = r[I]; }
+    double rsold = (double)cgm_dot(r, r, hf);
+    for (int stp = 0; stp < a.cg_steps; stp++) {
+      cgm_matvec(rd_m1, g_tile, sw, n, hf, ln, p, ap);
+      const float alpha = (float)(rsold / (double)cgm_dot(p, ap, hf));
+#pragma unroll
+      for (int I = 0; I < 4; I++) { x[I] = fmaf(alpha, p[I], x[I]); r[I] = fmaf(-alpha, ap[I], r[I]); }
+      const double rsnew = (double)cgm_dot(r, r, hf);
+      if (rsnew < (double)kCgTolMf) break;
+      const float beta = (float)(rsnew / rsold);
+#pragma unroll
+      for (int I = 0; I < 4; I++) p[I] = fmaf(p[I], beta, r[I]);
+      rsold = rsnew;
+    }
+    // ---- the row and its loss term: sum c - 2 y.b + y^T (M1 + M2) y + lambda |y|^2 ----
+    if (hf == 0) {
+#pragma unroll
+      for (int I = 0; I < 4; I++) yrow[32 * I + n] = x[I];
+    }
+    float q1[4], q2[4];
+    cgm_matvec(rd_m1, g_none, sw, n, hf, ln, x, q1);   // M1 y
+    auto rd_m2 = [&](auto tt, auto vt) {
+      constexpr int T = decltype(tt)::value, v = decltype(vt)::value;
+      if constexpr (T < 6) return mf_rd<160 + 16 * T + v>();
+      else return hi[T - 6][v];
+    };
+    cgm_matvec(rd_m2, g_none, sw, n, hf, ln, x, q2);   // M2 y
+    const float yb = cgm_dot(x, b, hf), yy = cgm_dot(x, x, hf);
+    float qq[4];
+#pragma unroll
+    for (int I = 0; I < 4; I++) qq[I] = q1[I] + q2[I];
+    const float yMy = cgm_dot(x, qq, hf);
+    const float sc = wave_sum(csum);
+    if (lane == 0) sw.loss += ((double)sc - 2.0 * (double)yb + (double)yMy) + a.lambda_loss * (double)yy;
+    wave_sync();
+  }
+  if (lane == 0) a.loss_partials[loss_slot0 + 4 * blockIdx.x + wv] = sw.loss;
+}
+
+}  // namespace
+}  // namespace rsparse_hip
+
+#define CGM_KERNEL(NAME, SYM)                                                                                                     \
+  extern "C" __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(128))) void NAME(                                  \
+      rsparse_hip::AlsArgs a, const int32_t* __restrict__ rows, int n_rows, int loss_slot0) {                                       \
+    rsparse_hip::als_cg_mf_body<SYM>(a, rows, n_rows, loss_slot0);                                                                  \
+  }
+CGM_KERNEL(rsparse_hip_als_cg_mf_implicit, true)
+CGM_KERNEL(rsparse_hip_als_cg_mf_implicit_any, false)
+#undef CGM_KERNEL
+
+namespace rsparse_hip {
+
+bool cg_mf_supported(int k, bool implicit) { return implicit && k == 128; }
+int cg_mf_grid(int n_rows) { return std::max(1, std::min((n_rows + 3) / 4, kCgMfGrid)); }
+// two launches (see the kernel's first lines), each with one slot per wave
+int cg_mf_loss_slots(int n_rows) { return 2 * 4 * cg_mf_grid(n_rows); }
+
+hipError_t launch_als_cg_mf(const AlsArgs& a, const int32_t* rows, int n_rows, int loss_slot0, hipStream_t s, hipEvent_t* ev_slot) {
+  if (n_rows <= 0) return hipSuccess;
+  if (!a.ne_stats || !cg_mf_supported(a.k, true) || (reinterpret_cast<uintptr_t>(a.X) & 3)) return hipErrorInvalidValue;
+  const int grid = cg_mf_grid(n_rows);
+  auto kern = rsparse_hip_als_cg_mf_implicit;
+  auto kern2 = rsparse_hip_als_cg_mf_implicit_any;
+  const int b1 = (int)sizeof(CgmSmem<12>), b2 = (int)sizeof(CgmSmem<20>);
+  hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, b1)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, b2)) != hipSuccess) return e;
+  prof_note(ev_slot, reinterpret_cast<const void*>(kern));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), b1, s, a, rows, n_rows, loss_slot0);
+  hipLaunchKernelGGL(kern2, dim3(grid), dim3(256), b2, s, a, rows, n_rows, loss_slot0 + 4 * grid);
+  return hipGetLastError();
+}
+
+}  // namespace rsparse_hip

@@ -1145,7 +1145,7 @@ hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int 
 // caller's stream with events, so the call stays asynchronous and ordered on that stream.
 struct BucketStreams {
   hipStream_t st[kNB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t fork = nullptr;
+  hipEvent_t fork = nullptr, fork0 = nullptr;   // fork0: in front of the first bucket's two launches (round 6)
   hipEvent_t done[kNB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int device = -1;
   hipError_t ensure() {
@@ -1155,6 +1155,7 @@ struct BucketStreams {
     if (dev == device) return hipSuccess;
     device = dev;  // streams belong to a device; a process drives one GPU, so this happens once
     if ((err = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return err;
+    if ((err = hipEventCreateWithFlags(&fork0, hipEventDisableTiming)) != hipSuccess) return err;
     for (int b = 0; b < kNB; b++) {
       if ((err = hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking)) != hipSuccess) return err;
       if ((err = hipEventCreateWithFlags(&done[b], hipEventDisableTiming)) != hipSuccess) return err;
@@ -1175,7 +1176,7 @@ size_t bucket_slots(const QSchedule& q, int b, int k, bool implicit) {
   const int cfg = cfg_of_kp(padded_rank(k));
   const BucketDef d = kBuckets[cfg][b];
   if (d.wpr <= 0) return 0;
-  if (d.stream && ne_supported(k)) return (size_t)(q.ne_entries + q.ne_nsplit);
+  if (d.stream && ne_supported(k)) return (size_t)(q.ne_entries + q.ne_nsplit) + (size_t)(q.mf_n > 0 ? cg_mf_loss_slots(q.mf_n) : 0);
   const int rows = q.off[b + 1] - q.off[b];
   if (b == kNB - 1 && rows > 0 && cgp_supported(k, implicit) && dense_mfma_enabled()) {
     const int split = std::min(std::max(q.pair_first, q.off[b]), q.off[b + 1]);
@@ -1214,8 +1215,30 @@ hipError_t launch_all(const AlsArgs& a, const QSchedule& q, hipStream_t s, hipEv
           if ((err = hipStreamWaitEvent(bs, g_bs.fork, 0)) != hipSuccess) return err;                       \
         }                                                                                                   \
         if (D.stream && ne_supported(a.k)) {                                                                \
-          if ((err = launch_als_ne(a, q, IMPLICIT, a.loss_partials + slot, bs, ev ? ev + B : nullptr)) != hipSuccess) \
+          /* rank 128 (round 6): the rows up to kCgMfMax non-zeros one wave per row (wrmf_cg_mf.hip) on the bucket's side stream, */ \
+          /* the giant rows on the normal-equation kernel beside it (few workgroups: they start first, they end last) */ \
+          /* (the giant rows' launch is SUBMITTED first: the wave-per-row workgroups live as long as their launch and */ \
+          /*  leave no register file for a partner, so a launch submitted behind them starts when they end) */ \
+          const bool mside = overlap && q.ne_wg > 0 && q.mf_n > 0;                                          \
+          /* (a fork point of its own in FRONT of the giant rows' launch; the other buckets still fork behind both) */ \
+          if (mside && (err = hipEventRecord(g_bs.fork0, s)) != hipSuccess) return err;                     \
+          if (q.ne_wg > 0 &&                                                                                \
+              (err = launch_als_ne(a, q, IMPLICIT, a.loss_partials + slot, bs, q.mf_n > 0 ? nullptr : (ev ? ev + B : nullptr))) != hipSuccess) \
             return err;                                                                                     \
+          if (q.mf_n > 0) {                                                                                 \
+            hipStream_t ms = bs;                                                                            \
+            if (mside) {                                                                                    \
+              ms = g_bs.st[B];                                                                              \
+              if ((err = hipStreamWaitEvent(ms, g_bs.fork0, 0)) != hipSuccess) return err;                  \
+            }                                                                                               \
+            if ((err = launch_als_cg_mf(a, q.mf_rows, q.mf_n, (int)(slot + (size_t)(q.ne_entries + q.ne_nsplit)), ms, \
+                                        ev ? ev + B : nullptr)) != hipSuccess)                              \
+              return err;                                                                                   \
+            if (mside) {                                                                                    \
+              if ((err = hipEventRecord(g_bs.done[B], ms)) != hipSuccess) return err;                       \
+              if ((err = hipStreamWaitEvent(s, g_bs.done[B], 0)) != hipSuccess) return err;                 \
+            }                                                                                               \
+          }                                                                                                 \
         } else if constexpr (D.stream && KP > 32) {   /* ranks above 32 always take the branch above */     \
           return hipErrorInvalidValue;                                                                      \
         } else if (B == kNB - 1 && cgp_supported(a.k, IMPLICIT) && dense_mfma_enabled()) {                    \

@@ -156,6 +156,8 @@ struct QSchedule {
   const int32_t* ne_split_rows;   // per split row: -(index of its first segment + 1); ne_split_ptr = 0, 1, 2, ...
   const int32_t* ne_split_ptr;
   int ne_nsplit;
+  const int32_t* mf_rows = nullptr;   // wrmf_cg_mf.hip's rows of the first bucket (the normal-equation lists above then hold the giant rows only)
+  int mf_n = 0;
 };
 int cgq_default_cfg();
 void cgq_set_launch_mode(int mode);   // rsparse_hip_set_launch_mode
@@ -175,7 +177,7 @@ hipError_t launch_als_cgp(const AlsArgs& a, const int32_t* rows, int n_rows, siz
 // long rows (bucket 0) by one-pass normal equations on the matrix cores (wrmf_ne.hip) instead of the streamed CG kernel
 bool ne_supported(int k);
 constexpr int kNeMinLen = 512;       // its rows: more non-zeros than the largest resident bucket of wrmf_cgq.hip holds
-constexpr int kNeCholMinLen = 64;   // solver == CHOLESKY: default threshold of the same launch (RSPARSE_HIP_NE_CHOL_MIN overrides, 64..512)
+constexpr int kNeCholMinLen = 64;   // (rounds 2-5: solver == CHOLESKY's threshold of the same launch; dev builds: RSPARSE_HIP_NE_CHOL_MIN)
 constexpr int kNeMaxSeg = 16;        // segments per split row
 constexpr int kNeMaxSegTotal = 64;   // ... per matrix
 constexpr int kNeSegFloats = 4 * (11 * 16 * 64 + 128 + 2);   // per segment: 4 waves x (<= 11 accumulator tiles + b + sum c)
@@ -237,6 +239,15 @@ int chol_mf_grid(int n_rows);
 int chol_mf_loss_slots(int n_rows, bool implicit);
 hipError_t launch_als_chol_mf(const AlsArgs& a, bool implicit, const int32_t* rows, int n_rows, int loss_slot0, hipStream_t s,
                               hipEvent_t* ev_slot);
+// rank 128, implicit feedback, conjugate gradient (round 6, wrmf_cg_mf.hip): the rows of kNeMinLen + 1 .. kCgMfMax non-zeros as one
+// wave per row -- both normal-equation matrices in the accumulator registers, CG from the tiles.  The rows beyond kCgMfMax stay
+// on wrmf_ne.hip (it splits them across workgroups).  Needs a.ne_stats.  Loss partials [loss_slot0, + cg_mf_loss_slots(n_rows))
+constexpr int kCgMfMax = 16384;
+constexpr int kCgMfGrid = 256 * 16;   // workgroups of four waves (a row each at a time), grid-stride over the rows (longest first)
+bool cg_mf_supported(int k, bool implicit);
+int cg_mf_grid(int n_rows);
+int cg_mf_loss_slots(int n_rows);
+hipError_t launch_als_cg_mf(const AlsArgs& a, const int32_t* rows, int n_rows, int loss_slot0, hipStream_t s, hipEvent_t* ev_slot);
 hipError_t launch_als_nnls(const AlsArgs& a, bool implicit, hipStream_t s, hipEvent_t* ev = nullptr);
 constexpr int kLuGrid = 64;          // workgroups (and loss slots) of the general-solver fallback
 constexpr int kFailCap = 1 << 16;    // rows it can take per half-iteration call

@@ -465,10 +465,6 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
         g[4 * q] = t.x; g[4 * q + 1] = t.y; g[4 * q + 2] = t.z; g[4 * q + 3] = t.w;
       }
     };
-    auto g_none = [&](auto, float (&g)[16]) {
-#pragma unroll
-      for (int v = 0; v < 16; v++) g[v] = 0.f;
-    };
     // ---- cg_solver_implicit (wrmf_implicit.hpp:8-32) on A = XtX + M1 ----
     float r[4], p[4], ap[4];
     cgm_matvec(rd_m1, g_tile, sw, n, hf, ln, x, ap);
@@ -492,19 +488,44 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
 #pragma unroll
       for (int I = 0; I < 4; I++) yrow[32 * I + n] = x[I];
     }
-    float q1[4], q2[4];
-    cgm_matvec(rd_m1, g_none, sw, n, hf, ln, x, q1);   // M1 y
     auto rd_m2 = [&](auto tt, auto vt) {
       constexpr int T = decltype(tt)::value, v = decltype(vt)::value;
       if constexpr (T < 6) return mf_rd<160 + 16 * T + v>();
       else return hi[T - 6][v];
     };
-    cgm_matvec(rd_m2, g_none, sw, n, hf, ln, x, q2);   // M2 y
-    const float yb = cgm_dot(x, b, hf), yy = cgm_dot(x, x, hf);
-    float qq[4];
+    // y^T (M1 + M2) y from the lower tiles: sum over the tiles of y_I(n) * (tile row . y_K), off-diagonal tiles twice -- the
+    // "direct" half of a product only, both matrices in one pass
+    float yMy;
+    {
+      wave_sync();
+      if (hf == 0) {
 #pragma unroll
-    for (int I = 0; I < 4; I++) qq[I] = q1[I] + q2[I];
-    const float yMy = cgm_dot(x, qq, hf);
+        for (int I = 0; I < 4; I++) sw.vec[32 * I + n] = x[I];
+      }
+      wave_sync();
+      float part = 0.f;
+      mf_sfor<4>([&](auto kt) {
+        constexpr int K = decltype(kt)::value;
+        float pc[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 t = *reinterpret_cast<const float4*>(&sw.vec[32 * K + 8 * q + 4 * hf]);
+          pc[4 * q] = t.x; pc[4 * q + 1] = t.y; pc[4 * q + 2] = t.z; pc[4 * q + 3] = t.w;
+        }
+        mf_sfor<4 - K>([&](auto st) {
+          constexpr int I = K + decltype(st)::value;
+          constexpr int T = mf_tid(I, K);
+          float d = 0.f;
+          mf_sfor<16>([&](auto vt) {
+            constexpr int v = decltype(vt)::value;
+            d = fmaf(rd_m1(std::integral_constant<int, T>{}, vt) + rd_m2(std::integral_constant<int, T>{}, vt), pc[v], d);
+          });
+          part = fmaf(I == K ? d : 2.f * d, x[I], part);
+        });
+      });
+      yMy = wave_sum(part);   // (both halves of the wave hold half of every row's columns: the sum over all 64 lanes is the form)
+    }
+    const float yb = cgm_dot(x, b, hf), yy = cgm_dot(x, x, hf);
     const float sc = wave_sum(csum);
     if (lane == 0) sw.loss += ((double)sc - 2.0 * (double)yb + (double)yMy) + a.lambda_loss * (double)yy;
     wave_sync();

@@ -399,16 +399,18 @@ def test_wrmf_double_every_solver_at_the_baseline_ranks(ml_train, k, feedback, s
     rng = np.random.default_rng(k + len(solver))
     kk = k + (2 if bias else 0)
     U0 = rng.standard_normal((n_user, kk)) * 0.01
+    V0 = rng.standard_normal((kk, n_item)) * 0.01   # (the non-CG solvers start from drawn item factors: R/model_WRMF.R:219-231)
     if solver == "nnls":
-        U0 = np.abs(U0)
+        U0, V0 = np.abs(U0), np.abs(V0)
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        model = WRMF(rank=k, lambda_=0.1, feedback=feedback, solver=solver, precision="double", with_user_item_bias=bias)
+        model = WRMF(rank=k, lambda_=0.1, feedback=feedback, solver=solver, precision="double", with_user_item_bias=bias,
+                     init=V0.copy())
     assert model._f64
     model._init_user_factors = U0
     emb = model.fit_transform(train, n_iter=2, convergence_tol=-1)
     ref = O.OracleWRMF(k, lam=0.1, feedback=feedback, solver=solver, dtype=np.float64, n_threads=8, with_user_item_bias=bias)
-    ref_emb = ref.fit_transform(n_user, n_item, p, i, x, U0.T.copy(), n_iter=2, convergence_tol=-1)
+    ref_emb = ref.fit_transform(n_user, n_item, p, i, x, U0.T.copy(), n_iter=2, convergence_tol=-1, init_components=V0.copy())
     tol = 1e-6 if solver == "nnls" else 1e-9
     assert emb.dtype == np.float64 and rel_fro(emb, ref_emb) < tol
     assert rel_fro(model.components, ref.components) < tol

@@ -49,17 +49,12 @@ namespace rsparse_hip {
 namespace {
 
 constexpr float kCgTolMf = 1e-10f;   // CG_TOL, inst/include/wrmf.hpp:22
-// Measured and not kept (profiles/r06/r6o_*): the previous step's matrix instructions in five groups of eight BETWEEN the pieces of
-// this step's vector work, their operands waiting in LDS -- 19.8 ms per launch against 17.3 with the operands in registers and the
-// 40 instructions in one block (the staging writes, 60 operand reads per step and the lost scheduling freedom cost more than the
-// 1280 cycles of matrix-pipe time they were meant to hide).  -DCGM_INTERLEAVE=1 builds it.
-#ifndef CGM_INTERLEAVE
-#define CGM_INTERLEAVE 0
-#endif
-#ifndef CGM_TOUCH
-#define CGM_TOUCH 0
-#endif
-
+// Measured and not kept, first version (two REGISTER buffers, asm loads, one `s_waitcnt vmcnt(0)` per step: 17.3 ms per launch):
+//  - the previous step's matrix instructions in five groups of eight BETWEEN the pieces of this step's vector work, their operands
+//    waiting in LDS: 19.8 ms (profiles/r06/r6o_*) -- the staging writes, 60 operand reads per step and the lost scheduling freedom
+//    cost more than the 1280 cycles of matrix-pipe time they were meant to hide;
+//  - one extra load per step touching the 64 cache lines of step s + 2 so that they are in L2 early: 17.7 ms (profiles/r06/r6p_*);
+//  - a third register buffer: 96 + 64 (M2's last tiles) + a step's operands do not fit 256 registers (31 scratch accesses per step).
 // the leading fp16 term alone (M2: one product)
 __device__ __forceinline__ void cgm_operands_hi(const float (&x)[16], f16x8& h0, f16x8& h1) {
   float b0[8], b1[8];
@@ -83,10 +78,11 @@ __device__ __forceinline__ void cgm_operands_hi(const float (&x)[16], f16x8& h0,
 template <int NOPS>
 struct CgmWave {               // per wave
   union {
-    float4 ops[2][12][64];     // streaming (SYM): a step's operands between their split and their products, which run interleaved
-                               // with the NEXT step's vector work -- M1 hi [0..3], lo [4..7], M2 hi [8..11]; double-buffered by step parity
+    float ring[3][2048];       // streaming: three steps of 16 vectors, written by LDS-DMA: non-zero j = 8 h + i of a step at [i][h][128]
     float T[32 * 36];          // solve: the transposed part of a product: [column][lane], rows padded to 36 floats (conflict-free b128 reads)
   };
+  int midx[3][64];             // three chunks of 64 (index, confidence) pairs, by LDS-DMA too
+  float mval[3][64];
   float vec[128];              // a vector in "register = column" order's source: p (or y) by coordinate
   float x0[128];               // warm start
   float rhs[128];              // b
@@ -219,53 +215,66 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       for (int e = 0; e < 16; e++) hi[t][e] = 0.f;
     float u0 = 0.f, u1 = 0.f, csum = 0.f;   // rhs (lane = coordinate), sum of the confidences (lane j: its slots')
     {
-      // A step = 16 non-zeros, two register buffers.  The NEXT step's vectors are requested first (asm loads: one coordinate per
-      // lane and register, the vector's address scalar arithmetic), then this step's right-hand side, scaling and split into fp16
-      // terms and its 40 matrix instructions run while they fly, then ONE wait.  One wave per SIMD has nobody to hide a stall
-      // behind: with the requests issued only in front of the matrix instructions (the exact solver's loop, two waves per SIMD)
-      // this kernel moved its rows no faster than the one it replaces (18.1 against 20.1 ms, profiles/r06/r6m_*).
-      const int vo0 = 4 * ln, vo1 = 4 * (ln + 64);
+      // A step = 16 non-zeros = 8 KB of vectors.  They arrive by LDS-DMA (global_load_lds_dwordx4: a lane brings 16 bytes, an
+      // instruction two whole vectors -- lanes 0..31 non-zero i, lanes 32..63 non-zero 8 + i -- into 1 KB of LDS at M0) in a ring of
+      // three steps per wave, and so do the row's indices and confidences, 64 at a time (a "chunk" = four steps).  Nothing in flight
+      // has a register: steps s + 1 and s + 2 are on their way while step s is consumed (twice what the two register buffers of the
+      // first version held, which moved 3.7 TB/s: 8 KB per wave x 4 waves per CU in flight is what the memory system returned in
+      // ~2 us), the queue is never drained (counted waits: the loads return in order), and the 32 registers of the second buffer are
+      // free.  Per sub-step: wait until step s has landed; request step s + 2 (its slot was consumed in sub-step s - 1) and, every
+      // fourth sub-step, chunk c + 2 of the indices; read step s out of LDS (lane = coordinate), right-hand side, split, 40 matrix
+      // instructions.
       const int nsteps = (p2 - p1 + 15) >> 4;
-      auto meta_pos = [&](const int st) __attribute__((always_inline)) {   // (steps beyond the row ask for its last entry: no branch; their weight is 0)
-        const int base = p1 + 16 * min(st, nsteps - 1);
-        return base + min(ln & 15, min(16, p2 - base) - 1);
+      const int hfl = ln >> 5;
+      const char* xlane = reinterpret_cast<const char*>(a.X) + 16 * (ln & 31);
+      const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sw.ring[0][0]);
+      const unsigned meta_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sw.midx[0][0]);
+      // chunk c of the row's (index, confidence) pairs -> sw.midx / sw.mval [c % 3]; positions beyond the row repeat its last entry
+      auto request_meta = [&](const int c) __attribute__((always_inline)) {
+        const int pos = min(p1 + 64 * c + ln, p2 - 1);
+        const int* gi = a.row_idx + pos;
+        const float* gv = a.vals + pos;
+        const unsigned dst = meta_lds + 256u * (unsigned)(c % 3);
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+            "global_load_lds_dword %[gi], off\n\ts_add_u32 m0, m0, 0x300\n\ts_nop 0\n\t"
+            "global_load_lds_dword %[gv], off\n\t"
+            "s_mov_b32 m0, %[k]"
+            : [k] "=&s"(keep)
+            : [l] "s"(dst), [gi] "v"(gi), [gv] "v"(gv)
+            : "memory", "scc");
       };
-      auto request = [&](const int idj, float (&x0)[16], float (&x1)[16]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s2 = 0; s2 < 16; s2++) {
-          const float* bp = a.X + (size_t)__builtin_amdgcn_readlane(idj, s2) * k;
-          mf_ld(x0[s2], bp, vo0);
-          mf_ld(x1[s2], bp, vo1);
-        }
+      // the 16 vectors of step st -> sw.ring[st % 3]: non-zero j = 8 h + i at [i][h][128]
+      auto request = [&](const int st, const int slot) __attribute__((always_inline)) {
+        const int* ip = &sw.midx[(st >> 2) % 3][16 * (st & 3) + 8 * hfl];
+        const int4 ia = *reinterpret_cast<const int4*>(ip), ib = *reinterpret_cast<const int4*>(ip + 4);
+        const char* g0 = xlane + (size_t)ia.x * (k * 4);
+        const char* g1 = xlane + (size_t)ia.y * (k * 4);
+        const char* g2 = xlane + (size_t)ia.z * (k * 4);
+        const char* g3 = xlane + (size_t)ia.w * (k * 4);
+        const char* g4 = xlane + (size_t)ib.x * (k * 4);
+        const char* g5 = xlane + (size_t)ib.y * (k * 4);
+        const char* g6 = xlane + (size_t)ib.z * (k * 4);
+        const char* g7 = xlane + (size_t)ib.w * (k * 4);
+        const unsigned dst = ring_lds + 8192u * (unsigned)slot;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[g0], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[g1], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[g2], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[g3], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[g4], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[g5], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[g6], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[g7], off\n\t"
+            "s_mov_b32 m0, %[k]"
+            : [k] "=&s"(keep)
+            : [l] "s"(dst), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3), [g4] "v"(g4), [g5] "v"(g5), [g6] "v"(g6), [g7] "v"(g7)
+            : "memory", "scc");
       };
-      // index / value of step st + 2 into (idf, cvf): asm loads too, covered by the step's one wait
-      auto request_meta = [&](const int st, int& idf, float& cvf) __attribute__((always_inline)) {
-        const int pos = meta_pos(st);
-        asm volatile("global_load_dword %0, %1, %2" : "=&v"(idf) : "v"(4 * pos), "s"(a.row_idx));
-        asm volatile("global_load_dword %0, %1, %2" : "=&v"(cvf) : "v"(4 * pos), "s"(a.vals));
-      };
-      // SYM: the matrix instructions of step st - 1 (operands in LDS, sw.ops[(st - 1) & 1]) in five groups of eight -- two tiles each,
-      // their three M1 products and one M2 product alternating so that no instruction waits for its predecessor's result --
-      // BETWEEN the five pieces of step st's vector work: one wave per SIMD has nobody else to fill the 32 cycles a matrix
-      // instruction holds the pipe (as one block of 40 behind the vector work they cost 1280 cycles per step on top of it)
-      auto mgroup = [&](auto gt, const int par) __attribute__((always_inline)) {
-        constexpr int G = decltype(gt)::value;
-        constexpr int GI[5][2] = {{0, 1}, {2, 3}, {1, 2}, {3, 2}, {3, 3}}, GK[5][2] = {{0, 0}, {0, 0}, {1, 1}, {1, 2}, {2, 3}};
-        constexpr int I0 = GI[G][0], K0 = GK[G][0], I1 = GI[G][1], K1 = GK[G][1];
-        auto ld = [&](const int t) { return __builtin_bit_cast(f16x8, sw.ops[par][t][ln]); };
-        const f16x8 ahK0 = ld(K0), alK0 = ld(4 + K0), mhK0 = ld(8 + K0), ahI0 = ld(I0), alI0 = ld(4 + I0), mhI0 = ld(8 + I0);
-        const f16x8 ahK1 = ld(K1), alK1 = ld(4 + K1), mhK1 = ld(8 + K1), ahI1 = ld(I1), alI1 = ld(4 + I1), mhI1 = ld(8 + I1);
-        constexpr int T0 = mf_tid(I0, K0), T1 = mf_tid(I1, K1);
-        mf_mma16<T0>(ahK0, ahI0); mf_mma16<T1>(ahK1, ahI1);
-        mf_mma16<T0>(ahK0, alI0); mf_mma16<T1>(ahK1, alI1);
-        mf_mma16<T0>(alK0, ahI0); mf_mma16<T1>(alK1, ahI1);
-        if constexpr (T0 < 6) mf_mma16<10 + T0>(mhK0, mhI0);
-        else hi[T0 - 6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mhK0, mhI0, hi[T0 - 6], 0, 0, 0);
-        if constexpr (T1 < 6) mf_mma16<10 + T1>(mhK1, mhI1);
-        else hi[T1 - 6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mhK1, mhI1, hi[T1 - 6], 0, 0, 0);
-      };
-      auto consume = [&](const int st, const int idj_unused, const float cvr, float (&xs0)[16], float (&xs1)[16]) __attribute__((always_inline)) {
-        (void)idj_unused;
+      auto consume = [&](const int st, const float cvr, float (&xs0)[16], float (&xs1)[16]) __attribute__((always_inline)) {
         const int ccnt = min(16, p2 - (p1 + 16 * st));
         const bool inl = (ln & 15) < ccnt;
         const float cvj = inl ? cvr : 0.f;
@@ -274,9 +283,6 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
         float f1;                                                                              // M1's
         if constexpr (SYM) f1 = inl ? sx * __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_) : 0.f;
         else f1 = inl ? (cvr - 1.f) * sw_ : 0.f;   // (!SYM: the A side's extra factor on top of the B side's 2^e x)
-        const int par = st & 1, prev = par ^ 1;
-        const bool have_prev = st > 0;   // wave-uniform
-        auto stash = [&](const int t, const f16x8& v) { sw.ops[par][t][ln] = __builtin_bit_cast(float4, v); };
         // the right-hand side from the raw vectors, which then become 2^e x IN PLACE (no second copy: three buffers of 32
         // registers are in flight or in use next to the 64 of M2's last four tiles)
 #pragma unroll
@@ -292,143 +298,102 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
         __builtin_amdgcn_sched_barrier(0);
         float (&xm0)[16] = xs0;
         float (&xm1)[16] = xs1;
-        if constexpr (SYM && CGM_INTERLEAVE) {
-          if (have_prev) mgroup(std::integral_constant<int, 0>{}, prev);
-          __builtin_amdgcn_sched_barrier(0);
-          f16x8 h0, l0, h1, l1;
-          cgm_operands_hi(xm0, h0, h1);
-          stash(8, h0); stash(9, h1);
-          cgm_operands_hi(xm1, h0, h1);
-          stash(10, h0); stash(11, h1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (have_prev) mgroup(std::integral_constant<int, 1>{}, prev);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int s2 = 0; s2 < 16; s2++) {
-            const float s_a = readlane_f(f1, s2);
-            xs0[s2] *= s_a;
-            xs1[s2] *= s_a;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (have_prev) mgroup(std::integral_constant<int, 2>{}, prev);
-          __builtin_amdgcn_sched_barrier(0);
-          mf_operands(xs0, h0, l0, h1, l1);
-          stash(0, h0); stash(4, l0); stash(1, h1); stash(5, l1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (have_prev) mgroup(std::integral_constant<int, 3>{}, prev);
-          __builtin_amdgcn_sched_barrier(0);
-          mf_operands(xs1, h0, l0, h1, l1);
-          stash(2, h0); stash(6, l0); stash(3, h1); stash(7, l1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (have_prev) mgroup(std::integral_constant<int, 4>{}, prev);
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
-          // The operands stay in registers and the 40 matrix instructions follow the vector work.  SYM: one operand set for M1
-          // (A side = B side).  Some confidence below 1: B side = 2^e x with both terms (M2 uses its leading term), A side =
-          // 2^e' (c - 1) 2^e x.
-          f16x8 ah[4], al[4], mh[4], bh[4], bl[4];
-          auto m2_products = [&]() __attribute__((always_inline)) {   // (first: their operand dies before M1's are built)
-            mf_sfor<4>([&](auto kt) {
-              constexpr int K = decltype(kt)::value;
-              mf_sfor<4 - K>([&](auto st2) {
-                constexpr int I = K + decltype(st2)::value;
-                constexpr int T = mf_tid(I, K);
-                if constexpr (T < 6) mf_mma16<10 + T>(mh[K], mh[I]);
-                else hi[T - 6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[K], mh[I], hi[T - 6], 0, 0, 0);
-              });
-            });
-          };
-          // g = f1 / f2: the factor that turns M2's operand 2^e x into M1's (SYM: sqrt((c - 1) 2^e'); else (c - 1) 2^e')
-          float gj;
-          if constexpr (SYM) gj = inl ? __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_) : 0.f;
-          else gj = f1;
-          if constexpr (SYM) {
-            cgm_operands_hi(xm0, mh[0], mh[1]);
-            cgm_operands_hi(xm1, mh[2], mh[3]);
-            __builtin_amdgcn_sched_barrier(0);
-            m2_products();
-            __builtin_amdgcn_sched_barrier(0);
-          } else {
-            mf_operands(xm0, bh[0], bl[0], bh[1], bl[1]);
-            mf_operands(xm1, bh[2], bl[2], bh[3], bl[3]);
-#pragma unroll
-            for (int t = 0; t < 4; t++) mh[t] = bh[t];
-            __builtin_amdgcn_sched_barrier(0);
-            m2_products();
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < 16; s2++) {
-            const float s_a = readlane_f(gj, s2);
-            xs0[s2] *= s_a;
-            xs1[s2] *= s_a;
-          }
-          mf_operands(xs0, ah[0], al[0], ah[1], al[1]);
-          __builtin_amdgcn_sched_barrier(0);
-          mf_operands(xs1, ah[2], al[2], ah[3], al[3]);
-          __builtin_amdgcn_sched_barrier(0);
-          mf_sfor<3>([&](auto pt) {
-            constexpr int pr = decltype(pt)::value;
-            mf_sfor<4>([&](auto kt) {
-              constexpr int K = decltype(kt)::value;
-              mf_sfor<4 - K>([&](auto st2) {
-                constexpr int I = K + decltype(st2)::value;
-                if constexpr (SYM) mf_mma16<mf_tid(I, K)>(pr == 2 ? al[K] : ah[K], pr == 1 ? al[I] : ah[I]);
-                else mf_mma16<mf_tid(I, K)>(pr == 2 ? al[K] : ah[K], pr == 1 ? bl[I] : bh[I]);
-              });
+        // The operands stay in registers and the 40 matrix instructions follow the vector work.  SYM: one operand set for M1
+        // (A side = B side).  Some confidence below 1: B side = 2^e x with both terms (M2 uses its leading term), A side =
+        // 2^e' (c - 1) 2^e x.
+        f16x8 ah[4], al[4], mh[4], bh[4], bl[4];
+        auto m2_products = [&]() __attribute__((always_inline)) {   // (first: their operand dies before M1's are built)
+          mf_sfor<4>([&](auto kt) {
+            constexpr int K = decltype(kt)::value;
+            mf_sfor<4 - K>([&](auto st2) {
+              constexpr int I = K + decltype(st2)::value;
+              constexpr int T = mf_tid(I, K);
+              if constexpr (T < 6) mf_mma16<10 + T>(mh[K], mh[I]);
+              else hi[T - 6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[K], mh[I], hi[T - 6], 0, 0, 0);
             });
           });
+        };
+        // g = f1 / f2: the factor that turns M2's operand 2^e x into M1's (SYM: sqrt((c - 1) 2^e'); else (c - 1) 2^e')
+        float gj;
+        if constexpr (SYM) gj = inl ? __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_) : 0.f;
+        else gj = f1;
+        if constexpr (SYM) {
+          cgm_operands_hi(xm0, mh[0], mh[1]);
+          cgm_operands_hi(xm1, mh[2], mh[3]);
+          __builtin_amdgcn_sched_barrier(0);
+          m2_products();
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          mf_operands(xm0, bh[0], bl[0], bh[1], bl[1]);
+          mf_operands(xm1, bh[2], bl[2], bh[3], bl[3]);
+#pragma unroll
+          for (int t = 0; t < 4; t++) mh[t] = bh[t];
+          __builtin_amdgcn_sched_barrier(0);
+          m2_products();
+          __builtin_amdgcn_sched_barrier(0);
         }
-      };
-      // TWO register buffers.  Per step s: the index / value pair of step s + 3 is requested (asm loads like the vectors: hipcc's
-      // own wait for a plain load would drain the queue), the 32 vector pieces of step s + 1 into the other buffer, step s is
-      // consumed, one `s_waitcnt vmcnt(0)`.  Measured and not kept: (i) a THIRD register buffer -- 96 + 64 (M2's last tiles) + a
-      // step's operands do not fit 256 vector registers, hipcc answered with 31 scratch accesses per step (compiled, not run);
-      // (ii) -DCGM_TOUCH=1: one load instruction per step that touches the 64 cache lines of step s + 2's vectors so that they are
-      // on their way into L2 two steps ahead: 17.7 ms per launch against 17.3 (profiles/r06/r6p_*).
-      auto wait_all = [&](float (&x0)[16], float (&x1)[16], int& id_, float& cv_, float& dummy) __attribute__((always_inline)) {
-        mf_wait(x0, x1);
-        asm volatile("" : "+v"(id_), "+v"(cv_), "+v"(dummy));
-      };
-      float xa0[16], xa1[16], xb0[16], xb1[16];
-      int m0i = a.row_idx[meta_pos(0)], m1i = a.row_idx[meta_pos(1)], m2i = a.row_idx[meta_pos(2)], m3i = 0;
-      float m0c = a.vals[meta_pos(0)], m1c = a.vals[meta_pos(1)], m2c = a.vals[meta_pos(2)], m3c = 0.f;
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(m0i), "+v"(m1i), "+v"(m2i), "+v"(m0c), "+v"(m1c), "+v"(m2c));
-      request(m0i, xa0, xa1);
-      {
-        int idd = 0; float cvd = 0.f, dd = 0.f;
-        wait_all(xa0, xa1, idd, cvd, dd);
-      }
-      const int tl = 128 * (ln & 3);   // (CGM_TOUCH) this lane's line of the vector it touches
-      (void)tl;
-      // sub-step: metas (m0, m1, m2) = steps (s, s + 1, s + 2), all landed; cur = buffer of step s, nxt = the other one
-      auto substep = [&](const int st, float (&cur0)[16], float (&cur1)[16], float (&nxt0)[16], float (&nxt1)[16]) __attribute__((always_inline)) {
-        request_meta(st + 3, m3i, m3c);
-        float dummy = 0.f;
-#if CGM_TOUCH
-        {
-          const int idt = __shfl(m2i, ln >> 2);   // (lane j mod 16 holds non-zero j: lanes 0..15 serve all 64)
-          const float* tp = a.X + (size_t)idt * k;
-          asm volatile("global_load_dword %0, %1, off offset:0" : "=&v"(dummy) : "v"(reinterpret_cast<const char*>(tp) + tl));
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) {
+          const float s_a = readlane_f(gj, s2);
+          xs0[s2] *= s_a;
+          xs1[s2] *= s_a;
         }
-#endif
-        request(m1i, nxt0, nxt1);
+        mf_operands(xs0, ah[0], al[0], ah[1], al[1]);
         __builtin_amdgcn_sched_barrier(0);
-        consume(st, m0i, m0c, cur0, cur1);
+        mf_operands(xs1, ah[2], al[2], ah[3], al[3]);
         __builtin_amdgcn_sched_barrier(0);
-        wait_all(nxt0, nxt1, m3i, m3c, dummy);
-        m0i = m1i; m0c = m1c; m1i = m2i; m1c = m2c; m2i = m3i; m2c = m3c;   // (all landed: a register in flight is never moved)
+        mf_sfor<3>([&](auto pt) {
+          constexpr int pr = decltype(pt)::value;
+          mf_sfor<4>([&](auto kt) {
+            constexpr int K = decltype(kt)::value;
+            mf_sfor<4 - K>([&](auto st2) {
+              constexpr int I = K + decltype(st2)::value;
+              if constexpr (SYM) mf_mma16<mf_tid(I, K)>(pr == 2 ? al[K] : ah[K], pr == 1 ? al[I] : ah[I]);
+              else mf_mma16<mf_tid(I, K)>(pr == 2 ? al[K] : ah[K], pr == 1 ? bl[I] : bh[I]);
+            });
+          });
+        });
       };
-      for (int st = 0; st < nsteps; st += 2) {
-        substep(st, xa0, xa1, xb0, xb1);
-        if (st + 1 >= nsteps) break;   // wave-uniform
-        substep(st + 1, xb0, xb1, xa0, xa1);
+      // prologue: chunks 0 and 1 of the indices, then steps 0 and 1
+      wave_sync();
+      request_meta(0);
+      request_meta(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      request(0, 0);
+      request(1, 1);
+      int slot = 0;   // = st % 3
+      for (int c = 0; 4 * c < nsteps; c++) {
+        bool done = false;
+        mf_sfor<4>([&](auto jt) {
+          constexpr int j = decltype(jt)::value;
+          const int st = 4 * c + j;
+          if (done || st >= nsteps) { done = true; return; }   // wave-uniform
+          const int slot2 = slot == 0 ? 2 : slot - 1;           // (st + 2) % 3
+          if (st + 2 < nsteps) {
+            // younger than step st in the queue: step st + 1 (8) and, behind sub-step j = 0, a chunk of indices (2)
+            if constexpr (j == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            request(st + 2, slot2);
+            if constexpr (j == 0) request_meta(c + 2);
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          const float cvr = sw.mval[c % 3][16 * j + (ln & 15)];
+          const float* rs = &sw.ring[slot][0];
+          float xs0[16], xs1[16];
+#pragma unroll
+          for (int s2 = 0; s2 < 16; s2++) {
+            xs0[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + ln];
+            xs1[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + 64 + ln];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          consume(st, cvr, xs0, xs1);
+          __builtin_amdgcn_sched_barrier(0);
+          slot = slot == 2 ? 0 : slot + 1;
+        });
+        if (done) break;
       }
-      if constexpr (SYM && CGM_INTERLEAVE) {   // the last step's matrix instructions
-        const int par = (nsteps - 1) & 1;
-        mf_sfor<5>([&](auto gt) { mgroup(gt, par); });
-      }
-      wave_sync();   // (the operands' LDS becomes the solve's)
+      wave_sync();   // (the ring's LDS becomes the solve's)
     }
     // ---- unscale (powers of two: exact); the right-hand side and the warm start per lane = row ----
     ln = lane;

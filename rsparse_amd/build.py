@@ -33,7 +33,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # compiler-generated accumulator-file instruction, nothing touches a register an asm load has in flight, two waves per SIMD);
 # if the audit fails -- another compiler, a lost flag -- the file is rebuilt with -DMF_SAFE (tiles above hipcc's own share of the
 # accumulator file, one wave per SIMD) and audited again; a build that passes neither is an error, never a silent corruption.
-EXTRA_FLAGS = {n: ["-mllvm", "-forceattrs-csv-path=" + str(CSRC / "wrmf_chol_mf.attrs.csv")] for n in ("wrmf_chol_mf.hip", "wrmf_cg_mf.hip")}
+EXTRA_FLAGS = {n: ["-mllvm", "-forceattrs-csv-path=" + str(CSRC / "wrmf_chol_mf.attrs.csv"), "-fno-slp-vectorize"] for n in ("wrmf_chol_mf.hip", "wrmf_cg_mf.hip")}
 AUDITED = {"wrmf_chol_mf.hip", "wrmf_cg_mf.hip"}
 REG_LIMIT = {"wrmf_cg_mf.hip": 512}   # (one wave per SIMD by design: 320 accumulator registers per row)
 
@@ -75,7 +75,15 @@ def audit_listing(src, extra, defines, obj):
 def build(force=False, verbose=False, defines=(), out=None):
     out = Path(out) if out else OUT
     out.parent.mkdir(exist_ok=True)
-    tag = hashlib.sha1(" ".join(sorted(defines)).encode()).hexdigest()[:8] if defines else "release"
+    import os
+    # dev builds only: RSPARSE_HIPCC_EXTRA="wrmf_cg_mf.hip=-fno-slp-vectorize;other.hip=-flag1,-flag2" (compiler switches of one source)
+    per_file = {}
+    for item in filter(None, os.environ.get("RSPARSE_HIPCC_EXTRA", "").split(";")):
+        name, _, fl = item.partition("=")
+        per_file[name] = [f for f in fl.split(",") if f]
+    if per_file and out == OUT:
+        raise RuntimeError("RSPARSE_HIPCC_EXTRA is for dev builds (--out)")
+    tag = hashlib.sha1((" ".join(sorted(defines)) + repr(sorted(per_file.items()))).encode()).hexdigest()[:8] if (defines or per_file) else "release"
     objdir = OUT.parent / "obj" / tag
     objdir.mkdir(parents=True, exist_ok=True)
     src = [s for s in SRC if s.exists()]
@@ -85,7 +93,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     hdr_text = "".join(h.read_text() for h in HEADERS if h.suffix == ".h")
     for s in src:
         o = objdir / (s.stem + ".o")
-        if defines and not any(n in s.read_text() or n in hdr_text for n in names):
+        if (defines or per_file) and s.name not in per_file and not any(n in s.read_text() or n in hdr_text for n in names):
             rel = OUT.parent / "obj" / "release" / (s.stem + ".o")   # a dev define this source never mentions: the release object
             if rel.exists() and rel.stat().st_mtime >= max(s.stat().st_mtime, hdr_m):
                 objs.append(rel)
@@ -99,7 +107,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     def compile_one(so):
         s, o = so
         t0 = time.time()
-        extra = list(EXTRA_FLAGS.get(s.name, []))
+        extra = list(EXTRA_FLAGS.get(s.name, [])) + per_file.get(s.name, [])
         cmd = ["hipcc", *FLAGS, *extra, *["-D" + d for d in defines], "-c", str(s), "-o", str(o)]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if r.returncode != 0:

@@ -854,6 +854,18 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   }
   e = launch_sum_partials(g_ws.partials, slots, out, s, g_ws.partials + g_ws.partial_slots);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
+#if defined(RSP_NE_PROF) && defined(RSP_MF_PROF)
+  if (cgq && std::getenv("RSPARSE_MF_PROF")) {   // phase ticks of wrmf_cg_mf.hip, summed over its waves
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long hp[11];
+    HIP_TRY(hipMemcpy(hp, prof_buf + 16, sizeof(hp), hipMemcpyDeviceToHost));
+    const char* nm[8] = {"row-head", "prologue", "wait", "request", "step", "flush+unscale", "cg", "loss+tail"};
+    std::fprintf(stderr, "[cgmf_prof] n_cols %d: rows %llu steps %llu, G ticks summed over the waves (total %.3f):", d.n_cols, hp[9], hp[8], (double)hp[10] / 1e9);
+    for (int j = 0; j < 8; j++) std::fprintf(stderr, " %s %.3f", nm[j], (double)hp[j] / 1e9);
+    std::fprintf(stderr, "\n");
+  }
+#endif
 #ifdef RSP_NE_PROF
   if ((cgq || ne_chol) && qs.ne_wg > 0 && std::getenv("RSPARSE_NE_PROF")) {   // (solver == CHOLESKY: mv_* = diagonal tile, panel, trailing, backward)
     HIP_TRY(hipStreamSynchronize(s));

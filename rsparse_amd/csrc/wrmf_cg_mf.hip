@@ -75,6 +75,30 @@ __device__ __forceinline__ void cgm_operands_hi(const float (&x)[16], f16x8& h0,
   h1 = mf_pack(hh1[0], hh1[1], hh1[2], hh1[3]);
 }
 
+// A step's fp16 operands by 32-coordinate block: M1's two terms and M2's one
+struct CgmOps {
+  f16x8 ah[4], al[4], mh[4];
+};
+// The 40 matrix instructions of a step in the order the pipelined loop issues them BETWEEN the next step's vector work: block
+// column K = 0 first (16: its operands die first), then K = 1 (12), then K = 2 and 3 together (12); inside a group product-major
+// (kind 0: M2's one product, 1..3: M1's hi hi / hi lo / lo hi), so consecutive instructions write different tiles.
+struct CgmProd {
+  int T, kind, K, I;
+};
+constexpr CgmProd cgm_prod(int idx) {
+  if (idx < 16) return {mf_tid(idx % 4, 0), idx / 4, 0, idx % 4};
+  idx -= 16;
+  if (idx < 12) return {mf_tid(1 + idx % 3, 1), idx / 3, 1, 1 + idx % 3};
+  idx -= 12;
+  const int w = idx % 3, K = w == 2 ? 3 : 2, I = w == 0 ? 2 : 3;
+  return {mf_tid(I, K), idx / 3, K, I};
+}
+// tile T += A B^T without the operand wait states of mf_mma16: the operands were written a step ago
+template <int T>
+__device__ __forceinline__ void cgm_mma16(const f16x8& a, const f16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(MF_A0 + 16 * T), "i"(MF_A0 + 16 * T + 15));
+}
+
 template <int NOPS>
 struct CgmWave {               // per wave
   union {
@@ -82,7 +106,9 @@ struct CgmWave {               // per wave
     float T[32 * 36];          // solve: the transposed part of a product: [column][lane], rows padded to 36 floats (conflict-free b128 reads)
   };
   int midx[3][64];             // three chunks of 64 (index, confidence) pairs, by LDS-DMA too
-  float mval[3][64];
+  float mval[3][64];           // (SYM: the confidences become c or 0 beyond the row in place; next to them the two operand scales)
+  float gval[3][64];           // sqrt((c - 1) 2^e'), 0 beyond the row
+  float wval[3][64];           // 2^e, 0 beyond the row
   float vec[128];              // a vector in "register = column" order's source: p (or y) by coordinate
   float x0[128];               // warm start
   float rhs[128];              // b
@@ -188,6 +214,15 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
   if (lane == 0) sw.loss = 0.0;
   __syncthreads();
 
+#ifdef RSP_MF_PROF   // dev builds (tools/gpu_cgmf_prof.sh): s_memtime ticks per phase, summed over the waves into a.ne_prof[16 ..]
+  unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long pt_start = pt0;
+#define CGM_TICK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pt0; pt0 = t_; }
+#define CGM_COUNT(i, n) pt[i] += (n);
+#else
+#define CGM_TICK(i)
+#define CGM_COUNT(i, n)
+#endif
   auto uni = [](const float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
   const int ex = rfl(mf_scale_exp(fmaxf(__uint_as_float(a.ne_stats[0]), 1e-30f)));
   const float wmax = uni(fmaxf(__uint_as_float(a.ne_stats[1]) - 1.f, 1.f));
@@ -198,6 +233,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
   const int n_waves = 4 * gridDim.x;
 
   for (int it = 4 * blockIdx.x + wv; it < n_rows; it += n_waves) {
+    CGM_TICK(7)
     const int row = rfl(rows[it]);
     const int p1 = rfl(a.col_ptrs[row]), p2 = rfl(a.col_ptrs[row + 1]);
     float* yrow = a.Y + (size_t)row * k;
@@ -214,6 +250,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
 #pragma unroll
       for (int e = 0; e < 16; e++) hi[t][e] = 0.f;
     float u0 = 0.f, u1 = 0.f, csum = 0.f;   // rhs (lane = coordinate), sum of the confidences (lane j: its slots')
+    float ua[4] = {0.f, 0.f, 0.f, 0.f}, ub[4] = {0.f, 0.f, 0.f, 0.f};   // SYM: rhs partials, coordinate 32 I + n over this half's non-zeros
     {
       // A step = 16 non-zeros = 8 KB of vectors.  They arrive by LDS-DMA (global_load_lds_dwordx4: a lane brings 16 bytes, an
       // instruction two whole vectors -- lanes 0..31 non-zero i, lanes 32..63 non-zero 8 + i -- into 1 KB of LDS at M0) in a ring of
@@ -354,13 +391,114 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
           });
         });
       };
+      // ---- SYM: the pipelined step.  One wave per SIMD issues in order: with a step's vector work in front of its 40 matrix
+      // instructions the two add up (measured: the wave spends ~4500 cycles per step, 1280 of them matrix-pipe time, and neither
+      // more bytes in flight nor fewer stalls change that).  Here step s - 1's matrix instructions (operands P, registers) go
+      // out one or two at a time between the pieces of step s's vector work, which builds N.  The vectors are read from the
+      // ring directly in the operand order -- lane (n, hf) takes coordinate 32 I + n of the non-zeros 8 hf .. 8 hf + 7: no lane
+      // swaps -- and the per-non-zero weights (c for the right-hand side, 2^e for M2's operand, sqrt((c - 1) 2^e') on top for
+      // M1's) come from LDS in that order too, prepared once per chunk of 64: no v_readlane.
+      CgmOps P;
+      if constexpr (SYM) {
+        const f16x8 z = mf_pack(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int t = 0; t < 4; t++) { P.ah[t] = z; P.al[t] = z; P.mh[t] = z; }   // (step 0 has no predecessor: its 40 instructions add zero)
+      }
+      auto mm = [&](auto it) __attribute__((always_inline)) {
+        constexpr CgmProd pd = cgm_prod(decltype(it)::value);
+#if defined(CGM_ABL) && (CGM_ABL & 1)   // timing-only dev build: no matrix instructions
+        return;
+#endif
+        if constexpr (pd.kind == 0) {
+          if constexpr (pd.T < 6) cgm_mma16<10 + pd.T>(P.mh[pd.K], P.mh[pd.I]);
+          else hi[pd.T - 6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P.mh[pd.K], P.mh[pd.I], hi[pd.T - 6], 0, 0, 0);
+        } else {
+          cgm_mma16<pd.T>(pd.kind == 3 ? P.al[pd.K] : P.ah[pd.K], pd.kind == 2 ? P.al[pd.I] : P.ah[pd.I]);
+        }
+      };
+      // chunk c has landed: c (0 beyond the row) in place, the two operand scales next to it; sum of the confidences
+      auto transform = [&](const int c) __attribute__((always_inline)) {
+        const int cs = c % 3;
+        const bool in = p1 + 64 * c + ln < p2;
+        const float cvr = sw.mval[cs][ln];
+        const float cm = in ? cvr : 0.f;
+        csum += cm;
+        wave_sync();
+        sw.mval[cs][ln] = cm;
+        sw.gval[cs][ln] = in ? __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_) : 0.f;
+        sw.wval[cs][ln] = in ? sx : 0.f;
+        wave_sync();
+      };
+      auto step_sym = [&](const int slot, const int cs, auto jt) __attribute__((always_inline)) {
+        constexpr int j = decltype(jt)::value;
+        const int lb = 128 * hfl + (ln & 31);
+        const float* rs = &sw.ring[slot][0] + lb;
+        float cw[8], gw[8], ww[8];
+        {
+          const float4* pc = reinterpret_cast<const float4*>(&sw.mval[cs][16 * j + 8 * hfl]);
+          const float4* pg = reinterpret_cast<const float4*>(&sw.gval[cs][16 * j + 8 * hfl]);
+          const float4* pw = reinterpret_cast<const float4*>(&sw.wval[cs][16 * j + 8 * hfl]);
+          const float4 c0 = pc[0], c1 = pc[1], g0 = pg[0], g1 = pg[1], w0 = pw[0], w1 = pw[1];
+          cw[0] = c0.x; cw[1] = c0.y; cw[2] = c0.z; cw[3] = c0.w; cw[4] = c1.x; cw[5] = c1.y; cw[6] = c1.z; cw[7] = c1.w;
+          gw[0] = g0.x; gw[1] = g0.y; gw[2] = g0.z; gw[3] = g0.w; gw[4] = g1.x; gw[5] = g1.y; gw[6] = g1.z; gw[7] = g1.w;
+          ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
+        }
+        float xr[8], xn[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) xr[e] = rs[e * 256];
+        CgmOps N;
+#if defined(CGM_ABL) && (CGM_ABL & 2)   // timing-only dev build: the matrix instructions alone
+        mf_sfor<40>([&](auto it) { mm(it); __builtin_amdgcn_sched_barrier(0); });
+        (void)rs; (void)cw; (void)gw; (void)ww; (void)xr; (void)xn;
+        return;
+#endif
+        mf_sfor<4>([&](auto It) {
+          constexpr int I = decltype(It)::value;
+          unsigned hm[4], hh[4], ll[4];
+          mf_sfor<4>([&](auto qt) {
+            constexpr int q = decltype(qt)::value, u = 4 * I + q, m0 = (5 * u) / 2, m1 = (5 * (u + 1)) / 2;
+            if constexpr (q == 0 && I < 3) {   // the next block's eight reads go out first
+#pragma unroll
+              for (int e = 0; e < 8; e++) xn[e] = rs[e * 256 + 32 * (I + 1)];
+            }
+            const float a0 = xr[2 * q], a1 = xr[2 * q + 1];
+            ua[I] = fmaf(cw[2 * q], a0, ua[I]);
+            ub[I] = fmaf(cw[2 * q + 1], a1, ub[I]);
+            const float t0 = a0 * ww[2 * q], t1 = a1 * ww[2 * q + 1];
+            {
+              const f32x2 tv = {t0, t1};
+              hm[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(tv, f16x2));
+            }
+            mm(std::integral_constant<int, m0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mf_split(t0 * gw[2 * q], t1 * gw[2 * q + 1], hh[q], ll[q]);
+            mm(std::integral_constant<int, m0 + 1>{});
+            if constexpr (m1 - m0 == 3) {
+              __builtin_amdgcn_sched_barrier(0);
+              mm(std::integral_constant<int, m0 + 2>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+          N.mh[I] = mf_pack(hm[0], hm[1], hm[2], hm[3]);
+          N.ah[I] = mf_pack(hh[0], hh[1], hh[2], hh[3]);
+          N.al[I] = mf_pack(ll[0], ll[1], ll[2], ll[3]);
+          if constexpr (I < 3) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) xr[e] = xn[e];
+          }
+        });
+        P = N;
+      };
       // prologue: chunks 0 and 1 of the indices, then steps 0 and 1
+      CGM_TICK(0)
+      CGM_COUNT(8, nsteps) CGM_COUNT(9, 1)
       wave_sync();
       request_meta(0);
       request_meta(1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       request(0, 0);
       request(1, 1);
+      CGM_TICK(1)
       int slot = 0;   // = st % 3
       for (int c = 0; 4 * c < nsteps; c++) {
         bool done = false;
@@ -373,25 +511,44 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
             // younger than step st in the queue: step st + 1 (8) and, behind sub-step j = 0, a chunk of indices (2)
             if constexpr (j == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            CGM_TICK(2)
             request(st + 2, slot2);
             if constexpr (j == 0) request_meta(c + 2);
+            CGM_TICK(3)
           } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CGM_TICK(2)
           }
-          const float cvr = sw.mval[c % 3][16 * j + (ln & 15)];
-          const float* rs = &sw.ring[slot][0];
-          float xs0[16], xs1[16];
+          if constexpr (SYM) {
+            if constexpr (j == 0) transform(c);
+            __builtin_amdgcn_sched_barrier(0);
+            step_sym(slot, c % 3, jt);
+          } else {
+            const float cvr = sw.mval[c % 3][16 * j + (ln & 15)];
+            const float* rs = &sw.ring[slot][0];
+            float xs0[16], xs1[16];
 #pragma unroll
-          for (int s2 = 0; s2 < 16; s2++) {
-            xs0[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + ln];
-            xs1[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + 64 + ln];
+            for (int s2 = 0; s2 < 16; s2++) {
+              xs0[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + ln];
+              xs1[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + 64 + ln];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            consume(st, cvr, xs0, xs1);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          consume(st, cvr, xs0, xs1);
-          __builtin_amdgcn_sched_barrier(0);
           slot = slot == 2 ? 0 : slot + 1;
+          CGM_TICK(4)
         });
         if (done) break;
+      }
+      if constexpr (SYM) {   // the last step's matrix instructions; the right-hand side: the halves' partials added
+        mf_sfor<40>([&](auto it) { mm(it); });
+#pragma unroll
+        for (int I = 0; I < 4; I++) {
+          const unsigned du = __float_as_uint(ua[I] + ub[I]);
+          const auto sw2 = __builtin_amdgcn_permlane32_swap(du, du, false, false);
+          ua[I] = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+        }
       }
       wave_sync();   // (the ring's LDS becomes the solve's)
     }
@@ -411,15 +568,23 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
     });
 #pragma unroll
     for (int t = 0; t < 4; t++) hi[t] *= un_m2;
-    wave_sync();
-    sw.rhs[ln] = u0;
-    sw.rhs[64 + ln] = u1;
-    wave_sync();
     float b[4], x[4];
+    if constexpr (SYM) {
 #pragma unroll
-    for (int I = 0; I < 4; I++) {
-      b[I] = sw.rhs[32 * I + n];
-      x[I] = sw.x0[32 * I + n];
+      for (int I = 0; I < 4; I++) {
+        b[I] = ua[I];
+        x[I] = sw.x0[32 * I + n];
+      }
+    } else {
+      wave_sync();
+      sw.rhs[ln] = u0;
+      sw.rhs[64 + ln] = u1;
+      wave_sync();
+#pragma unroll
+      for (int I = 0; I < 4; I++) {
+        b[I] = sw.rhs[32 * I + n];
+        x[I] = sw.x0[32 * I + n];
+      }
     }
     auto rd_m1 = [&](auto tt, auto vt) { return mf_rd<16 * decltype(tt)::value + decltype(vt)::value>(); };
     auto g_tile = [&](auto tt, float (&g)[16]) {
@@ -431,6 +596,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       }
     };
     // ---- cg_solver_implicit (wrmf_implicit.hpp:8-32) on A = XtX + M1 ----
+    CGM_TICK(5)
     float r[4], p[4], ap[4];
     cgm_matvec(rd_m1, g_tile, sw, n, hf, ln, x, ap);
 #pragma unroll
@@ -449,6 +615,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       rsold = rsnew;
     }
     // ---- the row and its loss term: sum c - 2 y.b + y^T (M1 + M2) y + lambda |y|^2 ----
+    CGM_TICK(6)
     if (hf == 0) {
 #pragma unroll
       for (int I = 0; I < 4; I++) yrow[32 * I + n] = x[I];
@@ -496,6 +663,12 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
     wave_sync();
   }
   if (lane == 0) a.loss_partials[loss_slot0 + 4 * blockIdx.x + wv] = sw.loss;
+#ifdef RSP_MF_PROF
+  CGM_TICK(7)
+  pt[10] = __builtin_amdgcn_s_memtime() - pt_start;
+  if (a.ne_prof && lane == 0)
+    for (int j = 0; j < 11; j++) atomicAdd(a.ne_prof + 16 + j, pt[j]);
+#endif
 }
 
 }  // namespace

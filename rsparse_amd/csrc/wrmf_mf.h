@@ -28,9 +28,13 @@ __device__ __forceinline__ void mf_sfor(F&& f) {
 
 // x (already scaled into fp16's range) -> fl16(x), fl16(x - fl16(x)) for a pair; the residual is exact in fp32
 __device__ __forceinline__ void mf_split(const float x0, const float x1, unsigned& hi, unsigned& lo) {
+  // (scalar subtractions on purpose: a packed fp32 instruction -- v_pk_add_f32 and friends -- issued behind a matrix instruction
+  // waits ~28 cycles for it where a plain one is free, tools/probes/mfma_filler_probe.hip; these files are also compiled with
+  // -fno-slp-vectorize so that hipcc does not pair them up again)
   const f32x2 v = {x0, x1};
   const f16x2 h = __builtin_convertvector(v, f16x2);
-  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+  const f32x2 r = {r0, r1};
   const f16x2 l = __builtin_convertvector(r, f16x2);
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);

@@ -106,9 +106,9 @@ struct CgmWave {               // per wave
     float T[32 * 36];          // solve: the transposed part of a product: [column][lane], rows padded to 36 floats (conflict-free b128 reads)
   };
   int midx[3][64];             // three chunks of 64 (index, confidence) pairs, by LDS-DMA too
-  float mval[3][64];           // (SYM: the confidences become c or 0 beyond the row in place; next to them the two operand scales)
-  float gval[3][64];           // sqrt((c - 1) 2^e'), 0 beyond the row
-  float wval[3][64];           // 2^e, 0 beyond the row
+  float mval[3][64];
+  float gval[3][64];           // (SYM) M1's operand scale per non-zero: sqrt((c - 1) 2^e')
+  unsigned long long maddr[3][64];   // the non-zero's vector: its address, less the offset field of the LDS-DMA piece that will fetch it
   float vec[128];              // a vector in "register = column" order's source: p (or y) by coordinate
   float x0[128];               // warm start
   float rhs[128];              // b
@@ -204,12 +204,15 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       return;
     }
   }
-  // XtX's lower tiles -> LDS in the accumulator's order: tile (I, K), lane (n, hf), register v = XtX[32 K + rho(v, hf)][32 I + n]
+  // COORDINATES.  Row n of coordinate block I is coordinate 4 n + I (not 32 I + n): a lane then reads its four blocks' entries of a
+  // vector with ONE ds_read_b128 from the ring (the matrix pipe does not care which coordinate a tile row is; XtX's tiles, the
+  // warm start and the stored row follow the same map, everything between them lives in (block, row) order).
+  // XtX's lower tiles -> LDS in the accumulator's order: tile (I, K), lane (n, hf), register v = XtX[(K, rho(v, hf))][(I, n)]
   for (int e = threadIdx.x; e < 10 * 64 * 16; e += 256) {
     const int t = e / 1024, l = (e >> 4) & 63, v = e & 15;
     const int I = t >= 6 ? 3 : (t >= 3 ? 2 : (t >= 1 ? 1 : 0)), K = t - I * (I + 1) / 2;
     const int nn = l & 31, hh = l >> 5;
-    reinterpret_cast<float*>(&sm.G[t][l][0])[v] = a.XtX[(size_t)(32 * K + 8 * (v >> 2) + 4 * hh + (v & 3)) * k + 32 * I + nn];
+    reinterpret_cast<float*>(&sm.G[t][l][0])[v] = a.XtX[(size_t)(4 * (8 * (v >> 2) + 4 * hh + (v & 3)) + K) * k + 4 * nn + I];
   }
   if (lane == 0) sw.loss = 0.0;
   __syncthreads();
@@ -263,9 +266,9 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       // instructions.
       const int nsteps = (p2 - p1 + 15) >> 4;
       const int hfl = ln >> 5;
-      const char* xlane = reinterpret_cast<const char*>(a.X) + 16 * (ln & 31);
-      const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sw.ring[0][0]);
-      const unsigned meta_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sw.midx[0][0]);
+      const unsigned long long xoff = 16ull * (unsigned)(ln & 31);   // a lane's 16 bytes of the vector its half of the wave fetches
+      const unsigned ring_lds = (unsigned)(uintptr_t)&sw.ring[0][0];   // (wave-uniform: wv went through readfirstlane)
+      const unsigned meta_lds = (unsigned)(uintptr_t)&sw.midx[0][0];
       // chunk c of the row's (index, confidence) pairs -> sw.midx / sw.mval [c % 3]; positions beyond the row repeat its last entry
       auto request_meta = [&](const int c) __attribute__((always_inline)) {
         const int pos = min(p1 + 64 * c + ln, p2 - 1);
@@ -282,34 +285,31 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
             : [l] "s"(dst), [gi] "v"(gi), [gv] "v"(gv)
             : "memory", "scc");
       };
-      // the 16 vectors of step st -> sw.ring[st % 3]: non-zero j = 8 h + i at [i][h][128]
+      // the 16 vectors of step st -> sw.ring[st % 3]: non-zero j = 8 h + i at [i][h][128].  ONE write of M0 (the middle of the slot):
+      // a piece's offset field (-4096 .. 3072) moves its LDS destination AND its global address, and the chunk's address table
+      // has the latter taken out again.
       auto request = [&](const int st, const int slot) __attribute__((always_inline)) {
-        const int* ip = &sw.midx[(st >> 2) % 3][16 * (st & 3) + 8 * hfl];
-        const int4 ia = *reinterpret_cast<const int4*>(ip), ib = *reinterpret_cast<const int4*>(ip + 4);
-        const char* g0 = xlane + (size_t)ia.x * (k * 4);
-        const char* g1 = xlane + (size_t)ia.y * (k * 4);
-        const char* g2 = xlane + (size_t)ia.z * (k * 4);
-        const char* g3 = xlane + (size_t)ia.w * (k * 4);
-        const char* g4 = xlane + (size_t)ib.x * (k * 4);
-        const char* g5 = xlane + (size_t)ib.y * (k * 4);
-        const char* g6 = xlane + (size_t)ib.z * (k * 4);
-        const char* g7 = xlane + (size_t)ib.w * (k * 4);
-        const unsigned dst = ring_lds + 8192u * (unsigned)slot;
+        const uint4* ap = reinterpret_cast<const uint4*>(&sw.maddr[(st >> 2) % 3][16 * (st & 3) + 8 * hfl]);
+        const uint4 q0 = ap[0], q1 = ap[1], q2 = ap[2], q3 = ap[3];
+        auto at = [&](const unsigned lo, const unsigned hi2) { return xoff + (((unsigned long long)hi2 << 32) | lo); };
+        const unsigned long long g0 = at(q0.x, q0.y), g1 = at(q0.z, q0.w), g2 = at(q1.x, q1.y), g3 = at(q1.z, q1.w);
+        const unsigned long long g4 = at(q2.x, q2.y), g5 = at(q2.z, q2.w), g6 = at(q3.x, q3.y), g7 = at(q3.z, q3.w);
+        const unsigned dst = ring_lds + 8192u * (unsigned)slot + 4096u;
         unsigned keep;
         asm volatile(
             "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %[g0], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %[g1], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %[g2], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %[g3], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %[g4], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %[g5], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %[g6], off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %[g7], off\n\t"
+            "global_load_lds_dwordx4 %[g0], off offset:-4096\n\t"
+            "global_load_lds_dwordx4 %[g1], off offset:-3072\n\t"
+            "global_load_lds_dwordx4 %[g2], off offset:-2048\n\t"
+            "global_load_lds_dwordx4 %[g3], off offset:-1024\n\t"
+            "global_load_lds_dwordx4 %[g4], off\n\t"
+            "global_load_lds_dwordx4 %[g5], off offset:1024\n\t"
+            "global_load_lds_dwordx4 %[g6], off offset:2048\n\t"
+            "global_load_lds_dwordx4 %[g7], off offset:3072\n\t"
             "s_mov_b32 m0, %[k]"
             : [k] "=&s"(keep)
             : [l] "s"(dst), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3), [g4] "v"(g4), [g5] "v"(g5), [g6] "v"(g6), [g7] "v"(g7)
-            : "memory", "scc");
+            : "memory");
       };
       auto consume = [&](const int st, const float cvr, float (&xs0)[16], float (&xs1)[16]) __attribute__((always_inline)) {
         const int ccnt = min(16, p2 - (p1 + 16 * st));
@@ -398,13 +398,13 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       // ring directly in the operand order -- lane (n, hf) takes coordinate 32 I + n of the non-zeros 8 hf .. 8 hf + 7: no lane
       // swaps -- and the per-non-zero weights (c for the right-hand side, 2^e for M2's operand, sqrt((c - 1) 2^e') on top for
       // M1's) come from LDS in that order too, prepared once per chunk of 64: no v_readlane.
-      CgmOps P;
+      CgmOps OA, OB;   // ping-pong: even steps read OA (their predecessor's operands) and build OB, odd steps the other way round
       if constexpr (SYM) {
         const f16x8 z = mf_pack(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int t = 0; t < 4; t++) { P.ah[t] = z; P.al[t] = z; P.mh[t] = z; }   // (step 0 has no predecessor: its 40 instructions add zero)
+        for (int t = 0; t < 4; t++) { OA.ah[t] = z; OA.al[t] = z; OA.mh[t] = z; }   // (step 0 has no predecessor: its 40 instructions add zero)
       }
-      auto mm = [&](auto it) __attribute__((always_inline)) {
+      auto mm = [&](auto it, const CgmOps& P) __attribute__((always_inline)) {
         constexpr CgmProd pd = cgm_prod(decltype(it)::value);
 #if defined(CGM_ABL) && (CGM_ABL & 1)   // timing-only dev build: no matrix instructions
         return;
@@ -416,78 +416,98 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
           cgm_mma16<pd.T>(pd.kind == 3 ? P.al[pd.K] : P.ah[pd.K], pd.kind == 2 ? P.al[pd.I] : P.ah[pd.I]);
         }
       };
-      // chunk c has landed: c (0 beyond the row) in place, the two operand scales next to it; sum of the confidences
+      // chunk c has landed: its vectors' addresses (see request), M1's operand scale sqrt((c - 1) 2^e') next to the confidences,
+      // their sum (the row's entries only)
       auto transform = [&](const int c) __attribute__((always_inline)) {
         const int cs = c % 3;
-        const bool in = p1 + 64 * c + ln < p2;
         const float cvr = sw.mval[cs][ln];
-        const float cm = in ? cvr : 0.f;
-        csum += cm;
+        const int id = sw.midx[cs][ln];
+        if constexpr (SYM) csum += p1 + 64 * c + ln < p2 ? cvr : 0.f;
         wave_sync();
-        sw.mval[cs][ln] = cm;
-        sw.gval[cs][ln] = in ? __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_) : 0.f;
-        sw.wval[cs][ln] = in ? sx : 0.f;
+        sw.maddr[cs][ln] = reinterpret_cast<unsigned long long>(a.X) + (unsigned long long)(unsigned)id * (k * 4) - (long long)(((ln & 7) - 4) * 1024);
+        if constexpr (SYM) sw.gval[cs][ln] = __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_);
         wave_sync();
       };
-      auto step_sym = [&](const int slot, const int cs, auto jt) __attribute__((always_inline)) {
+      // the row's last step: the vectors beyond its end (copies of the last entry) become zeros in the ring -- no mask anywhere else
+      auto zero_tail = [&](const int slot, const int ccnt) __attribute__((always_inline)) {
+        float* rs = &sw.ring[slot][0];
+#pragma unroll 1
+        for (int jz = ccnt; jz < 16; jz++) {
+          rs[(jz & 7) * 256 + (jz >> 3) * 128 + ln] = 0.f;
+          rs[(jz & 7) * 256 + (jz >> 3) * 128 + 64 + ln] = 0.f;
+        }
+        wave_sync();
+      };
+      auto step_sym = [&](const int slot, const int cs, auto jt, const CgmOps& P, CgmOps& N) __attribute__((always_inline)) {
         constexpr int j = decltype(jt)::value;
-        const int lb = 128 * hfl + (ln & 31);
-        const float* rs = &sw.ring[slot][0] + lb;
-        float cw[8], gw[8], ww[8];
+        const float* rs = &sw.ring[slot][0] + 128 * hfl + 4 * (ln & 31);
+        float cw[8], gw[8];
         {
           const float4* pc = reinterpret_cast<const float4*>(&sw.mval[cs][16 * j + 8 * hfl]);
           const float4* pg = reinterpret_cast<const float4*>(&sw.gval[cs][16 * j + 8 * hfl]);
-          const float4* pw = reinterpret_cast<const float4*>(&sw.wval[cs][16 * j + 8 * hfl]);
-          const float4 c0 = pc[0], c1 = pc[1], g0 = pg[0], g1 = pg[1], w0 = pw[0], w1 = pw[1];
+          const float4 c0 = pc[0], c1 = pc[1], g0 = pg[0], g1 = pg[1];
           cw[0] = c0.x; cw[1] = c0.y; cw[2] = c0.z; cw[3] = c0.w; cw[4] = c1.x; cw[5] = c1.y; cw[6] = c1.z; cw[7] = c1.w;
           gw[0] = g0.x; gw[1] = g0.y; gw[2] = g0.z; gw[3] = g0.w; gw[4] = g1.x; gw[5] = g1.y; gw[6] = g1.z; gw[7] = g1.w;
-          ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
         }
-        float xr[8], xn[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) xr[e] = rs[e * 256];
-        CgmOps N;
+        // unit (q, I): the non-zeros 2 q and 2 q + 1 (of this half's eight) at coordinate block I; a pair's two reads -- the lane's
+        // four blocks of one vector each -- go out while its predecessor is worked on
+        float4 va[2], vb[2];
+        va[0] = *reinterpret_cast<const float4*>(rs);
+        vb[0] = *reinterpret_cast<const float4*>(rs + 256);
 #if defined(CGM_ABL) && (CGM_ABL & 2)   // timing-only dev build: the matrix instructions alone
-        mf_sfor<40>([&](auto it) { mm(it); __builtin_amdgcn_sched_barrier(0); });
-        (void)rs; (void)cw; (void)gw; (void)ww; (void)xr; (void)xn;
+        mf_sfor<40>([&](auto it) { mm(it, P); __builtin_amdgcn_sched_barrier(0); });
+        (void)cw; (void)gw;
+        N = P;
         return;
 #endif
-        mf_sfor<4>([&](auto It) {
-          constexpr int I = decltype(It)::value;
-          unsigned hm[4], hh[4], ll[4];
-          mf_sfor<4>([&](auto qt) {
-            constexpr int q = decltype(qt)::value, u = 4 * I + q, m0 = (5 * u) / 2, m1 = (5 * (u + 1)) / 2;
-            if constexpr (q == 0 && I < 3) {   // the next block's eight reads go out first
-#pragma unroll
-              for (int e = 0; e < 8; e++) xn[e] = rs[e * 256 + 32 * (I + 1)];
-            }
-            const float a0 = xr[2 * q], a1 = xr[2 * q + 1];
+        unsigned hm[4][4], hh[4][4], ll[4][4];   // [block][pair]
+        mf_sfor<4>([&](auto qt) {
+          constexpr int q = decltype(qt)::value;
+          if constexpr (q < 3) {
+            va[(q + 1) & 1] = *reinterpret_cast<const float4*>(rs + (2 * q + 2) * 256);
+            vb[(q + 1) & 1] = *reinterpret_cast<const float4*>(rs + (2 * q + 3) * 256);
+          }
+          const float4 xa = va[q & 1], xb = vb[q & 1];
+          const float a0s[4] = {xa.x, xa.y, xa.z, xa.w}, a1s[4] = {xb.x, xb.y, xb.z, xb.w};
+          mf_sfor<4>([&](auto It) {
+            constexpr int I = decltype(It)::value, u = 4 * q + I, m0 = (5 * u) / 2, m1 = (5 * (u + 1)) / 2;
+            const float a0 = a0s[I], a1 = a1s[I];
             ua[I] = fmaf(cw[2 * q], a0, ua[I]);
             ub[I] = fmaf(cw[2 * q + 1], a1, ub[I]);
-            const float t0 = a0 * ww[2 * q], t1 = a1 * ww[2 * q + 1];
+            const float t0 = a0 * sx, t1 = a1 * sx;
             {
               const f32x2 tv = {t0, t1};
-              hm[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(tv, f16x2));
+              hm[I][q] = __builtin_bit_cast(unsigned, __builtin_convertvector(tv, f16x2));
             }
-            mm(std::integral_constant<int, m0>{});
+            mm(std::integral_constant<int, m0>{}, P);
             __builtin_amdgcn_sched_barrier(0);
-            mf_split(t0 * gw[2 * q], t1 * gw[2 * q + 1], hh[q], ll[q]);
-            mm(std::integral_constant<int, m0 + 1>{});
+            {
+              // M1's two fp16 terms of t g: the leading one rounds the product, the second takes the EXACT remainder
+              // fma(t, g, -hi) (v_fma_mix_f32: the fp16 half is an operand; one instruction where a conversion and a subtraction were two)
+              const float g0 = gw[2 * q], g1 = gw[2 * q + 1];
+              const f32x2 yv = {t0 * g0, t1 * g1};
+              const unsigned hv = __builtin_bit_cast(unsigned, __builtin_convertvector(yv, f16x2));
+              float r0, r1;
+              asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(t0), "v"(g0), "v"(hv));
+              asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(t1), "v"(g1), "v"(hv));
+              const f32x2 rv = {r0, r1};
+              hh[I][q] = hv;
+              ll[I][q] = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, f16x2));
+            }
+            mm(std::integral_constant<int, m0 + 1>{}, P);
             if constexpr (m1 - m0 == 3) {
               __builtin_amdgcn_sched_barrier(0);
-              mm(std::integral_constant<int, m0 + 2>{});
+              mm(std::integral_constant<int, m0 + 2>{}, P);
             }
             __builtin_amdgcn_sched_barrier(0);
           });
-          N.mh[I] = mf_pack(hm[0], hm[1], hm[2], hm[3]);
-          N.ah[I] = mf_pack(hh[0], hh[1], hh[2], hh[3]);
-          N.al[I] = mf_pack(ll[0], ll[1], ll[2], ll[3]);
-          if constexpr (I < 3) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) xr[e] = xn[e];
-          }
         });
-        P = N;
+#pragma unroll
+        for (int I = 0; I < 4; I++) {
+          N.mh[I] = mf_pack(hm[I][0], hm[I][1], hm[I][2], hm[I][3]);
+          N.ah[I] = mf_pack(hh[I][0], hh[I][1], hh[I][2], hh[I][3]);
+          N.al[I] = mf_pack(ll[I][0], ll[I][1], ll[I][2], ll[I][3]);
+        }
       };
       // prologue: chunks 0 and 1 of the indices, then steps 0 and 1
       CGM_TICK(0)
@@ -496,8 +516,10 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       request_meta(0);
       request_meta(1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      transform(0);
       request(0, 0);
       request(1, 1);
+      const int tail_st = ((p2 - p1) & 15) ? nsteps - 1 : -1;
       CGM_TICK(1)
       int slot = 0;   // = st % 3
       for (int c = 0; 4 * c < nsteps; c++) {
@@ -507,6 +529,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
           const int st = 4 * c + j;
           if (done || st >= nsteps) { done = true; return; }   // wave-uniform
           const int slot2 = slot == 0 ? 2 : slot - 1;           // (st + 2) % 3
+          if constexpr (j == 1) transform(c + 1);   // (landed two sub-steps ago at the latest; its first request is sub-step j = 2's)
           if (st + 2 < nsteps) {
             // younger than step st in the queue: step st + 1 (8) and, behind sub-step j = 0, a chunk of indices (2)
             if constexpr (j == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -520,17 +543,18 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
             CGM_TICK(2)
           }
           if constexpr (SYM) {
-            if constexpr (j == 0) transform(c);
+            if (st == tail_st) zero_tail(slot, (p2 - p1) & 15);   // wave-uniform
             __builtin_amdgcn_sched_barrier(0);
-            step_sym(slot, c % 3, jt);
+            if constexpr (j & 1) step_sym(slot, c % 3, jt, OB, OA);
+            else step_sym(slot, c % 3, jt, OA, OB);
           } else {
             const float cvr = sw.mval[c % 3][16 * j + (ln & 15)];
             const float* rs = &sw.ring[slot][0];
             float xs0[16], xs1[16];
 #pragma unroll
             for (int s2 = 0; s2 < 16; s2++) {
-              xs0[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + ln];
-              xs1[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + 64 + ln];
+              xs0[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + 4 * (ln & 31) + hfl];       // (block hfl, row ln & 31)
+              xs1[s2] = rs[(s2 & 7) * 256 + (s2 >> 3) * 128 + 4 * (ln & 31) + 2 + hfl];   // (block 2 + hfl)
             }
             __builtin_amdgcn_sched_barrier(0);
             consume(st, cvr, xs0, xs1);
@@ -542,7 +566,8 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
         if (done) break;
       }
       if constexpr (SYM) {   // the last step's matrix instructions; the right-hand side: the halves' partials added
-        mf_sfor<40>([&](auto it) { mm(it); });
+        if (nsteps & 1) mf_sfor<40>([&](auto it) { mm(it, OB); });   // (wave-uniform: which set the last step built)
+        else mf_sfor<40>([&](auto it) { mm(it, OA); });
 #pragma unroll
         for (int I = 0; I < 4; I++) {
           const unsigned du = __float_as_uint(ua[I] + ub[I]);
@@ -573,7 +598,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
 #pragma unroll
       for (int I = 0; I < 4; I++) {
         b[I] = ua[I];
-        x[I] = sw.x0[32 * I + n];
+        x[I] = sw.x0[4 * n + I];
       }
     } else {
       wave_sync();
@@ -583,7 +608,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
 #pragma unroll
       for (int I = 0; I < 4; I++) {
         b[I] = sw.rhs[32 * I + n];
-        x[I] = sw.x0[32 * I + n];
+        x[I] = sw.x0[4 * n + I];
       }
     }
     auto rd_m1 = [&](auto tt, auto vt) { return mf_rd<16 * decltype(tt)::value + decltype(vt)::value>(); };
@@ -618,7 +643,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
     CGM_TICK(6)
     if (hf == 0) {
 #pragma unroll
-      for (int I = 0; I < 4; I++) yrow[32 * I + n] = x[I];
+      for (int I = 0; I < 4; I++) yrow[4 * n + I] = x[I];
     }
     auto rd_m2 = [&](auto tt, auto vt) {
       constexpr int T = decltype(tt)::value, v = decltype(vt)::value;

@@ -858,10 +858,11 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (cgq && std::getenv("RSPARSE_MF_PROF")) {   // phase ticks of wrmf_cg_mf.hip, summed over its waves
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipDeviceSynchronize());
-    unsigned long long hp[11];
+    unsigned long long hp[12];
     HIP_TRY(hipMemcpy(hp, prof_buf + 16, sizeof(hp), hipMemcpyDeviceToHost));
     const char* nm[8] = {"row-head", "prologue", "wait", "request", "step", "flush+unscale", "cg", "loss+tail"};
-    std::fprintf(stderr, "[cgmf_prof] n_cols %d: rows %llu steps %llu, G ticks summed over the waves (total %.3f):", d.n_cols, hp[9], hp[8], (double)hp[10] / 1e9);
+    std::fprintf(stderr, "[cgmf_prof] n_cols %d: rows %llu steps %llu, shader clock %.3f GHz (s_memtime / s_memrealtime), wave-seconds %.3f, G ticks summed over the waves (total %.3f):",
+                 d.n_cols, hp[9], hp[8], hp[11] ? (double)hp[10] / (double)hp[11] * 0.1 : 0.0, (double)hp[11] / 1e8, (double)hp[10] / 1e9);
     for (int j = 0; j < 8; j++) std::fprintf(stderr, " %s %.3f", nm[j], (double)hp[j] / 1e9);
     std::fprintf(stderr, "\n");
   }

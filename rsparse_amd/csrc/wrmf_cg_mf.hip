@@ -219,7 +219,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
 
 #ifdef RSP_MF_PROF   // dev builds (tools/gpu_cgmf_prof.sh): s_memtime ticks per phase, summed over the waves into a.ne_prof[16 ..]
   unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
-  const unsigned long long pt_start = pt0;
+  const unsigned long long pt_start = pt0, rt_start = __builtin_amdgcn_s_memrealtime();   // (100 MHz: ticks / realtime = the shader clock)
 #define CGM_TICK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pt0; pt0 = t_; }
 #define CGM_COUNT(i, n) pt[i] += (n);
 #else
@@ -253,7 +253,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
 #pragma unroll
       for (int e = 0; e < 16; e++) hi[t][e] = 0.f;
     float u0 = 0.f, u1 = 0.f, csum = 0.f;   // rhs (lane = coordinate), sum of the confidences (lane j: its slots')
-    float ua[4] = {0.f, 0.f, 0.f, 0.f}, ub[4] = {0.f, 0.f, 0.f, 0.f};   // SYM: rhs partials, coordinate 32 I + n over this half's non-zeros
+    float ua[4] = {0.f, 0.f, 0.f, 0.f};   // SYM: rhs partials, row n of block I over this half's non-zeros
     {
       // A step = 16 non-zeros = 8 KB of vectors.  They arrive by LDS-DMA (global_load_lds_dwordx4: a lane brings 16 bytes, an
       // instruction two whole vectors -- lanes 0..31 non-zero i, lanes 32..63 non-zero 8 + i -- into 1 KB of LDS at M0) in a ring of
@@ -266,7 +266,8 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       // instructions.
       const int nsteps = (p2 - p1 + 15) >> 4;
       const int hfl = ln >> 5;
-      const unsigned long long xoff = 16ull * (unsigned)(ln & 31);   // a lane's 16 bytes of the vector its half of the wave fetches
+      // a lane's 16 bytes of the vector its half of the wave fetches, from the first vector on (the address table holds offsets)
+      const unsigned long long xoff = reinterpret_cast<unsigned long long>(a.X) + 16ull * (unsigned)(ln & 31);
       const unsigned ring_lds = (unsigned)(uintptr_t)&sw.ring[0][0];   // (wave-uniform: wv went through readfirstlane)
       const unsigned meta_lds = (unsigned)(uintptr_t)&sw.midx[0][0];
       // chunk c of the row's (index, confidence) pairs -> sw.midx / sw.mval [c % 3]; positions beyond the row repeat its last entry
@@ -420,12 +421,14 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       // their sum (the row's entries only)
       auto transform = [&](const int c) __attribute__((always_inline)) {
         const int cs = c % 3;
-        const float cvr = sw.mval[cs][ln];
-        const int id = sw.midx[cs][ln];
-        if constexpr (SYM) csum += p1 + 64 * c + ln < p2 ? cvr : 0.f;
+        int l2 = ln;   // (this sub-step's own copy: the LDS addresses below are recomputed from it, not carried through the loop in
+        asm volatile("" : "+v"(l2));   //  registers -- hipcc spilled them, and a scratch reload is a counted load that drains the LDS-DMA queue)
+        const float cvr = sw.mval[cs][l2];
+        const int id = sw.midx[cs][l2];
+        if constexpr (SYM) csum += p1 + 64 * c + l2 < p2 ? cvr : 0.f;
         wave_sync();
-        sw.maddr[cs][ln] = reinterpret_cast<unsigned long long>(a.X) + (unsigned long long)(unsigned)id * (k * 4) - (long long)(((ln & 7) - 4) * 1024);
-        if constexpr (SYM) sw.gval[cs][ln] = __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_);
+        sw.maddr[cs][l2] = (unsigned long long)(unsigned)id * (k * 4) - (long long)(((l2 & 7) - 4) * 1024);
+        if constexpr (SYM) sw.gval[cs][l2] = __builtin_amdgcn_sqrtf(fmaxf(cvr - 1.f, 0.f) * sw_);
         wave_sync();
       };
       // the row's last step: the vectors beyond its end (copies of the last entry) become zeros in the ring -- no mask anywhere else
@@ -438,25 +441,23 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
         }
         wave_sync();
       };
-      auto step_sym = [&](const int slot, const int cs, auto jt, const CgmOps& P, CgmOps& N) __attribute__((always_inline)) {
+      auto step_sym = [&](const int slot, const int cs, auto jt, const CgmOps& P, CgmOps& N, const float4 va0, const float4 vb0, const float2 wc0, const float2 wg0) __attribute__((always_inline)) {
         constexpr int j = decltype(jt)::value;
         const float* rs = &sw.ring[slot][0] + 128 * hfl + 4 * (ln & 31);
-        float cw[8], gw[8];
-        {
-          const float4* pc = reinterpret_cast<const float4*>(&sw.mval[cs][16 * j + 8 * hfl]);
-          const float4* pg = reinterpret_cast<const float4*>(&sw.gval[cs][16 * j + 8 * hfl]);
-          const float4 c0 = pc[0], c1 = pc[1], g0 = pg[0], g1 = pg[1];
-          cw[0] = c0.x; cw[1] = c0.y; cw[2] = c0.z; cw[3] = c0.w; cw[4] = c1.x; cw[5] = c1.y; cw[6] = c1.z; cw[7] = c1.w;
-          gw[0] = g0.x; gw[1] = g0.y; gw[2] = g0.z; gw[3] = g0.w; gw[4] = g1.x; gw[5] = g1.y; gw[6] = g1.z; gw[7] = g1.w;
-        }
+        // (the weights of a pair of non-zeros are read with the pair's vectors: sixteen of them held through the step were the
+        // registers hipcc spilled -- a scratch reload is a counted load, it drained the LDS-DMA queue)
+        const float2* pc = reinterpret_cast<const float2*>(&sw.mval[cs][16 * j + 8 * hfl]);
+        const float2* pg = reinterpret_cast<const float2*>(&sw.gval[cs][16 * j + 8 * hfl]);
+        float2 wc[2], wg[2];
+        wc[0] = wc0;
+        wg[0] = wg0;
         // unit (q, I): the non-zeros 2 q and 2 q + 1 (of this half's eight) at coordinate block I; a pair's two reads -- the lane's
         // four blocks of one vector each -- go out while its predecessor is worked on
         float4 va[2], vb[2];
-        va[0] = *reinterpret_cast<const float4*>(rs);
-        vb[0] = *reinterpret_cast<const float4*>(rs + 256);
+        va[0] = va0;
+        vb[0] = vb0;
 #if defined(CGM_ABL) && (CGM_ABL & 2)   // timing-only dev build: the matrix instructions alone
         mf_sfor<40>([&](auto it) { mm(it, P); __builtin_amdgcn_sched_barrier(0); });
-        (void)cw; (void)gw;
         N = P;
         return;
 #endif
@@ -466,14 +467,16 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
           if constexpr (q < 3) {
             va[(q + 1) & 1] = *reinterpret_cast<const float4*>(rs + (2 * q + 2) * 256);
             vb[(q + 1) & 1] = *reinterpret_cast<const float4*>(rs + (2 * q + 3) * 256);
+            wc[(q + 1) & 1] = pc[q + 1];
+            wg[(q + 1) & 1] = pg[q + 1];
           }
+          const float c0 = wc[q & 1].x, c1 = wc[q & 1].y, g0 = wg[q & 1].x, g1 = wg[q & 1].y;
           const float4 xa = va[q & 1], xb = vb[q & 1];
           const float a0s[4] = {xa.x, xa.y, xa.z, xa.w}, a1s[4] = {xb.x, xb.y, xb.z, xb.w};
           mf_sfor<4>([&](auto It) {
             constexpr int I = decltype(It)::value, u = 4 * q + I, m0 = (5 * u) / 2, m1 = (5 * (u + 1)) / 2;
             const float a0 = a0s[I], a1 = a1s[I];
-            ua[I] = fmaf(cw[2 * q], a0, ua[I]);
-            ub[I] = fmaf(cw[2 * q + 1], a1, ub[I]);
+            ua[I] = fmaf(c1, a1, fmaf(c0, a0, ua[I]));
             const float t0 = a0 * sx, t1 = a1 * sx;
             {
               const f32x2 tv = {t0, t1};
@@ -484,7 +487,6 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
             {
               // M1's two fp16 terms of t g: the leading one rounds the product, the second takes the EXACT remainder
               // fma(t, g, -hi) (v_fma_mix_f32: the fp16 half is an operand; one instruction where a conversion and a subtraction were two)
-              const float g0 = gw[2 * q], g1 = gw[2 * q + 1];
               const f32x2 yv = {t0 * g0, t1 * g1};
               const unsigned hv = __builtin_bit_cast(unsigned, __builtin_convertvector(yv, f16x2));
               float r0, r1;
@@ -529,24 +531,40 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
           const int st = 4 * c + j;
           if (done || st >= nsteps) { done = true; return; }   // wave-uniform
           const int slot2 = slot == 0 ? 2 : slot - 1;           // (st + 2) % 3
+          float4 fva, fvb;   // the step's first pair of vectors and its weights
+          float2 fwc, fwg;
+          auto first_reads = [&](const int sl, const int cs, const int jj) __attribute__((always_inline)) {
+            const float* rs = &sw.ring[sl][0] + 128 * hfl + 4 * (ln & 31);
+            fva = *reinterpret_cast<const float4*>(rs);
+            fvb = *reinterpret_cast<const float4*>(rs + 256);
+            fwc = *reinterpret_cast<const float2*>(&sw.mval[cs][16 * jj + 8 * hfl]);
+            fwg = *reinterpret_cast<const float2*>(&sw.gval[cs][16 * jj + 8 * hfl]);
+          };
           if constexpr (j == 1) transform(c + 1);   // (landed two sub-steps ago at the latest; its first request is sub-step j = 2's)
-          if (st + 2 < nsteps) {
+          const bool more = st + 2 < nsteps;
+          if (more) {
             // younger than step st in the queue: step st + 1 (8) and, behind sub-step j = 0, a chunk of indices (2)
             if constexpr (j == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             CGM_TICK(2)
+            if constexpr (SYM) first_reads(slot, c % 3, j);   // (their latency passes while the requests below are issued)
+            // (measured and not kept: the eight pieces one by one BETWEEN the step's matrix instructions, like the vector work:
+            // 16.8 ms per launch against 15.0 -- a piece costs more there than the ~55 cycles it takes in a block in front)
             request(st + 2, slot2);
             if constexpr (j == 0) request_meta(c + 2);
             CGM_TICK(3)
           } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             CGM_TICK(2)
+            if constexpr (SYM) {
+              if (st == tail_st) zero_tail(slot, (p2 - p1) & 15);   // wave-uniform (the row's last step is never in the branch above)
+              first_reads(slot, c % 3, j);
+            }
           }
           if constexpr (SYM) {
-            if (st == tail_st) zero_tail(slot, (p2 - p1) & 15);   // wave-uniform
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j & 1) step_sym(slot, c % 3, jt, OB, OA);
-            else step_sym(slot, c % 3, jt, OA, OB);
+            if constexpr (j & 1) step_sym(slot, c % 3, jt, OB, OA, fva, fvb, fwc, fwg);
+            else step_sym(slot, c % 3, jt, OA, OB, fva, fvb, fwc, fwg);
           } else {
             const float cvr = sw.mval[c % 3][16 * j + (ln & 15)];
             const float* rs = &sw.ring[slot][0];
@@ -570,7 +588,7 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
         else mf_sfor<40>([&](auto it) { mm(it, OA); });
 #pragma unroll
         for (int I = 0; I < 4; I++) {
-          const unsigned du = __float_as_uint(ua[I] + ub[I]);
+          const unsigned du = __float_as_uint(ua[I]);
           const auto sw2 = __builtin_amdgcn_permlane32_swap(du, du, false, false);
           ua[I] = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
         }
@@ -591,8 +609,14 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
       constexpr int R = 160 + decltype(rt)::value;
       mf_wr<R>(mf_rd<R>() * un_m2);
     });
+    {
+      float um = un_m2;   // (a register of this point's own: held as a pair from the kernel's first lines it was the one spill)
+      asm volatile("" : "+v"(um));
 #pragma unroll
-    for (int t = 0; t < 4; t++) hi[t] *= un_m2;
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) hi[t][e] *= um;
+    }
     float b[4], x[4];
     if constexpr (SYM) {
 #pragma unroll
@@ -642,8 +666,10 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
     // ---- the row and its loss term: sum c - 2 y.b + y^T (M1 + M2) y + lambda |y|^2 ----
     CGM_TICK(6)
     if (hf == 0) {
-#pragma unroll
-      for (int I = 0; I < 4; I++) yrow[4 * n + I] = x[I];
+      int row2 = row;   // (the row's address again from scalar registers: held in a vector pair since the warm start it was the one spill)
+      asm volatile("" : "+s"(row2));
+      float* yr = a.Y + (size_t)row2 * k;
+      *reinterpret_cast<float4*>(yr + 4 * n) = make_float4(x[0], x[1], x[2], x[3]);
     }
     auto rd_m2 = [&](auto tt, auto vt) {
       constexpr int T = decltype(tt)::value, v = decltype(vt)::value;
@@ -691,8 +717,9 @@ __device__ __forceinline__ void als_cg_mf_body(const AlsArgs& a, const int32_t* 
 #ifdef RSP_MF_PROF
   CGM_TICK(7)
   pt[10] = __builtin_amdgcn_s_memtime() - pt_start;
+  pt[11] = __builtin_amdgcn_s_memrealtime() - rt_start;
   if (a.ne_prof && lane == 0)
-    for (int j = 0; j < 11; j++) atomicAdd(a.ne_prof + 16 + j, pt[j]);
+    for (int j = 0; j < 12; j++) atomicAdd(a.ne_prof + 16 + j, pt[j]);
 #endif
 }
 

@@ -377,10 +377,15 @@ def main():
                   for sd in live]
             name = kern[live[0]]["names"][b]
             ne = name.startswith("als_ne_kernel")
+            mf = "cg_mf" in name
             wpr = int(info["users"]["bucket_wpr"][b])
             buckets.append({"kernel": name,
                             "what": "rows beyond 512 non-zeros: one pass, normal equations on the matrix cores (fp32 operands as "
                                     "2 fp16 / 3 bf16 split terms, fp32 accumulation), CG on the k x k system in LDS" if ne else
+                                    "rows beyond 512 non-zeros: one WAVE per row, one pass, normal equations in the wave's matrix-core "
+                                    "accumulator registers (fp32 operands as 2 fp16 split terms), CG from the tiles (wrmf_cg_mf.hip); the "
+                                    "segment also covers the rows beyond 16384 non-zeros, split across workgroups by als_ne_kernel on a "
+                                    "second stream, and its bytes count both" if mf else
                                     "rows on teams of %d wave(s), register-resident" % wpr,
                             "launches_per_iteration": len(ms), "avg_launch_ms": float(np.mean(ms)),
                             "bytes_per_launch": float(np.mean(by)), "total_ms_per_iteration": float(np.sum(ms))})

@@ -8,18 +8,19 @@
 //     A = XtX + M1;   y = CG(A, b; warm start, cg_steps);   sum_j c_j (1 - x_j.y)^2 = sum c - 2 y.b + y^T (M1 + M2) y.
 // als_ne_kernel moves these rows' bytes at 0.42 of the HBM peak (20 ms per launch on the bench line, the dominant launch of
 // rounds 3-5): four waves consume the same 16-non-zero step from an LDS ring, and 114..227 of a step's 315..500 instructions are
-// scalar bookkeeping of that ring (DESIGN.md 3.2 "Round 5").  The wave-per-row assembly of wrmf_chol_mf.hip has no ring and no
-// partner: a lane reads its two coordinates of each of a step's 16 vectors with asm loads whose addresses are 6 scalar
-// instructions per non-zero, the previous step's matrix instructions run while they fly.  Measured with the exact solver's
-// kernel on the same rows: 4.9 TB/s of algorithmic bytes on the HBM-resident side (profiles/r06/r6k*).  What that kernel lacks
-// for conjugate gradient is the loss-only matrix M2: 20 tiles = 320 accumulator registers.  One wave per SIMD can hold them --
-// the accumulator file a0..a255 takes M1 (tiles 0..9) and six tiles of M2, the other four tiles of M2 are vector registers of
-// the compiler's (a plain accumulate chain: nothing hipcc can get wrong) -- and four waves per CU, each with 32 + 32 loads of its
-// own in flight, are what the memory system needs to stay busy.
+// scalar bookkeeping of that ring (DESIGN.md 3.2 "Round 5").  Here a wave has no partner: the row's vectors arrive by LDS-DMA in
+// a ring of its own, the accumulator tiles are the wave's.  What conjugate gradient needs next to the system matrix is the loss-only
+// matrix M2: 20 tiles = 320 accumulator registers.  One wave per SIMD can hold them -- the accumulator file a0..a255 takes M1
+// (tiles 0..9) and six tiles of M2, the other four tiles of M2 are vector registers of the compiler's (a plain accumulate chain:
+// nothing hipcc can get wrong) -- and one wave per SIMD issues strictly in order: a step's vector work and its 40 matrix
+// instructions add up unless the instruction stream interleaves them itself (the pipelined step below; what a vector instruction
+// costs behind a matrix instruction: tools/probes/mfma_filler_probe.hip).  15.0 ms per launch at 0.54 of the HBM peak, at the
+// chip's power limit (1.57 GHz: DESIGN.md 3.2 "Round 6").
 //
 // Per row: stream (M1 from two fp16 terms of 2^e sqrt(c - 1) x, three products; M2 from the leading fp16 term of 2^e x alone, one
 // product: it feeds only the loss, as in wrmf_ne.hip) -> unscale -> conjugate gradient with A p evaluated FROM THE TILES: tile
-// (I, K) of the lower triangle holds, at lane (n, hf), register v, the entry [row 32 I + n][column 32 K + rho(v, hf)], so
+// (I, K) of the lower triangle holds, at lane (n, hf), register v, the entry [(block I, row n)][(block K, row rho(v, hf))] -- row r of
+// block I being coordinate 4 r + I, see "COORDINATES" below --, so
 //     (A p)_I += sum over the lane's registers of  tile * p[column]          ("direct": 16 FMAs per tile, then the halves added)
 //     (A p)_K += sum over the LANES of             tile * p[row]   (I > K)   ("transposed": through a 32 x 36 LDS tile)
 // with XtX's tiles added on the fly from a copy in LDS in the same lane / register order (shared by the workgroup's four waves,

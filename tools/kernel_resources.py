@@ -24,7 +24,7 @@ from rsparse_amd import build as B   # noqa: E402
 
 
 def usage_of(src, tmp):
-    r = subprocess.run(["hipcc", *B.FLAGS, "-c", str(src), "-o", str(Path(tmp) / (src.stem + ".o")),
+    r = subprocess.run(["hipcc", *B.FLAGS, *B.EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(Path(tmp) / (src.stem + ".o")),
                         "-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s" % (src.name, r.stderr[-3000:]))

@@ -20,7 +20,8 @@ for c in vals:
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] != c:
                     continue
-                m = re.search(r"((?:als|gramian|top_product)\w*<[^()]*>)\s*\(", r.get("Kernel_Name", ""))
+                kn = r.get("Kernel_Name", "")
+                m = re.search(r"((?:als|gramian|top_product)\w*<[^()]*>)\s*\(", kn) or re.match(r"(rsparse_hip_\w+)", kn)   # (extern "C": the bare name)
                 if m:
                     vals[c][m.group(1)].append(float(r["Counter_Value"]))
 workload = None
@@ -41,4 +42,4 @@ for k in sorted(vals["FETCH_SIZE"]):
     res["kernels"][k] = {"fetch_kb_per_launch": f, "write_kb_per_launch": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
                          "dispatches": len(vals["FETCH_SIZE"][k])}
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps({"workload": workload, **{k: v["hbm_bytes_per_launch"] for k, v in res["kernels"].items() if k.startswith("als_")}}, indent=1))
+print(json.dumps({"workload": workload, **{k: v["hbm_bytes_per_launch"] for k, v in res["kernels"].items() if k.startswith("als_") or k.startswith("rsparse_hip_")}}, indent=1))

@@ -162,7 +162,9 @@ def cpu_baseline(data, U, V, k, lam, cg_steps, target_s=12.0, implicit=True, sol
     main = res["f64"]
     return {
         "value": main["value"], "unit": "iterations/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port", "dtype": "f64",
-        "sample": "%d random users + %d random items, extrapolated in nnz; Gramians incl. (user one from 1M rows)"
+        "sample": "%d random users + %d random items, extrapolated in nnz; Gramians incl. (user one from 1M rows).  The extrapolation "
+                  "FLATTERS the CPU: a whole user half-iteration of config 2 measured once on these cores took 1.97 x its sampled "
+                  "estimate (the sample's factor rows stay in cache; profiles/r06/r6s/cpu_full_half_config2.json)"
                   % (main["take_u"], main["take_i"]),
         "value_f32": res["f32"]["value"], "user_rows_per_s": main["user_rows_per_s"],
         "user_rows_per_s_f32": res["f32"]["user_rows_per_s"], "gramians_s": main["t_gram"],

@@ -431,6 +431,36 @@ def test_implicit_cg_long_rows_with_confidence_below_one(k):
     assert abs(loss - lref) <= TOL * abs(lref)
 
 
+@pytest.mark.parametrize("below_one", [False, True])
+def test_cg_wave_per_row_kernel_every_row_length_class(below_one):
+    """wrmf_cg_mf.hip (rank 128, rows of 513..16384 non-zeros) streams a row in steps of 16 non-zeros through a ring of three
+    LDS slots, its indices in chunks of 64, ping-pongs two operand sets by step parity and zeroes the last step's tail: a row of
+    every length 513..658 (all residues mod 16 and mod 64, odd and even step counts, 9..11 chunks), the powers of two around
+    1024 / 4096, and the two lengths either side of the hand-over to the split kernel (16384 | 16385).  Per row against the
+    fp64 oracle; `below_one`: the instantiation for matrices with a confidence < 1 (no square root, both operand sets)."""
+    k, n_items = 128, 20000
+    lens = list(range(513, 659)) + [1023, 1024, 1025, 4095, 4096, 4097, 16383, 16384, 16385, 300, 40, 0]
+    rng = np.random.default_rng(2026 + below_one)
+    p = np.zeros(len(lens) + 1, dtype=np.int32)
+    p[1:] = np.cumsum(lens)
+    idx = np.concatenate([np.sort(rng.choice(n_items, size=n, replace=False)).astype(np.int32) for n in lens])
+    x = 1.0 + rng.geometric(0.5, size=idx.size).astype(np.float64)
+    if below_one:
+        x[::9] = 0.3
+    X = np.asfortranarray((rng.standard_normal((k, n_items)) * 0.05).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, len(lens))) * 0.05).astype(np.float32))
+    csc = (n_items, len(lens), p, idx, x)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 1, 3, True)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, 0.1, 1, 1, 3, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    err[np.asarray(lens) == 0] = 0.0
+    assert np.all(Y[:, -1] == 0.0)                                   # the empty column (wrmf_implicit.hpp:281)
+    bad = int(err.argmax())
+    assert err.max() < TOL, (bad, lens[bad], float(err.max()))
+    assert abs(loss - lref) <= TOL * abs(lref)
+
+
 def test_factor_scale_does_not_matter_to_the_fp16_path():
     """The fp16 normal-equation kernel rescales its operands by powers of two taken from max |x| and max c: factors of
     the order 1e-4 or 30 (far outside fp16's comfortable range unscaled) give the same relative accuracy."""

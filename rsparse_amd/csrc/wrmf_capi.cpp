@@ -854,6 +854,16 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   }
   e = launch_sum_partials(g_ws.partials, slots, out, s, g_ws.partials + g_ws.partial_slots);
   if (e != hipSuccess) return hip_fail(e, "launch_sum_partials");
+#if defined(RSP_NE_PROF) && defined(RSP_NNLS_PROF)
+  if (solver == RSPARSE_SOLVER_NNLS && std::getenv("RSPARSE_NNLS_PROF")) {   // phase ticks of als_nnls_wave_kernel, summed over its waves
+    HIP_TRY(hipStreamSynchronize(s));
+    unsigned long long hp[8];
+    HIP_TRY(hipMemcpy(hp, prof_buf + 32, sizeof(hp), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[nnls_prof] n_cols %d: rows %llu, sweeps per row %.1f, coordinates visited per sweep %.1f; G ticks summed over the waves: assembly %.3f square %.3f sweeps %.3f loss %.3f row-head %.3f\n",
+                 d.n_cols, hp[5], hp[5] ? (double)hp[6] / (double)hp[5] : 0.0, hp[6] ? (double)hp[7] / (double)hp[6] : 0.0,
+                 (double)hp[0] / 1e9, (double)hp[1] / 1e9, (double)hp[2] / 1e9, (double)hp[3] / 1e9, (double)hp[4] / 1e9);
+  }
+#endif
 #if defined(RSP_NE_PROF) && defined(RSP_MF_PROF)
   if (cgq && std::getenv("RSPARSE_MF_PROF")) {   // phase ticks of wrmf_cg_mf.hip, summed over its waves
     HIP_TRY(hipStreamSynchronize(s));

@@ -326,6 +326,14 @@ __global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
   const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
   const unsigned long long in_range = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
   double wloss = 0.0;
+#ifdef RSP_NNLS_PROF   // dev builds (tools/gpu_nnls_prof.sh): s_memtime ticks per phase, sweeps and coordinate visits, summed over the waves into a.ne_prof[32 ..]
+  unsigned long long nt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nt0 = __builtin_amdgcn_s_memtime();
+#define NNLS_TICK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); nt[i] += t_ - nt0; nt0 = t_; }
+#define NNLS_COUNT(i, n) nt[i] += (n);
+#else
+#define NNLS_TICK(i)
+#define NNLS_COUNT(i, n)
+#endif
 
   for (int it = blockIdx.x; it < a.n_cols; it += gridDim.x) {
     const int row = a.nnls_order ? rfl(a.nnls_order[it]) : it;
@@ -342,6 +350,8 @@ __global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
     // loops below out of the row loop (KP 64-bit pointers, KP masks) and spills them
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    NNLS_TICK(4)
+    NNLS_COUNT(5, 1)
 
     // ---------------- assembly: lane l holds lhs(:, l) and rhs_l ----------------
     float acol[KP];
@@ -406,6 +416,7 @@ __global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
     float h = lk ? yrow[ln] : 0.f;  // init = current Y.col(i)  (wrmf_implicit.hpp:185)
 
     // ---------------- mu = XtX init - lhs^T rhs, first half: t_l = sum_m lhs(m, l) rhs_m ----------------
+    NNLS_TICK(0)
     wave_sync();
     if (on) {
       sX[ln] = h;
@@ -497,6 +508,7 @@ __global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
     // sequence the compiler's own expansion uses, without its range scaling -- mu / XtX_ll is nowhere near the subnormals).
     // The stopping rule needs only  max step_err <= tol: a step far from the threshold is decided by two products, the exact
     // division fabs(diff) / (fabs(old) + EPS) runs only inside a +-0.1 % band around it.
+    NNLS_TICK(1)
     float rdg;
     {
       const float r0 = __builtin_amdgcn_rcpf(dg);
@@ -514,6 +526,8 @@ __global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
       float nv, df;
       step_of(nv, df);
       unsigned long long act = __ballot(df != 0.f) & in_range;
+      NNLS_COUNT(6, 1)
+      NNLS_COUNT(7, __builtin_popcountll(act))
 #pragma unroll
       for (int c = 0; c < KP; c++) {
         if (__builtin_expect((act >> c) & 1ull, 0)) {
@@ -533,6 +547,7 @@ __global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
       if (!moved_far) break;
     }
     if (lk) yrow[ln] = h;
+    NNLS_TICK(2)
 
     // ---------------- loss row term: lane j takes non-zero j of a chunk ----------------
     wave_sync();
@@ -565,8 +580,13 @@ __global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
     const float lpart = wave_sum(lacc);
     const float xxp = wave_sum(h * h);
     wloss += IMPLICIT ? (double)lpart + a.lambda_loss * (double)xxp : (double)(lpart + lam_use * xxp);
+    NNLS_TICK(3)
   }
   if (lane == 0) a.loss_partials[blockIdx.x] = wloss;
+#ifdef RSP_NNLS_PROF
+  if (a.ne_prof && lane == 0)
+    for (int j = 0; j < 8; j++) atomicAdd(a.ne_prof + 32 + j, nt[j]);
+#endif
 }
 
 template <int KP, bool IMPLICIT>

@@ -20,6 +20,8 @@ without user/item biases:
   * consequently `fit_transform(x) == transform(x)` holds here with a global bias too (the reference's own invariant,
     tests/testthat/test-wrmf.R:57, is only tested without one).
 """
+import logging
+
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -36,6 +38,9 @@ class TopItems(np.ndarray):
     """Result of `WRMF.predict`: (n_users x k) item indices with the scores attached, like the `scores`
     attribute of the reference's integer matrix (R/MatrixFactorizationRecommender.R:68-76)."""
     scores = None
+
+
+logger = logging.getLogger("rsparse_amd")   # the reference logs through lgr's "rsparse" logger (R/zzz.R); silent unless configured
 
 
 class WRMF:
@@ -253,11 +258,15 @@ class WRMF:
         self.losses = []
         for it in range(int(n_iter)):
             li = als.half_iteration("items", U, V, self._solver_code)              # :321
+            logger.info("iter %d (items) loss = %.4f", it + 1, li)                 # :324 (the reference's lgr lines, on `logging`)
             lu = als.half_iteration("users", U, V, self._solver_code)              # :327
+            logger.info("iter %d (users) loss = %.4f", it + 1, lu)                 # :330
             self.losses.append((li, lu))
             if (loss_prev / lu if lu != 0 else float("inf")) - 1 < convergence_tol:   # :332-335 (R: x / 0 = Inf)
+                logger.info("Converged after %d iterations", it + 1)               # :333
                 break
             loss_prev = lu
+        logger.debug("solver finished")                                            # :339
         be.check_numeric()
         self._V, self._cnt_item = V, als.cnt_item
         self._drop_replicas(be)
@@ -389,8 +398,12 @@ class WRMF:
         for it in range(int(n_iter)):
             li = als.half_iteration("items", U, V, self._solver_code, defer_exchange=True)
             lu = als.half_iteration("users", U, V, self._solver_code, defer_exchange=True)
+            if self._dist()[1] == 0:                                               # (one line per half-iteration, not one per rank)
+                logger.info("iter %d (items) loss = %.4f", it + 1, li)             # R/model_WRMF.R:324
+                logger.info("iter %d (users) loss = %.4f", it + 1, lu)             # :330
             self.losses.append((li, lu))
             if (loss_prev / lu if lu != 0 else float("inf")) - 1 < convergence_tol:   # every rank sees the same loss
+                logger.info("Converged after %d iterations", it + 1)               # :333
                 break
             loss_prev = lu
         als.finish()

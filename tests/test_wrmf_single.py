@@ -261,3 +261,26 @@ def test_csr_input_is_uploaded_as_it_stands_and_gives_the_same_device_arrays():
                  backend=OracleBackend(), rng=3)
     model.fit_transform(m, n_iter=1, convergence_tol=-1)
     assert model.global_bias == pytest.approx(before.mean(), rel=1e-12) and np.array_equal(m.data, before)
+
+
+def test_fit_logs_the_loss_of_every_half_iteration_like_the_reference(ml_train, caplog):
+    """R/model_WRMF.R:324,330,333: `logger$info("iter %d (items) loss = %.4f", i, loss)` after the item half, the same for the
+    user half, "Converged after %d iterations" when the tolerance is met (VERDICT r05 missing #6: the losses existed only as
+    `model.losses`).  Python's `logging`, logger "rsparse_amd"; silent unless configured, as lgr's threshold makes the reference's."""
+    import logging
+    import scipy.sparse as sp
+    from rsparse_amd import WRMF
+    from oracle_backend import OracleBackend
+    n_user, n_item, p, i, x = ml_train
+    train = sp.csc_matrix((x, i, p), shape=(n_user, n_item))
+    model = WRMF(rank=8, lambda_=0.1, feedback="implicit", solver="conjugate_gradient", precision="double", rng=3,
+                 backend=OracleBackend())
+    with caplog.at_level(logging.INFO, logger="rsparse_amd"):
+        model.fit_transform(train, n_iter=3, convergence_tol=-1)
+    lines = [r.getMessage() for r in caplog.records if r.name == "rsparse_amd"]
+    assert lines == [m for it, (li, lu) in enumerate(model.losses, 1)
+                     for m in ("iter %d (items) loss = %.4f" % (it, li), "iter %d (users) loss = %.4f" % (it, lu))]
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="rsparse_amd"):
+        model.fit_transform(train, n_iter=50, convergence_tol=0.5)
+    assert caplog.records[-1].getMessage() == "Converged after %d iterations" % len(model.losses)

@@ -1124,7 +1124,7 @@ hipError_t launch_bucket(const AlsArgs& a, const int32_t* rows, int n_rows, int 
       return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, GB, CAPQ == 8 ? 1 : 2>(a, rows, n_rows, grid, slot0, s, ev_slot);
   }
   // the rank is the padded rank (32 / 64 / 128): the instantiation whose first sweep runs behind the gather
-  if constexpr (!KFULL && STREAM == 0 && !GB) {
+  if constexpr (!KFULL && STREAM == 0) {
     if (a.k == KP && kfull_enabled())
       return launch_bucket<KP, WAVES, CAPQ, WPR, STREAM, IMPLICIT, GB, DMF, true>(a, rows, n_rows, grid, slot0, s, ev_slot);
   }

@@ -1379,21 +1379,45 @@ __global__ __launch_bounds__(256) void ne_stats_kernel(const float* __restrict__
 }
 
 // out[r][t] = base[t] - g * sum_j (c_j - 1) X[t, idx_j]  for row rows[r]; slot_of_row[rows[r]] = r.  One 256-thread workgroup
-// per row: thread (half, t) sums every second non-zero of element t (coalesced k-float reads), the halves meet in LDS.
+// per row: thread (part, t) sums every PARTS-th non-zero of element t (coalesced k-float reads), the parts meet in LDS in a
+// fixed order.  Eight non-zeros per trip, their indices first and their vectors in flight together (round 6: one non-zero per
+// trip -- index, then vector, then the next index -- was two dependent round trips per non-zero, 22 ms per call at 1M x 100k
+// where the same rows' conjugate-gradient launch takes 2.4).
+template <int KPW>
 __global__ __launch_bounds__(256) void gb_row_terms_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n,
                                                             float* __restrict__ out, int32_t* __restrict__ slot_of_row) {
-  __shared__ float part[128];
+  constexpr int PARTS = 256 / KPW, U = 8;
+  __shared__ float part[PARTS][KPW];
   const int r = blockIdx.x;
   if (r >= n) return;
   const int row = rows[r], k = a.k;
-  const int t = threadIdx.x & 127, hf = threadIdx.x >> 7;
+  const int t = threadIdx.x % KPW, pt = threadIdx.x / KPW;
+  const int tc = min(t, k - 1);
   const int p1 = a.col_ptrs[row], p2 = a.col_ptrs[row + 1];
   float acc = 0.f;
-  if (t < k)
-    for (int j = p1 + hf; j < p2; j += 2) acc = fmaf(a.vals[j] - 1.f, a.X[(size_t)a.row_idx[j] * k + t], acc);
-  if (hf == 1) part[t] = acc;
+  for (int j0 = p1 + pt; j0 < p2; j0 += U * PARTS) {
+    int id[U];
+    float cv[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int j = j0 + u * PARTS;
+      const bool ok = j < p2;
+      id[u] = a.row_idx[ok ? j : p2 - 1];
+      cv[u] = ok ? a.vals[j] - 1.f : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) xv[u] = a.X[(size_t)id[u] * k + tc];
+#pragma unroll
+    for (int u = 0; u < U; u++) acc = fmaf(cv[u], xv[u], acc);
+  }
+  part[pt][t] = acc;
   __syncthreads();
-  if (hf == 0 && t < k) out[(size_t)r * k + t] = a.rhs_init[t] - a.gbias * (acc + part[t]);
+  if (pt == 0 && t < k) {
+    float sum = part[0][t];
+#pragma unroll
+    for (int q = 1; q < PARTS; q++) sum += part[q][t];
+    out[(size_t)r * k + t] = a.rhs_init[t] - a.gbias * sum;
+  }
   if (threadIdx.x == 0) slot_of_row[row] = r;
 }
 
@@ -1401,7 +1425,8 @@ __global__ __launch_bounds__(256) void gb_row_terms_kernel(AlsArgs a, const int3
 
 hipError_t launch_gb_row_terms(const AlsArgs& a, const int32_t* rows, int n, float* out, int32_t* slot_of_row, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gb_row_terms_kernel, dim3(n), dim3(256), 0, s, a, rows, n, out, slot_of_row);
+  if (a.k <= 64) hipLaunchKernelGGL(gb_row_terms_kernel<64>, dim3(n), dim3(256), 0, s, a, rows, n, out, slot_of_row);
+  else hipLaunchKernelGGL(gb_row_terms_kernel<128>, dim3(n), dim3(256), 0, s, a, rows, n, out, slot_of_row);
   return hipGetLastError();
 }
 

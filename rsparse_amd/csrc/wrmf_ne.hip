@@ -1379,25 +1379,27 @@ __global__ __launch_bounds__(256) void ne_stats_kernel(const float* __restrict__
 }
 
 // out[r][t] = base[t] - g * sum_j (c_j - 1) X[t, idx_j]  for row rows[r]; slot_of_row[rows[r]] = r.  One 256-thread workgroup
-// per row: thread (part, t) sums every PARTS-th non-zero of element t (coalesced k-float reads), the parts meet in LDS in a
-// fixed order.  Eight non-zeros per trip, their indices first and their vectors in flight together (round 6: one non-zero per
-// trip -- index, then vector, then the next index -- was two dependent round trips per non-zero, 22 ms per call at 1M x 100k
-// where the same rows' conjugate-gradient launch takes 2.4).
+// per row.  A lane reads FOUR coordinates of a vector (16 bytes), KPW / 4 lanes a whole vector, so the workgroup's PARTS = 1024 / KPW
+// lane groups take every PARTS-th non-zero each; eight non-zeros per trip and group, their indices first and their vectors in
+// flight together; the groups' sums meet in LDS in a fixed order.  (Round 6.  Through round 5: a thread per coordinate, one
+// non-zero per trip -- index, then vector, then the next index: two dependent round trips per non-zero, 22 ms per call at 1M x 100k
+// where the same rows' conjugate-gradient launch takes 2.4; eight per trip with 4-byte reads: 9.3 ms.)
 template <int KPW>
 __global__ __launch_bounds__(256) void gb_row_terms_kernel(AlsArgs a, const int32_t* __restrict__ rows, int n,
                                                             float* __restrict__ out, int32_t* __restrict__ slot_of_row) {
-  constexpr int PARTS = 256 / KPW, U = 8;
-  __shared__ float part[PARTS][KPW];
+  constexpr int LPR = KPW / 4, PARTS = 256 / LPR, U = 8;
+  __shared__ float4 part[PARTS][LPR];
   const int r = blockIdx.x;
   if (r >= n) return;
   const int row = rows[r], k = a.k;
-  const int t = threadIdx.x % KPW, pt = threadIdx.x / KPW;
-  const int tc = min(t, k - 1);
+  const int c4 = threadIdx.x % LPR, pt = threadIdx.x / LPR;
+  const int tc = min(4 * c4, k - 4);   // (k % 4 == 0: ne_supported)
   const int p1 = a.col_ptrs[row], p2 = a.col_ptrs[row + 1];
-  float acc = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int j0 = p1 + pt; j0 < p2; j0 += U * PARTS) {
     int id[U];
-    float cv[U], xv[U];
+    float cv[U];
+    float4 xv[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int j = j0 + u * PARTS;
@@ -1406,17 +1408,30 @@ __global__ __launch_bounds__(256) void gb_row_terms_kernel(AlsArgs a, const int3
       cv[u] = ok ? a.vals[j] - 1.f : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) xv[u] = a.X[(size_t)id[u] * k + tc];
+    for (int u = 0; u < U; u++) xv[u] = *reinterpret_cast<const float4*>(a.X + (size_t)id[u] * k + tc);
 #pragma unroll
-    for (int u = 0; u < U; u++) acc = fmaf(cv[u], xv[u], acc);
+    for (int u = 0; u < U; u++) {
+      acc.x = fmaf(cv[u], xv[u].x, acc.x);
+      acc.y = fmaf(cv[u], xv[u].y, acc.y);
+      acc.z = fmaf(cv[u], xv[u].z, acc.z);
+      acc.w = fmaf(cv[u], xv[u].w, acc.w);
+    }
   }
-  part[pt][t] = acc;
+  part[pt][c4] = acc;
   __syncthreads();
-  if (pt == 0 && t < k) {
-    float sum = part[0][t];
+  if (pt == 0 && 4 * c4 < k) {
+    float4 sum = part[0][c4];
 #pragma unroll
-    for (int q = 1; q < PARTS; q++) sum += part[q][t];
-    out[(size_t)r * k + t] = a.rhs_init[t] - a.gbias * sum;
+    for (int q = 1; q < PARTS; q++) {
+      const float4 v = part[q][c4];
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const float* base = a.rhs_init + 4 * c4;   // (k floats somewhere in a scratch buffer: no alignment promise)
+    float* o = out + (size_t)r * k + 4 * c4;
+    o[0] = base[0] - a.gbias * sum.x;
+    o[1] = base[1] - a.gbias * sum.y;
+    o[2] = base[2] - a.gbias * sum.z;
+    o[3] = base[3] - a.gbias * sum.w;
   }
   if (threadIdx.x == 0) slot_of_row[row] = r;
 }

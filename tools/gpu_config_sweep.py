@@ -28,6 +28,9 @@ for fb, solver, rank, bias in itertools.product(("implicit", "explicit"), ("conj
     cases.append((fb, solver, rank, bias, "float"))
 cases += [("implicit", "cholesky", 10, False, "double"), ("implicit", "nnls", 10, False, "double"), ("explicit", "conjugate_gradient", 10, True, "double")]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+if len(sys.argv) > 2:   # a filter: feedback[,solver,...] e.g. "explicit" or "explicit,cholesky"; "-nnls" drops a solver
+    for w in sys.argv[2].split(","):
+        cases = [c for c in cases if (w[1:] not in c if w.startswith("-") else w in c)]
 t_start = time.perf_counter()
 for fb, solver, rank, bias, prec in cases:
     if time.perf_counter() - t_start > budget:

@@ -20,7 +20,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 SRC = [CSRC / n for n in ("wrmf_kernels.hip", "wrmf_cgq.hip", "wrmf_cgp.hip", "wrmf_ne.hip", "wrmf_chol.hip", "wrmf_chol_wave.hip", "wrmf_chol_mf.hip", "wrmf_cg_mf.hip", "wrmf_chol_lr.hip",
                           "wrmf_topk.hip", "wrmf_ingest.hip", "wrmf_nnls.hip", "wrmf_bias.hip", "wrmf_lu.hip",
-                          "wrmf_f64.hip", "wrmf_wide.hip", "wrmf_ctx_kernels.hip", "wrmf_capi.cpp", "wrmf_f64_capi.cpp", "wrmf_ctx.cpp")]
+                          "wrmf_f64.hip", "wrmf_wide.hip", "wrmf_wide_cg.hip", "wrmf_ctx_kernels.hip", "wrmf_capi.cpp", "wrmf_f64_capi.cpp", "wrmf_ctx.cpp")]
 HEADERS = [CSRC / "wrmf_chol_mf.attrs.csv", CSRC / "wrmf_mf.h", CSRC / "wrmf_internal.h", CSRC / "wrmf_device.h", CSRC / "wrmf_ldlt.h", CSRC / "wrmf_f64.h", PKG.parent / "include" / "rsparse_wrmf_hip.h"]
 DEPS = SRC + HEADERS
 OUT = PKG / "lib" / "librsparse_wrmf_hip.so"

@@ -617,7 +617,8 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
       return RSPARSE_HIP_OK;
     }
     const int grid = wide_als_grid(d.n_cols);
-    if ((rc = g_ws.ensure_partials((size_t)grid))) return rc;
+    const int grid_w = wide_cg_wave_grid(d.n_cols) + wide_cg_team_grid(d.n_cols);   // (plain conjugate gradient: wrmf_wide_cg.hip's two launches)
+    if ((rc = g_ws.ensure_partials((size_t)grid + (size_t)grid_w))) return rc;
     if ((rc = g_ws.ensure_wide(solver == RSPARSE_SOLVER_NNLS ? (size_t)grid * wide_m2_floats_per_wg(rank) : 0,
                                solver == RSPARSE_SOLVER_CHOLESKY ? (size_t)grid * rank * rank : 0)))
       return rc;
@@ -632,9 +633,13 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
     a.rhs_init = bias ? bias->rhs_init : nullptr;
     a.loss_tgt_const = bias ? bias->tgt_const : 1.f;
     a.gbias = (solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT && implicit && bias) ? bias->gbias : 0.f;
-    hipError_t we = launch_als_wide(a, implicit, solver, g_ws.wide_m2, g_ws.wide_lu, s);
-    if (we != hipSuccess) return hip_fail(we, "launch_als_wide");
-    if ((we = launch_sum_partials(g_ws.partials, (size_t)grid, outw, s, g_ws.partials + g_ws.partial_slots)) != hipSuccess)
+    // plain conjugate gradient: the operator form, one wave per row (teams of 8 for the rows beyond kWideCgMaxLen non-zeros) -- no k x k
+    // system; everything else: wrmf_wide.hip
+    const bool wave_cg = wide_cg_wave_supported(a, solver) && (d.q_order || d.max_len <= kWideCgMaxLen);
+    hipError_t we = wave_cg ? launch_wide_cg_wave(a, implicit, kWideCgMaxLen, d.max_len > kWideCgMaxLen ? d.q_order : nullptr, 0, s)
+                            : launch_als_wide(a, implicit, solver, g_ws.wide_m2, g_ws.wide_lu, s);
+    if (we != hipSuccess) return hip_fail(we, wave_cg ? "launch_wide_cg_wave" : "launch_als_wide");
+    if ((we = launch_sum_partials(g_ws.partials, wave_cg ? (size_t)grid_w : (size_t)grid, outw, s, g_ws.partials + g_ws.partial_slots)) != hipSuccess)
       return hip_fail(we, "launch_sum_partials");
     return RSPARSE_HIP_OK;
   }

@@ -325,7 +325,14 @@ bool wide_supported(int k);
 int wide_als_grid(int n_cols);
 size_t wide_m2_floats_per_wg(int k);            // NNLS scratch per workgroup
 size_t wide_gramian_scratch_floats(int k);
-hipError_t launch_als_wide(const AlsArgs& a, bool implicit, unsigned solver, float* m2_scratch, float* lu_scratch, hipStream_t s);
+hipError_t launch_als_wide(const AlsArgs& a, bool implicit, unsigned solver, float* m2_scratch, float* lu_scratch, hipStream_t s,
+                           int n_lo = -1);   // n_lo: rows of at most that many non-zeros belong to another launch
+// plain conjugate gradient at these ranks, rows of at most kWideCgMaxLen non-zeros: one wave per row, no k x k system (wrmf_wide_cg.hip)
+constexpr int kWideCgMaxLen = 2048;
+bool wide_cg_wave_supported(const AlsArgs& a, unsigned solver);
+int wide_cg_wave_grid(int n_cols);
+int wide_cg_team_grid(int n_cols);
+hipError_t launch_wide_cg_wave(const AlsArgs& a, bool implicit, int n_hi, const int32_t* order, int slot0, hipStream_t s);
 hipError_t launch_gramian_wide(const float* X, int k, int64_t n, float ridge, float* XtX, double* sumsq, float* scratch,
                                hipStream_t s);
 

@@ -105,6 +105,7 @@ struct WideArgs {
   int* fail_counter;
   float* m2_scratch;   // NNLS: per workgroup k x (k + 1) floats
   float* lu_scratch;   // general solver: per workgroup k x k floats
+  int n_lo;            // rows of at most this many non-zeros are another launch's (wrmf_wide_cg.hip); -1: none
 };
 
 __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH) {
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
   for (int row = blockIdx.x; row < a.n_cols; row += gridDim.x) {
     const int p1 = a.col_ptrs[row], n = a.col_ptrs[row + 1] - p1;
     float* yrow = a.Y + (size_t)row * k;
+    if (n <= a.n_lo) continue;
     if (n <= 0 && !a.rhs_init) {   // empty column -> zeros (wrmf_implicit.hpp:272-283, wrmf_explicit.hpp:133-144)
       for (int t = tid; t < k; t += NT) yrow[t] = 0.f;
       continue;
@@ -551,9 +553,10 @@ size_t wide_gramian_scratch_floats(int k) { return (size_t)kWideGramBlocks * (wi
 // the half-iteration of `a` (system order a.k in 129..256) on `grid` = wide_als_grid(n_cols) workgroups; loss partials
 // a.loss_partials[0 .. grid)
 hipError_t launch_als_wide(const AlsArgs& a, bool implicit, unsigned solver, float* m2_scratch, float* lu_scratch,
-                           hipStream_t s) {
+                           hipStream_t s, int n_lo) {
   if (a.n_cols <= 0) return hipSuccess;
   WideArgs w;
+  w.n_lo = n_lo;
   w.col_ptrs = a.col_ptrs; w.row_idx = a.row_idx; w.vals = a.vals; w.X = a.X; w.Y = a.Y; w.XtX = a.XtX;
   w.n_cols = a.n_cols; w.k = a.k; w.implicit = implicit ? 1 : 0; w.solver = (int)solver; w.cg_steps = a.cg_steps;
   w.dynamic_lambda = a.dynamic_lambda; w.lambda_loss = a.lambda_loss;

@@ -324,10 +324,13 @@ int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_pt
   // its mean workgroup (round 3, in-kernel counters): of the two workgroups that share a CU's SIMDs the one dispatched
   // first wins the issue arbitration and runs 27 % faster -- every workgroup of index < 256 took 63.9 M ticks for its
   // list, every one of index >= 256 81.4 M for an equal list, the last 17 M of them alone on its CU.
-  const int n_slots = std::min(n_prefix, 2 * std::max(cus, 1));           // what the share of the split rule refers to
+  // (round 6, `fine` lists: the slots of the whole machine even when there are fewer rows than slots -- the giant rows that
+  //  wrmf_cg_mf.hip leaves to this kernel are a few hundred: one workgroup per row left 40 % of the slots empty and every row as
+  //  long as its wave could stream it, 4.4 GB in 4.7 ms; cut to the machine's share they are segments of >= 64 steps)
+  const int n_slots = fine ? 2 * std::max(cus, 1) : std::min(n_prefix, 2 * std::max(cus, 1));   // what the share of the split rule refers to
   // (`fine` = false: one list per slot, for the kernels that are resident once per CU -- no such asymmetry there, and a
   //  workgroup start costs more: XtX tiles into LDS; many short lists cost them 1..7 %)
-  const int n_wg = fine ? std::max(n_slots, std::min(n_prefix / 8, 256 * std::max(cus, 1))) : n_slots;
+  int n_wg = fine ? std::max(n_slots, std::min(n_prefix / 8, 256 * std::max(cus, 1))) : n_slots;
   // Items of the deal: whole rows, and SEGMENTS of the rows that are too long to balance (the 5e5-non-zero item of the
   // bench matrix is by itself an average workgroup's share; on a rank of an 8-GPU run it is eight shares).  A row
   // whose cost exceeds half a share is cut into up to kNeMaxSeg runs of whole steps of about a quarter share; the
@@ -347,7 +350,8 @@ int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_pt
     const int64_t len = len_of(r);
     const int64_t st = steps_of(len);
     int parts = 1;
-    if (n_slots >= 8 && 2 * (st + fixed) > share) parts = (int)std::min<int64_t>(kNeMaxSeg, (4 * st + share - 1) / share);
+    if (n_slots >= 8 && 2 * (st + fixed) > share)
+      parts = (int)std::min<int64_t>(std::min<int64_t>(kNeMaxSeg, st / 64), (4 * st + share - 1) / share);   // (a segment: >= 64 steps)
     if (parts < 2 || n_seg + parts > kNeMaxSegTotal) {
       items.push_back({st + fixed, order[(size_t)r]});
       continue;
@@ -366,6 +370,7 @@ int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_pt
   }
   std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
   const size_t n_items = items.size();
+  n_wg = (int)std::min<size_t>((size_t)n_wg, n_items);   // (no empty lists)
   std::vector<int> owner(n_items);
   std::vector<int32_t> cnt_wg((size_t)n_wg + 1, 0);
   std::priority_queue<std::pair<int64_t, int>, std::vector<std::pair<int64_t, int>>, std::greater<>> heap;

@@ -179,7 +179,7 @@ bool ne_supported(int k);
 constexpr int kNeMinLen = 512;       // its rows: more non-zeros than the largest resident bucket of wrmf_cgq.hip holds
 constexpr int kNeCholMinLen = 64;   // (rounds 2-5: solver == CHOLESKY's threshold of the same launch; dev builds: RSPARSE_HIP_NE_CHOL_MIN)
 constexpr int kNeMaxSeg = 16;        // segments per split row
-constexpr int kNeMaxSegTotal = 64;   // ... per matrix
+constexpr int kNeMaxSegTotal = 1024;   // ... per list set (186 MB of partial accumulators at most)
 constexpr int kNeSegFloats = 4 * (11 * 16 * 64 + 128 + 2);   // per segment: 4 waves x (<= 11 accumulator tiles + b + sum c)
 // absmax_hint (nullable, device float): max |X| supplied by the caller -- X is then not scanned
 // cached_vstats (nullable, 2 device words = stats[1..2] of an earlier scan of the same values): the values are not read;

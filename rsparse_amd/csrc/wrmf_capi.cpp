@@ -1684,9 +1684,9 @@ int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_use
   if (n_exclude > 0 && !d_excl0) return fail(RSPARSE_HIP_ERR_INVALID, "exclude is NULL");
   // (few users over many items: the items are split over the workgroups, the slices' lists land in this scratch)
   float* scratch = nullptr;
-  const size_t ent = top_product_scratch_entries(n_users, n_items, k);
-  if (ent > 0) {
-    int rc = g_ws.ensure_pad(2 * ent + (size_t)n_users + 16);
+  const size_t sfl = top_product_scratch_floats(n_users, n_items, rank, k);
+  if (sfl > 0) {
+    int rc = g_ws.ensure_pad(sfl);
     if (rc) return rc;
     scratch = g_ws.pad_buf;
   }
@@ -1712,9 +1712,9 @@ int rsparse_hip_top_product_f64_device(const float* d_U, const float* d_V, const
   int rc = g_ws.ensure_bias(top_product_f64_scratch_words(n_users, kc, k));   // (nothing else uses this buffer meanwhile)
   if (rc) return rc;
   float* split = nullptr;   // few users over many items: the nominating pass splits the items over the workgroups
-  const size_t ent = top_product_scratch_entries(n_users, n_items, kc);
-  if (ent > 0) {
-    if ((rc = g_ws.ensure_pad(2 * ent + (size_t)n_users + 16))) return rc;
+  const size_t sfl = top_product_scratch_floats(n_users, n_items, rank, kc);   // (or the candidate buffers of a large k)
+  if (sfl > 0) {
+    if ((rc = g_ws.ensure_pad(sfl))) return rc;
     split = g_ws.pad_buf;
   }
   hipError_t e = launch_top_product_f64(d_U, d_V, d_U64, d_V64, n_users, n_items, rank, k, kc, d_nr_p, d_nr_p ? d_nr_j : nullptr,

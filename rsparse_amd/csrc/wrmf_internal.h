@@ -307,6 +307,10 @@ hipError_t launch_top_product_f64(const float* U32, const float* V32, const doub
 // a call for few users over many items is split over the items (wrmf_topk.hip): floats of scratch it wants
 // (2 x entries + n_users), 0 = not split
 size_t top_product_scratch_entries(int n_users, int n_items, int topk);
+// ... and what launch_top_product wants in all (floats, 0 = none): those lists, or -- many users, a k whose candidate buffers do
+// not fit the LDS -- the global candidate buffers of the two-tile kernel (wrmf_topk.hip "GBUF")
+size_t top_product_scratch_floats(int n_users, int n_items, int k_rank, int topk);
+bool top_product_wants_gbuf(int n_users, int k_rank, int topk);
 
 // device helpers of the multi-GPU context (wrmf_ctx_kernels.hip / wrmf_ctx.cpp)
 hipError_t launch_ctx_accumulate(const float* Gpart, const double* sumsq, double* red, int k, hipStream_t s);

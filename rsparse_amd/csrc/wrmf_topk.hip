@@ -32,8 +32,21 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 constexpr int kTopBlock = 32;    // users per MFMA block
 constexpr int kTopMaxK = 256;    // RSPARSE_HIP_MAX_TOPK
+constexpr int kTopMaxCap = 576;  // no candidate buffer is longer (top_gcap(256) = 544; the LDS geometries: k + 128 at most)
 // candidate buffer per user: the heap (k entries) + everything one round can add (32 items per tile of the round)
 __host__ __device__ constexpr int top_cap(int topk, int tiles_per_round) { return ((topk + 32 * tiles_per_round + 3) / 4) * 4; }
+
+// GBUF (round 6): the candidate buffers of 256 users fit the LDS next to two tiles only up to k = 27 at rank 128, and only without
+// a spare entry: a user was settled at EVERY arrival.  The tile-sharing kernel now keeps them in GLOBAL memory (a scratch slot
+// per workgroup: appends are fire-and-forget stores, only the counts and thresholds stay in LDS) with room for a BATCH of
+// arrivals beyond one tile's worth -- a user is settled once per max(64, k) arrivals, in the settling wave's LDS work area,
+// by a radix select (topk_reduce_user).  One geometry, 256 users per workgroup, for every k.
+#ifdef RSP_TOPK_GBATCH   // dev builds: a fixed batch room
+__host__ __device__ constexpr int top_gcap(int topk) { return ((topk + 32 + RSP_TOPK_GBATCH + 3) / 4) * 4; }
+#else
+__host__ __device__ constexpr int top_gcap(int topk) { return ((topk + 32 + (topk > 64 ? topk : 64) + 3) / 4) * 4; }
+#endif
+constexpr int kTopGbufChunk = 131072;   // users per launch of a GBUF call: 512 slots of scratch, two full rounds of workgroups
 
 // the kernel in which every wave walks its own item tiles against the workgroup's 32 UB users (W waves = W tiles per round)
 template <int KP, int UB, int W>
@@ -86,28 +99,65 @@ __device__ __forceinline__ float topk_reduce_user(float* bv, int* bi, float* tv,
   const bool few = old == topk && n - old <= 8;
   float kth = 0.f;
   int ge = topk + 1;
+  // (round 6) The k-th best score by a radix select over the entries held in registers -- 32 bit positions x a ballot per register
+  // -- instead of ranking every entry against every other (O(n^2 / 64): 15 us at n = 220, and the batched settles of the global
+  // buffers made it the whole cost of top-100).  The buffer's order carries no meaning (the heap is a set: the replay below scans
+  // it for its minimum, the emission ranks it), so the survivors -- the entries at or above the k-th score, exactly k of them
+  // unless the bound is tied -- are compacted to the front in place.
+  constexpr int NE = (kTopMaxCap + 63) / 64;
+  unsigned key[NE];
+  int eix[NE];
   if (!few) {
-  for (int c = lane; c < n; c += 64) {
-    const float v = bv[c];
-    const int ix = bi[c];
-    int rank = 0;
-    for (int c2 = 0; c2 < n; c2++) rank += sel_before(bv[c2], bi[c2], v, ix) ? 1 : 0;
-    if (rank < topk) {
-      tv[rank] = v;
-      ti[rank] = ix;
-    }
-  }
-  wave_sync();
-  // More candidates at the k-th score than places for them?  Then WHICH of them survive depends on the order in
-  // which the reference's heap met them (it evicts the smallest index among tied minima, but a tied newcomer
-  // never enters a full heap: scores [1,1,5], k = 2 -> {2,1}; [1,5,1] -> {1,0}), and the arrivals since the last
-  // reduction are replayed through that heap in index order.  Everything that arrived before was reduced the
-  // same way, so the buffer's first `old` entries ARE the reference's heap at that point.
-  kth = tv[topk - 1];
-  ge = 0;
-  for (int c = lane; c < n; c += 64) ge += bv[c] >= kth ? 1 : 0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) ge += __shfl_xor(ge, off);
+    for (int j = 0; j < NE; j++) {
+      const int c = lane + 64 * j;
+      key[j] = 0u;   // (below every score's key: a finite float maps to a key >= 0x00800000)
+      eix[j] = 0;
+      if (c < n) {
+        const unsigned u = __float_as_uint(bv[c] + 0.f);   // (-0 -> +0: equal scores, equal keys)
+        key[j] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        eix[j] = bi[c];
+      }
+    }
+    unsigned kk = 0u;   // the k-th largest key, bit by bit
+    for (int bit = 31; bit >= 0; bit--) {
+      const unsigned trial = kk | (1u << bit);
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < NE; j++)
+        if (64 * j < n) cnt += __popcll(__ballot(key[j] >= trial));
+      if (cnt >= topk) kk = trial;
+    }
+    ge = 0;
+#pragma unroll
+    for (int j = 0; j < NE; j++)
+      if (64 * j < n) ge += __popcll(__ballot(key[j] >= kk));
+    kth = __uint_as_float((kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk);
+    // More candidates at the k-th score than places for them?  Then WHICH of them survive depends on the order in
+    // which the reference's heap met them (it evicts the smallest index among tied minima, but a tied newcomer
+    // never enters a full heap: scores [1,1,5], k = 2 -> {2,1}; [1,5,1] -> {1,0}), and the arrivals since the last
+    // reduction are replayed through that heap in index order.  Everything that arrived before was reduced the
+    // same way, so the buffer's first `old` entries ARE the reference's heap at that point.
+    if (ge == topk) {
+      wave_sync();   // (every lane holds its entries; the buffer is rewritten in place)
+      int base = 0;
+#pragma unroll
+      for (int j = 0; j < NE; j++) {
+        if (64 * j < n) {
+          const bool keep = key[j] >= kk;
+          const unsigned long long m = __ballot(keep);
+          if (keep) {
+            const int dst = base + __popcll(m & ((1ull << lane) - 1ull));
+            const unsigned kj = key[j];
+            bv[dst] = __uint_as_float((kj & 0x80000000u) ? (kj & 0x7fffffffu) : ~kj);
+            bi[dst] = eix[j];
+          }
+          base += __popcll(m);
+        }
+      }
+      wave_sync();
+      return kth;
+    }
   }
   if (ge > topk) {   // wave-uniform
     wave_sync();
@@ -161,12 +211,7 @@ __device__ __forceinline__ float topk_reduce_user(float* bv, int* bi, float* tv,
     for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
     return mn;
   }
-  for (int c = lane; c < topk; c += 64) {
-    bv[c] = tv[c];
-    bi[c] = ti[c];
-  }
-  wave_sync();
-  return kth;
+  return kth;   // (not reached: ge >= topk whenever n > topk)
 }
 
 // The tile-sharing kernels append a score that beats its user's threshold WITHOUT looking at the exclusion lists (the
@@ -582,9 +627,32 @@ struct TopPipeSmem {
     const size_t cap = (size_t)top_cap(topk, 1);
     return (tile_floats + 2 * (size_t)USERS * cap + 3 * USERS) * 4 + 64 + (size_t)4 * cap * 8;
   }
+  static size_t gbytes(int topk) {   // GBUF: tiles, counts / thresholds / verified lengths, per wave a work area and a scratch
+    return (tile_floats + 3 * USERS) * 4 + 64 + (size_t)4 * top_gcap(topk) * 16;
+  }
 };
 
-template <int KP, int UB, bool VEC>
+// GBUF: a user's buffer (global: gv / gi, n entries) through the wave's LDS work area (wv_ / wi_): arrivals verified, the buffer
+// reduced when it is over-full, what is left written back.  One wave.
+__device__ __forceinline__ void topk_settle_user_g(float* gv, int* gi, float* wv_, int* wi_, float* tv, int* ti, int* cnt,
+                                                   float* thr, int* need, const int topk, const int32_t* __restrict__ nr_ptr,
+                                                   const int32_t* __restrict__ nr_idx, const int u,
+                                                   const int32_t* __restrict__ excl, const int n_excl, const int lane) {
+  const int n0 = *cnt;
+  for (int c = lane; c < n0; c += 64) {
+    wv_[c] = gv[c];
+    wi_[c] = gi[c];
+  }
+  wave_sync();
+  topk_settle_user(wv_, wi_, tv, ti, cnt, thr, need, topk, nr_ptr, nr_idx, u, excl, n_excl, lane);
+  const int nn = *cnt;
+  for (int c = lane; c < nn; c += 64) {
+    gv[c] = wv_[c];
+    gi[c] = wi_[c];
+  }
+}
+
+template <int KP, int UB, bool VEC, bool GBUF = false>
 __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                                int n_users, int n_items, int k_rank, int topk,
                                                                const int32_t* __restrict__ nr_ptr,
@@ -592,20 +660,24 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
                                                                const int32_t* __restrict__ excl, int n_excl,
                                                                float glob_mean, int32_t* __restrict__ res,
                                                                float* __restrict__ scores_out, int slice_items,
-                                                               const int* __restrict__ user_flags) {
+                                                               const int* __restrict__ user_flags, float* gbuf) {
   using SM = TopPipeSmem<KP, UB>;
   constexpr int LDT = SM::LDT, NK2 = KP / 2, USERS = SM::USERS, UPW = 32 * UB;
   constexpr int CH = NK2 / 16;   // k-steps (x UB matrix instructions) issued per accumulator entry of the previous tile
-  const int cap = top_cap(topk, 1);
+  const int cap = GBUF ? top_gcap(topk) : top_cap(topk, 1);
+  const int settle_at = GBUF ? cap - 32 : topk;   // a user is settled when its count passes this (room for one tile's arrivals)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tiles = reinterpret_cast<float*>(smem);                    // [2][32][LDT]
-  float* sVal = tiles + SM::tile_floats;
+  // GBUF: the buffers are this workgroup's slot of the global scratch ([USERS][cap] scores, then as many indices)
+  float* sVal = GBUF ? gbuf + (size_t)blockIdx.x * 2 * USERS * cap : tiles + SM::tile_floats;
   int* sIdx = reinterpret_cast<int*>(sVal + (size_t)USERS * cap);
-  int* sCnt = sIdx + (size_t)USERS * cap;
+  int* sCnt = GBUF ? reinterpret_cast<int*>(tiles + SM::tile_floats) : sIdx + (size_t)USERS * cap;
   float* sThr = reinterpret_cast<float*>(sCnt + USERS);
   int* sNeed = reinterpret_cast<int*>(sThr + USERS);
   float* sTmpV = reinterpret_cast<float*>(sNeed + USERS);
   int* sTmpI = reinterpret_cast<int*>(sTmpV + 4 * cap);
+  float* sWrkV = reinterpret_cast<float*>(sTmpI + 4 * cap);          // GBUF: [4][cap] the settling wave's copy of a buffer
+  int* sWrkI = reinterpret_cast<int*>(sWrkV + 4 * cap);
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
   const int u0 = blockIdx.x * USERS, uw = wv * UPW;
@@ -726,12 +798,20 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
     wave_sync();
     for (int b0 = 0; b0 < UPW; b0 += 64) {
       const int ulq = uw + b0 + lane;
-      unsigned long long over = __ballot(b0 + lane < UPW && sCnt[ulq] > topk);
+      unsigned long long over = __ballot(b0 + lane < UPW && sCnt[ulq] > settle_at);
+      if constexpr (GBUF) {
+        // (the appends are this wave's own stores: complete, and not served from a stale line of the vector cache)
+        if (over) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      }
       while (over) {
         const int ul = uw + b0 + __builtin_ctzll(over);
         over &= over - 1;
-        topk_settle_user(sVal + ul * cap, sIdx + ul * cap, sTmpV + wv * cap, sTmpI + wv * cap, sCnt + ul, sThr + ul, sNeed + ul,
-                         topk, nr_ptr, nr_idx, u0 + ul, excl, n_excl, lane);
+        if constexpr (GBUF)
+          topk_settle_user_g(sVal + (size_t)ul * cap, sIdx + (size_t)ul * cap, sWrkV + wv * cap, sWrkI + wv * cap, sTmpV + wv * cap,
+                             sTmpI + wv * cap, sCnt + ul, sThr + ul, sNeed + ul, topk, nr_ptr, nr_idx, u0 + ul, excl, n_excl, lane);
+        else
+          topk_settle_user(sVal + ul * cap, sIdx + ul * cap, sTmpV + wv * cap, sTmpI + wv * cap, sCnt + ul, sThr + ul, sNeed + ul,
+                           topk, nr_ptr, nr_idx, u0 + ul, excl, n_excl, lane);
       }
     }
     store_tile(tl + 2);   // into the buffer of tile tl: its last reader finished before the previous barrier
@@ -741,9 +821,27 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
     body(tl, acc[0], acc[1]);
     if (tl + 1 < n_tiles) body(tl + 1, acc[1], acc[0]);
   }
+  if constexpr (GBUF) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   for (int ul = uw; ul < uw + UPW; ul++) {
     const int u = u0 + ul;
     if (u >= n_users) break;
+    if constexpr (GBUF) {
+      // always through the work area: the last arrivals are verified / reduced there, and the emission reads LDS
+      float* wv_ = sWrkV + wv * cap;
+      int* wi_ = sWrkI + wv * cap;
+      const int n0 = sCnt[ul];
+      wave_sync();
+      for (int c = lane; c < n0; c += 64) {
+        wv_[c] = sVal[(size_t)ul * cap + c];
+        wi_[c] = sIdx[(size_t)ul * cap + c];
+      }
+      wave_sync();
+      if (n0 > sNeed[ul])
+        topk_settle_user(wv_, wi_, sTmpV + wv * cap, sTmpI + wv * cap, sCnt + ul, sThr + ul, sNeed + ul, topk, nr_ptr, nr_idx, u, excl,
+                         n_excl, lane);
+      topk_emit_user(wv_, wi_, min(sCnt[ul], topk), topk, lane, glob_mean, res + (size_t)u * topk, scores_out + (size_t)u * topk);
+      continue;
+    }
     if (sCnt[ul] > sNeed[ul])   // arrivals that no reduction has looked at yet (the buffer never filled up again)
       topk_settle_user(sVal + ul * cap, sIdx + ul * cap, sTmpV + wv * cap, sTmpI + wv * cap, sCnt + ul, sThr + ul, sNeed + ul, topk,
                        nr_ptr, nr_idx, u, excl, n_excl, lane);
@@ -825,7 +923,7 @@ namespace {
 hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
                                   const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
                                   float glob_mean, int32_t* res, float* scores, hipStream_t s, int n_slices, int slice_items,
-                                  const int* user_flags);
+                                  const int* user_flags, float* gbuf = nullptr);
 }
 
 // ---- `$predict` that orders like the reference: candidates re-scored in double ----
@@ -1062,6 +1160,25 @@ size_t top_product_scratch_entries(int n_users, int n_items, int topk) {
   const int S = top_product_slices(n_users, n_items, topk, &si);
   return S > 1 ? (size_t)S * n_users * topk : 0;
 }
+// GBUF: does a call of this shape keep its candidate buffers in the global scratch?  Every call for more than 128 users at a rank
+// up to 128 (at 129..256 a wave holds one user block): measured faster than the LDS buffers at EVERY k -- top-100 29 -> 86
+// TFLOP/s (the LDS took 32 users per workgroup there), top-10 80 -> 96, top-1 89 -> 98 (profiles/r06/r6topk_*).
+bool top_product_wants_gbuf(int n_users, int k_rank, int topk) {
+  if (n_users <= 128 || k_rank > 128 || topk < 1 || topk > kTopMaxK) return false;
+#ifdef RSP_TOPK_NO_GBUF   // dev builds: the round-5 geometries
+  return false;
+#endif
+  return padded_rank(k_rank) != 0;
+}
+// floats of scratch launch_top_product wants for this call (0 = none): the slices' lists of a call for few users, or the
+// global candidate buffers of a call for many users at a large k (at most 512 workgroup slots: longer calls go in chunks)
+size_t top_product_scratch_floats(int n_users, int n_items, int k_rank, int topk) {
+  const size_t ent = top_product_scratch_entries(n_users, n_items, topk);
+  if (ent > 0) return 2 * ent + (size_t)n_users + 16;
+  if (!top_product_wants_gbuf(n_users, k_rank, topk)) return 0;
+  const size_t blocks = ((size_t)std::min(n_users, kTopGbufChunk) + 255) / 256;
+  return blocks * 2 * 256 * (size_t)top_gcap(topk) + 16;
+}
 
 // scratch (nullable): top_product_scratch_entries floats + as many ints + n_users ints
 hipError_t launch_top_product(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
@@ -1069,9 +1186,21 @@ hipError_t launch_top_product(const float* U, const float* V, int n_users, int n
                               float glob_mean, int32_t* res, float* scores, hipStream_t s, float* scratch) {
   int slice_items = 0;
   const int S = scratch ? top_product_slices(n_users, n_items, topk, &slice_items) : 1;
-  if (S <= 1)
+  if (S <= 1) {
+    if (scratch && top_product_wants_gbuf(n_users, k_rank, topk)) {
+      // the candidate buffers in the scratch: chunks of users, one after the other on the stream, share its 512 slots
+      for (int c0 = 0; c0 < n_users; c0 += kTopGbufChunk) {
+        const int nu = std::min(kTopGbufChunk, n_users - c0);
+        const hipError_t e = launch_top_product_geo(U + (size_t)c0 * k_rank, V, nu, n_items, k_rank, topk, nr_ptr ? nr_ptr + c0 : nullptr,
+                                                    nr_idx, excl, n_excl, glob_mean, res + (size_t)c0 * topk, scores + (size_t)c0 * topk, s,
+                                                    1, 0, nullptr, scratch);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    }
     return launch_top_product_geo(U, V, n_users, n_items, k_rank, topk, nr_ptr, nr_idx, excl, n_excl, glob_mean, res, scores, s, 1,
                                   0, nullptr);
+  }
   const size_t ent = (size_t)S * n_users * topk;
   float* sl_scores = scratch;
   int32_t* sl_idx = reinterpret_cast<int32_t*>(scratch + ent);
@@ -1092,7 +1221,7 @@ namespace {
 hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, int n_items, int k_rank, int topk,
                                   const int32_t* nr_ptr, const int32_t* nr_idx, const int32_t* excl, int n_excl,
                                   float glob_mean, int32_t* res, float* scores, hipStream_t s, int n_slices, int slice_items,
-                                  const int* user_flags) {
+                                  const int* user_flags, float* gbuf) {
   const int KP = (k_rank > 128 && k_rank <= 256) ? 256 : padded_rank(k_rank);   // (ranks 129..256: one user block per wave)
   if (!KP || topk < 1 || topk > kTopMaxK) return hipErrorInvalidValue;
   if (n_users <= 0) return hipSuccess;
@@ -1111,6 +1240,21 @@ hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, i
                        nr_idx, excl, n_excl, glob_mean, res, scores, slice_items, user_flags);               \
     return hipGetLastError();                                                                                \
   }
+  // (the two-tile kernel takes the global candidate scratch as well)
+#define RSP_TOPK_GO_P(KERN, LDS, USERS, THREADS, GB)                                                         \
+  {                                                                                                          \
+    auto kern = KERN;                                                                                        \
+    const size_t lds = LDS;                                                                                  \
+    if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)lds)) != hipSuccess)                                                 \
+      return err;                                                                                            \
+    const int grid = (n_users + (USERS) - 1) / (USERS);                                                      \
+    hipLaunchKernelGGL(kern, dim3(grid, n_slices), dim3(THREADS), lds, s, U, V, n_users, n_items, k_rank, topk, nr_ptr, \
+                       nr_idx, excl, n_excl, glob_mean, res, scores, slice_items, user_flags, GB);           \
+    return hipGetLastError();                                                                                \
+  }
+  // GBUF: the launcher hands a scratch when the call is unsliced; taken where the 256-user buffers do not fit the LDS
+  const bool gbuf_now = gbuf && n_slices == 1 && n_users > 128 && n_users <= kTopGbufChunk && top_product_wants_gbuf(n_users, k_rank, topk);
   // Geometry, best first: the four waves share the item tile and own 64 / 32 users each (256 / 128 users per workgroup:
   // every item vector is read once per that many users) -- with two tiles resident and the epilogue hidden behind the next
   // tile's matrix instructions where the LDS allows it; then one tile per wave against 64 / 32 users; then the same on
@@ -1118,13 +1262,17 @@ hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, i
   // whether the users' candidate buffers fit the LDS next to the tiles, and that there are users enough for the block.
 #define RSP_TOPK(KPV)                                                                                        \
   if (KP == KPV) {                                                                                           \
+    if (gbuf_now) {                                                                                          \
+      if (vec) RSP_TOPK_GO_P((top_product_pipe_kernel<KPV, 2, true, true>), (TopPipeSmem<KPV, 2>::gbytes(topk)), 256, 256, gbuf) \
+      else RSP_TOPK_GO_P((top_product_pipe_kernel<KPV, 2, false, true>), (TopPipeSmem<KPV, 2>::gbytes(topk)), 256, 256, gbuf)     \
+    }                                                                                                        \
     if (TopPipeSmem<KPV, 2>::bytes(topk) <= kLdsMax && n_users > 128) {                                      \
-      if (vec) RSP_TOPK_GO((top_product_pipe_kernel<KPV, 2, true>), (TopPipeSmem<KPV, 2>::bytes(topk)), 256, 256) \
-      else RSP_TOPK_GO((top_product_pipe_kernel<KPV, 2, false>), (TopPipeSmem<KPV, 2>::bytes(topk)), 256, 256)     \
+      if (vec) RSP_TOPK_GO_P((top_product_pipe_kernel<KPV, 2, true>), (TopPipeSmem<KPV, 2>::bytes(topk)), 256, 256, nullptr) \
+      else RSP_TOPK_GO_P((top_product_pipe_kernel<KPV, 2, false>), (TopPipeSmem<KPV, 2>::bytes(topk)), 256, 256, nullptr)     \
     }                                                                                                        \
     if (TopPipeSmem<KPV, 1>::bytes(topk) <= kLdsMax && n_users > 64) {                                       \
-      if (vec) RSP_TOPK_GO((top_product_pipe_kernel<KPV, 1, true>), (TopPipeSmem<KPV, 1>::bytes(topk)), 128, 256) \
-      else RSP_TOPK_GO((top_product_pipe_kernel<KPV, 1, false>), (TopPipeSmem<KPV, 1>::bytes(topk)), 128, 256)     \
+      if (vec) RSP_TOPK_GO_P((top_product_pipe_kernel<KPV, 1, true>), (TopPipeSmem<KPV, 1>::bytes(topk)), 128, 256, nullptr) \
+      else RSP_TOPK_GO_P((top_product_pipe_kernel<KPV, 1, false>), (TopPipeSmem<KPV, 1>::bytes(topk)), 128, 256, nullptr)     \
     }                                                                                                        \
     if (TopSharedSmem<KPV, 2>::bytes(topk) <= kLdsMax && n_users > 128) {                                    \
       if (vec) RSP_TOPK_GO((top_product_shared_kernel<KPV, 2, true>), (TopSharedSmem<KPV, 2>::bytes(topk)), 256, 256) \
@@ -1150,8 +1298,8 @@ hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, i
   RSP_TOPK(128)
   if (KP == 256) {   // the user block of a wave is 128 registers at this rank: one block per wave in every geometry
     if (TopPipeSmem<256, 1>::bytes(topk) <= kLdsMax && n_users > 64) {
-      if (vec) RSP_TOPK_GO((top_product_pipe_kernel<256, 1, true>), (TopPipeSmem<256, 1>::bytes(topk)), 128, 256)
-      else RSP_TOPK_GO((top_product_pipe_kernel<256, 1, false>), (TopPipeSmem<256, 1>::bytes(topk)), 128, 256)
+      if (vec) RSP_TOPK_GO_P((top_product_pipe_kernel<256, 1, true>), (TopPipeSmem<256, 1>::bytes(topk)), 128, 256, nullptr)
+      else RSP_TOPK_GO_P((top_product_pipe_kernel<256, 1, false>), (TopPipeSmem<256, 1>::bytes(topk)), 128, 256, nullptr)
     }
     if (TopSharedSmem<256, 1>::bytes(topk) <= kLdsMax && n_users > 64) {
       if (vec) RSP_TOPK_GO((top_product_shared_kernel<256, 1, true>), (TopSharedSmem<256, 1>::bytes(topk)), 128, 256)
@@ -1166,6 +1314,7 @@ hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, i
   }
 #undef RSP_TOPK
 #undef RSP_TOPK_GO
+#undef RSP_TOPK_GO_P
   return hipErrorInvalidValue;
 }
 }  // namespace

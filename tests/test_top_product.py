@@ -185,6 +185,39 @@ def test_hip_orders_like_the_double_product(rank, nr, nc, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rank,nr,nc,k", [(128, 700, 20000, 100), (64, 520, 9000, 60), (32, 300, 7000, 200)])
+def test_hip_large_k_many_users_candidates_in_global_memory(rank, nr, nc, k):
+    """Many users at a k whose candidate buffers do not fit the LDS next to two item tiles: the tile-sharing kernel keeps them in
+    a global scratch and settles a user once per batch of arrivals (wrmf_topk.hip GBUF).  Several workgroups, the last one
+    partly filled, hundreds of tiles, exclusion lists; indices equal to the oracle's."""
+    rng = np.random.default_rng(11 * rank + k)
+    x = rng.standard_normal((nr, rank))
+    y = rng.standard_normal((rank, nc))
+    notrec = sp.random(nr, nc, density=0.01, random_state=9, format="csr")
+    for args in (dict(), dict(nr=notrec, exclude=[5, 6, nc - 1], glob_mean=-1.25)):
+        ref_i, ref_s = O.top_product(x, y, k, *(None, None) if "nr" not in args else (notrec.indptr, notrec.indices),
+                                     exclude=args.get("exclude", ()), glob_mean=args.get("glob_mean", 0.0))
+        got_i, got_s = _hip_top_product(x, y, k, **args)
+        assert np.array_equal(got_i, ref_i)
+        assert np.allclose(got_s, ref_s, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_large_k_user_chunks_share_the_scratch():
+    """More users than one launch of the global-buffer geometry takes (131072): the chunks run one after the other on the stream and
+    reuse the scratch slots; the first and the last users (the second chunk's) against the oracle."""
+    rng = np.random.default_rng(5)
+    rank, nc, k, nr = 32, 4200, 60, 131072 + 200
+    x = rng.standard_normal((nr, rank))
+    y = rng.standard_normal((rank, nc))
+    got_i, got_s = _hip_top_product(x, y, k, exclude=[10, 11])
+    for rows in (slice(0, 64), slice(131072 - 32, 131072 + 200)):
+        ref_i, ref_s = O.top_product(x[rows], y, k, exclude=[10, 11])
+        assert np.array_equal(got_i[rows], ref_i)
+        assert np.allclose(got_s[rows], ref_s, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
 def test_hip_near_ties_resolve_in_double():
     """Pairs of items whose vectors differ by 1e-9 relative: equal scores in fp32 (where the larger index would come first),
     ordered by the double product in the reference."""

@@ -15,6 +15,8 @@
 //              v_readlane, a handful of scalar-like VALU ops, and one axpy with row k of XtX from LDS
 //   loss       second pass over the row's chunks, as the Cholesky kernel
 // LDS: two KP x KP matrices (128 KB at KP = 128) + the gather tile -> one workgroup per CU at rank 128.
+#include <utility>
+
 #include "wrmf_internal.h"
 #include "wrmf_device.h"
 
@@ -302,6 +304,19 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
 // (KP registers: the update mu += diff XtX[:, c] of a coordinate c reads register c, the sweep is unrolled over c), mu_l, h_l
 // and XtX_ll; LDS (half of lhs at a time, 8.7 KB per wave) only carries the broadcasts of the assembly and of the square.
 // Twelve chains per CU (168 registers: three waves per SIMD).
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) in order: an unrolled loop whose index is a constant
+// expression (the lane number of a v_writelane_b32 has to be one)
+template <class F, int... Cs>
+__device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, Cs...>) {
+  (f(std::integral_constant<int, Cs>{}), ...);
+}
+// h with lane C replaced by the (wave-uniform) value sval
+template <int C>
+__device__ __forceinline__ float writelane_c(float h, float sval) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(h) : "s"(sval), "n"(C));
+  return h;
+}
+
 template <int KP>
 struct NnlsWaveSmem {
   static constexpr int HR = KP / 2;          // columns of lhs staged at a time
@@ -517,33 +532,36 @@ __global__ __launch_bounds__(64, 3) void als_nnls_wave_kernel(AlsArgs a) {
     auto step_of = [&](float& nv_, float& df_) {
       const float q0 = mu * rdg;
       const float q = fmaf(fmaf(-q0, dg, mu), rdg, q0);   // mu / dg, correctly rounded
-      nv_ = (h - q) < 0.f ? 0.f : (h - q);                // the reference's `if (new_value < 0) new_value = 0`
+      nv_ = fmaxf(h - q, 0.f);                            // the reference's `if (new_value < 0) new_value = 0`: one v_max_f32
       df_ = nv_ - h;
     };
     constexpr float kTolHi = 1.001e-4f, kTolLo = 0.999e-4f;
     for (int t = 0; t < kScdMaxIter; t++) {
-      bool moved_far = false;   // some step of this sweep exceeded the tolerance
+      int moved_far = 0;   // some step of this sweep exceeded the tolerance (an int: a wave-uniform bool lives in a lane mask)
       float nv, df;
       step_of(nv, df);
       unsigned long long act = __ballot(df != 0.f) & in_range;
       NNLS_COUNT(6, 1)
       NNLS_COUNT(7, __builtin_popcountll(act))
-#pragma unroll
-      for (int c = 0; c < KP; c++) {
+      static_for_seq([&](auto c_tag) {
+        constexpr int c = decltype(c_tag)::value;
         if (__builtin_expect((act >> c) & 1ull, 0)) {
           const float d_c = readlane_f(df, c);
           if (!moved_far) {   // step_err of this move against the tolerance
             const float den = fabsf(h) + kNnlsEps;
             const unsigned long long far = __ballot(fabsf(df) > kTolHi * den), near = __ballot(fabsf(df) >= kTolLo * den);
-            if ((far >> c) & 1ull) moved_far = true;
-            else if ((near >> c) & 1ull) moved_far = fabsf(d_c) / (fabsf(readlane_f(h, c)) + kNnlsEps) > kScdTol;
+            if ((far >> c) & 1ull) moved_far = 1;
+            else if ((near >> c) & 1ull) moved_far = __ballot(fabsf(d_c) / (fabsf(readlane_f(h, c)) + kNnlsEps) > kScdTol) != 0ull ? 1 : 0;
           }
-          if (ln == c) h = nv;
+          // lane c takes its step -- read and written BY LANE NUMBER: a select on `ln == c` makes 64 loop-invariant lane masks that
+          // hipcc hoists out of the sweeps into 128 scalar registers, spills to a vector register and reads back two lanes per
+          // visit (the 360 scalar spills of rounds 4-5)
+          h = writelane_c<c>(h, readlane_f(nv, c));
           mu = fmaf(d_c, m2[c], mu);
           step_of(nv, df);
           act = __ballot(df != 0.f) & in_range;
         }
-      }
+      }, std::make_integer_sequence<int, KP>{});
       if (!moved_far) break;
     }
     if (lk) yrow[ln] = h;

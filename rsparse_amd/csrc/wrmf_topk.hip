@@ -7,6 +7,10 @@
 // stays), emit them best first -- equal scores come out with the larger index first, because the heap pops
 // (score, index) pairs in ascending pair order and the output is filled from the end (:88-95).
 //
+// (What follows describes the first geometry -- a wave per item tile, the candidate buffers in LDS --, which still serves calls
+// for up to 32 / 64 users.  Calls for more than 128 users run top_product_pipe_kernel<.., GBUF>: the four waves share the item
+// tile and own 64 users each, two tiles resident, the candidate buffers in a global scratch and settled once per batch of
+// arrivals by a radix select; few users over many items are split over the items and merged.  See launch_top_product_geo.)
 // One 256-thread workgroup per block of 32 * UB users (UB = 2 when the candidate buffers fit LDS, i.e. k <= 16).  The
 // user blocks are the MFMA A operands and stay in registers (UB * k/2 VGPRs); each of the 4 waves walks its own 32-item
 // tiles: while the matrix cores work on tile n, the 16-byte coalesced loads of tile n + 1 are in flight into registers

@@ -327,10 +327,14 @@ int build_ne_lists(const std::vector<int32_t>& order, const int32_t* host_col_pt
   // (round 6, `fine` lists: the slots of the whole machine even when there are fewer rows than slots -- the giant rows that
   //  wrmf_cg_mf.hip leaves to this kernel are a few hundred: one workgroup per row left 40 % of the slots empty and every row as
   //  long as its wave could stream it, 4.4 GB in 4.7 ms; cut to the machine's share they are segments of >= 64 steps)
-  const int n_slots = fine ? 2 * std::max(cus, 1) : std::min(n_prefix, 2 * std::max(cus, 1));   // what the share of the split rule refers to
+  // The CUT must not depend on the deal: the two list sets of a matrix (fine / one list per slot) share ONE segment table and
+  // one list of split rows (build_q_schedule) -- cut by the fine rule only, a row was whole in the coarse lists and "split" in
+  // the table, and the collecting launch overwrote its solution with the sum of two stale partials (ranks up to 96, fewer
+  // than 512 long rows, a row of >= 2048 non-zeros: tests/test_bias.py caught it at the end of round 6).
+  const int n_slots = 2 * std::max(cus, 1);   // what the share of the split rule refers to
   // (`fine` = false: one list per slot, for the kernels that are resident once per CU -- no such asymmetry there, and a
   //  workgroup start costs more: XtX tiles into LDS; many short lists cost them 1..7 %)
-  int n_wg = fine ? std::max(n_slots, std::min(n_prefix / 8, 256 * std::max(cus, 1))) : n_slots;
+  int n_wg = fine ? std::max(n_slots, std::min(n_prefix / 8, 256 * std::max(cus, 1))) : n_slots;   // (at most one per item: below)
   // Items of the deal: whole rows, and SEGMENTS of the rows that are too long to balance (the 5e5-non-zero item of the
   // bench matrix is by itself an average workgroup's share; on a rank of an 8-GPU run it is eight shares).  A row
   // whose cost exceeds half a share is cut into up to kNeMaxSeg runs of whole steps of about a quarter share; the

@@ -65,10 +65,11 @@ __device__ __forceinline__ void rank_update_packed(float* A, const float* xs, in
     for (int j = 0; j < cn; j++) {
       const float wj = w ? w[j] : 1.f;
       float av[4], bv[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) av[r] = xa[j * kp + r];
-#pragma unroll
-      for (int c = 0; c < 4; c++) bv[c] = wj * xc[j * kp + c];
+      // (xs is 16-byte aligned and kp a multiple of 4: one ds_read_b128 per operand instead of four 4-byte reads)
+      const float4 a4 = *reinterpret_cast<const float4*>(xa + j * kp);
+      const float4 c4 = *reinterpret_cast<const float4*>(xc + j * kp);
+      av[0] = a4.x, av[1] = a4.y, av[2] = a4.z, av[3] = a4.w;
+      bv[0] = wj * c4.x, bv[1] = wj * c4.y, bv[2] = wj * c4.z, bv[3] = wj * c4.w;
 #pragma unroll
       for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
   float* sv = ap + KP;      // X_nnz (c - 1): the global-bias term of the first CG residual
   float* invd = sv + KP;    // Cholesky: 1 / L_jj
   float* red = invd + KP;   // 8
-  float* xs = red + 8;      // [CH][KP] staged factor vectors of the current chunk
+  float* xs = sm + (((red + 8) - sm + 3) & ~3);   // [CH][KP] staged factor vectors of the current chunk (16-byte aligned)
   float* cw = xs + (size_t)CH * KP;
   float* rw = cw + CH;
   float* lw = rw + CH;
@@ -152,9 +153,21 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
       lt[tid] = implicit ? (a.loss_tgt ? a.loss_tgt[e] : a.loss_tgt_const) : c;
     }
     __syncthreads();
-    for (int e = tid; e < cn * KP; e += NT) {
-      const int j = e / KP, t = e - j * KP;
-      xs[e] = t < k ? a.X[(size_t)sidx[j] * k + t] : 0.f;
+    // thread t brings coordinate t of every vector, SG vectors in flight at a time (one load per trip with a division in front
+    // of it was a round trip to HBM per KP / NT-th of a vector: 26 in a row for a chunk of 50 at order 132)
+    constexpr int SG = 16;
+    for (int t = tid; t < KP; t += NT) {
+      for (int j0 = 0; j0 < cn; j0 += SG) {
+        float v[SG];
+#pragma unroll
+        for (int u = 0; u < SG; u++) {
+          const int j = min(j0 + u, cn - 1);
+          v[u] = a.X[(size_t)sidx[j] * k + min(t, k - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < SG; u++)
+          if (j0 + u < cn) xs[(j0 + u) * KP + t] = t < k ? v[u] : 0.f;
+      }
     }
     __syncthreads();
   };
@@ -184,11 +197,22 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
       __syncthreads();
       for (int e = tid; e < tri(KP); e += NT) A[e] = 0.f;
       __syncthreads();
-      if (implicit)
-        for (int e = tid; e < k * k; e += NT) {
-          const int c = e / k, i = e - c * k;
-          if (i >= c) A[tri(i) + c] = a.XtX[i + (size_t)c * k];
+      if (implicit) {
+        // thread i brings row i of the lower triangle, GU columns in flight at a time (coalesced over i; was one load per trip
+        // behind a division: k k / NT = 68 round trips to L2 in a row at order 132)
+        constexpr int GU = 16;
+        for (int i = tid; i < k; i += NT) {
+          float* rowi = A + tri(i);
+          for (int c0 = 0; c0 <= i; c0 += GU) {
+            float v[GU];
+#pragma unroll
+            for (int u = 0; u < GU; u++) v[u] = a.XtX[i + (size_t)min(c0 + u, i) * k];
+#pragma unroll
+            for (int u = 0; u < GU; u++)
+              if (c0 + u <= i) rowi[c0 + u] = v[u];
+          }
         }
+      }
       for (int t = tid; t < KP; t += NT) {
         rhs[t] = (a.rhs_init && t < k) ? a.rhs_init[t] : 0.f;
         sv[t] = 0.f;
@@ -352,11 +376,15 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
         }
         __syncthreads();
         const float zj = x[j];
-        for (int i = j + 1 + ri; i < k; i += RT) {
+        // rows over 32 threads, the columns of a row over 8: a thread per ROW (what RT = NT gives at these orders) left the
+        // longest row's k - j multiply-adds to one thread, pivot after pivot, and half of the workgroup without any
+        constexpr int RTC = 32, CGC = NT / RTC;
+        const int rc = tid & (RTC - 1), cc = tid / RTC;
+        for (int i = j + 1 + rc; i < k; i += RTC) {
           float* rowi = A + tri(i);
           const float li = rowi[j];
-          for (int c = j + 1 + cgi; c <= i; c += CGR) rowi[c] = fmaf(-li, A[tri(c) + j], rowi[c]);
-          if (cgi == 0) rhs[i] = fmaf(-li, zj, rhs[i]);
+          for (int c = j + 1 + cc; c <= i; c += CGC) rowi[c] = fmaf(-li, A[tri(c) + j], rowi[c]);
+          if (cc == 0) rhs[i] = fmaf(-li, zj, rhs[i]);
         }
       }
       __syncthreads();
@@ -488,7 +516,7 @@ __global__ __launch_bounds__(NT) void wide_gramian_partial_kernel(const float* _
                                                                   float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* A = reinterpret_cast<float*>(smem_raw);
-  float* xs = A + (size_t)tri(KP);
+  float* xs = A + (((size_t)tri(KP) + 3) & ~(size_t)3);   // (16-byte aligned: rank_update_packed reads it in 16-byte pieces)
   const int tid = threadIdx.x;
   const int T4 = KP / 4, ntiles = T4 * (T4 + 1) / 2;
   for (int e = tid; e < tri(KP); e += NT) A[e] = 0.f;
@@ -497,9 +525,16 @@ __global__ __launch_bounds__(NT) void wide_gramian_partial_kernel(const float* _
   __syncthreads();
   for (int64_t c0 = e0; c0 < e1; c0 += CH) {
     const int cn = (int)min((int64_t)CH, e1 - c0);
-    for (int e = tid; e < cn * KP; e += NT) {
-      const int j = e / KP, t = e - j * KP;
-      xs[e] = t < k ? X[(size_t)(c0 + j) * k + t] : 0.f;
+    constexpr int SG = 16;   // rows in flight per thread (thread t brings coordinate t; see als_wide_kernel's stage)
+    for (int t = tid; t < KP; t += NT) {
+      for (int j0 = 0; j0 < cn; j0 += SG) {
+        float v[SG];
+#pragma unroll
+        for (int u = 0; u < SG; u++) v[u] = X[(size_t)(c0 + min(j0 + u, cn - 1)) * k + min(t, k - 1)];
+#pragma unroll
+        for (int u = 0; u < SG; u++)
+          if (j0 + u < cn) xs[(j0 + u) * KP + t] = t < k ? v[u] : 0.f;
+      }
     }
     __syncthreads();
     rank_update_packed(A, xs, KP, nullptr, cn, ntiles);
@@ -583,8 +618,8 @@ hipError_t launch_gramian_wide(const float* X, int k, int64_t n, float ridge, fl
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kWideGramBlocks, (n + 63) / 64));
   const size_t mat = (size_t)KP * (KP + 1) / 2;
   int ch = 64;
-  while (ch > 4 && (mat + (size_t)ch * KP) * 4 > kWideLds) ch >>= 1;
-  const size_t lds = (mat + (size_t)ch * KP) * 4;
+  while (ch > 4 && (mat + (size_t)ch * KP) * 4 + 16 > kWideLds) ch >>= 1;
+  const size_t lds = (mat + (size_t)ch * KP) * 4 + 16;   // (+ the alignment of the staged rows)
   auto kern = wide_gramian_partial_kernel;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;

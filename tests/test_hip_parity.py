@@ -705,6 +705,30 @@ def test_one_giant_row_is_split_across_workgroups(k, implicit):
     assert abs(loss - lref) <= TOL * abs(lref)
 
 
+@pytest.mark.parametrize("k", [64, 96, 128])
+@pytest.mark.parametrize("lens", [(2300,), (513, 700, 1100, 2300), (2300, 2300, 600), (6000, 513)])
+def test_a_few_long_rows_one_of_them_cut(k, lens):
+    """Fewer long rows than workgroup slots, one of them long enough (>= 2048 non-zeros) to be cut into segments by the rule of the
+    fine lists.  The matrix's two list sets (two workgroups per CU at rank 97..128, one below) share one segment table: the cut
+    must be the same in both -- at the end of round 6 it was not, the coarse lists held the row whole, and the collecting launch
+    overwrote its solution at ranks up to 96 (tools/dbg/gb_split_dbg2.py)."""
+    rng = np.random.default_rng(3 * k + len(lens))
+    n_fix = 8000
+    lens = np.concatenate([np.asarray(lens), rng.integers(1, 90, 200)])
+    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    i = np.concatenate([np.sort(rng.choice(n_fix, int(n), replace=False)) for n in lens]).astype(np.int32)
+    x = 1.0 + rng.geometric(0.5, size=i.size).astype(np.float64)
+    X = np.asfortranarray((rng.standard_normal((k, n_fix)) * 0.1).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, lens.size)) * 0.1).astype(np.float32))
+    csc = (n_fix, lens.size, p, i, x)
+    Yref, lref = _oracle64(csc, X, Y0, 0.1, 1, 3, True)
+    Y = Y0.copy(order="F")
+    loss = als.als_implicit(csc, X, Y, 0.1, 1, 1, 3, "float", False, False)
+    err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-30)
+    assert err.max() < TOL, (int(err.argmax()), int(lens[err.argmax()]), float(err.max()))
+    assert abs(loss - lref) <= TOL * abs(lref)
+
+
 @pytest.mark.parametrize("solver", [1, 0])
 @pytest.mark.parametrize("ratio", [2.0 ** 8, 2.0 ** 12, 2.0 ** 16, 2.0 ** 20])
 def test_factor_rows_of_very_different_norms_on_the_fp16_paths(ratio, solver):

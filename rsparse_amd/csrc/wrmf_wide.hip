@@ -28,6 +28,9 @@ constexpr int kScdMaxIterW = 10000;
 constexpr float kScdTolW = 1e-4f;
 constexpr float kNnlsEpsW = 1e-16f;
 constexpr int NT = 256;
+#ifndef RSP_WIDE_ABL   // dev builds (timing only, results are garbage): bits switch phases of als_wide_kernel off
+#define RSP_WIDE_ABL 0   // 1 trailing update, 2 rank-one updates, 4 loss pass, 8 Gramian copy, 16 backward substitution, 32 staging
+#endif
 
 __device__ __forceinline__ int tri(const int i) { return (i * (i + 1)) >> 1; }
 
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
       __syncthreads();
       for (int e = tid; e < tri(KP); e += NT) A[e] = 0.f;
       __syncthreads();
-      if (implicit) {
+      if (implicit && !(RSP_WIDE_ABL & 8)) {
         // thread i brings row i of the lower triangle, GU columns in flight at a time (coalesced over i; was one load per trip
         // behind a division: k k / NT = 68 round trips to L2 in a row at order 132)
         constexpr int GU = 16;
@@ -220,8 +223,8 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
       __syncthreads();
       for (int c0 = 0; c0 < n; c0 += CH) {
         const int cn = min(CH, n - c0);
-        stage(p1, c0, cn);
-        rank_update_packed(A, xs, KP, cw, cn, ntiles);
+        if (!(RSP_WIDE_ABL & 32)) stage(p1, c0, cn);
+        if (!(RSP_WIDE_ABL & 2)) rank_update_packed(A, xs, KP, cw, cn, ntiles);
         for (int t = tid; t < k; t += NT) {
           float s1 = 0.f, s2 = 0.f;
           for (int j = 0; j < cn; j++) {
@@ -361,7 +364,18 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
     } else {
       // ---- Cholesky on the packed triangle; z = L^-1 rhs rides along in x ----
       bool ok = true;
-      for (int j = 0; j < k; j++) {
+      // Two pivots per pass over the trailing matrix: column j is scaled, column j + 1 (and the right-hand side) takes ITS update
+      // alone, is scaled in turn, and the rest of the matrix takes both updates in one read-modify-write -- element by element
+      // the same two multiply-adds in the same order, two thirds of the LDS traffic.  Column j lives in p, column j + 1 in ap
+      // (both free in this branch) as contiguous vectors: the update reads them by column index instead of walking the packed
+      // triangle with a stride of c + 1 floats.  Rows over 32 threads, the columns of a row over 8 (a thread per ROW -- what
+      // RT = NT gives at these orders -- left the longest row to one thread, pivot after pivot); eight elements per trip, all
+      // reads before the first write: the compiler cannot know that the elements differ, and one read-multiply-write per trip
+      // was an LDS round trip per multiply-add.
+      constexpr int RTC = 32, CGC = NT / RTC, CU = 8;
+      const int rc = tid & (RTC - 1), cc = tid / RTC;
+      for (int j = 0; j < k; j += 2) {
+        const int j1 = j + 1;
         __syncthreads();
         const float d = A[tri(j) + j];
         if (!(d > 0.f)) {
@@ -369,27 +383,63 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
           break;
         }
         const float dinv = 1.f / sqrtf(d);
-        for (int i = j + 1 + tid; i < k; i += NT) A[tri(i) + j] *= dinv;
+        for (int i = j + 1 + tid; i < k; i += NT) {
+          const float l = A[tri(i) + j] * dinv;
+          A[tri(i) + j] = l;
+          p[i] = l;
+        }
         if (tid == 0) {
           invd[j] = dinv;
           x[j] = rhs[j] * dinv;
         }
         __syncthreads();
-        const float zj = x[j];
-        // rows over 32 threads, the columns of a row over 8: a thread per ROW (what RT = NT gives at these orders) left the
-        // longest row's k - j multiply-adds to one thread, pivot after pivot, and half of the workgroup without any
-        constexpr int RTC = 32, CGC = NT / RTC;
-        const int rc = tid & (RTC - 1), cc = tid / RTC;
-        for (int i = j + 1 + rc; i < k; i += RTC) {
+        if (j1 >= k) break;
+        const float zj = x[j], lj1 = p[j1];
+        for (int i = j1 + tid; i < k; i += NT) {   // column j + 1 and the right-hand side: pivot j's update
+          const float li = p[i];
+          A[tri(i) + j1] = fmaf(-li, lj1, A[tri(i) + j1]);
+          rhs[i] = fmaf(-li, zj, rhs[i]);
+        }
+        __syncthreads();
+        const float d1 = A[tri(j1) + j1];
+        if (!(d1 > 0.f)) {
+          ok = false;
+          break;
+        }
+        const float dinv1 = 1.f / sqrtf(d1);
+        for (int i = j1 + 1 + tid; i < k; i += NT) {
+          const float l = A[tri(i) + j1] * dinv1;
+          A[tri(i) + j1] = l;
+          ap[i] = l;
+        }
+        if (tid == 0) {
+          invd[j1] = dinv1;
+          x[j1] = rhs[j1] * dinv1;
+        }
+        __syncthreads();
+        const float zj1 = x[j1];
+        for (int i = j + 2 + rc; i < k && !(RSP_WIDE_ABL & 1); i += RTC) {
           float* rowi = A + tri(i);
-          const float li = rowi[j];
-          for (int c = j + 1 + cc; c <= i; c += CGC) rowi[c] = fmaf(-li, A[tri(c) + j], rowi[c]);
-          if (cc == 0) rhs[i] = fmaf(-li, zj, rhs[i]);
+          const float li = p[i], li1 = ap[i];
+          int c = j + 2 + cc;
+          for (; c + (CU - 1) * CGC <= i; c += CU * CGC) {
+            float av[CU], bv[CU], b1[CU];
+#pragma unroll
+            for (int u = 0; u < CU; u++) {
+              av[u] = rowi[c + u * CGC];
+              bv[u] = p[c + u * CGC];
+              b1[u] = ap[c + u * CGC];
+            }
+#pragma unroll
+            for (int u = 0; u < CU; u++) rowi[c + u * CGC] = fmaf(-li1, b1[u], fmaf(-li, bv[u], av[u]));
+          }
+          for (; c <= i; c += CGC) rowi[c] = fmaf(-li1, ap[c], fmaf(-li, p[c], rowi[c]));
+          if (cc == 0) rhs[i] = fmaf(-li1, zj1, rhs[i]);
         }
       }
       __syncthreads();
       if (ok) {
-        if (wv == 0) {   // L^T y = z: lane l holds entries l + 64 q; row m of L is contiguous in the packed triangle
+        if (wv == 0 && !(RSP_WIDE_ABL & 16)) {   // L^T y = z: lane l holds entries l + 64 q; row m of L is contiguous in the packed triangle
           float z[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) z[q] = lane + 64 * q < k ? x[lane + 64 * q] : 0.f;
@@ -490,7 +540,7 @@ __global__ __launch_bounds__(NT) void als_wide_kernel(WideArgs a, int KP, int CH
     // ---- write back, loss term ----
     for (int t = tid; t < k; t += NT) yrow[t] = x[t];
     float lpart = 0.f;
-    for (int c0 = 0; c0 < n; c0 += CH) {
+    for (int c0 = 0; c0 < n && !(RSP_WIDE_ABL & 4); c0 += CH) {
       const int cn = min(CH, n - c0);
       stage(p1, c0, cn);
       for (int j = wv; j < cn; j += 4) {

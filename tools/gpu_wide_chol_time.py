@@ -20,6 +20,8 @@ for fb in ("implicit", "explicit"):
     mats[fb] = sp.csc_matrix((x.astype(np.float64), i, p), shape=(NI, NU)).T.tocsr()
 cases = (("implicit", 128, True, "cholesky"), ("explicit", 128, True, "cholesky"), ("implicit", 160, False, "cholesky"),
          ("implicit", 256, False, "cholesky"), ("explicit", 128, True, "conjugate_gradient"), ("implicit", 128, False, "cholesky"))
+if len(sys.argv) > 1:   # a filter: indices of the cases, e.g. "0" or "0,2"
+    cases = tuple(cases[int(c)] for c in sys.argv[1].split(","))
 for fb, rank, bias, solver in cases:
     model = WRMF(rank=rank, lambda_=0.1, feedback=fb, solver=solver, precision="float", rng=1, with_user_item_bias=bias)
     model.fit_transform(mats[fb], n_iter=1, convergence_tol=-1)

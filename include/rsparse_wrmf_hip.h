@@ -328,7 +328,10 @@ int rsparse_hip_top_product(const double* x, const double* y, int nr, int nc, in
                             double glob_mean, int32_t* res, double* scores);
 
 /* device-resident form: d_U n_users x rank and d_V n_items x rank row-major fp32 (= rank x n column-major),
- * d_exclude0: sorted 0-based item indices, d_res / d_scores: n_users x k row-major. */
+ * d_exclude0: sorted 0-based item indices, d_res / d_scores: n_users x k row-major.
+ * A call for more than 128 users (rank <= 128) keeps its per-user candidate buffers in the library's grow-only workspace:
+ * min(n_users, 131072) x 2 x (k + 32 + max(64, k)) words, 121 MB at k = 10, 570 MB at k = 256; longer calls run in chunks of
+ * 131072 users on the stream and reuse it. */
 int rsparse_hip_top_product_device(const float* d_U, const float* d_V, int n_users, int n_items, int rank,
                                    int k, const int32_t* d_not_recommend_p, const int32_t* d_not_recommend_j,
                                    const int32_t* d_exclude0, int n_exclude, double glob_mean,

@@ -14,6 +14,7 @@
 // It is the functional path of these ranks (one workgroup per row, k^2 flops per non-zero), not a tuned one; the bench line
 // (rank 128) does not run through it.  Gramian of a factor matrix at these ranks: the same packed tiles (below).
 #include <algorithm>
+#include <cstdlib>
 
 #include "wrmf_internal.h"
 #include "wrmf_device.h"
@@ -652,9 +653,26 @@ hipError_t launch_als_wide(const AlsArgs& a, bool implicit, unsigned solver, flo
   w.lu_scratch = lu_scratch;
   const int KP = wide_kp(a.k);
   const size_t fixed = ((size_t)KP * (KP + 1) / 2 + 7 * (size_t)KP + 8) * 4;
+  auto lds_of = [&](int c) { return fixed + (size_t)c * (KP + 4) * 4 + (size_t)(c + 4) * 4 + 16; };
   int ch = 64;
-  while (ch > 4 && fixed + (size_t)ch * (KP + 4) * 4 + (size_t)(ch + 4) * 4 + 16 > kWideLds) ch >>= 1;
-  const size_t lds = fixed + (size_t)ch * (KP + 4) * 4 + (size_t)(ch + 4) * 4 + 16;
+  while (ch > 4 && lds_of(ch) > kWideLds) ch >>= 1;
+  // A row is a chain of barriers and LDS round trips: what hides one workgroup's is ANOTHER workgroup on the CU.  Where a smaller
+  // chunk of staged vectors (16 at least: one trip of the staging loop) buys a third or a second resident workgroup, take it
+  // (order 132: 74 KB -> 48 KB, three per CU; order 160: 98 KB -> 77 KB, two).  RSPARSE_HIP_WIDE_CHUNK pins the chunk (dev).
+  for (int wg = 3; wg >= 2; wg--) {
+    const size_t budget = (size_t)160 * 1024 / wg - 1024;
+    int c = 64;
+    while (c >= 16 && lds_of(c) > budget) c >>= 1;
+    if (c >= 16) {
+      ch = std::min(ch, c);
+      break;
+    }
+  }
+  if (const char* e = std::getenv("RSPARSE_HIP_WIDE_CHUNK")) {
+    const int c = std::atoi(e);
+    if (c >= 4 && c <= 64 && (c & (c - 1)) == 0 && lds_of(c) <= kWideLds) ch = c;
+  }
+  const size_t lds = lds_of(ch);
   auto kern = als_wide_kernel;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;

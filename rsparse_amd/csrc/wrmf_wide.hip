@@ -657,16 +657,13 @@ hipError_t launch_als_wide(const AlsArgs& a, bool implicit, unsigned solver, flo
   int ch = 64;
   while (ch > 4 && lds_of(ch) > kWideLds) ch >>= 1;
   // A row is a chain of barriers and LDS round trips: what hides one workgroup's is ANOTHER workgroup on the CU.  Where a smaller
-  // chunk of staged vectors (16 at least: one trip of the staging loop) buys a third or a second resident workgroup, take it
-  // (order 132: 74 KB -> 48 KB, three per CU; order 160: 98 KB -> 77 KB, two).  RSPARSE_HIP_WIDE_CHUNK pins the chunk (dev).
-  for (int wg = 3; wg >= 2; wg--) {
-    const size_t budget = (size_t)160 * 1024 / wg - 1024;
-    int c = 64;
-    while (c >= 16 && lds_of(c) > budget) c >>= 1;
-    if (c >= 16) {
-      ch = std::min(ch, c);
-      break;
-    }
+  // chunk of staged vectors (16 at least: one trip of the staging loop) buys a SECOND resident workgroup, take it: order 160,
+  // 98 KB -> 77 KB, 335 -> 194 ms per iteration.  (A third one -- order 132 at 16 vectors per chunk -- measured 13 % slower than
+  // two at 64: profiles/r06/r6wide_ab_*.  RSPARSE_HIP_WIDE_CHUNK pins the chunk for such measurements.)
+  if (2 * lds_of(ch) > (size_t)158 * 1024) {
+    int c = ch;
+    while (c >= 16 && 2 * lds_of(c) > (size_t)158 * 1024) c >>= 1;
+    if (c >= 16) ch = c;
   }
   if (const char* e = std::getenv("RSPARSE_HIP_WIDE_CHUNK")) {
     const int c = std::atoi(e);

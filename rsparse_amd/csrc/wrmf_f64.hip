@@ -1479,6 +1479,13 @@ F64Geo f64_geometry(int k1, int solver) {
   const int mats = 1 + g.m2_in_lds;
   int ch = 64;
   while (ch > 4 && bytes(mats, ch) > kF64LdsBudget) ch >>= 1;
+  // NNLS with the squared system in LDS (rank 33..64: 106 KB at 64 staged vectors): the sweeps of a row are ONE wave's serial
+  // chain, and what fills the CU meanwhile is another workgroup -- a chunk of 16 leaves room for a second one (end of round 6)
+  if (g.m2_in_lds) {
+    int c = ch;
+    while (c >= 8 && 2 * bytes(mats, c) > (size_t)158 * 1024) c >>= 1;
+    if (c >= 8) ch = c;
+  }
   // small systems: no need for the whole LDS (more workgroups per CU instead)
   if (g.KP <= 32) ch = std::min(ch, 32);
   g.CH = ch;

@@ -16,7 +16,7 @@ from rsparse_amd import WRMF, synth
 d = synth.make_dataset(1_000_000, 100_000, device="cpu", feedback="implicit")
 p, i, x = (t.numpy() for t in d["c_iu"])
 m = sp.csc_matrix((x.astype(np.float64), i, p), shape=(100_000, 1_000_000)).T.tocsr()
-model = WRMF(rank=64, lambda_=0.1, feedback="implicit", solver="conjugate_gradient", precision="float", rng=1)
+model = WRMF(rank=int(os.environ.get("RANK", "64")), lambda_=0.1, feedback="implicit", solver="conjugate_gradient", precision="float", rng=1)
 model.fit_transform(m, n_iter=1, convergence_tol=-1)
 torch.cuda.synchronize()
 for n_iter in (1, 10):

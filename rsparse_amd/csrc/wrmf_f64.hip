@@ -33,6 +33,7 @@
 // per row (a wave per chunk of a long row), the operator applied from the gathered vectors as the reference does (no k1 x k1
 // matrix).  Everything else goes through the workgroup-per-row family.
 #include <algorithm>
+#include <cstdlib>
 
 #include <type_traits>
 #include <utility>
@@ -1488,6 +1489,10 @@ F64Geo f64_geometry(int k1, int solver) {
   }
   // small systems: no need for the whole LDS (more workgroups per CU instead)
   if (g.KP <= 32) ch = std::min(ch, 32);
+  if (const char* e = std::getenv("RSPARSE_HIP_F64_CHUNK")) {   // dev: pin the chunk of staged vectors (occupancy experiments)
+    const int c = std::atoi(e);
+    if (c >= 4 && c <= 64 && (c & (c - 1)) == 0 && bytes(mats, c) <= kF64LdsBudget) ch = c;
+  }
   g.CH = ch;
   g.lds = bytes(mats, ch);
   return g;

@@ -210,6 +210,16 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
         h[s2] = c < KP ? sH[c] : 0.f;
         dg[s2] = c < KP ? sB[c * KP + c] : 1.f;
       }
+      // mu / XtX_kk as the wave-per-row kernel forms it (end of round 6): the reciprocal refined once per row, a residual correction
+      // per quotient -- the correctly rounded quotient in three vector instructions for every lane at once, instead of a full
+      // division (thirty) on three values read lane by lane; and the moving coordinate's column of XtX is requested from LDS before
+      // the step is known (one wave sweeps while the workgroup waits: the read's latency was exposed at every visit)
+      float rdg[NS > 0 ? NS : 1];
+#pragma unroll
+      for (int s2 = 0; s2 < NSL; s2++) {
+        const float r0 = __builtin_amdgcn_rcpf(dg[s2]);
+        rdg[s2] = fmaf(fmaf(-dg[s2], r0, 1.f), r0, r0);
+      }
       // A coordinate that sits at its bound (h = 0) with a non-negative gradient does not move: new = max(0, 0 - mu / d) = 0,
       // diff = 0 (d > 0), and the reference's loop body does nothing for it (nnls.hpp:24).  Three quarters of the coordinate
       // visits are of that kind (measured on the config-2 shape: 172 sweeps per row, 23 % of the visits move), so the sweep
@@ -226,20 +236,23 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
           while (act) {
             const int l = __builtin_ctzll(act);
             const int kk = 64 * s2 + l;
+            const float* brow = sB + kk * KP;  // column kk = row kk (symmetric)
+            float bcol[NS > 0 ? NS : 1];
+#pragma unroll
+            for (int s3 = 0; s3 < NSL; s3++) bcol[s3] = brow[min(lane + 64 * s3, KP - 1)];
+            const float q0 = mu[s2] * rdg[s2];
+            const float qv = fmaf(fmaf(-q0, dg[s2], mu[s2]), rdg[s2], q0);   // mu / dg, correctly rounded, every lane's
+            const float nvv = fmaxf(h[s2] - qv, 0.f);
             const float old_v = readlane_f(h[s2], l);
-            const float m_k = readlane_f(mu[s2], l);
-            const float d_k = readlane_f(dg[s2], l);
-            float new_v = old_v - m_k / d_k;
-            if (new_v < 0.f) new_v = 0.f;
+            const float new_v = readlane_f(nvv, l);
             const float diff = new_v - old_v;
             const unsigned long long above = l >= 63 ? 0ull : (~0ull << (l + 1));
             if (diff != 0.f) {  // wave-uniform
               if (lane == l) h[s2] = new_v;
-              const float* brow = sB + kk * KP;  // column kk = row kk (symmetric)
 #pragma unroll
               for (int s3 = 0; s3 < NSL; s3++) {
                 const int c = lane + 64 * s3;
-                if (c < KP) mu[s3] = fmaf(diff, brow[c], mu[s3]);
+                if (c < KP) mu[s3] = fmaf(diff, bcol[s3], mu[s3]);
               }
               const float step_err = fabsf(diff) / (fabsf(old_v) + kNnlsEps);
               rel = fmaxf(rel, step_err);

@@ -684,8 +684,28 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
   int* sWrkI = reinterpret_cast<int*>(sWrkV + 4 * cap);
 
   const int tid = threadIdx.x, lane = tid & 63, wv = rfl(tid >> 6);
-  const int u0 = blockIdx.x * USERS, uw = wv * UPW;
-  RSP_TOPK_SLICE(USERS, 256)
+  const int uw = wv * UPW;
+  int item_base = 0;
+  if (slice_items > 0) {   // a split launch: this workgroup's slice of the items (see RSP_TOPK_SLICE)
+    item_base = (int)blockIdx.y * slice_items;
+    V += (size_t)item_base * k_rank;
+    n_items = max(0, min(n_items - item_base, slice_items));
+    res += (size_t)blockIdx.y * n_users * topk;
+    scores_out += (size_t)blockIdx.y * n_users * topk;
+  }
+  // A workgroup takes the user blocks blockIdx.x, + gridDim.x, ...: one block each in the ordinary launch; the fall-back launch for
+  // flagged users (user_flags) comes with a grid of at most 512 and every workgroup walks its blocks' flags -- a workgroup that only
+  // finds out that it has nothing to do still costs 6..12 us of a CU that it owns alone (150 KB of LDS, 512 registers per lane),
+  // and a grid of one such workgroup per block was 7 % (top-10) / 11 % (top-100) of a call that flags nobody (round 6, rocprof)
+  const int n_blocks = (n_users + USERS - 1) / USERS;
+  for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+  const int u0 = blk * USERS;
+  if (user_flags) {
+    int f_ = 0;
+    for (int e_ = tid; e_ < USERS; e_ += 256)
+      if (u0 + e_ < n_users) f_ |= user_flags[u0 + e_];
+    if (!__syncthreads_or(f_)) continue;
+  }
   const int col = lane & 31, half = lane >> 5;
   for (int e = tid; e < USERS; e += 256) {
     sCnt[e] = 0;
@@ -851,6 +871,8 @@ __global__ __launch_bounds__(256) void top_product_pipe_kernel(const float* __re
                        nr_ptr, nr_idx, u, excl, n_excl, lane);
     topk_emit_user(sVal + ul * cap, sIdx + ul * cap, min(sCnt[ul], topk), topk, lane, glob_mean, res + (size_t)u * topk,
                    scores_out + (size_t)u * topk);
+  }
+  __syncthreads();   // (the next block of this workgroup starts from the LDS areas again)
   }
 }
 
@@ -1123,8 +1145,12 @@ hipError_t launch_top_product_f64_t(const float* U32, const float* V32, const TF
                      flags, static_cast<const int*>(nullptr));
   if ((err = hipGetLastError()) != hipSuccess) return err;
   if (kc > topk) {
+    // (the tile-sharing kernel with its block loop and the global buffers where the scratch was sized for them -- an unsliced call
+    //  for more than 128 users --, else the geometry the LDS allows)
+    float* rerun_gbuf = (split_scratch && top_product_scratch_entries(n_users, n_items, kc) == 0 && top_product_wants_gbuf(n_users, rank, topk))
+                            ? split_scratch : nullptr;
     if ((err = launch_top_product_geo(U32, V32, n_users, n_items, rank, topk, nr_ptr, nr_idx, excl, n_excl, 0.f, res2, sc2, s, 1, 0,
-                                      flags)) != hipSuccess)
+                                      flags, rerun_gbuf)) != hipSuccess)
       return err;
     hipLaunchKernelGGL(top_rescore_kernel<TF>, grid, dim3(256), 0, s, U, V, n_users, rank, topk, topk, res2, glob_mean, res, scores,
                        static_cast<int*>(nullptr), flags);
@@ -1252,13 +1278,14 @@ hipError_t launch_top_product_geo(const float* U, const float* V, int n_users, i
     if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)lds)) != hipSuccess)                                                 \
       return err;                                                                                            \
-    const int grid = (n_users + (USERS) - 1) / (USERS);                                                      \
+    const int grid = std::min((n_users + (USERS) - 1) / (USERS), user_flags ? 512 : 0x7fffffff);  /* (see the kernel's block loop) */ \
     hipLaunchKernelGGL(kern, dim3(grid, n_slices), dim3(THREADS), lds, s, U, V, n_users, n_items, k_rank, topk, nr_ptr, \
                        nr_idx, excl, n_excl, glob_mean, res, scores, slice_items, user_flags, GB);           \
     return hipGetLastError();                                                                                \
   }
   // GBUF: the launcher hands a scratch when the call is unsliced; taken where the 256-user buffers do not fit the LDS
-  const bool gbuf_now = gbuf && n_slices == 1 && n_users > 128 && n_users <= kTopGbufChunk && top_product_wants_gbuf(n_users, k_rank, topk);
+  // (a flagged launch has at most 512 workgroups = scratch slots, whatever the number of users)
+  const bool gbuf_now = gbuf && n_slices == 1 && n_users > 128 && (n_users <= kTopGbufChunk || user_flags) && top_product_wants_gbuf(n_users, k_rank, topk);
   // Geometry, best first: the four waves share the item tile and own 64 / 32 users each (256 / 128 users per workgroup:
   // every item vector is read once per that many users) -- with two tiles resident and the epilogue hidden behind the next
   // tile's matrix instructions where the LDS allows it; then one tile per wave against 64 / 32 users; then the same on

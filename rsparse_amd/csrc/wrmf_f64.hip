@@ -1489,10 +1489,12 @@ F64Geo f64_geometry(int k1, int solver) {
   }
   // small systems: no need for the whole LDS (more workgroups per CU instead)
   if (g.KP <= 32) ch = std::min(ch, 32);
+#ifdef RSP_AB   // (dev builds: the shipped library reads no environment variable)
   if (const char* e = std::getenv("RSPARSE_HIP_F64_CHUNK")) {   // dev: pin the chunk of staged vectors (occupancy experiments)
     const int c = std::atoi(e);
     if (c >= 4 && c <= 64 && (c & (c - 1)) == 0 && bytes(mats, c) <= kF64LdsBudget) ch = c;
   }
+#endif
   g.CH = ch;
   g.lds = bytes(mats, ch);
   return g;

@@ -659,16 +659,18 @@ hipError_t launch_als_wide(const AlsArgs& a, bool implicit, unsigned solver, flo
   // A row is a chain of barriers and LDS round trips: what hides one workgroup's is ANOTHER workgroup on the CU.  Where a smaller
   // chunk of staged vectors (16 at least: one trip of the staging loop) buys a SECOND resident workgroup, take it: order 160,
   // 98 KB -> 77 KB, 335 -> 194 ms per iteration.  (A third one -- order 132 at 16 vectors per chunk -- measured 13 % slower than
-  // two at 64: profiles/r06/r6wide_ab_*.  RSPARSE_HIP_WIDE_CHUNK pins the chunk for such measurements.)
+  // two at 64: profiles/r06/r6wide_ab_*.  RSPARSE_HIP_WIDE_CHUNK pins the chunk for such measurements in -DRSP_AB builds.)
   if (2 * lds_of(ch) > (size_t)158 * 1024) {
     int c = ch;
     while (c >= 16 && 2 * lds_of(c) > (size_t)158 * 1024) c >>= 1;
     if (c >= 16) ch = c;
   }
+#ifdef RSP_AB   // (dev builds: the shipped library reads no environment variable)
   if (const char* e = std::getenv("RSPARSE_HIP_WIDE_CHUNK")) {
     const int c = std::atoi(e);
     if (c >= 4 && c <= 64 && (c & (c - 1)) == 0 && lds_of(c) <= kWideLds) ch = c;
   }
+#endif
   const size_t lds = lds_of(ch);
   auto kern = als_wide_kernel;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

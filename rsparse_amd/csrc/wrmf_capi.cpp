@@ -725,6 +725,11 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   a.chol_list = nullptr; a.chol_first = 0; a.chol_n_main = 0; a.chol_empty_first = 0;
   a.lr_rows = nullptr; a.n_lr = 0; a.lr_flags = nullptr; a.lr_M = nullptr; a.lr_n_gt32 = a.lr_n_gt16 = a.lr_n_gt48 = -1; a.lrx = 0;
   a.nnls_order = solver == RSPARSE_SOLVER_NNLS ? d.q_order : nullptr;
+  a.nnls_lhs = nullptr;
+  if (solver == RSPARSE_SOLVER_NNLS && padded_rank(rank) == 128) {   // (the wide family's buffer: no rank uses both)
+    if ((rc = g_ws.ensure_wide(chol_loss_slots(d.n_cols) * (size_t)128 * 128, 0))) return rc;
+    a.nnls_lhs = g_ws.wide_m2;
+  }
   a.k = rank; a.cg_steps = (int)cg_steps;
   a.lambda = (float)lambda; a.lambda_loss = lambda; a.dynamic_lambda = dynamic_lambda ? 1 : 0;
   a.loss_partials = g_ws.partials; a.fail_counter = g_ws.fails; a.zero_row = g_ws.zero_row;

@@ -127,6 +127,7 @@ struct AlsArgs {
   int n_lr;
   int lr_n_gt32, lr_n_gt16;   // how many of them (a prefix: the list is longest first) have more than 32 / 16 non-zeros; -1 = unknown
   int lr_n_gt48;              // ... more than 48
+  float* nnls_lhs;            // NNLS, rank 65..128: chol_loss_slots(n_cols) x 128 x 128 floats -- lhs of the workgroup's row (nullable: lhs in LDS)
   const int32_t* nnls_order;  // NNLS, one wave per row: the rows longest first (nullable: natural order) -- a row's cost is its sweep count,
                               // which grows with its length, and what runs last decides when the launch ends
   int lrx;                    // explicit feedback: lr_rows are solved by the push-through wave kernel (wrmf_chol_lr.hip) and the k x k kernels skip them

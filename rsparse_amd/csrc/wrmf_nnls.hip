@@ -29,37 +29,41 @@ constexpr int kScdMaxIter = 10000;   // SCD_MAX_ITER, inst/include/wrmf.hpp:20
 constexpr float kScdTol = 1e-4f;     // SCD_TOL, inst/include/wrmf.hpp:21
 constexpr float kNnlsEps = 1e-16f;   // EPS, inst/include/nnls.hpp:8
 
-template <int KP>
+template <int KP, bool GLHS = false>
 struct NnlsSmem {
+  // GLHS (end of round 6, rank 65..128): lhs lives in a global scratch of the workgroup (L2) and the tile holds 16 vectors, so that
+  // the squared system, which the sweeps read, is all the LDS holds -- 75 KB instead of 148: TWO workgroups per CU.  A row's cost is
+  // its descent, one wave's serial chain; what fills the CU meanwhile is another workgroup's.
   static constexpr int BS = KP / 16;
-  static constexpr int TC = 32;
+  static constexpr int TC = GLHS ? 16 : 32;
   static constexpr int LDT = KP + 4;
   static constexpr size_t tile_floats = (size_t)TC * LDT;
   static constexpr size_t mat_floats = (size_t)KP * KP;
   static constexpr size_t vec_floats = (size_t)3 * KP + 2 * TC;  // rhs, init/result, spare, c, c1
-  static constexpr size_t bytes = (tile_floats + 2 * mat_floats + vec_floats + 16) * 4 + 64;
+  static constexpr size_t bytes = (tile_floats + (GLHS ? 1 : 2) * mat_floats + vec_floats + 16) * 4 + 64;
 };
 
-template <int KP, bool VEC>
+template <int KP, bool VEC, int TC = 32>
 __device__ __forceinline__ void nnls_gather_chunk(const AlsArgs& a, int base, int ccnt, float* sT, int wv, int lane) {
-  constexpr int LDT = KP + 4;
+  constexpr int LDT = KP + 4, TCW = TC / 4;   // (TCW vectors of the chunk per wave)
   const int k = a.k;
   if constexpr (VEC) {
-    constexpr int LPV = KP / 4, VPI = 64 / LPV, NQ = 8 / VPI;
+    constexpr int LPV = KP / 4, VPI = 64 / LPV, NQ = TCW / VPI;
+    static_assert(NQ >= 1, "a wave's share of the chunk is at least one load instruction");
     const int c4 = lane % LPV, jo = lane / LPV;
     int ids[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) ids[q] = a.row_idx[base + min(8 * wv + q * VPI + jo, ccnt - 1)];
+    for (int q = 0; q < NQ; q++) ids[q] = a.row_idx[base + min(TCW * wv + q * VPI + jo, ccnt - 1)];
     float4 v[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) v[q] = *reinterpret_cast<const float4*>(a.X + (size_t)ids[q] * k + min(c4 * 4, k - 4));
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-      const int j = 8 * wv + q * VPI + jo;
+      const int j = TCW * wv + q * VPI + jo;
       if (j < ccnt && c4 * 4 < k) *reinterpret_cast<float4*>(sT + j * LDT + c4 * 4) = v[q];
     }
   } else {
-    for (int j = 8 * wv; j < min(8 * wv + 8, ccnt); j++) {
+    for (int j = TCW * wv; j < min(TCW * wv + TCW, ccnt); j++) {
       const int id = rfl(a.row_idx[base + j]);
       const float* src = a.X + (size_t)id * k;
       for (int e = lane; e < k; e += 64) sT[j * LDT + e] = src[e];
@@ -67,15 +71,17 @@ __device__ __forceinline__ void nnls_gather_chunk(const AlsArgs& a, int base, in
   }
 }
 
-template <int KP, bool IMPLICIT, bool VEC>
+template <int KP, bool IMPLICIT, bool VEC, bool GLHS = false>
 __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
-  using SM = NnlsSmem<KP>;
+  using SM = NnlsSmem<KP, GLHS>;
   constexpr int BS = SM::BS, TC = SM::TC, LDT = SM::LDT, NS = KP / 64;  // NS coordinates per lane of wave 0
   static_assert(KP % 64 == 0 || KP == 32, "rank padding");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = reinterpret_cast<float*>(smem);
-  float* sA = sT + SM::tile_floats;   // lhs, full symmetric, row-major
-  float* sB = sA + SM::mat_floats;    // XtX = lhs^2
+  // lhs, full symmetric, row-major: in LDS, or (GLHS) this workgroup's KP x KP floats of a global scratch -- written and read by
+  // this workgroup only, between its barriers
+  float* sA = GLHS ? a.nnls_lhs + (size_t)blockIdx.x * SM::mat_floats : sT + SM::tile_floats;
+  float* sB = GLHS ? sT + SM::tile_floats : sA + SM::mat_floats;    // XtX = lhs^2
   float* sR = sB + SM::mat_floats;    // [KP] rhs
   float* sH = sR + KP;                // [KP] warm start -> result
   float* sC = sH + 2 * KP;            // [TC] confidence / rating
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
         sC[tid] = a.rhs_vals ? a.rhs_vals[base + tid] : cvv;   // coefficient in the right-hand side
         sC1[tid] = IMPLICIT ? cvv - 1.f : 1.f;
       }
-      nnls_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
+      nnls_gather_chunk<KP, VEC, TC>(a, base, ccnt, sT, wv, lane);
       __syncthreads();
       if (lower) {
         for (int j = 0; j < ccnt; j++) {
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void als_nnls_kernel(AlsArgs a) {
           sC[tid] = a.vals[base + tid];
           sC1[tid] = a.loss_tgt ? a.loss_tgt[base + tid] : a.loss_tgt_const;
         }
-        nnls_gather_chunk<KP, VEC>(a, base, ccnt, sT, wv, lane);
+        nnls_gather_chunk<KP, VEC, TC>(a, base, ccnt, sT, wv, lane);
         __syncthreads();
         if (wv == 0) {
           const float t = tile_dot<KP, TC>(sT, sH, lane);
@@ -640,12 +646,15 @@ hipError_t launch_nnls_wave_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
   return hipSuccess;
 }
 
-template <int KP, bool IMPLICIT, bool VEC>
+template <int KP, bool IMPLICIT, bool VEC, bool GLHS = false>
 hipError_t launch_nnls_t(const AlsArgs& a, hipStream_t s, hipEvent_t* ev) {
-  using SM = NnlsSmem<KP>;
+  if constexpr (KP == 128 && VEC && !GLHS) {   // two workgroups per CU where the caller brought the scratch for lhs
+    if (a.nnls_lhs) return launch_nnls_t<KP, IMPLICIT, VEC, true>(a, s, ev);
+  }
+  using SM = NnlsSmem<KP, GLHS>;
   hipError_t err;
   const int grid = (int)chol_loss_slots(a.n_cols);
-  auto kc = als_nnls_kernel<KP, IMPLICIT, VEC>;
+  auto kc = als_nnls_kernel<KP, IMPLICIT, VEC, GLHS>;
   if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)SM::bytes)) != hipSuccess)
     return err;

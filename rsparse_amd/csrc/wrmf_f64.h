@@ -62,6 +62,12 @@ hipError_t launch_f64_rhs_init(const double* X, int k, int off, int k1, int bias
 hipError_t launch_f64_weighted_sumsq(const double* X, int k, int64_t n, const double* w, double* out, double* partials,
                                      hipStream_t s);
 
+// explicit feedback with biases, conjugate gradient: the operands re-packed for the wave-per-row kernels (wrmf_f64.hip)
+hipError_t launch_f64_pack_rows(const double* src, int ld, int off, int k1, int64_t n, double* dst, hipStream_t s);
+hipError_t launch_f64_unpack_rows(const double* src, int k1, int64_t n, int ld, int off, double* dst, hipStream_t s);
+hipError_t launch_f64_shift_values(const double* vals, const int32_t* idx, const double* X, int ld, int xb, int64_t nnz,
+                                   double* out, hipStream_t s);
+
 // double overloads of the bias-initialisation pieces (wrmf_bias.hip)
 hipError_t launch_bias_sweep(const int32_t* p, const int32_t* i, const double* x, const double* other, int n_cols,
                              double lambda, int dynamic_lambda, int non_negative, double* out, hipStream_t s);

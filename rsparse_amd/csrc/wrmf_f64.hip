@@ -1502,6 +1502,53 @@ F64Geo f64_geometry(int k1, int solver) {
 
 }  // namespace
 
+// ---- explicit feedback with user/item biases and the conjugate-gradient solver: re-packed for the wave-per-row kernels ----
+// The generic kernel takes the bias operands as offsets (xoff / xb / ioff / ooff) but pays k1^2 flops per non-zero and a workgroup
+// per row; the wave-per-row conjugate-gradient kernels want plain matrices.  As in the fp32 layer (wrmf_bias.hip): X' = the k1
+// kept rows of X, Y' = the warm start, r' = r - x_bias[index]; solve at rank k1; the result goes back to its rows of Y.
+namespace {
+__global__ __launch_bounds__(256) void f64_pack_rows_kernel(const double* __restrict__ src, int ld, int off, int k1, int64_t n,
+                                                            double* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n * k1) {
+    const int64_t j = e / k1;
+    const int t = (int)(e - j * k1);
+    dst[e] = src[j * ld + off + t];
+  }
+}
+__global__ __launch_bounds__(256) void f64_unpack_rows_kernel(const double* __restrict__ src, int k1, int64_t n, int ld, int off,
+                                                              double* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n * k1) {
+    const int64_t j = e / k1;
+    const int t = (int)(e - j * k1);
+    dst[j * ld + off + t] = src[e];
+  }
+}
+__global__ __launch_bounds__(256) void f64_shift_values_kernel(const double* __restrict__ vals, const int32_t* __restrict__ idx,
+                                                               const double* __restrict__ X, int ld, int xb, int64_t nnz,
+                                                               double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < nnz) out[e] = vals[e] - X[(size_t)idx[e] * ld + xb];   // wrmf_explicit.hpp:89
+}
+}  // namespace
+hipError_t launch_f64_pack_rows(const double* src, int ld, int off, int k1, int64_t n, double* dst, hipStream_t s) {
+  if (n <= 0 || k1 <= 0) return hipSuccess;
+  hipLaunchKernelGGL(f64_pack_rows_kernel, dim3((unsigned)((n * k1 + 255) / 256)), dim3(256), 0, s, src, ld, off, k1, n, dst);
+  return hipGetLastError();
+}
+hipError_t launch_f64_unpack_rows(const double* src, int k1, int64_t n, int ld, int off, double* dst, hipStream_t s) {
+  if (n <= 0 || k1 <= 0) return hipSuccess;
+  hipLaunchKernelGGL(f64_unpack_rows_kernel, dim3((unsigned)((n * k1 + 255) / 256)), dim3(256), 0, s, src, k1, n, ld, off, dst);
+  return hipGetLastError();
+}
+hipError_t launch_f64_shift_values(const double* vals, const int32_t* idx, const double* X, int ld, int xb, int64_t nnz,
+                                   double* out, hipStream_t s) {
+  if (nnz <= 0) return hipSuccess;
+  hipLaunchKernelGGL(f64_shift_values_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, vals, idx, X, ld, xb, nnz, out);
+  return hipGetLastError();
+}
+
 size_t f64_long_scratch_doubles(int k, int n_long, int n_chunks) { return ((size_t)n_chunks + 2 * (size_t)n_long) * k + 4 * (size_t)n_long; }
 int f64_als_grid(int n_cols) { return std::max(1, std::min(n_cols, kF64MaxGrid)); }
 bool f64_needs_m2_scratch(int k1, int solver) { return solver == 2 && !f64_geometry(k1, solver).m2_in_lds; }

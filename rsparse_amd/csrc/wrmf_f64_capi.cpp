@@ -86,11 +86,22 @@ struct WorkspaceF64 {
   size_t m2_n = 0;
   double* longs = nullptr;      // the long rows' partial sums and vectors (f64_long_scratch_doubles)
   size_t longs_n = 0;
+  double* repack = nullptr;     // explicit feedback with biases, conjugate gradient: X', Y', shifted ratings
+  size_t repack_n = 0;
   int device = -1;
   void release() {
-    for (double** q : {&gram, &partials, &scalars, &rinit, &m2, &longs})
+    for (double** q : {&gram, &partials, &scalars, &rinit, &m2, &longs, &repack})
       if (*q) { (void)hipFree(*q); *q = nullptr; }
-    gram_n = m2_n = longs_n = 0;
+    gram_n = m2_n = longs_n = repack_n = 0;
+  }
+  int ensure_repack(size_t n) {
+    if (n > repack_n) {
+      if (repack) (void)hipFree(repack);
+      repack = nullptr; repack_n = 0;
+      HIP_TRY(hipMalloc(&repack, n * sizeof(double)));
+      repack_n = n;
+    }
+    return RSPARSE_HIP_OK;
   }
   int ensure_longs(size_t n) {
     if (n > longs_n) {
@@ -218,7 +229,33 @@ int f64_half_iteration(const rsparse_hip_csc_f64* conf, bool implicit, const dou
     a.chunk_off = a.chunk_long + conf->n_chunks;
     a.long_scratch = g_w64.longs;
   }
-  if ((e = launch_f64_als(a, s)) != hipSuccess) return capi_hip_fail(e, "launch_f64_als");
+  // explicit feedback with user/item biases and conjugate gradient -- the usual configuration of an explicit fit in the reference's
+  // default precision -- re-packed for the wave-per-row kernels (end of round 6: it ran the generic kernel, 143 ms per iteration
+  // at 1M x 100k and rank 10 where the float fit takes 10)
+  const bool repack = !implicit && with_biases && solver == RSPARSE_SOLVER_CONJUGATE_GRADIENT && a.k1 >= 1;
+  if (repack) {
+    const int k1 = a.k1;
+    const size_t nx = (size_t)conf->n_rows * k1, ny = (size_t)conf->n_cols * k1, nv = (size_t)conf->nnz;
+    if ((rc = g_w64.ensure_repack(nx + ny + nv + 16))) return rc;
+    double* Xp = g_w64.repack;
+    double* Yp = Xp + nx;
+    double* Vp = Yp + ny;
+    if ((e = launch_f64_pack_rows(d_X, rank, a.xoff, k1, conf->n_rows, Xp, s)) != hipSuccess) return capi_hip_fail(e, "launch_f64_pack_rows");
+    if ((e = launch_f64_pack_rows(d_Y, rank, a.ioff, k1, conf->n_cols, Yp, s)) != hipSuccess) return capi_hip_fail(e, "launch_f64_pack_rows");
+    if ((e = launch_f64_shift_values(conf->vals, conf->row_idx, d_X, rank, a.xb, conf->nnz, Vp, s)) != hipSuccess)
+      return capi_hip_fail(e, "launch_f64_shift_values");
+    F64Args b = a;
+    b.X = Xp; b.Y = Yp; b.vals = Vp;
+    b.k = k1; b.k1 = k1;
+    b.xoff = 0; b.xb = -1; b.ioff = 0; b.ooff = 0;
+    if (conf->n_long > 0) {   // (the long rows' scratch was sized for `rank` coordinates: enough for k1)
+      b.long_scratch = g_w64.longs;
+    }
+    if ((e = launch_f64_als(b, s)) != hipSuccess) return capi_hip_fail(e, "launch_f64_als");
+    if ((e = launch_f64_unpack_rows(Yp, k1, conf->n_cols, rank, a.ooff, d_Y, s)) != hipSuccess) return capi_hip_fail(e, "launch_f64_unpack_rows");
+  } else {
+    if ((e = launch_f64_als(a, s)) != hipSuccess) return capi_hip_fail(e, "launch_f64_als");
+  }
   if ((e = launch_sum_partials(g_w64.partials, (size_t)grid, out, s)) != hipSuccess) return capi_hip_fail(e, "launch_sum_partials");
   return RSPARSE_HIP_OK;
 }

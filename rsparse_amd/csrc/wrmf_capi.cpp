@@ -586,12 +586,17 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   if (rc) return rc;
   if ((rc = g_ws.ensure_device())) return rc;
   const DevCSC& d = conf->d;
-  if (rank % 4 != 0 && rank < 128 && zero_padding_is_neutral(implicit, solver, lambda)) {
+  // (end of round 6) the exact solver at the ranks 65..127: the rank-128 kernels (matrix-core assembly, a wave per row) on copies
+  // padded to 128 beat the routes of a rank below the padded rank by 1.5-5 x (1M x 100k, ms per iteration: explicit rank 100
+  // 102 -> 21, implicit 44 -> 29, explicit rank 64 with biases -- a system of order 65 -- 99 -> 28).  A padded coordinate is an exact
+  // zero of an exact solve (identity / lambda on its diagonal, zero right-hand side); without per-non-zero bias operands only
+  const bool pad_to_128 = solver == RSPARSE_SOLVER_CHOLESKY && !bias && rank > 64 && rank < 128 && zero_padding_is_neutral(implicit, solver, lambda);
+  if (((rank % 4 != 0 && rank < 128) || pad_to_128) && zero_padding_is_neutral(implicit, solver, lambda)) {
     // A rank that is not a multiple of 4 (the reference's default is 10): the register-resident kernels take their vectors in
     // 16-byte pieces, and the LDS-tile fallback that took these ranks through round 3 is several times slower.  Coordinates of
     // zeros change nothing (wrmf_bias.hip, launch_pad_rows: the same argument as for the biased half-iterations), so the
     // half-iteration runs on copies padded to the next multiple of 4 and the solved rows are copied back.
-    const int kp = (rank + 3) & ~3;
+    const int kp = pad_to_128 ? 128 : ((rank + 3) & ~3);
     const size_t nx = (size_t)d.n_rows * kp, ny = (size_t)d.n_cols * kp, ng = (size_t)kp * kp;
     if ((rc = g_ws.ensure_pad(nx + ny + ng + 256 + 16))) return rc;
     float* Xp = g_ws.pad_buf;

@@ -591,12 +591,17 @@ int run_half_iteration(const rsparse_hip_csc* conf, bool implicit, const float* 
   // 102 -> 21, implicit 44 -> 29, explicit rank 64 with biases -- a system of order 65 -- 99 -> 28).  A padded coordinate is an exact
   // zero of an exact solve (identity / lambda on its diagonal, zero right-hand side); without per-non-zero bias operands only
   const bool pad_to_128 = solver == RSPARSE_SOLVER_CHOLESKY && !bias && rank > 64 && rank < 128 && zero_padding_is_neutral(implicit, solver, lambda);
-  if (((rank % 4 != 0 && rank < 128) || pad_to_128) && zero_padding_is_neutral(implicit, solver, lambda)) {
+  // ... and below rank 64 on copies padded to 64: the one-wave-per-row kernel with its matrix-core assembly exists at the padded rank
+  // 64 only (1M x 100k, ms per iteration: rank 10 35 -> 20, rank 20 50 -> 20, rank 32 36 -> 20, rank 48 26 -> 20).  (First measured
+  // with a failing cell of the reference's grid -- explicit feedback, lambda = 1000, the factors at 1e-28 --: that was the
+  // explicit low-rank kernel's scaled solve overflowing, a bug of the native ranks 64 and 128 too, fixed in wrmf_chol_lr.hip.)
+  const bool pad_to_64 = solver == RSPARSE_SOLVER_CHOLESKY && !bias && rank < 64 && zero_padding_is_neutral(implicit, solver, lambda);
+  if (((rank % 4 != 0 && rank < 128) || pad_to_128 || pad_to_64) && zero_padding_is_neutral(implicit, solver, lambda)) {
     // A rank that is not a multiple of 4 (the reference's default is 10): the register-resident kernels take their vectors in
     // 16-byte pieces, and the LDS-tile fallback that took these ranks through round 3 is several times slower.  Coordinates of
     // zeros change nothing (wrmf_bias.hip, launch_pad_rows: the same argument as for the biased half-iterations), so the
     // half-iteration runs on copies padded to the next multiple of 4 and the solved rows are copied back.
-    const int kp = pad_to_128 ? 128 : ((rank + 3) & ~3);
+    const int kp = pad_to_128 ? 128 : (pad_to_64 ? 64 : ((rank + 3) & ~3));
     const size_t nx = (size_t)d.n_rows * kp, ny = (size_t)d.n_cols * kp, ng = (size_t)kp * kp;
     if ((rc = g_ws.ensure_pad(nx + ny + ng + 256 + 16))) return rc;
     float* Xp = g_ws.pad_buf;

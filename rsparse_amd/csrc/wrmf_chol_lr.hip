@@ -1442,10 +1442,16 @@ __global__ __launch_bounds__(512) void als_chol_lrx_kernel(AlsArgs a, const int3
         }
       }
     }
-    // ---- 3. (T + lambda I) z = r, in the scaled system: (T sx^2 + lambda sx^2 I) z' = r, z = z' sx^2 ----
+    // ---- 3. (T + lambda I) z = r.  T is taken out of the operands' scale first (two exact multiplications per entry; through round
+    // 6 the system was solved in the scaled form (T sx^2 + lambda sx^2 I) z' = r, and with factors that have shrunk far enough --
+    // lambda = 1000 of the reference's test grid takes them to 1e-28 in five iterations -- lambda sx^2 overflowed, z' = 0, and every
+    // such row came back as zeros: tools/dbg/chol_lambda1000_fit.py, native ranks 64 and 128).  A T that underflows here is below
+    // 2^-126 against lambda; powers of two commute with every operation of the solve, so nothing else changes by a bit. ----
     float z = 0.f, dummy = 0.f;
-    lrw_solve<SL, NS>(rl, rating, ln, false, (lam_i * sx) * sx, z, dummy);
-    const float e_i = valid ? (z * sx) * sx : 0.f;
+#pragma unroll
+    for (int t = 0; t < NS; t++) rl[t] = (rl[t] * ux) * ux;
+    lrw_solve<SL, NS>(rl, rating, ln, false, lam_i, z, dummy);
+    const float e_i = valid ? z : 0.f;
     const float res = lam_i * e_i;   // r_j - x_j . y
     const float loss_i = valid ? res * res : 0.f;
     asm volatile("" : "+v"(id_nx), "+v"(c_nx), "+v"(p1_nn), "+v"(n_nn), "+v"(rid_n3));   // (see the implicit kernel)

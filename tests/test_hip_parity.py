@@ -705,6 +705,31 @@ def test_one_giant_row_is_split_across_workgroups(k, implicit):
     assert abs(loss - lref) <= TOL * abs(lref)
 
 
+@pytest.mark.parametrize("k", [10, 48, 64, 100, 128])
+@pytest.mark.parametrize("scale", [1e-12, 1e-20, 1e-27])
+def test_explicit_cholesky_with_factors_that_have_shrunk(k, scale):
+    """lambda = 1000 of the reference's grid (test-wrmf.R) drives an explicit fit's factors to 1e-28 within five iterations.  The
+    exact solver must follow: through round 6 the explicit low-rank kernel solved (T s^2 + lambda s^2 I) z' = r in the scale s of
+    its fp16 operands, lambda s^2 overflowed below max |X| ~ 1e-14 and every row of <= 64 non-zeros came back as zeros at the
+    native ranks 64 and 128 (tools/dbg/chol_lambda1000_fit.py; the reference grid's ranks, 4..12, took other kernels)."""
+    d = synth.make_dataset(3000, 800, seed=5, mean_deg=40, d_max=600, feedback="explicit", device="cpu")
+    p, i, x = (t.numpy() for t in d["c_iu"])
+    x = x.astype(np.float64)
+    n_fix, n_cols = 800, 3000
+    cnt = np.bincount(i, minlength=n_fix).astype(np.float64)
+    rng = np.random.default_rng(k)
+    X = np.asfortranarray((rng.standard_normal((k, n_fix)) * scale).astype(np.float32))
+    Y0 = np.asfortranarray((rng.standard_normal((k, n_cols)) * scale).astype(np.float32))
+    csc = (n_fix, n_cols, p, i, x)
+    for dyn in (False, True):
+        Yref, lref = _oracle64(csc, X, Y0, 1000.0, 0, 3, False, dyn, cnt)
+        Y = Y0.copy(order="F")
+        loss = als.als_explicit(csc, X, Y, cnt.astype(np.float32), 1000.0, 1, 0, 3, dyn, "float", False, False)
+        err = np.linalg.norm(Y - Yref, axis=0) / np.maximum(np.linalg.norm(Yref, axis=0), 1e-300)
+        assert err.max() < TOL, (dyn, int(err.argmax()), float(err.max()))
+        assert abs(loss - lref) <= TOL * abs(lref)
+
+
 @pytest.mark.parametrize("k", [64, 96, 128])
 @pytest.mark.parametrize("lens", [(2300,), (513, 700, 1100, 2300), (2300, 2300, 600), (6000, 513)])
 def test_a_few_long_rows_one_of_them_cut(k, lens):

@@ -190,8 +190,11 @@ __device__ __forceinline__ void rank_update_mfma(double* A, int lda, int kp, con
 #define F64_T(j)
 #endif
 
+#ifndef RSP_F64_W64   // waves per SIMD asked of the one-wave instantiation (ranks <= 32): see the measurement at the launch
+#define RSP_F64_W64 2
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT, 2) void f64_als_kernel(F64Args a, int KP, int CH, int m2_in_lds) {   // (two waves per SIMD: two workgroups of 256 at rank 33..64, one of 512 beyond)
+__global__ __launch_bounds__(NT, NT == 64 ? RSP_F64_W64 : 2) void f64_als_kernel(F64Args a, int KP, int CH, int m2_in_lds) {   // (two waves per SIMD: two workgroups of 256 at rank 33..64, one of 512 beyond)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   constexpr int NW = NT / 64;
